@@ -1,0 +1,170 @@
+"""oracle/pin_oracle.py -- pins the C restatement against the reference library itself.
+
+Runs in the build container (needs oracle/_ref, i.e. /root/reference).  For every
+case it demands BIT-identical x, lam, fval and identical exitflag/iter between
+oracle/liboracle.so and the strict-IEEE reference build, and reports the
+agreement of the reference's own release (fast-math) build with both.
+
+    python oracle/pin_oracle.py [--n-per-config 300]
+"""
+import argparse
+import sys
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O  # noqa: E402
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def same(a, b):
+    return np.array_equal(bits(a), bits(b))
+
+
+def edge_cases(rng):
+    """Small hand-made problems exercising the non-random branches."""
+    cases = []
+    H2, f2 = np.eye(2), np.array([1.0, 1.0])
+    A2 = np.array([[1.0, 1.0], [1.0, -1.0]])
+    # reference python demo (interfaces/daqp-python/test/example_test.py:17-26)
+    cases.append(("py_demo", dict(H=H2, f=f2, A=A2, bupper=np.array([1., 2, 3, 4]), blower=-np.array([1., 2, 3, 4]),
+                                  sense=np.zeros(4, np.int32))))
+    # _make_qp of example_test.py:175-183 -> x = [-1,-1]
+    cases.append(("py_model", dict(H=np.eye(2), f=np.array([2.0, 2.0]), A=np.zeros((0, 2)),
+                                   bupper=np.ones(2), blower=-np.ones(2), sense=np.zeros(2, np.int32))))
+    # dense H, unconstrained optimum feasible
+    q = O.generate_qp(6, 12, 2, 2, rng=rng)
+    q2 = dict(q); q2["bupper"] = q["bupper"] + 1e3; q2["blower"] = q["blower"] - 1e3
+    cases.append(("unconstrained", q2))
+    # crossed bounds -> -1
+    q3 = dict(q); q3["bupper"] = q["bupper"].copy(); q3["bupper"][3] = q3["blower"][3] - 1.0
+    cases.append(("crossed", q3))
+    # infeasible: two parallel constraints that exclude each other
+    A = np.array([[1.0, 0.5, 0.0], [1.0, 0.5, 0.0], [0.0, 1.0, 1.0]])
+    cases.append(("infeasible", dict(H=np.array([[2.0, 0.3, 0], [0.3, 1.0, 0.1], [0, 0.1, 1.5]]), f=np.ones(3), A=A,
+                                     bupper=np.array([1.0, 5.0, 2.0]), blower=np.array([-1.0, 3.0, -2.0]),
+                                     sense=np.zeros(3, np.int32))))
+    # equality (sense 5) + soft (sense 8) + a pre-activated lower bound (sense 3)
+    q4 = O.generate_qp(8, 20, 3, 4, rng=rng)
+    s = np.zeros(20, np.int32); s[5] = 5; s[7] = 8; s[9] = 8; s[11] = 3
+    bu, bl = q4["bupper"].copy(), q4["blower"].copy()
+    bl[5] = bu[5]
+    bu[7] = bl[7] + 1e-3
+    q4.update(sense=s, bupper=bu, blower=bl)
+    cases.append(("eq_soft_warm", q4))
+    # unmarked equality (bupper == blower) found by check_bounds
+    q5 = O.generate_qp(8, 20, 0, 4, rng=rng)
+    bu, bl = q5["bupper"].copy(), q5["blower"].copy(); bl[2] = bu[2]; bl[13] = bu[13]
+    q5.update(bupper=bu, blower=bl)
+    cases.append(("implicit_eq", q5))
+    # zero row in A (normalize_M marks it immutable)
+    q6 = O.generate_qp(6, 14, 0, 3, rng=rng)
+    A6 = q6["A"].copy(); A6[4] = 0; bu = q6["bupper"].copy(); bl = q6["blower"].copy(); bu[4] = 1; bl[4] = -1
+    q6.update(A=A6, bupper=bu, blower=bl)
+    cases.append(("zero_row", q6))
+    # zero row with excluding bounds -> infeasible at setup
+    q7 = dict(q6); bu7 = bu.copy(); bl7 = bl.copy(); bu7[4] = -1.0; bl7[4] = -2.0
+    q7.update(bupper=bu7, blower=bl7)
+    cases.append(("zero_row_infeasible", q7))
+    # nearly dependent constraints: exercises pivoting / singular branches / refinement
+    for t, eps in enumerate([1e-4, 1e-7, 1e-9, 1e-12]):
+        qq = O.generate_qp(10, 30, 0, 6, rng=rng)
+        A = qq["A"].copy()
+        A[1] = A[0] + eps * rng.standard_normal(10)
+        A[3] = A[2] * (1 + eps) + eps * rng.standard_normal(10)
+        A[5] = A[0] + A[2] + eps * rng.standard_normal(10)
+        bu = qq["bupper"].copy(); bl = qq["blower"].copy()
+        bu[:6] = -np.abs(bu[:6]) * 0.1 - 0.5          # force violations on the dependent rows
+        bl[:6] = bu[:6] - 1.0
+        qq.update(A=A, bupper=bu, blower=bl)
+        cases.append((f"near_dep_{t}", qq))
+    # more active constraints than variables possible (m >> n, tight box)
+    qq = O.generate_qp(4, 30, 4, 3, rng=rng)
+    qq.update(bupper=qq["bupper"] - 0.3, blower=qq["blower"] + 0.0)
+    cases.append(("tight", qq))
+    # diagonal (non-identity) Hessian with simple bounds
+    qd = O.generate_qp(7, 18, 5, 4, rng=rng)
+    qd.update(H=np.diag(1.0 + 3 * rng.random(7)))
+    cases.append(("diag_H", qd))
+    return cases
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-per-config", type=int, default=300)
+    args = ap.parse_args()
+    ora, strict, fast = O.Oracle(), O.Reference(strict=True), O.Reference(strict=False)
+    bad = 0
+    total = 0
+
+    def check(name, q, settings=None):
+        nonlocal bad, total
+        a = ora.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q.get("sense"), settings)
+        b = strict.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q.get("sense"), settings)
+        total += 1
+        ok = a[3] == b[3] and (a[3] < 0 and a[4] == b[4] or
+                               (a[4] == b[4] and same(a[0], b[0]) and same(a[1], b[1]) and same(a[2], b[2])))
+        if a[3] < 0 and b[3] < 0 and a[3] == b[3]:
+            ok = a[3] == b[3] and (a[4] == b[4] or b[4] == 0)
+        if not ok:
+            bad += 1
+            print(f"MISMATCH {name}: oracle flag/iter {a[3]}/{a[4]} ref {b[3]}/{b[4]} "
+                  f"dx {np.abs(a[0] - b[0]).max():.3e}")
+        return a, b
+
+    rng = np.random.default_rng(7)
+    for name, q in edge_cases(rng):
+        a, b = check(name, q)
+        print(f"  {name:22s} flag {b[3]:3d} iter {b[4]:4d}")
+    # iteration limit (core_tests.jl:33-35)
+    q = O.generate_qp(20, 40, 0, 8, rng=[1234, 0])
+    a, b = check("iter_limit_1", q, O.default_settings(iter_limit=1))
+    print(f"  iter_limit=1           flag {b[3]} iter {b[4]}")
+
+    for cfg, (n, m, ms, na, seed, _) in O.CONFIGS.items():
+        N = args.n_per_config if n < 100 else max(10, args.n_per_config // 15)
+        nfast_same = 0
+        dxmax = 0.0
+        its = []
+        for k in range(N):
+            q = O.generate_qp(n, m, ms, na, rng=[seed, k])
+            a, b = check(f"{cfg}[{k}]", q)
+            c = fast.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+            nfast_same += int(c[4] == b[4] and c[3] == b[3] and np.array_equal(np.sign(c[1]), np.sign(b[1])))
+            dxmax = max(dxmax, np.abs(c[0] - b[0]).max(), np.abs(b[0] - q["x"]).max())
+            its.append(b[4])
+        print(f"{cfg}: n={n} m={m} ms={ms}: {N} QPs, mean iter {np.mean(its):.1f} max {max(its)}; "
+              f"release-flags reference: identical active set+iter on {nfast_same}/{N}, max|dx| {dxmax:.2e}")
+
+    # workspace sequence: setup_daqp -> solve -> {update(v) -> solve}* 
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    for k in range(max(3, args.n_per_config // 30)):
+        q = O.generate_qp(n, m, ms, na, rng=[seed, k])
+        om, rm = ora.model(n, m, ms), strict.model(n, m, ms)
+        fa, fb = om.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"]), \
+            rm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        seq = [(om.solve(), rm.solve())]
+        f = q["f"].copy()
+        for t in range(5):
+            f = f + 0.05 * np.random.default_rng([45, k, t]).standard_normal(n)
+            ua, ub = om.update(O.UPDATE_v, f=f), rm.update(O.UPDATE_v, f=f)
+            assert ua == ub == 0, (ua, ub)
+            seq.append((om.solve(), rm.solve()))
+        for t, (a, b) in enumerate(seq):
+            total += 1
+            if not (a[3] == b[3] and a[4] == b[4] and same(a[0], b[0]) and same(a[1], b[1]) and same(a[2], b[2])):
+                bad += 1
+                print(f"MISMATCH warm[{k}][{t}] {a[3]}/{a[4]} vs {b[3]}/{b[4]}")
+        if k == 0:
+            print("warm sequence iters:", [b[4] for _, b in seq], "setup flags", fa, fb)
+        rm.close()
+    print(f"pin result: {total - bad}/{total} bit-identical to the strict reference build")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,162 @@
+"""Loader/builder for libdaqp_amd.so (the C ABI of include/daqp_amd.h).
+
+The shared library is compiled in-tree with hipcc for gfx950 and loaded with ctypes.  There is
+no Python or CPU implementation of the solver behind it: if the library cannot be built or
+loaded, importing the solver entry points raises.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIBPATH = os.path.join(LIBDIR, "libdaqp_amd.so")
+SOURCES = ["daqp_amd.hip", "kernels.hip.h", "wave_ldp.hip.h"]
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class DAQPSettings(C.Structure):  # include/daqp_amd.h (layout of reference types.h:52-74)
+    _fields_ = [("primal_tol", C.c_double), ("dual_tol", C.c_double), ("zero_tol", C.c_double),
+                ("pivot_tol", C.c_double), ("progress_tol", C.c_double),
+                ("cycle_tol", C.c_int), ("iter_limit", C.c_int),
+                ("fval_bound", C.c_double), ("eps_prox", C.c_double), ("eta_prox", C.c_double),
+                ("rho_soft", C.c_double), ("rel_subopt", C.c_double), ("abs_subopt", C.c_double),
+                ("sing_tol", C.c_double), ("refactor_tol", C.c_double), ("time_limit", C.c_double)]
+
+
+class DAQPProblem(C.Structure):  # reference types.h:14-50
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("ms", C.c_int),
+                ("H", c_double_p), ("f", c_double_p), ("A", c_double_p),
+                ("bupper", c_double_p), ("blower", c_double_p), ("sense", c_int_p),
+                ("break_points", c_int_p), ("nh", C.c_int), ("problem_type", C.c_int)]
+
+
+class DAQPResult(C.Structure):  # reference api.h:15-27
+    _fields_ = [("x", c_double_p), ("lam", c_double_p), ("fval", C.c_double), ("soft_slack", C.c_double),
+                ("exitflag", C.c_int), ("iter", C.c_int), ("nodes", C.c_int),
+                ("solve_time", C.c_double), ("setup_time", C.c_double)]
+
+
+class DAQPBatchProblem(C.Structure):
+    _fields_ = [("N", C.c_int), ("n", C.c_int), ("m", C.c_int), ("ms", C.c_int),
+                ("H", C.c_void_p), ("f", C.c_void_p), ("A", C.c_void_p),
+                ("bupper", C.c_void_p), ("blower", C.c_void_p), ("sense", C.c_void_p),
+                ("memory", C.c_int)]
+
+
+class DAQPBatchResult(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("lam", C.c_void_p), ("fval", C.c_void_p), ("soft_slack", C.c_void_p),
+                ("exitflag", C.c_void_p), ("iter", C.c_void_p), ("memory", C.c_int),
+                ("setup_time", C.c_double), ("solve_time", C.c_double)]
+
+
+WORKSPACE_BYTES = 288  # sizeof(DAQPWorkspace) in include/daqp_amd.h == reference types.h:187-264
+MEM_HOST, MEM_DEVICE = 0, 1
+
+EXPORTS = [
+    "daqp_quadprog", "daqp_solve", "setup_daqp", "setup_daqp_main", "daqp_update_ldp", "daqp_default_settings",
+    "allocate_daqp_settings", "free_daqp_workspace", "free_daqp_ldp", "daqp_primal_init_active",
+    "daqp_dual_init_active", "daqp_batch_create", "daqp_batch_free", "daqp_batch_set_stream",
+    "daqp_batch_set_settings", "daqp_batch_setup", "daqp_batch_update", "daqp_batch_solve",
+    "daqp_batch_setup_flags", "daqp_batch_working_sets", "daqp_quadprog_batch", "daqp_batch_kernel_ms",
+    "daqp_batch_device_bytes", "daqp_amd_last_error", "daqp_amd_device_count", "daqp_amd_version",
+]
+
+
+def _stale():
+    if not os.path.exists(LIBPATH):
+        return True
+    t = os.path.getmtime(LIBPATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(ROOT, "include", "daqp_amd.h")]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> daqp_amd/lib/libdaqp_amd.so (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIBPATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        if os.path.exists(LIBPATH):
+            return LIBPATH
+        raise RuntimeError("hipcc not found and no prebuilt libdaqp_amd.so")
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           os.path.join(CSRC, "daqp_amd.hip"), "-o", LIBPATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIBPATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C ABI.  Raises if the HIP library is missing: there is nothing to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        build()
+    L = C.CDLL(LIBPATH)
+    vp, ci = C.c_void_p, C.c_int
+    L.daqp_amd_last_error.restype = C.c_char_p
+    L.daqp_amd_version.restype = C.c_char_p
+    L.daqp_batch_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci, C.POINTER(DAQPSettings), ci]
+    L.daqp_batch_free.argtypes = [vp]
+    L.daqp_batch_free.restype = None
+    L.daqp_batch_set_stream.argtypes = [vp, vp]
+    L.daqp_batch_set_stream.restype = None
+    L.daqp_batch_set_settings.argtypes = [vp, C.POINTER(DAQPSettings)]
+    L.daqp_batch_set_settings.restype = None
+    L.daqp_batch_setup.argtypes = [vp, C.POINTER(DAQPBatchProblem), ci]
+    L.daqp_batch_update.argtypes = [vp, ci, C.POINTER(DAQPBatchProblem)]
+    L.daqp_batch_solve.argtypes = [vp, C.POINTER(DAQPBatchResult)]
+    L.daqp_batch_setup_flags.argtypes = [vp, c_int_p]
+    L.daqp_batch_working_sets.argtypes = [vp, c_int_p, c_int_p]
+    L.daqp_quadprog_batch.argtypes = [C.POINTER(DAQPBatchResult), C.POINTER(DAQPBatchProblem), C.POINTER(DAQPSettings)]
+    L.daqp_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.daqp_batch_device_bytes.argtypes = [vp]
+    L.daqp_batch_device_bytes.restype = C.c_ulonglong
+    L.daqp_batch_enable_trace.argtypes = [vp, ci]
+    L.daqp_batch_read_trace.argtypes = [vp, c_int_p]
+    L.daqp_batch_read_ldp.argtypes = [vp, ci] + [c_double_p] * 6
+    L.daqp_quadprog.argtypes = [C.POINTER(DAQPResult), C.POINTER(DAQPProblem), C.POINTER(DAQPSettings)]
+    L.daqp_quadprog.restype = None
+    L.daqp_solve.argtypes = [C.POINTER(DAQPResult), vp]
+    L.daqp_solve.restype = None
+    L.setup_daqp.argtypes = [C.POINTER(DAQPProblem), vp, c_double_p]
+    L.setup_daqp_main.argtypes = [C.POINTER(DAQPProblem), vp, c_double_p, ci]
+    L.daqp_update_ldp.argtypes = [ci, vp, C.POINTER(DAQPProblem)]
+    L.daqp_default_settings.argtypes = [C.POINTER(DAQPSettings)]
+    L.daqp_default_settings.restype = None
+    L.free_daqp_workspace.argtypes = [vp]
+    L.free_daqp_workspace.restype = None
+    L.free_daqp_ldp.argtypes = [vp]
+    L.free_daqp_ldp.restype = None
+    L.daqp_primal_init_active.argtypes = [C.POINTER(DAQPProblem), c_double_p]
+    L.daqp_primal_init_active.restype = None
+    L.daqp_dual_init_active.argtypes = [C.POINTER(DAQPProblem), c_double_p]
+    L.daqp_dual_init_active.restype = None
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().daqp_amd_last_error().decode()
+
+
+def default_settings(**kw):
+    s = DAQPSettings()
+    lib().daqp_default_settings(C.byref(s))
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise TypeError(f"unknown DAQP setting {k!r}")
+        setattr(s, k, v)
+    return s

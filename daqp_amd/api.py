@@ -1,0 +1,323 @@
+"""Host-side mirror of the reference's Python binding for the dense QP path, plus its batch twin.
+
+  solve(H, f, A, bupper, blower, sense, **settings)      reference daqp.pyx:68-221  -> daqp_quadprog
+  Model().setup/solve/update                              reference daqp.pyx:222-572 -> setup_daqp /
+                                                          daqp_solve / daqp_update_ldp
+  solve_batch(...), BatchModel                            N problems of one shape -> daqp_batch_*
+
+Everything goes through the C ABI of libdaqp_amd.so; torch tensors on the GPU are passed by
+device pointer (no copy), numpy arrays are staged by the library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (DAQPBatchProblem, DAQPBatchResult, DAQPProblem, DAQPResult, MEM_DEVICE, MEM_HOST,
+                   c_double_p, c_int_p, default_settings, lib)
+
+UPDATE_Rinv, UPDATE_M, UPDATE_v, UPDATE_d, UPDATE_sense = 1, 2, 4, 8, 16
+UPDATE_unconstrained, UPDATE_eliminate = 64, 128
+INF = 1e30
+
+try:  # torch is plumbing only (device memory, streams); the package works on numpy without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _np64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _np32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_int_p)
+
+
+# ---------------------------------------------------------------------------
+# single problem: same call shape as the reference binding
+# ---------------------------------------------------------------------------
+def solve(H, f, A, bupper, blower=None, sense=None, **settings):
+    """x, fval, exitflag, info = solve(H, f, A, bupper, blower, sense, primal_tol=..., iter_limit=...)"""
+    H, f, A, bupper = _np64(H), _np64(f), _np64(A), _np64(bupper)
+    n, m = f.size, bupper.size
+    mA = A.shape[0] if (A is not None and A.ndim == 2) else 0
+    blower = np.full(m, -INF) if blower is None else _np64(blower)
+    sense = np.zeros(m, np.int32) if sense is None else _np32(sense)
+    x, lam = np.empty(n), np.empty(m)
+    qp = DAQPProblem(n, m, m - mA, _dp(H), _dp(f), _dp(A) if mA else None, _dp(bupper), _dp(blower), _ip(sense),
+                     None, 0, 0)
+    st = default_settings(**settings)
+    res = DAQPResult(_dp(x), _dp(lam), 0, 0, 0, 0, 0, 0, 0)
+    lib().daqp_quadprog(C.byref(res), C.byref(qp), C.byref(st))
+    if res.exitflag == -8 and _lib.last_error():
+        info_err = _lib.last_error()
+    else:
+        info_err = ""
+    return x, res.fval, res.exitflag, {"solve_time": res.solve_time, "setup_time": res.setup_time,
+                                       "iterations": res.iter, "nodes": res.nodes, "lam": lam, "error": info_err}
+
+
+class Model:
+    """Persistent workspace (reference daqp.pyx:222-572): setup once, then solve / update / solve ..."""
+
+    def __init__(self):
+        self._ws = None
+        self._keep = {}
+        self._qp = None
+        self._settings = default_settings()
+        self.n = self.m = self.ms = 0
+
+    def _problem(self):
+        k = self._keep
+        self._qp = DAQPProblem(self.n, self.m, self.ms, _dp(k["H"]), _dp(k["f"]), _dp(k.get("A")), _dp(k["bupper"]),
+                               _dp(k["blower"]), _ip(k.get("sense")), None, 0, 0)
+        return self._qp
+
+    def setup(self, H, f, A, bupper, blower=None, sense=None, **settings):
+        self._free()
+        H, f, A, bupper = _np64(H), _np64(f), _np64(A), _np64(bupper)
+        self.n, self.m = f.size, bupper.size
+        mA = A.shape[0] if (A is not None and A.ndim == 2) else 0
+        self.ms = self.m - mA
+        blower = np.full(self.m, -INF) if blower is None else _np64(blower)
+        sense = np.zeros(self.m, np.int32) if sense is None else _np32(sense)
+        self._keep = dict(H=H, f=f, A=A if mA else None, bupper=bupper, blower=blower, sense=sense)
+        self._settings = default_settings(**settings)
+        self._ws = C.create_string_buffer(_lib.WORKSPACE_BYTES)
+        C.c_void_p.from_buffer(self._ws, 224).value = C.addressof(self._settings)  # work->settings (borrowed)
+        t = C.c_double(0)
+        flag = lib().setup_daqp(C.byref(self._problem()), self._ws, C.byref(t))
+        if flag < 0:
+            self._ws = None
+        return flag, t.value
+
+    def settings(self, **kw):
+        for k, v in kw.items():
+            setattr(self._settings, k, v)
+        return {k: getattr(self._settings, k) for k, _ in self._settings._fields_}
+
+    def update(self, H=None, f=None, A=None, bupper=None, blower=None, sense=None):
+        if self._ws is None:
+            raise RuntimeError("Model.update called before setup")
+        mask = 0
+        if H is not None:
+            self._keep["H"] = _np64(H); mask |= UPDATE_Rinv
+        if A is not None:
+            self._keep["A"] = _np64(A); mask |= UPDATE_M
+        if f is not None:
+            self._keep["f"] = _np64(f); mask |= UPDATE_v
+        if bupper is not None or blower is not None:
+            if bupper is not None:
+                self._keep["bupper"] = _np64(bupper)
+            if blower is not None:
+                self._keep["blower"] = _np64(blower)
+            mask |= UPDATE_d
+        if sense is not None:
+            self._keep["sense"] = _np32(sense); mask |= UPDATE_sense
+        if mask & (UPDATE_Rinv | UPDATE_M | UPDATE_sense):   # anything but f/bounds: full re-setup on the device
+            mask = UPDATE_Rinv | UPDATE_M | UPDATE_v | UPDATE_d | UPDATE_sense
+        return lib().daqp_update_ldp(mask, self._ws, C.byref(self._problem()))
+
+    def solve(self):
+        if self._ws is None:
+            raise RuntimeError("Model.solve called before setup")
+        x, lam = np.empty(self.n), np.empty(self.m)
+        res = DAQPResult(_dp(x), _dp(lam), 0, 0, 0, 0, 0, 0, 0)
+        lib().daqp_solve(C.byref(res), self._ws)
+        return x, res.fval, res.exitflag, {"solve_time": res.solve_time, "setup_time": 0.0, "iterations": res.iter,
+                                           "nodes": res.nodes, "lam": lam}
+
+    def _free(self):
+        if self._ws is not None:
+            C.c_void_p.from_buffer(self._ws, 224).value = None  # borrowed settings are not ours to free
+            lib().free_daqp_workspace(self._ws)
+            lib().free_daqp_ldp(self._ws)
+            self._ws = None
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
+# batches
+# ---------------------------------------------------------------------------
+def _is_torch(a):
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+def _ptr(a, dtype, keep):
+    """(pointer, memory) of a numpy array or torch tensor, made contiguous and of the right dtype."""
+    if a is None:
+        return None, None
+    if _is_torch(a):
+        tdt = torch.float64 if dtype == np.float64 else torch.int32
+        t = a.to(tdt).contiguous()
+        keep.append(t)
+        return t.data_ptr(), (MEM_DEVICE if t.is_cuda else MEM_HOST)
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    keep.append(arr)
+    return arr.ctypes.data, MEM_HOST
+
+
+class BatchModel:
+    """Device-resident workspaces of N QPs of one shape: setup -> solve -> {update(f, bounds) -> solve}*.
+
+    Inputs may be numpy arrays (staged over PCIe by the library) or CUDA/HIP torch tensors (used in
+    place; they must stay alive until the next setup/update replaces them).  Shapes: H (N,n,n),
+    f (N,n), A (N,m-ms,n), bupper/blower (N,m), sense (N,m) int32 or None.
+    """
+
+    def __init__(self, N, n, m, ms=0, ns_max=0, device=None, **settings):
+        self.N, self.n, self.m, self.ms, self.ns = N, n, m, ms, ns_max
+        self._settings = default_settings(**settings)
+        h = C.c_void_p()
+        dev = -1 if device is None else int(device)
+        rc = lib().daqp_batch_create(C.byref(h), N, n, m, ms, ns_max, C.byref(self._settings), dev)
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_create failed ({rc}): {_lib.last_error()}")
+        self._h = h
+        self._keep = []
+        self._out_keep = []
+        self.device = device
+        if torch is not None and torch.cuda.is_available():
+            lib().daqp_batch_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().daqp_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _problem(self, H=None, f=None, A=None, bupper=None, blower=None, sense=None):
+        keep = []
+        mems = set()
+        ptrs = []
+        for a, dt in ((H, np.float64), (f, np.float64), (A, np.float64), (bupper, np.float64), (blower, np.float64),
+                      (sense, np.int32)):
+            p, mem = _ptr(a, dt, keep)
+            ptrs.append(p)
+            if mem is not None:
+                mems.add(mem)
+        if len(mems) > 1:
+            raise ValueError("mix of host and device arrays in one call")
+        mem = mems.pop() if mems else MEM_HOST
+        self._keep = keep if mem == MEM_DEVICE else self._keep
+        return DAQPBatchProblem(self.N, self.n, self.m, self.ms, *ptrs, mem), keep
+
+    def setup(self, H, f, A, bupper, blower, sense=None, init_mask=0):
+        p, keep = self._problem(H, f, A, bupper, blower, sense)
+        rc = lib().daqp_batch_setup(self._h, C.byref(p), init_mask)
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_setup failed ({rc}): {_lib.last_error()}")
+        return self
+
+    def setup_flags(self):
+        fl = np.zeros(self.N, np.int32)
+        lib().daqp_batch_setup_flags(self._h, _ip(fl))
+        return fl
+
+    def update(self, f=None, bupper=None, blower=None):
+        mask = (UPDATE_v if f is not None else 0) | (UPDATE_d if (bupper is not None or blower is not None) else 0)
+        p, keep = self._problem(None, f, None, bupper, blower, None)
+        self._upd_keep = keep
+        rc = lib().daqp_batch_update(self._h, mask, C.byref(p))
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_update failed ({rc}): {_lib.last_error()}")
+        return self
+
+    def solve(self, out="numpy"):
+        """Returns dict(x, lam, fval, exitflag, iter, soft_slack); out='numpy' or 'torch' (device tensors)."""
+        N, n, m = self.N, self.n, self.m
+        if out == "torch":
+            dev = torch.device("cuda", torch.cuda.current_device())
+            o = dict(x=torch.empty((N, n), dtype=torch.float64, device=dev),
+                     lam=torch.empty((N, m), dtype=torch.float64, device=dev),
+                     fval=torch.empty(N, dtype=torch.float64, device=dev),
+                     soft_slack=torch.empty(N, dtype=torch.float64, device=dev),
+                     exitflag=torch.empty(N, dtype=torch.int32, device=dev),
+                     iter=torch.empty(N, dtype=torch.int32, device=dev))
+            r = DAQPBatchResult(o["x"].data_ptr(), o["lam"].data_ptr(), o["fval"].data_ptr(), o["soft_slack"].data_ptr(),
+                                o["exitflag"].data_ptr(), o["iter"].data_ptr(), MEM_DEVICE, 0, 0)
+        else:
+            o = dict(x=np.empty((N, n)), lam=np.empty((N, m)), fval=np.empty(N), soft_slack=np.empty(N),
+                     exitflag=np.empty(N, np.int32), iter=np.empty(N, np.int32))
+            r = DAQPBatchResult(o["x"].ctypes.data, o["lam"].ctypes.data, o["fval"].ctypes.data, o["soft_slack"].ctypes.data,
+                                o["exitflag"].ctypes.data, o["iter"].ctypes.data, MEM_HOST, 0, 0)
+        rc = lib().daqp_batch_solve(self._h, C.byref(r))
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_solve failed ({rc}): {_lib.last_error()}")
+        self._out_keep = [o]
+        return o
+
+    def kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        lib().daqp_batch_kernel_ms(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def working_sets(self):
+        cap = self.n + self.ns + 1
+        na, ws = np.zeros(self.N, np.int32), np.zeros((self.N, cap), np.int32)
+        lib().daqp_batch_working_sets(self._h, _ip(na), _ip(ws))
+        return na, ws
+
+    def device_bytes(self):
+        return int(lib().daqp_batch_device_bytes(self._h))
+
+    # test hooks
+    def enable_trace(self, cap=4096):
+        lib().daqp_batch_enable_trace(self._h, cap)
+        self._trace_cap = cap
+
+    def read_trace(self):
+        t = np.zeros((self.N, self._trace_cap), np.int32)
+        lib().daqp_batch_read_trace(self._h, _ip(t))
+        return [t[q, : min(t[q, -1], self._trace_cap - 1)].copy() for q in range(self.N)]
+
+    def read_ldp(self, q):
+        n, m, ms = self.n, self.m, self.ms
+        M, R, v = np.zeros((m - ms, n)), np.zeros(n * (n + 1) // 2), np.zeros(n)
+        du, dl, sc = np.zeros(m), np.zeros(m), np.zeros(m)
+        lib().daqp_batch_read_ldp(self._h, q, _dp(M), _dp(R), _dp(v), _dp(du), _dp(dl), _dp(sc))
+        return M, R, v, du, dl, sc
+
+
+def solve_batch(H, f, A, bupper, blower=None, sense=None, ms=None, out="numpy", **settings):
+    """N x daqp_quadprog in one call (daqp_quadprog_batch semantics: unconstrained shortcut on).
+
+    Returns dict(x, lam, fval, exitflag, iter, soft_slack)."""
+    N, n = f.shape[0], f.shape[1]
+    m = bupper.shape[1]
+    mA = A.shape[1] if A is not None and A.ndim == 3 else 0
+    ms = m - mA if ms is None else ms
+    if blower is None:
+        blower = (torch.full_like(bupper, -INF) if _is_torch(bupper) else np.full(bupper.shape, -INF))
+    ns = 0
+    if sense is not None:
+        s = sense.cpu().numpy() if _is_torch(sense) else np.asarray(sense)
+        ns = int(((s & 8) != 0).sum(axis=1).max()) if s.size else 0
+    bm = BatchModel(N, n, m, ms, ns, **settings)
+    try:
+        bm.setup(H, f, A, bupper, blower, sense, init_mask=UPDATE_unconstrained | UPDATE_eliminate)
+        res = bm.solve(out=out)
+        if out == "torch":
+            torch.cuda.synchronize()
+    finally:
+        bm.close()
+    return res

@@ -1,0 +1,639 @@
+// daqp_amd.hip -- host side of libdaqp_amd.so: the C ABI declared in include/daqp_amd.h.
+// Thin by design: argument checks, device buffers, three kernel launches.  No numerical work
+// happens on the host and there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "kernels.hip.h"
+
+using namespace daqp_amd;
+
+namespace {
+
+thread_local char g_err[512] = "";
+void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return DAQP_EXIT_UNSUPPORTED;                                                     \
+        }                                                                                     \
+    } while (0)
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void default_settings(DAQPSettings *s) // reference constants.h:15-29 / api.c:505-527
+{
+    s->primal_tol = 1e-6; s->dual_tol = 1e-12; s->zero_tol = 1e-11; s->pivot_tol = 1e-6;
+    s->progress_tol = 1e-14; s->cycle_tol = 10; s->iter_limit = 10000; s->fval_bound = DAQP_INF;
+    s->eps_prox = -1e-6; s->eta_prox = -1.0; s->rho_soft = 1e-6; s->rel_subopt = 0; s->abs_subopt = 0;
+    s->sing_tol = 3.7e-11; s->refactor_tol = 1e-9; s->time_limit = 0;
+}
+
+} // namespace
+
+struct DAQPBatch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    BatchDev d{};
+    std::vector<void *> owned;
+    unsigned long long bytes = 0;
+    // staging copies of host inputs (allocated on first use)
+    double *sH = nullptr, *sf = nullptr, *sA = nullptr, *sbu = nullptr, *sbl = nullptr;
+    int *ssense = nullptr;
+    // library-owned result buffers
+    double *ox = nullptr, *olam = nullptr, *ofval = nullptr, *osoft = nullptr;
+    int *oflag = nullptr, *oiter = nullptr;
+    int C = 1;
+    bool spill = false;
+    size_t lds_setup = 0, lds_ldp = 0, lds_update = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timed_setup = false, timed_solve = false;
+    bool is_setup = false;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(DAQPBatch *b, T **p, size_t count)
+{
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    b->owned.push_back(*p);
+    b->bytes += count * sizeof(T);
+    return 0;
+}
+
+typedef void (*ldp_kernel_t)(BatchDev, int);
+ldp_kernel_t pick_ldp(int C, bool spill)
+{
+    if (!spill) {
+        if (C == 1) return k_ldp<1, false>;
+        if (C == 2) return k_ldp<2, false>;
+        return k_ldp<4, false>;
+    }
+    if (C == 1) return k_ldp<1, true>;
+    if (C == 2) return k_ldp<2, true>;
+    return k_ldp<4, true>;
+}
+
+int launch_ldp(DAQPBatch *b, int mode)
+{
+    ldp_kernel_t k = pick_ldp(b->C, b->spill);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
+    hipLaunchKernelGGL(k, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, b->d, mode);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// copy (host) or adopt (device) one input array
+template <typename T>
+int stage(DAQPBatch *b, const T *src, int memory, size_t count, T **slot, const T **out)
+{
+    if (src == nullptr) { *out = nullptr; return 0; }
+    if (memory == DAQP_MEM_DEVICE) { *out = src; return 0; }
+    if (*slot == nullptr) { if (dev_alloc(b, slot, count)) return DAQP_EXIT_UNSUPPORTED; }
+    HIPCHK(hipMemcpyAsync(*slot, src, count * sizeof(T), hipMemcpyHostToDevice, b->stream));
+    *out = *slot;
+    return 0;
+}
+
+int check_problem(const DAQPBatch *b, const DAQPBatchProblem *p)
+{
+    if (!b || !p) { set_err("null batch or problem"); return DAQP_EXIT_UNSUPPORTED; }
+    if (p->N != b->d.N || p->n != b->d.n || p->m != b->d.m || p->ms != b->d.ms) {
+        set_err("problem shape (N=%d n=%d m=%d ms=%d) does not match the batch (N=%d n=%d m=%d ms=%d)", p->N, p->n, p->m,
+                p->ms, b->d.N, b->d.n, b->d.m, b->d.ms);
+        return DAQP_EXIT_UNSUPPORTED;
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *daqp_amd_last_error(void) { return g_err; }
+const char *daqp_amd_version(void) { return "daqp_amd 0.1 (gfx950, fp64, one wavefront per QP)"; }
+int daqp_amd_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+void daqp_default_settings(DAQPSettings *settings) { default_settings(settings); }
+
+int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, const DAQPSettings *settings, int device)
+{
+    if (!out) return DAQP_EXIT_UNSUPPORTED;
+    *out = nullptr;
+    if (N <= 0 || n <= 0 || m < 0 || ms < 0 || ms > m || ms > n || ns_max < 0) {
+        set_err("bad dimensions N=%d n=%d m=%d ms=%d ns=%d", N, n, m, ms, ns_max);
+        return DAQP_EXIT_UNSUPPORTED;
+    }
+    const int cap = n + ns_max + 1;
+    if (cap > 256 || n > 255) { set_err("n + ns + 1 = %d exceeds the 256-row working-set limit of this build", cap); return DAQP_EXIT_UNSUPPORTED; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_err("no HIP device: libdaqp_amd has no CPU path");
+        return DAQP_EXIT_UNSUPPORTED;
+    }
+    DAQPBatch *b = new DAQPBatch();
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    b->device = device;
+    if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); delete b; return DAQP_EXIT_UNSUPPORTED; }
+    BatchDev &d = b->d;
+    d.N = N; d.n = n; d.m = m; d.ms = ms; d.cap = cap; d.mA = m - ms;
+    d.npair = (n + 1) / 2; d.nblk = (m + 63) / 64; d.ldr = n | 1;
+    d.ltri = cap * (cap + 1) / 2; d.rtri = n * (n + 1) / 2;
+    if (settings) d.st = *settings; else default_settings(&d.st);
+    b->C = cap <= 64 ? 1 : (cap <= 128 ? 2 : 4);
+    const char *env = getenv("DAQP_AMD_LDS_LIMIT");
+    const int lds_limit = env ? atoi(env) : 80 * 1024;
+    b->spill = ldp_lds(n, m, cap, false).total_bytes > lds_limit;
+    if (getenv("DAQP_AMD_FORCE_SPILL")) b->spill = true;
+    b->lds_ldp = (size_t)ldp_lds(n, m, cap, b->spill).total_bytes;
+    b->lds_setup = (size_t)setup_lds(n, m).total_bytes;
+    b->lds_update = (size_t)round_up(n, 2) * 16;
+    if (b->lds_ldp > 160 * 1024 || b->lds_setup > 160 * 1024) {
+        set_err("problem too large for the LDS-staged setup (needs %zu / %zu bytes)", b->lds_setup, b->lds_ldp);
+        delete b;
+        return DAQP_EXIT_UNSUPPORTED;
+    }
+    const size_t Nn = (size_t)N;
+    int rc = 0;
+    rc |= dev_alloc(b, &d.Mblk, Nn * d.nblk * d.npair * 128);
+    rc |= dev_alloc(b, &d.Rinv, Nn * d.rtri);
+    rc |= dev_alloc(b, &d.v, Nn * n);
+    rc |= dev_alloc(b, &d.scaling, Nn * m);
+    rc |= dev_alloc(b, &d.dupper, Nn * m);
+    rc |= dev_alloc(b, &d.dlower, Nn * m);
+    rc |= dev_alloc(b, &d.sense, Nn * m);
+    rc |= dev_alloc(b, &d.xunc, Nn * n);
+    rc |= dev_alloc(b, &d.L, Nn * d.ltri);
+    rc |= dev_alloc(b, &d.vecs, Nn * 5 * cap);
+    rc |= dev_alloc(b, &d.WS, Nn * cap);
+    rc |= dev_alloc(b, &d.qs, Nn);
+    if (b->spill) rc |= dev_alloc(b, &d.rowc_g, Nn * cap * d.ldr);
+    rc |= dev_alloc(b, &b->ox, Nn * n);
+    rc |= dev_alloc(b, &b->olam, Nn * m);
+    rc |= dev_alloc(b, &b->ofval, Nn);
+    rc |= dev_alloc(b, &b->osoft, Nn);
+    rc |= dev_alloc(b, &b->oflag, Nn);
+    rc |= dev_alloc(b, &b->oiter, Nn);
+    if (rc) { daqp_batch_free(b); return DAQP_EXIT_UNSUPPORTED; }
+    // padding rows/columns of the blocked M image are never written by the kernels: keep them defined
+    if (hipMemset(d.Mblk, 0, Nn * d.nblk * d.npair * 128 * sizeof(double)) != hipSuccess ||
+        hipMemset(d.vecs, 0, Nn * 5 * cap * sizeof(double)) != hipSuccess ||
+        hipMemset(d.qs, 0, Nn * sizeof(QState)) != hipSuccess) {
+        set_err("hipMemset failed");
+        daqp_batch_free(b);
+        return DAQP_EXIT_UNSUPPORTED;
+    }
+    for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) { set_err("hipEventCreate failed"); daqp_batch_free(b); return DAQP_EXIT_UNSUPPORTED; }
+    *out = b;
+    return 0;
+}
+
+void daqp_batch_free(DAQPBatch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    for (void *p : b->owned) (void)hipFree(p);
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+void daqp_batch_set_stream(DAQPBatch *b, void *hip_stream) { if (b) b->stream = reinterpret_cast<hipStream_t>(hip_stream); }
+void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings)
+{
+    if (!b) return;
+    if (settings) b->d.st = *settings; else default_settings(&b->d.st);
+}
+unsigned long long daqp_batch_device_bytes(const DAQPBatch *b) { return b ? b->bytes : 0; }
+
+// debugging aid used by the parity tests: per-problem add/remove event trace (cap ints each;
+// the last slot receives the event count).  Pass cap 0 to switch it off.
+int daqp_batch_enable_trace(DAQPBatch *b, int cap)
+{
+    if (!b) return DAQP_EXIT_UNSUPPORTED;
+    (void)hipSetDevice(b->device);
+    if (cap <= 0) { b->d.trace = nullptr; b->d.trace_cap = 0; return 0; }
+    int *t = nullptr;
+    if (dev_alloc(b, &t, (size_t)b->d.N * cap)) return DAQP_EXIT_UNSUPPORTED;
+    HIPCHK(hipMemset(t, 0, (size_t)b->d.N * cap * sizeof(int)));
+    b->d.trace = t; b->d.trace_cap = cap;
+    return 0;
+}
+int daqp_batch_read_trace(DAQPBatch *b, int *host)
+{
+    if (!b || !b->d.trace) return DAQP_EXIT_UNSUPPORTED;
+    (void)hipSetDevice(b->device);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(host, b->d.trace, (size_t)b->d.N * b->d.trace_cap * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+// debugging aid: copy the LDP of problem q to the host (M as the reference stores it: (m-ms) x n
+// row-major; R packed upper; v; dupper; dlower; scaling).  Any pointer may be NULL.
+int daqp_batch_read_ldp(DAQPBatch *b, int q, double *M, double *R, double *v, double *dupper, double *dlower, double *scaling)
+{
+    if (!b || q < 0 || q >= b->d.N) return DAQP_EXIT_UNSUPPORTED;
+    (void)hipSetDevice(b->device);
+    const BatchDev &d = b->d;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (M) {
+        const size_t per = (size_t)d.nblk * d.npair * 128;
+        std::vector<double> blk(per);
+        HIPCHK(hipMemcpy(blk.data(), d.Mblk + per * q, per * sizeof(double), hipMemcpyDeviceToHost));
+        for (int r = d.ms; r < d.m; ++r)
+            for (int k = 0; k < d.n; ++k)
+                M[(size_t)(r - d.ms) * d.n + k] = blk[(((size_t)(r >> 6) * d.npair + (k >> 1)) * 64 + (r & 63)) * 2 + (k & 1)];
+    }
+    if (R) HIPCHK(hipMemcpy(R, d.Rinv + (size_t)q * d.rtri, d.rtri * sizeof(double), hipMemcpyDeviceToHost));
+    if (v) HIPCHK(hipMemcpy(v, d.v + (size_t)q * d.n, d.n * sizeof(double), hipMemcpyDeviceToHost));
+    if (dupper) HIPCHK(hipMemcpy(dupper, d.dupper + (size_t)q * d.m, d.m * sizeof(double), hipMemcpyDeviceToHost));
+    if (dlower) HIPCHK(hipMemcpy(dlower, d.dlower + (size_t)q * d.m, d.m * sizeof(double), hipMemcpyDeviceToHost));
+    if (scaling) HIPCHK(hipMemcpy(scaling, d.scaling + (size_t)q * d.m, d.m * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
+{
+    int rc = check_problem(b, p);
+    if (rc) return rc;
+    if (!p->H || !p->f || !p->bupper || !p->blower || (b->d.mA > 0 && !p->A)) {
+        set_err("H, f, A, bupper, blower are required (LPs / missing linear term are outside this path)");
+        return DAQP_EXIT_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(b->device));
+    BatchDev &d = b->d;
+    const size_t N = d.N;
+    rc |= stage(b, p->H, p->memory, N * d.n * d.n, &b->sH, &d.H);
+    rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &d.f);
+    rc |= stage(b, p->A, p->memory, N * d.mA * d.n, &b->sA, &d.A);
+    rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &d.bu);
+    rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &d.bl);
+    rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &d.sense_in);
+    if (rc) return DAQP_EXIT_UNSUPPORTED;
+    const int mask = init_mask | DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_setup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_setup));
+    HIPCHK(hipEventRecord(b->ev[0], b->stream));
+    hipLaunchKernelGGL(k_setup, dim3(d.N), dim3(64), b->lds_setup, b->stream, d, mask);
+    HIPCHK(hipGetLastError());
+    // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
+    if (p->sense != nullptr || true) { rc = launch_ldp(b, 1); if (rc) return rc; }
+    HIPCHK(hipEventRecord(b->ev[1], b->stream));
+    b->timed_setup = true;
+    b->is_setup = true;
+    return 0;
+}
+
+int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
+{
+    int rc = check_problem(b, p);
+    if (rc) return rc;
+    if (!b->is_setup) { set_err("daqp_batch_update before daqp_batch_setup"); return DAQP_EXIT_UNSUPPORTED; }
+    const int full = DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
+    if ((mask & full) == full) {
+        DAQPBatchProblem pp = *p;   // unchanged arrays may be omitted: reuse what the batch already has
+        BatchDev &d = b->d;
+        if (!pp.H) { pp.H = d.H; } if (!pp.f) pp.f = d.f; if (!pp.A) pp.A = d.A;
+        if (!pp.bupper) pp.bupper = d.bu; if (!pp.blower) pp.blower = d.bl;
+        if (!p->H || !p->f || !p->A || !p->bupper || !p->blower) {
+            if (p->memory != DAQP_MEM_DEVICE) { set_err("full re-setup from host memory needs every array"); return DAQP_EXIT_UNSUPPORTED; }
+        }
+        return daqp_batch_setup(b, &pp, mask & (DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate));
+    }
+    if (mask & ~(DAQP_UPDATE_v | DAQP_UPDATE_d)) {
+        set_err("update mask %d: only DAQP_UPDATE_v|DAQP_UPDATE_d or a full re-setup are built", mask);
+        return DAQP_EXIT_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(b->device));
+    BatchDev &d = b->d;
+    const size_t N = d.N;
+    const double *tmp = nullptr;
+    if (mask & DAQP_UPDATE_v) {
+        if (!p->f) { set_err("DAQP_UPDATE_v needs f"); return DAQP_EXIT_UNSUPPORTED; }
+        rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &tmp); d.f = tmp;
+    }
+    if (p->bupper) { rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &tmp); d.bu = tmp; }
+    if (p->blower) { rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &tmp); d.bl = tmp; }
+    if (rc) return DAQP_EXIT_UNSUPPORTED;
+    HIPCHK(hipEventRecord(b->ev[0], b->stream));
+    hipLaunchKernelGGL(k_update, dim3(d.N), dim3(64), b->lds_update, b->stream, d, mask);
+    HIPCHK(hipGetLastError());
+    rc = launch_ldp(b, 1);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(b->ev[1], b->stream));
+    b->timed_setup = true;
+    return 0;
+}
+
+int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
+{
+    if (!b || !r) { set_err("null batch or result"); return DAQP_EXIT_UNSUPPORTED; }
+    if (!b->is_setup) { set_err("daqp_batch_solve before daqp_batch_setup"); return DAQP_EXIT_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(b->device));
+    BatchDev &d = b->d;
+    const bool dev = r->memory == DAQP_MEM_DEVICE;
+    d.x = (dev && r->x) ? r->x : b->ox;
+    d.lam = (dev && r->lam) ? r->lam : b->olam;
+    d.fval = (dev && r->fval) ? r->fval : b->ofval;
+    d.soft = (dev && r->soft_slack) ? r->soft_slack : b->osoft;
+    d.exitflag = (dev && r->exitflag) ? r->exitflag : b->oflag;
+    d.iter = (dev && r->iter) ? r->iter : b->oiter;
+    const double t0 = now_s();
+    HIPCHK(hipEventRecord(b->ev[2], b->stream));
+    int rc = launch_ldp(b, 0);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(b->ev[3], b->stream));
+    b->timed_solve = true;
+    if (!dev) {
+        const size_t N = d.N;
+        if (r->x) HIPCHK(hipMemcpyAsync(r->x, b->ox, N * d.n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        if (r->lam) HIPCHK(hipMemcpyAsync(r->lam, b->olam, N * d.m * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        if (r->fval) HIPCHK(hipMemcpyAsync(r->fval, b->ofval, N * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        if (r->soft_slack) HIPCHK(hipMemcpyAsync(r->soft_slack, b->osoft, N * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        if (r->exitflag) HIPCHK(hipMemcpyAsync(r->exitflag, b->oflag, N * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+        if (r->iter) HIPCHK(hipMemcpyAsync(r->iter, b->oiter, N * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        r->solve_time = now_s() - t0;
+    }
+    return 0;
+}
+
+int daqp_batch_setup_flags(DAQPBatch *b, int *flags_host)
+{
+    if (!b || !flags_host) return DAQP_EXIT_UNSUPPORTED;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    std::vector<QState> qs(b->d.N);
+    HIPCHK(hipMemcpy(qs.data(), b->d.qs, sizeof(QState) * b->d.N, hipMemcpyDeviceToHost));
+    for (int i = 0; i < b->d.N; ++i) flags_host[i] = qs[i].setup_flag;
+    return 0;
+}
+
+int daqp_batch_working_sets(DAQPBatch *b, int *n_active_host, int *ws_host)
+{
+    if (!b) return DAQP_EXIT_UNSUPPORTED;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (n_active_host) {
+        std::vector<QState> qs(b->d.N);
+        HIPCHK(hipMemcpy(qs.data(), b->d.qs, sizeof(QState) * b->d.N, hipMemcpyDeviceToHost));
+        for (int i = 0; i < b->d.N; ++i) n_active_host[i] = qs[i].n_active;
+    }
+    if (ws_host) HIPCHK(hipMemcpy(ws_host, b->d.WS, sizeof(int) * (size_t)b->d.N * b->d.cap, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int daqp_batch_kernel_ms(DAQPBatch *b, float *setup_ms, float *solve_ms)
+{
+    if (!b) return DAQP_EXIT_UNSUPPORTED;
+    HIPCHK(hipSetDevice(b->device));
+    if (setup_ms) {
+        *setup_ms = 0;
+        if (b->timed_setup) { HIPCHK(hipEventSynchronize(b->ev[1])); HIPCHK(hipEventElapsedTime(setup_ms, b->ev[0], b->ev[1])); }
+    }
+    if (solve_ms) {
+        *solve_ms = 0;
+        if (b->timed_solve) { HIPCHK(hipEventSynchronize(b->ev[3])); HIPCHK(hipEventElapsedTime(solve_ms, b->ev[2], b->ev[3])); }
+    }
+    return 0;
+}
+
+int daqp_quadprog_batch(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQPSettings *settings)
+{
+    if (!r || !p) { set_err("null argument"); return DAQP_EXIT_UNSUPPORTED; }
+    int ns = 0;
+    if (p->sense && p->memory == DAQP_MEM_HOST) {
+        for (int q = 0; q < p->N; ++q) {
+            int c = 0;
+            for (int i = 0; i < p->m; ++i) c += (p->sense[(size_t)q * p->m + i] & DAQP_SOFT) ? 1 : 0;
+            if (c > ns) ns = c;
+        }
+    } else if (p->sense) ns = p->m < 256 - p->n - 1 ? p->m : 256 - p->n - 1; // device-resident sense: size for the worst case
+    DAQPBatch *b = nullptr;
+    int rc = daqp_batch_create(&b, p->N, p->n, p->m, p->ms, ns, settings, -1);
+    if (rc) return rc;
+    const double t0 = now_s();
+    rc = daqp_batch_setup(b, p, DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate);
+    if (rc == 0) {
+        if (hipStreamSynchronize(b->stream) != hipSuccess) rc = DAQP_EXIT_UNSUPPORTED;
+        r->setup_time = now_s() - t0;
+    }
+    if (rc == 0) rc = daqp_batch_solve(b, r);
+    if (rc == 0 && r->memory == DAQP_MEM_DEVICE) { if (hipStreamSynchronize(b->stream) != hipSuccess) rc = DAQP_EXIT_UNSUPPORTED; }
+    daqp_batch_free(b);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// single-problem drop-in entry points: a batch of one behind the reference's workspace struct
+// ------------------------------------------------------------------------------------
+static DAQPBatch *ws_batch(DAQPWorkspace *w) { return reinterpret_cast<DAQPBatch *>(w->timer); }
+
+static DAQPBatchProblem one_problem(const DAQPProblem *qp)
+{
+    DAQPBatchProblem p;
+    p.N = 1; p.n = qp->n; p.m = qp->m; p.ms = qp->ms;
+    p.H = qp->H; p.f = qp->f; p.A = qp->A; p.bupper = qp->bupper; p.blower = qp->blower; p.sense = qp->sense;
+    p.memory = DAQP_MEM_HOST;
+    return p;
+}
+
+static void refresh_mirrors(DAQPWorkspace *w)
+{
+    DAQPBatch *b = ws_batch(w);
+    if (!b) return;
+    QState qs;
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    if (hipMemcpy(&qs, b->d.qs, sizeof(QState), hipMemcpyDeviceToHost) != hipSuccess) return;
+    w->n_active = qs.n_active; w->reuse_ind = qs.reuse_ind; w->sing_ind = qs.sing_ind;
+    w->iterations = qs.iterations; w->fval = qs.fval; w->soft_slack = qs.soft_slack;
+    if (w->WS) (void)hipMemcpy(w->WS, b->d.WS, sizeof(int) * b->d.cap, hipMemcpyDeviceToHost);
+    if (w->sense) (void)hipMemcpy(w->sense, b->d.sense, sizeof(int) * b->d.m, hipMemcpyDeviceToHost);
+    if (w->lam_star) {
+        const double *src = b->d.vecs + (qs.lam_swapped ? 3 : 4) * (size_t)b->d.cap;
+        (void)hipMemcpy(w->lam_star, src, sizeof(double) * b->d.cap, hipMemcpyDeviceToHost);
+    }
+}
+
+void allocate_daqp_settings(DAQPWorkspace *work)
+{
+    if (work->settings == nullptr) {
+        work->settings = static_cast<DAQPSettings *>(malloc(sizeof(DAQPSettings)));
+        default_settings(work->settings);
+    }
+}
+
+int setup_daqp_main(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time, int init_mask)
+{
+    const double t0 = now_s();
+    if (setup_time) *setup_time = 0;
+    int own_settings = 1;
+    if (qp->problem_type != 0 || qp->nh > 1 || qp->break_points != nullptr || qp->H == nullptr || qp->f == nullptr) {
+        set_err("AVI / hierarchical / LP problems are outside this path");
+        return DAQP_EXIT_UNSUPPORTED;
+    }
+    int ns = 0;
+    if (qp->sense)
+        for (int i = 0; i < qp->m; ++i) {
+            if (qp->sense[i] & DAQP_SOFT) ns++;
+            if (qp->sense[i] & DAQP_BINARY) { set_err("binary constraints are outside this path"); return DAQP_EXIT_UNSUPPORTED; }
+        }
+    if (work->settings == nullptr) allocate_daqp_settings(work); else own_settings = 0;
+    DAQPBatch *b = nullptr;
+    int rc = daqp_batch_create(&b, 1, qp->n, qp->m, qp->ms, ns, work->settings, -1);
+    if (rc == 0) {
+        DAQPBatchProblem p = one_problem(qp);
+        rc = daqp_batch_setup(b, &p, init_mask);
+        int flag = 1;
+        if (rc == 0) rc = daqp_batch_setup_flags(b, &flag);
+        if (rc == 0 && flag < 0) rc = flag;
+    }
+    if (rc < 0) {
+        if (b) daqp_batch_free(b);
+        if (own_settings) { free(work->settings); }
+        work->settings = own_settings ? nullptr : work->settings;
+        return rc;
+    }
+    // host-visible part of the workspace (everything numerical stays on the device)
+    work->qp = qp; work->n = qp->n; work->m = qp->m; work->ms = qp->ms;
+    work->M = work->dupper = work->dlower = work->Rinv = work->v = nullptr;
+    work->scaling = work->RinvD = work->xold = work->lam = work->u = nullptr;
+    work->L = work->D = work->xldl = work->zldl = work->Mu = nullptr;
+    work->prox_mask = nullptr; work->n_prox = 0; work->bnb = nullptr; work->avi = nullptr; work->eq = nullptr;
+    work->nh = 1; work->break_points = nullptr;
+    work->sense = static_cast<int *>(calloc(qp->m > 0 ? qp->m : 1, sizeof(int)));
+    work->x = static_cast<c_float *>(calloc(qp->n, sizeof(c_float)));
+    work->lam_star = static_cast<c_float *>(calloc(b->d.cap, sizeof(c_float)));
+    work->WS = static_cast<int *>(calloc(b->d.cap, sizeof(int)));
+    work->timer = b;
+    refresh_mirrors(work);
+    if (setup_time) *setup_time = now_s() - t0;
+    return 1;
+}
+
+int setup_daqp(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time) { return setup_daqp_main(qp, work, setup_time, 0); }
+
+int daqp_update_ldp(const int mask, DAQPWorkspace *work, DAQPProblem *qp)
+{
+    DAQPBatch *b = ws_batch(work);
+    if (!b) { set_err("workspace has not been set up"); return DAQP_EXIT_UNSUPPORTED; }
+    work->qp = qp;
+    DAQPBatchProblem p = one_problem(qp);
+    int m = mask & ~(DAQP_UPDATE_hierarchy);
+    int rc = daqp_batch_update(b, m, &p);
+    if (rc < 0) return rc;
+    int flag = 1;
+    rc = daqp_batch_setup_flags(b, &flag);
+    if (rc < 0) return rc;
+    refresh_mirrors(work);
+    return flag < 0 ? flag : 0;
+}
+
+void daqp_solve(DAQPResult *res, DAQPWorkspace *work)
+{
+    DAQPBatch *b = ws_batch(work);
+    if (!b) { res->exitflag = DAQP_EXIT_UNSUPPORTED; set_err("workspace has not been set up"); return; }
+    const double t0 = now_s();
+    if (work->settings) daqp_batch_set_settings(b, work->settings);
+    DAQPBatchResult r;
+    memset(&r, 0, sizeof(r));
+    double fval = 0, soft = 0;
+    int flag = 0, iter = 0;
+    r.x = work->x; r.lam = res->lam; r.fval = &fval; r.soft_slack = &soft; r.exitflag = &flag; r.iter = &iter;
+    r.memory = DAQP_MEM_HOST;
+    const int rc = daqp_batch_solve(b, &r);
+    if (rc < 0) { res->exitflag = rc; return; }
+    res->exitflag = flag; res->iter = iter; res->fval = fval; res->soft_slack = soft; res->nodes = 1;
+    if (flag > 0 || true)
+        for (int i = 0; i < work->n; ++i) res->x[i] = work->x[i];
+    refresh_mirrors(work);
+    res->solve_time = now_s() - t0;
+}
+
+void free_daqp_workspace(DAQPWorkspace *work)
+{
+    if (work->timer) { daqp_batch_free(ws_batch(work)); work->timer = nullptr; }
+    free(work->x); work->x = nullptr;
+    free(work->lam_star); work->lam_star = nullptr;
+    free(work->WS); work->WS = nullptr;
+    if (work->settings != nullptr) { free(work->settings); work->settings = nullptr; }
+}
+
+void free_daqp_ldp(DAQPWorkspace *work)
+{
+    if (work->sense == nullptr) return;
+    free(work->sense);
+    work->sense = nullptr;
+}
+
+void daqp_quadprog(DAQPResult *res, DAQPProblem *qp, DAQPSettings *settings)
+{
+    DAQPWorkspace work;
+    memset(&work, 0, sizeof(work));
+    work.settings = settings;
+    res->setup_time = 0; res->solve_time = 0;
+    const int flag = setup_daqp_main(qp, &work, &res->setup_time, DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate);
+    res->exitflag = flag;
+    if (flag >= 0) {
+        daqp_solve(res, &work);
+        if (settings != nullptr) work.settings = nullptr;
+        free_daqp_workspace(&work);
+        free_daqp_ldp(&work);
+    }
+}
+
+// warm-start helpers: pure host code on the caller's sense array (api.c:579-633)
+void daqp_primal_init_active(DAQPProblem *qp, c_float *x)
+{
+    const c_float tol = 1e-9;
+    for (int i = 0; i < qp->m; ++i) {
+        if (qp->sense[i] & DAQP_IMMUTABLE) continue;
+        c_float ax;
+        if (i < qp->ms) ax = x[i];
+        else {
+            ax = 0;
+            const c_float *row = qp->A + (size_t)(i - qp->ms) * qp->n;
+            for (int j = 0; j < qp->n; ++j) ax += x[j] * row[j];
+        }
+        c_float slack = ax - qp->bupper[i];
+        if (slack < tol && slack > -tol) { qp->sense[i] |= DAQP_ACTIVE; qp->sense[i] &= ~DAQP_LOWER; }
+        else {
+            slack = ax - qp->blower[i];
+            if (slack < tol && slack > -tol) qp->sense[i] |= DAQP_ACTIVE + DAQP_LOWER;
+        }
+    }
+}
+void daqp_dual_init_active(DAQPProblem *qp, c_float *lam)
+{
+    const c_float tol = 1e-12;
+    for (int i = 0; i < qp->m; ++i) {
+        if (qp->sense[i] & DAQP_IMMUTABLE) continue;
+        if (lam[i] > tol) { qp->sense[i] |= DAQP_ACTIVE; qp->sense[i] &= ~DAQP_LOWER; }
+        else if (lam[i] < -tol) qp->sense[i] |= DAQP_ACTIVE + DAQP_LOWER;
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,556 @@
+// kernels.hip.h -- the three device entry points of the path, one wavefront per QP:
+//   k_setup   QP -> LDP        (reference src/utils.c:58-687: check_bounds, Cholesky, R^-1, v,
+//                               unconstrained shortcut, M = A R^-1, normalisation, d)
+//   k_update  new f / bounds   (reference daqp_update_ldp with DAQP_UPDATE_v | DAQP_UPDATE_d)
+//   k_ldp     solve            (reference daqp_solve: daqp_ldp, ldp2qp_solution, daqp_extract_result)
+#pragma once
+#include "wave_ldp.hip.h"
+
+namespace daqp_amd {
+
+struct BatchDev {
+    int N, n, m, ms, cap, mA;
+    int npair, nblk, ldr, ltri, rtri;
+    // problem data (device pointers; owned by the caller or by the batch's staging buffers)
+    const double *H, *f, *A, *bu, *bl;
+    const int *sense_in;
+    // LDP (persistent)
+    double *Mblk;      // [N][nblk][npair][64][2]
+    double *Rinv;      // [N][rtri]   packed upper R^-1, rows < ms normalised
+    double *v;         // [N][n]
+    double *scaling, *dupper, *dlower; // [N][m]
+    int *sense;        // [N][m]
+    double *xunc;      // [N][n]   unconstrained optimum when the shortcut fired
+    // iterate (persistent: warm start)
+    double *L;         // [N][ltri]
+    double *vecs;      // [N][5][cap]: D, xldl, zldl, lam buffer A, lam buffer B
+    int *WS;           // [N][cap]
+    QState *qs;        // [N]
+    double *rowc_g;    // [N][cap*ldr] only when the active-row cache / L spill out of LDS
+    // outputs
+    double *x, *lam, *fval, *soft;
+    int *exitflag, *iter;
+    // debugging
+    int *trace; int trace_cap;
+    DAQPSettings st;
+};
+
+__host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------
+// LDS carve-ups (doubles first, ints last; every offset a multiple of 16 bytes)
+// ------------------------------------------------------------------------------------
+struct SetupLds { int R, Rout, fv, vv, xu, sc, du, dl, tile, sens, total_bytes; };
+__host__ __device__ inline SetupLds setup_lds(int n, int m)
+{
+    SetupLds s;
+    const int rt = round_up(n * (n + 1) / 2, 2), np = round_up(n, 2), mp = round_up(m, 2), ldr = n | 1;
+    int o = 0;
+    s.R = o; o += rt; s.Rout = o; o += rt;
+    s.fv = o; o += np; s.vv = o; o += np; s.xu = o; o += np;
+    s.sc = o; o += mp; s.du = o; o += mp; s.dl = o; o += mp;
+    s.tile = o; o += round_up(64 * ldr, 2);
+    s.sens = o;
+    s.total_bytes = o * 8 + round_up(m, 4) * 4;
+    return s;
+}
+struct LdpLds { int L, rowc, D, xl, zl, lamA, lamB, u, pend_lam, dbl; int ws, sense, pend_id, ints; int total_bytes; };
+__host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill)
+{
+    LdpLds s;
+    const int ldr = n | 1, cp = round_up(cap, 2);
+    int o = 0;
+    s.L = o; if (!spill) o += round_up(cap * (cap + 1) / 2, 2);
+    s.rowc = o; if (!spill) o += round_up(cap * ldr, 2);
+    s.D = o; o += cp; s.xl = o; o += cp; s.zl = o; o += cp; s.lamA = o; o += cp; s.lamB = o; o += cp;
+    s.u = o; o += round_up(n, 2) + 2;
+    s.pend_lam = o; o += cp;
+    s.dbl = o;                       // ints start at double offset s.dbl
+    int oi = 0;
+    s.ws = oi; oi += round_up(cap, 4);
+    s.sense = oi; oi += round_up(m, 4);
+    s.pend_id = oi; oi += round_up(cap, 4);
+    s.ints = oi;
+    s.total_bytes = o * 8 + oi * 4;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------
+// k_setup: one wave per QP
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int q = blockIdx.x, lane = lane_id();
+    const int n = b.n, m = b.m, ms = b.ms, mA = b.mA, ldr = b.ldr;
+    const SetupLds o = setup_lds(n, m);
+    double *R = smem + o.R, *Ro = smem + o.Rout, *fl = smem + o.fv, *vv = smem + o.vv, *xu = smem + o.xu;
+    double *sc = smem + o.sc, *du = smem + o.du, *dl = smem + o.dl, *tile = smem + o.tile;
+    int *sens = reinterpret_cast<int *>(smem + o.sens);
+    const double *H = b.H + (size_t)q * n * n, *f = b.f + (size_t)q * n, *A = b.A + (size_t)q * mA * n;
+    const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
+    const DAQPSettings &st = b.st;
+    QState *qs = b.qs + q;
+    int flag = 1, activate = 0;
+
+    // --- sense (utils.c:84-91) and early bound check (utils.c:546-567)
+    int bad = 0;
+    for (int i = lane; i < m; i += 64) {
+        int s = b.sense_in ? b.sense_in[(size_t)q * m + i] : 0;
+        if (s & DAQP_BINARY) bad |= 2;
+        if (!(s & DAQP_IMMUTABLE)) {
+            const double diff = bu[i] - bl[i];
+            if (diff < -st.primal_tol) bad |= 1;
+            else if (diff < st.zero_tol && !(s & DAQP_SOFT)) { s |= DAQP_ACTIVE + DAQP_IMMUTABLE; bad |= 4; }
+        }
+        sens[i] = s;
+    }
+    {
+        const int any = __any(bad & 2) ? 2 : 0, inf = __any(bad & 1) ? 1 : 0, eq = __any(bad & 4) ? 4 : 0;
+        bad = any | inf | eq;
+    }
+    if (b.sense_in) activate = 1;
+    if (bad & 4) activate = 1;
+    if (bad & 2) flag = DAQP_EXIT_UNSUPPORTED;
+    else if (bad & 1) flag = DAQP_EXIT_INFEASIBLE;
+    if (st.eps_prox > 0.0) flag = DAQP_EXIT_UNSUPPORTED; // forced proximal mode is outside this path
+    for (int i = lane; i < n; i += 64) fl[i] = f[i];
+    WSYNC();
+
+    // --- Cholesky of 1/2(H+H') in packed-upper form, 1/r_ii on the diagonal (utils.c:318-352).
+    // Row i: lane <-> column j, k-ordered subtraction chain kept in a register.
+    double pmin = DAQP_INF, pmax = 0.0;
+    if (flag > 0) {
+        for (int e = lane; e < n * n; e += 64) {
+            const int i = e / n, j = e - i * n;
+            if (j >= i) R[roff(i, n) + j] = (i == j) ? H[e] : 0.5 * (H[e] + H[(size_t)j * n + i]);
+        }
+        WSYNC();
+        for (int i = 0; i < n && flag > 0; ++i) {
+            const int pi = roff(i, n);
+            const int nch = (n - i + 63) >> 6;
+            double dgi = 0;
+            for (int ch = 0; ch < nch; ++ch) {   // chunk 0 holds the diagonal (lane 0)
+                const int j = i + ch * 64 + lane;
+                double acc = (j < n) ? R[pi + j] : 0.0;
+                if (j < n)
+                    for (int k = 0; k < i; ++k) {
+                        const int pk = roff(k, n);
+                        acc -= R[pk + i] * R[pk + j];
+                    }
+                if (ch == 0) {
+                    const double dg = rl(acc, 0);
+                    if (dg <= st.zero_tol) { flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED; break; }
+                    if (dg < pmin) pmin = dg;
+                    if (dg > pmax) pmax = dg;
+                    dgi = 1 / sqrt(dg);
+                    if (lane == 0) acc = dgi; else acc *= dgi;
+                } else acc *= dgi;
+                if (j < n) R[pi + j] = acc;
+            }
+            WSYNC();
+        }
+        if (flag > 0 && pmin <= st.zero_tol * pmax)
+            flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED;
+    }
+    // --- R -> R^-1, row by row as utils.c:380-389: lane <-> row k works on its own copy,
+    // reading the untouched Cholesky rows i > k
+    if (flag > 0) {
+        for (int e = lane; e < b.rtri; e += 64) Ro[e] = R[e];
+        WSYNC();
+        for (int kc = 0; kc < n; kc += 64) {
+            const int k = kc + lane;
+            const bool own = k < n;
+            const int pk = own ? roff(k, n) : 0;
+            const double rkk = own ? Ro[pk + k] : 0.0;
+            if (own) for (int j = k + 1; j < n; ++j) Ro[pk + j] *= -rkk;
+            for (int i = kc + 1; i < n; ++i) {
+                const int pi = roff(i, n);
+                if (own && i > k) {
+                    const double t = Ro[pk + i] * R[pi + i];
+                    Ro[pk + i] = t;
+                    for (int j = i + 1; j < n; ++j) Ro[pk + j] -= R[pi + j] * t;
+                }
+            }
+        }
+        WSYNC();
+        // --- v = R^-T f (utils.c:474-497, mask has UPDATE_Rinv: no column scaling)
+        for (int ic = 0; ic < n; ic += 64) {
+            const int i = ic + lane;
+            if (i < n) {
+                double acc = Ro[roff(i, n) + i] * fl[i];
+                for (int j = i - 1; j >= 0; --j) acc += Ro[roff(j, n) + i] * fl[j];
+                vv[i] = acc;
+            }
+        }
+        WSYNC();
+    }
+    // --- unconstrained optimum x = -R^-1 v (utils.c:618-662), only for the quadprog variant
+    int unc = 0;
+    if (flag > 0 && (mask & DAQP_UPDATE_unconstrained)) {
+        int fixed = 0;
+        for (int i = lane; i < m; i += 64) fixed |= sens[i] & (DAQP_ACTIVE + DAQP_IMMUTABLE);
+        if (!__any(fixed)) {
+            unc = 1;
+            for (int ic = 0; ic < n; ic += 64) {
+                const int i = ic + lane;
+                if (i < n) {
+                    const int pi = roff(i, n);
+                    double s = 0;
+                    for (int j = i; j < n; ++j) s += Ro[pi + j] * vv[j];
+                    xu[i] = -s;
+                }
+            }
+            WSYNC();
+        }
+    }
+    // equality elimination would change the arithmetic of daqp_quadprog: not built (eq_elim.c:127-164)
+    if (flag > 0 && (mask & DAQP_UPDATE_eliminate)) {
+        int neq = 0;
+        for (int base = ms; base < m; base += 64) {
+            const int i = base + lane;
+            const int isq = i < m && ((sens[i] & (DAQP_ACTIVE + DAQP_IMMUTABLE + DAQP_SOFT + DAQP_BINARY)) == (DAQP_ACTIVE + DAQP_IMMUTABLE));
+            neq += __popcll(__ballot(isq));
+        }
+        if (neq > 5 && 10 * neq > n) flag = DAQP_EXIT_UNSUPPORTED;
+    }
+
+    // --- general rows: M = A R^-1 (utils.c:434-472), normalise (utils.c:586-613), d (utils.c:499-544
+    // or, after the shortcut, utils.c:664-676 + 151-159).  64 rows at a time through an LDS tile;
+    // lane <-> row; the row is overwritten in place from the last column down.
+    int feasible = 1;
+    double *Mq = b.Mblk + (size_t)q * b.nblk * b.npair * 128;
+    if (flag > 0) {
+        for (int tb = 0; tb < mA && flag > 0; tb += 64) {
+            const int rows = (mA - tb) < 64 ? (mA - tb) : 64;
+            WSYNC();
+            for (int e = lane; e < rows * n; e += 64) {
+                const int rr = e / n, cc = e - rr * n;
+                tile[rr * ldr + cc] = A[(size_t)tb * n + e];
+            }
+            WSYNC();
+            const int k = tb + lane;
+            const bool own = lane < rows;
+            double *a = tile + lane * ldr;
+            double sunc = 0, scal = 1.0, dsum = 0;
+            int zero_row = 0, rowbad = 0;
+            if (own) {
+                const int gi = ms + k;
+                if (unc) { for (int j = 0; j < n; ++j) sunc += a[j] * xu[j]; }
+                for (int c = n - 1; c >= 0; --c) {
+                    double acc = Ro[roff(c, n) + c] * a[c];
+                    for (int r = c - 1; r >= 0; --r) acc += Ro[roff(r, n) + c] * a[r];
+                    a[c] = acc;
+                }
+                double s = 0;
+                for (int c = 0; c < n; ++c) s += a[c] * a[c];
+                if (s < st.zero_tol) {
+                    zero_row = 1;
+                    if (bu[gi] < -st.zero_tol || bl[gi] > st.zero_tol)
+                        if (!(sens[gi] & DAQP_IMMUTABLE) && !(sens[gi] & DAQP_SOFT)) rowbad = 1;
+                    sens[gi] = DAQP_IMMUTABLE;
+                } else {
+                    scal = 1 / sqrt(s);
+                    for (int c = 0; c < n; ++c) a[c] *= scal;
+                }
+                sc[gi] = scal;
+                if (unc) {
+                    const double u0 = bu[gi] - sunc, l0 = bl[gi] - sunc;
+                    if (u0 < -st.primal_tol || l0 > st.primal_tol) feasible = 0;
+                    du[gi] = u0 * scal; dl[gi] = l0 * scal;
+                } else {
+                    for (int j = 0; j < n; ++j) dsum += a[j] * vv[j];
+                    du[gi] = bu[gi] * scal + dsum;
+                    dl[gi] = bl[gi] * scal + dsum;
+                }
+                // blocked store: [row/64][k/2][row%64][k%2]
+                double2 *dst = reinterpret_cast<double2 *>(Mq) + ((size_t)(gi >> 6) * b.npair) * 64 + (gi & 63);
+                for (int t = 0; t < b.npair; ++t) {
+                    double2 vpair;
+                    vpair.x = a[2 * t];
+                    vpair.y = (2 * t + 1 < n) ? a[2 * t + 1] : 0.0;
+                    dst[(size_t)t * 64] = vpair;
+                }
+            }
+            (void)zero_row;
+            if (__any(rowbad)) flag = DAQP_EXIT_INFEASIBLE; // reference returns at the first such row
+        }
+    }
+    // --- simple bounds: normalise rows < ms of R^-1 (utils.c:569-585), their d, and their dense image in M
+    if (flag > 0) {
+        WSYNC();
+        for (int ic = 0; ic < ms; ic += 64) {
+            const int i = ic + lane;
+            if (i < ms) {
+                const int pi = roff(i, n);
+                double s = 0;
+                for (int j = i; j < n; ++j) s += Ro[pi + j] * Ro[pi + j];
+                s = 1 / sqrt(s);
+                sc[i] = s;
+                for (int j = i; j < n; ++j) Ro[pi + j] *= s;
+                if (unc) {
+                    const double u0 = bu[i] - xu[i], l0 = bl[i] - xu[i];
+                    if (u0 < -st.primal_tol || l0 > st.primal_tol) feasible = 0;
+                    du[i] = u0 * s; dl[i] = l0 * s;
+                } else {
+                    double t = 0;
+                    for (int j = i; j < n; ++j) t += Ro[pi + j] * vv[j];
+                    du[i] = bu[i] * s + t;
+                    dl[i] = bl[i] * s + t;
+                }
+                double2 *dst = reinterpret_cast<double2 *>(Mq) + ((size_t)(i >> 6) * b.npair) * 64 + (i & 63);
+                for (int t = 0; t < b.npair; ++t) {
+                    double2 vpair;
+                    vpair.x = (2 * t >= i) ? Ro[pi + 2 * t] : 0.0;
+                    vpair.y = (2 * t + 1 >= i && 2 * t + 1 < n) ? Ro[pi + 2 * t + 1] : 0.0;
+                    dst[(size_t)t * 64] = vpair;
+                }
+            }
+        }
+        WSYNC();
+    }
+    const int all_feasible = __all(feasible);
+    int sing = kEmpty;
+    if (flag > 0 && unc && all_feasible) { sing = DAQP_UNCONSTRAINED_OPTIMAL; activate = 0; }
+    // --- write back
+    if (flag > 0) {
+        for (int e = lane; e < b.rtri; e += 64) b.Rinv[(size_t)q * b.rtri + e] = Ro[e];
+        for (int i = lane; i < n; i += 64) { b.v[(size_t)q * n + i] = vv[i]; if (unc) b.xunc[(size_t)q * n + i] = xu[i]; }
+        for (int i = lane; i < m; i += 64) {
+            b.scaling[(size_t)q * m + i] = sc[i];
+            b.dupper[(size_t)q * m + i] = du[i];
+            b.dlower[(size_t)q * m + i] = dl[i];
+        }
+    }
+    for (int i = lane; i < m; i += 64) b.sense[(size_t)q * m + i] = sens[i];
+    if (lane == 0) {
+        qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
+        qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_update: DAQP_UPDATE_v and/or DAQP_UPDATE_d on an existing LDP (utils.c:58-221 with those masks)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int q = blockIdx.x, lane = lane_id();
+    const int n = b.n, m = b.m, ms = b.ms;
+    double *vv = smem, *fl = smem + round_up(n, 2);
+    QState *qs = b.qs + q;
+    if (qs->setup_flag < 0) return;
+    const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
+    const double *Rq = b.Rinv + (size_t)q * b.rtri;
+    const double *scq = b.scaling + (size_t)q * m;
+    int *sens = b.sense + (size_t)q * m;
+    const DAQPSettings &st = b.st;
+    int bad = 0;
+    for (int i = lane; i < m; i += 64) {   // check_bounds (utils.c:546-567) on the stored sense
+        int s = sens[i];
+        if (!(s & DAQP_IMMUTABLE)) {
+            const double diff = bu[i] - bl[i];
+            if (diff < -st.primal_tol) bad |= 1;
+            else if (diff < st.zero_tol && !(s & DAQP_SOFT)) { sens[i] = s | DAQP_ACTIVE | DAQP_IMMUTABLE; bad |= 4; }
+        }
+    }
+    const int inf = __any(bad & 1), eq = __any(bad & 4);
+    if (inf) {
+        if (lane == 0) { qs->exitflag = DAQP_EXIT_INFEASIBLE; qs->setup_flag = DAQP_EXIT_INFEASIBLE; }
+        return;
+    }
+    if (mask & DAQP_UPDATE_v) {   // utils.c:474-497 without UPDATE_Rinv: rows < ms of R^-1 are normalised
+        const double *f = b.f + (size_t)q * n;
+        for (int i = lane; i < n; i += 64) fl[i] = (i < ms) ? f[i] / scq[i] : f[i];
+        WSYNC();
+        for (int ic = 0; ic < n; ic += 64) {
+            const int i = ic + lane;
+            if (i < n) {
+                double acc = Rq[roff(i, n) + i] * fl[i];
+                for (int j = i - 1; j >= 0; --j) acc += Rq[roff(j, n) + i] * fl[j];
+                vv[i] = acc;
+                b.v[(size_t)q * n + i] = acc;
+            }
+        }
+    } else {
+        for (int i = lane; i < n; i += 64) vv[i] = b.v[(size_t)q * n + i];
+    }
+    WSYNC();
+    // d = b*scaling + (row . v) for all m rows of the dense blocked image (utils.c:499-544)
+    const double2 *v2 = reinterpret_cast<const double2 *>(vv);
+    const bool odd = (n & 1) != 0;
+    const int full = odd ? b.npair - 1 : b.npair;
+    const double *Mq = b.Mblk + (size_t)q * b.nblk * b.npair * 128;
+    for (int blk = 0; blk < b.nblk; ++blk) {
+        const int r = blk * 64 + lane;
+        if (r < m) {
+            const double2 *src = reinterpret_cast<const double2 *>(Mq) + ((size_t)blk * b.npair) * 64 + lane;
+            double s = 0;
+            for (int t = 0; t < full; ++t) {
+                const double2 mm = src[(size_t)t * 64];
+                const double2 vk = v2[t];
+                s += mm.x * vk.x;
+                s += mm.y * vk.y;
+            }
+            if (odd) s += src[(size_t)full * 64].x * vv[n - 1];
+            b.dupper[(size_t)q * m + r] = bu[r] * scq[r] + s;
+            b.dlower[(size_t)q * m + r] = bl[r] * scq[r] + s;
+        }
+    }
+    if (lane == 0) {
+        qs->reuse_ind = 0;
+        qs->sing_ind = kEmpty;   // utils.c:80-81
+        if (eq) qs->need_activate = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_ldp: mode 0 = daqp_solve, mode 1 = only (re)build the working set from the ACTIVE bits
+// (the tail of daqp_update_ldp, utils.c:199-211)
+// ------------------------------------------------------------------------------------
+template <int C, bool SPILL>
+__global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int q = blockIdx.x, lane = lane_id();
+    const int n = b.n, m = b.m, cap = b.cap;
+    QState *qs = b.qs + q;
+    const int sflag = qs->setup_flag;
+    if (mode == 1) { if (sflag < 0 || !qs->need_activate) return; }
+    if (sflag < 0) {   // setup failed: x/lam untouched, no solve (api.c:70-78)
+        if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
+        return;
+    }
+    const LdpLds o = ldp_lds(n, m, cap, SPILL);
+    int *ibase = reinterpret_cast<int *>(smem + o.dbl);
+    Wave<C> w;
+    w.n = n; w.m = m; w.ms = b.ms; w.cap = cap; w.npair = b.npair; w.nblk = b.nblk; w.ldr = b.ldr;
+    if (SPILL) {
+        w.L = b.L + (size_t)q * b.ltri;
+        w.rowc = b.rowc_g + (size_t)q * cap * b.ldr;
+    } else {
+        w.L = smem + o.L;
+        w.rowc = smem + o.rowc;
+    }
+    w.D = smem + o.D; w.xl = smem + o.xl; w.zl = smem + o.zl;
+    double *lamA = smem + o.lamA, *lamB = smem + o.lamB;
+    w.u = smem + o.u; w.pend_lam = smem + o.pend_lam;
+    w.ws = ibase + o.ws; w.sense = ibase + o.sense; w.pend_id = ibase + o.pend_id;
+    w.Mblk = b.Mblk + (size_t)q * b.nblk * b.npair * 128;
+    w.dupper = b.dupper + (size_t)q * m; w.dlower = b.dlower + (size_t)q * m; w.scaling = b.scaling + (size_t)q * m;
+    w.st = b.st;
+    w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
+    w.trace_cap = b.trace_cap; w.trace_len = 0;
+    w.na = qs->n_active; w.reuse = qs->reuse_ind; w.sing = qs->sing_ind;
+    w.fval = qs->fval; w.soft = qs->soft_slack;
+    const int swapped = qs->lam_swapped;
+    w.lam = swapped ? lamB : lamA; w.lams = swapped ? lamA : lamB;
+
+    // ---- load the persistent iterate
+    int *gsense = b.sense + (size_t)q * m;
+    int softbits = 0;
+    for (int i = lane; i < m; i += 64) { const int s = gsense[i]; w.sense[i] = s; softbits |= s & DAQP_SOFT; }
+    w.has_soft = __any(softbits) ? 1 : 0;
+    double *gv = b.vecs + (size_t)q * 5 * cap;
+    int *gws = b.WS + (size_t)q * cap;
+    if (w.sing != DAQP_UNCONSTRAINED_OPTIMAL) {
+        for (int i = lane; i < cap; i += 64) {
+            w.D[i] = gv[i]; w.xl[i] = gv[cap + i]; w.zl[i] = gv[2 * cap + i];
+            lamA[i] = gv[3 * cap + i]; lamB[i] = gv[4 * cap + i];
+            w.ws[i] = gws[i];
+        }
+        if (!SPILL) {
+            const int used = tri(w.na);
+            const double *gL = b.L + (size_t)q * b.ltri;
+            for (int e = lane; e < used; e += 64) w.L[e] = gL[e];
+        }
+        for (int e = lane; e < round_up(n, 2) + 2; e += 64) w.u[e] = 0;
+        WSYNC();
+        for (int i = 0; i < w.na; ++i) fetch_row(w, w.ws[i], i);   // rebuild the active-row cache
+    }
+    WSYNC();
+
+    int flag = 1, iters = 0;
+    if (mode == 1) {
+        reset_ws(w);
+        flag = activate_marked(w);
+        if (lane == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
+    } else if (w.sing == DAQP_UNCONSTRAINED_OPTIMAL) {
+        // api.c:40-45: x = unconstrained optimum, no multipliers
+        const double *xu = b.xunc + (size_t)q * n, *vq = b.v + (size_t)q * n;
+        if (b.x) for (int i = lane; i < n; i += 64) b.x[(size_t)q * n + i] = xu[i];
+        if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = 0;
+        double fv = 0;
+        for (int i = 0; i < n; ++i) { const double vi = vq[i]; fv -= vi * vi; }
+        fv *= 0.5;
+        if (lane == 0) {
+            b.exitflag[q] = DAQP_EXIT_OPTIMAL; b.iter[q] = 1;
+            if (b.fval) b.fval[q] = fv;
+            if (b.soft) b.soft[q] = 0;
+            qs->iterations = 1; qs->fval = 0; qs->soft_slack = 0; qs->exitflag = DAQP_EXIT_OPTIMAL;
+        }
+        return;
+    } else {
+        if (qs->need_activate) {   // defensive: setup/update normally runs mode 1 itself
+            reset_ws(w);
+            flag = activate_marked(w);
+        }
+        if (flag >= 0) flag = ldp_loop(w, iters);
+        // ---- ldp2qp_solution (daqp.c:111-139) + daqp_extract_result (api.c:455-495)
+        const double *Rq = b.Rinv + (size_t)q * b.rtri, *vq = b.v + (size_t)q * n;
+        if (flag > 0) {
+            for (int i = lane; i < n; i += 64) w.u[i] = w.u[i] - vq[i];
+            WSYNC();
+            for (int ic = 0; ic < n; ic += 64) {
+                const int i = ic + lane;
+                if (i < n) {
+                    const double *row = Rq + roff(i, n);
+                    double xi = w.u[i] * row[i];
+                    for (int j = i + 1; j < n; ++j) xi += row[j] * w.u[j];
+                    if (i < b.ms) xi /= w.scaling[i];
+                    if (b.x) b.x[(size_t)q * n + i] = xi;
+                }
+            }
+            for (int i = lane; i < w.na; i += 64) w.lams[i] *= w.scaling[w.ws[i]];
+            WSYNC();
+        } else if (b.x) {
+            // the reference copies whatever work->x holds; give the LDP iterate back as is
+            for (int i = lane; i < n; i += 64) b.x[(size_t)q * n + i] = w.u[i];
+        }
+        if (b.lam) {
+            for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = 0;
+            WSYNC();
+            for (int i = lane; i < w.na; i += 64) b.lam[(size_t)q * m + w.ws[i]] = w.lams[i];
+        }
+        double fv = w.fval;
+        for (int i = 0; i < n; ++i) { const double vi = vq[i]; fv -= vi * vi; }
+        fv *= 0.5;
+        if (lane == 0) {
+            b.exitflag[q] = flag; b.iter[q] = iters;
+            if (b.fval) b.fval[q] = fv;
+            if (b.soft) b.soft[q] = w.soft;
+            qs->iterations = iters; qs->exitflag = flag; qs->need_activate = 0;
+        }
+    }
+    // ---- store the persistent iterate
+    for (int i = lane; i < cap; i += 64) {
+        gv[i] = w.D[i]; gv[cap + i] = w.xl[i]; gv[2 * cap + i] = w.zl[i];
+        gv[3 * cap + i] = lamA[i]; gv[4 * cap + i] = lamB[i];
+        gws[i] = (i < w.na) ? w.ws[i] : -1;
+    }
+    for (int i = lane; i < m; i += 64) gsense[i] = w.sense[i];
+    if (!SPILL) {
+        const int used = tri(w.na);
+        double *gL = b.L + (size_t)q * b.ltri;
+        for (int e = lane; e < used; e += 64) gL[e] = w.L[e];
+    }
+    if (lane == 0) {
+        qs->n_active = w.na; qs->reuse_ind = w.reuse; qs->sing_ind = w.sing;
+        qs->lam_swapped = (w.lam == lamB) ? 1 : 0;
+        qs->fval = w.fval; qs->soft_slack = w.soft;
+        if (b.trace) b.trace[(size_t)q * b.trace_cap + b.trace_cap - 1] = w.trace_len;
+    }
+}
+
+} // namespace daqp_amd

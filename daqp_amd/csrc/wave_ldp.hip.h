@@ -1,0 +1,799 @@
+// wave_ldp.hip.h -- the dual active-set iteration of one LDP, executed by ONE wavefront.
+//
+// What it computes: the path daqp_ldp -> {compute_CSP, remove_blocking, compute_primal_and_fval,
+// add_infeasible, update_LDL_add/remove, pivot_last, compute_singular_direction, refine_active,
+// activate_constraints} of DAQP v0.9.1 (reference src/daqp.c:6-108, src/auxiliary.c,
+// src/factorization.c).  How: designed for a 64-lane CDNA4 wavefront --
+//   * lane <-> row of the working set for every triangular solve (column-oriented
+//     substitution: one v_readlane broadcast + one LDS row read per step),
+//   * lane <-> constraint row for the feasibility scan M*u (M streamed from HBM in a
+//     row-blocked, k-pair-interleaved layout: one 16-byte load per lane, 1 KiB per wave),
+//   * L (packed), D, the working set and a cache of the ACTIVE rows of M live in LDS,
+//   * every floating-point accumulation keeps the reference's operation order (the file is
+//     compiled with -ffp-contract=off), so a decision can only differ from the CPU reference
+//     through the one documented tree reduction-free exception: none -- all sums are ordered.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/daqp_amd.h"
+
+namespace daqp_amd {
+
+constexpr int kEmpty = DAQP_EMPTY_IND;
+constexpr int kBig = 0x7fffffff;
+
+#define WSYNC() __syncthreads()
+
+__device__ __forceinline__ int tri(int k) { return (k * (k + 1)) >> 1; }
+__device__ __forceinline__ int roff(int i, int n) { return ((2 * n - i - 1) * i) / 2; }
+__device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
+
+// broadcast lane `src` (wave-uniform) of v to every lane: two v_readlane_b32
+__device__ __forceinline__ double rl(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+// element `idx` (wave-uniform) of a vector held as a[c] in lane (idx&63), chunk (idx>>6)
+template <int C>
+__device__ __forceinline__ double rlc(const double (&a)[C], int idx)
+{
+    double v = a[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c)
+        if ((idx >> 6) == c) v = a[c];
+    return rl(v, idx & 63);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dmin2(double a, double b) { return b < a ? b : a; }
+
+// wave-wide minimum of v (no NaNs expected): 4 DPP steps inside each row of 16, then 4 readlanes
+__device__ __forceinline__ double wave_min(double v)
+{
+    v = dmin2(v, dpp_f64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = dmin2(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = dmin2(v, dpp_f64<0x141>(v));  // row_half_mirror
+    v = dmin2(v, dpp_f64<0x140>(v));  // row_mirror
+    double a = rl(v, 0), b = rl(v, 16), c = rl(v, 32), d = rl(v, 48);
+    return dmin2(dmin2(a, b), dmin2(c, d));
+}
+// (value, index) argmin with lowest index on ties; lanes without a candidate pass idx = kBig.
+// Returns the wave-uniform winner; idx stays kBig if nobody had one. `aux` rides along.
+__device__ __forceinline__ void wave_argmin(double &v, int &idx, int &aux)
+{
+    const double vin = (idx == kBig) ? (double)DAQP_INF : v;
+    const double mn = wave_min(vin);
+    unsigned long long msk = __ballot(idx != kBig && vin == mn);
+    int bi = kBig, ba = 0;
+    while (msk) {                                   // one pass unless two lanes tie exactly
+        const int l = __ffsll((long long)msk) - 1;
+        const int ci = __builtin_amdgcn_readlane(idx, l);
+        const int ca = __builtin_amdgcn_readlane(aux, l);
+        if (ci < bi) { bi = ci; ba = ca; }
+        msk &= msk - 1;
+    }
+    v = mn; idx = bi; aux = ba;
+}
+
+struct QState {   // per-problem scalars kept in HBM between launches
+    int n_active, reuse_ind, sing_ind, iterations;
+    int lam_swapped, setup_flag, need_activate, exitflag;
+    double fval, soft_slack;
+};
+
+// One wave's view of one LDP.  L and rowc are LDS (or HBM scratch when spilled); the small
+// vectors are always LDS; M and the bounds are read-only HBM.
+template <int C>
+struct Wave {
+    // sizes
+    int n, m, ms, cap, npair, nblk, ldr;
+    // LDS / scratch
+    double *L, *rowc;
+    double *D, *xl, *zl, *lam, *lams, *u;
+    int *ws, *sense, *pend_id;
+    double *pend_lam;
+    // HBM, read-only during the iteration
+    const double *Mblk, *dupper, *dlower, *scaling;
+    // uniform iterate state
+    int na, reuse, sing, has_soft;
+    double fval, soft;
+    DAQPSettings st;
+    // optional event trace (+id+1 add, -(id+1) remove)
+    int *trace; int trace_cap, trace_len;
+};
+
+template <int C>
+__device__ __forceinline__ void trace_ev(Wave<C> &w, int ev)
+{
+    if (w.trace) {
+        if (lane_id() == 0 && w.trace_len < w.trace_cap) w.trace[w.trace_len] = ev;
+        w.trace_len++;
+    }
+}
+
+// rowc[slot][0..n) <- row `id` of the LDP constraint matrix (HBM, blocked layout
+// [row/64][k/2][row%64][k%2]); simple-bound rows are stored densely with a zero prefix
+template <int C>
+__device__ __forceinline__ void fetch_row(Wave<C> &w, int id, int slot)
+{
+    const int lane = lane_id();
+    const double2 *src = reinterpret_cast<const double2 *>(w.Mblk) + ((size_t)(id >> 6) * w.npair) * 64 + (id & 63);
+    double *dst = w.rowc + (size_t)slot * w.ldr;
+    for (int t = lane; t < w.npair; t += 64) {
+        const double2 v = src[(size_t)t * 64];
+        dst[2 * t] = v.x;
+        if (2 * t + 1 < w.n) dst[2 * t + 1] = v.y;
+    }
+    WSYNC();
+}
+
+// factorization.c:4-15 (4 interleaved partial sums, then (s0+s1)+(s2+s3))
+__device__ __forceinline__ double dot4(const double *a, const double *b, int len)
+{
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int i = 0;
+    for (; i + 3 < len; i += 4) {
+        s0 += a[i] * b[i];
+        s1 += a[i + 1] * b[i + 1];
+        s2 += a[i + 2] * b[i + 2];
+        s3 += a[i + 3] * b[i + 3];
+    }
+    for (; i < len; i++) s0 += a[i] * b[i];
+    return (s0 + s1) + (s2 + s3);
+}
+
+// ---------------------------------------------------------------------------------------
+// LDL' row append (factorization.c:21-111): Gram column by lane<->active row, forward
+// substitution column by column, ordered Schur complement
+// ---------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void ldl_append(Wave<C> &w, int id)
+{
+    const int lane = lane_id(), na = w.na, n = w.n, base = tri(na);
+    fetch_row(w, id, na);
+    const int c0 = id < w.ms ? id : 0;
+    w.sing = kEmpty;
+    const double *Mi = w.rowc + (size_t)na * w.ldr;
+    double g[C];
+    int ns_act = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int k = lane + 64 * c;
+        g[c] = 0;
+        int soft_k = 0;
+        if (k <= na) {
+            const int idk = (k < na) ? w.ws[k] : id;
+            const int j = (k < na && idk < w.ms) ? (c0 > idk ? c0 : idk) : c0;
+            g[c] = dot4(w.rowc + (size_t)k * w.ldr + j, Mi + j, n - j);
+            soft_k = (w.sense[idk] & DAQP_SOFT) ? 1 : 0;
+        }
+        if (w.has_soft) ns_act += __popcll(__ballot(soft_k));
+    }
+    double dnew = rlc<C>(g, na);
+    if (w.sense[id] & DAQP_SOFT) dnew += w.st.rho_soft;
+    if (na == 0) {
+        if (lane == 0) w.D[0] = dnew;
+        WSYNC();
+        return;
+    }
+    // forward substitution  l <- L \ g   (factorization.c:81-88)
+    for (int j = 0; j < na - 1; ++j) {
+        const double lj = rlc<C>(g, j);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int k = lane + 64 * c;
+            if (k > j && k < na) g[c] -= w.L[tri(k) + j] * lj;
+        }
+    }
+    // l_k /= D_k ; d_new -= sum_k l_k^2 D_k, in k order (factorization.c:93-103)
+    double p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int k = lane + 64 * c;
+        p[c] = 0;
+        if (k < na) {
+            const double t = g[c];
+            const double lk = t / w.D[k];
+            w.L[base + k] = lk;
+            p[c] = t * lk;
+        }
+    }
+    double acc = dnew;
+    for (int k = 0; k < na; ++k) acc -= rlc<C>(p, k);
+    int sing = kEmpty;
+    if (acc < w.st.sing_tol || na >= n + ns_act) { sing = na; acc = 0; }
+    if (lane == 0) w.D[na] = acc;
+    w.sing = sing;
+    WSYNC();
+}
+
+// ---------------------------------------------------------------------------------------
+// LDL' row delete (factorization.c:112-151): staged compaction of packed L, then the
+// Gill-Golub-Murray-Saunders C1 rank-one update with lane<->trailing row
+// ---------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void ldl_delete(Wave<C> &w, int r)
+{
+    const int lane = lane_id(), na = w.na;
+    if (na == r + 1) return;
+    const int nupd = na - r - 1;
+    double wv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int t = lane + 64 * c;
+        wv[c] = (t < nupd) ? w.L[tri(r + 1 + t) + r] : 0.0;
+    }
+    // move rows r+1.. up by one and drop column r.  Destination e always reads from a higher
+    // address, so ascending chunks with "read all, then write all" never clobber a live source.
+    const int e0 = tri(r), e1 = tri(na - 1);
+    constexpr int U = 4;
+    for (int cb = e0; cb < e1; cb += 64 * U) {
+        double tmp[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int e = cb + q * 64 + lane;
+            tmp[q] = 0;
+            if (e < e1) {
+                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while (tri(i + 1) <= e) ++i;
+                while (tri(i) > e) --i;
+                const int j = e - tri(i);
+                tmp[q] = w.L[tri(i + 1) + j + (j >= r ? 1 : 0)];
+            }
+        }
+        WSYNC();
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int e = cb + q * 64 + lane;
+            if (e < e1) w.L[e] = tmp[q];
+        }
+        WSYNC();
+    }
+    double alpha = w.D[r];
+    for (int j = 0; j < nupd; ++j) {
+        const int i = r + 1 + j;
+        const double p = rlc<C>(wv, j);
+        const double Di = w.D[i];
+        const double dbar = Di + alpha * p * p;
+        const double beta = p * alpha / dbar;
+        alpha = Di * alpha / dbar;
+        if (lane == 0) w.D[i - 1] = dbar;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int t = lane + 64 * c;
+            if (t > j && t < nupd) {
+                const int pos = tri(r + t) + r + j;
+                const double l = w.L[pos];
+                wv[c] -= p * l;
+                w.L[pos] = l + beta * wv[c];
+            }
+        }
+    }
+    WSYNC();
+}
+
+// auxiliary.c:3-22 without the trailing pivot; returns 1 if the factor became singular
+template <int C>
+__device__ __forceinline__ int drop_core(Wave<C> &w, int r)
+{
+    const int lane = lane_id();
+    const int idr = w.ws[r];
+    trace_ev(w, -(idr + 1));
+    if (lane == 0) w.sense[idr] &= ~DAQP_ACTIVE;
+    ldl_delete(w, r);
+    w.na--;
+    int wsn[C];
+    double lmn[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        wsn[c] = 0; lmn[c] = 0;
+        if (i >= r && i < w.na) { wsn[c] = w.ws[i + 1]; lmn[c] = w.lam[i + 1]; }
+    }
+    WSYNC();
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        if (i >= r && i < w.na) { w.ws[i] = wsn[c]; w.lam[i] = lmn[c]; }
+    }
+    // the active-row cache is indexed by working-set position: close the gap (each lane moves
+    // its own columns, rows ascending, so no lane reads what another lane wrote)
+    for (int i = r; i < w.na; ++i) {
+        const double *src = w.rowc + (size_t)(i + 1) * w.ldr;
+        double *dst = w.rowc + (size_t)i * w.ldr;
+        for (int j = lane; j < w.n; j += 64) dst[j] = src[j];
+    }
+    if (r < w.reuse) w.reuse = r;
+    int took = 0;
+    if (w.na > 0 && w.D[w.na - 1] < w.st.sing_tol) {
+        w.sing = w.na - 1;
+        took = 1;
+    }
+    WSYNC();
+    if (took && lane == 0) w.D[w.na - 1] = 0;
+    WSYNC();
+    return took;
+}
+
+template <int C>
+__device__ __forceinline__ void push_core(Wave<C> &w, int id, double lamv) // auxiliary.c:27-40
+{
+    const int lane = lane_id();
+    trace_ev(w, id + 1);
+    if (lane == 0) w.sense[id] |= DAQP_ACTIVE;
+    WSYNC();
+    ldl_append(w, id);
+    if (lane == 0) { w.ws[w.na] = id; w.lam[w.na] = lamv; }
+    w.na++;
+    WSYNC();
+}
+
+// daqp_pivot_last (auxiliary.c:379-396): its recursion through remove/add_constraint becomes
+// an explicit stack (in LDS) of constraints waiting to be re-inserted
+template <int C>
+__device__ __forceinline__ void pivot_tail(Wave<C> &w)
+{
+    const int lane = lane_id();
+    int depth = 0;
+    for (;;) {
+        const int r = w.na - 2;
+        bool piv = false;
+        if (w.na > 1) {
+            const double dr = w.D[r], dl = w.D[w.na - 1];
+            piv = dr < w.st.pivot_tol && dr < dl;
+        }
+        if (piv) {
+            if (lane == 0) { w.pend_id[depth] = w.ws[r]; w.pend_lam[depth] = w.lam[r]; }
+            depth++;
+            WSYNC();
+            if (drop_core(w, r)) break;
+            continue;
+        }
+        if (depth == 0) break;
+        if (w.sing != kEmpty) break;
+        depth--;
+        const int id = w.pend_id[depth];
+        const double lv = w.pend_lam[depth];
+        push_core(w, id, lv);
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void remove_constraint(Wave<C> &w, int r)
+{
+    if (!drop_core(w, r)) pivot_tail(w);
+}
+template <int C>
+__device__ __forceinline__ void add_constraint(Wave<C> &w, int id, double lamv)
+{
+    push_core(w, id, lamv);
+    pivot_tail(w);
+}
+
+// ---------------------------------------------------------------------------------------
+// constrained stationary point: L D L' lam* = -d_k  (auxiliary.c:314-354)
+// ---------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void forward_rows(Wave<C> &w, double (&acc)[C], int from)
+{
+    // acc[c] holds the right-hand side of rows >= from; rows < from are final in xl
+    const int lane = lane_id(), na = w.na;
+    for (int j = 0; j < from; ++j) {
+        const double xj = w.xl[j];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int i = lane + 64 * c;
+            if (i >= from && i < na) acc[c] -= w.L[tri(i) + j] * xj;
+        }
+    }
+    for (int j = from; j < na - 1; ++j) {
+        const double xj = rlc<C>(acc, j);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int i = lane + 64 * c;
+            if (i > j && i < na) acc[c] -= w.L[tri(i) + j] * xj;
+        }
+    }
+}
+// b <- L' \ b for the leading `cnt` rows; multiplication order as the reference: b_j * L[j][i]
+template <int C>
+__device__ __forceinline__ void backward_rows(Wave<C> &w, double (&b)[C], int cnt)
+{
+    const int lane = lane_id();
+    for (int j = cnt - 1; j >= 1; --j) {
+        const double bj = rlc<C>(b, j);
+        const double *Lj = w.L + tri(j);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int i = lane + 64 * c;
+            if (i < j) b[c] -= bj * Lj[i];
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void solve_csp(Wave<C> &w)
+{
+    const int lane = lane_id(), na = w.na, from = w.reuse;
+    double acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        acc[c] = 0;
+        if (i >= from && i < na) {
+            const int id = w.ws[i];
+            acc[c] = (w.sense[id] & DAQP_LOWER) ? -w.dlower[id] : -w.dupper[id];
+        }
+    }
+    forward_rows<C>(w, acc, from);
+    double b[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        b[c] = 0;
+        if (i < na) {
+            if (i >= from) {
+                w.xl[i] = acc[c];
+                b[c] = acc[c] / w.D[i];
+                w.zl[i] = b[c];
+            } else b[c] = w.zl[i];
+        }
+    }
+    backward_rows<C>(w, b, na);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        if (i < na) w.lams[i] = b[c];
+    }
+    w.reuse = na;
+    WSYNC();
+}
+
+template <int C>
+__device__ __forceinline__ void singular_direction(Wave<C> &w) // auxiliary.c:357-376
+{
+    const int lane = lane_id(), s = w.sing, base = tri(s);
+    double b[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        b[c] = (i < s) ? -w.L[base + i] : 0.0;
+    }
+    backward_rows<C>(w, b, s);
+    const bool flip = (w.sense[w.ws[s]] & DAQP_LOWER) != 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        if (i <= s) {
+            double v = (i == s) ? 1.0 : b[c];
+            w.lams[i] = flip ? -v : v;
+        }
+    }
+    WSYNC();
+}
+
+// auxiliary.c:277-311 (SOFT_WEIGHTS off): ratio test over the working set, drop the argmin
+template <int C>
+__device__ __forceinline__ int remove_blocking(Wave<C> &w)
+{
+    const int lane = lane_id(), na = w.na;
+    const double dtol = w.st.dual_tol;
+    const bool regular = (w.sing == kEmpty);
+    double bv = DAQP_INF;
+    int bi = kBig, aux = 0;
+    double lm[C], ls[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        lm[c] = 0; ls[c] = 0;
+        if (i < na) {
+            lm[c] = w.lam[i]; ls[c] = w.lams[i];
+            const int sn = w.sense[w.ws[i]];
+            bool blocking = !(sn & DAQP_IMMUTABLE);
+            if (sn & DAQP_LOWER) { if (ls[c] < dtol) blocking = false; }
+            else if (ls[c] > -dtol) blocking = false;
+            if (blocking) {
+                const double cand = regular ? -lm[c] / (ls[c] - lm[c]) : -lm[c] / ls[c];
+                if (cand < bv) { bv = cand; bi = i; }
+            }
+        }
+    }
+    wave_argmin(bv, bi, aux);
+    if (bi == kBig) return 0;
+    const double alpha = bv;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        if (i < na) w.lam[i] = regular ? lm[c] + alpha * (ls[c] - lm[c]) : lm[c] + alpha * ls[c];
+    }
+    w.sing = kEmpty;
+    WSYNC();
+    remove_constraint(w, bi);
+    return 1;
+}
+
+// u = -M_k' lam*, fval = rho*sum_soft lam*^2 + |u|^2 (auxiliary.c:46-88); every sum is in
+// the reference's order: over the working set for u, over j for |u|^2
+template <int C>
+__device__ __forceinline__ void primal_u(Wave<C> &w)
+{
+    const int lane = lane_id(), na = w.na, n = w.n;
+    double uu[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) uu[c] = 0;
+    for (int i = 0; i < na; ++i) {
+        const double li = w.lams[i];
+        const double *row = w.rowc + (size_t)i * w.ldr;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int j = lane + 64 * c;
+            if (j < n) uu[c] -= row[j] * li;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int j = lane + 64 * c;
+        if (j < n) w.u[j] = uu[c];
+    }
+    double fv = 0;
+    if (w.has_soft) {
+        for (int i = 0; i < na; ++i)
+            if (w.sense[w.ws[i]] & DAQP_SOFT) { const double li = w.lams[i]; fv += li * li; }
+    }
+    fv = fv * w.st.rho_soft;
+    w.soft = fv;
+    WSYNC();
+}
+template <int C>
+__device__ __forceinline__ double ordered_norm2(Wave<C> &w, double start)
+{
+    double fv = start;
+    for (int j = 0; j < w.n; ++j) { const double uj = w.u[j]; fv += uj * uj; }
+    return fv;
+}
+
+// feasibility scan + most-violated pick (auxiliary.c:89-198).  Returns the row (or kBig) and
+// sets `upper`.  When `with_fval`, |u|^2 is accumulated in the first row block's k loop.
+template <int C>
+__device__ __forceinline__ int scan_rows(Wave<C> &w, int &upper, bool with_fval)
+{
+    const int lane = lane_id(), n = w.n;
+    const double ep = -w.st.primal_tol;
+    double bv = 0.0;
+    int bi = kBig, bup = 0;
+    double fv = w.soft;
+    const bool odd = (n & 1) != 0;
+    const double2 *u2 = reinterpret_cast<const double2 *>(w.u);
+    for (int blk = 0; blk < w.nblk; ++blk) {
+        const int r = blk * 64 + lane;
+        const double2 *src = reinterpret_cast<const double2 *>(w.Mblk) + ((size_t)blk * w.npair) * 64 + lane;
+        double mu = 0;
+        const int full = odd ? w.npair - 1 : w.npair;
+        if (r < w.m) {
+#pragma unroll 5
+            for (int t = 0; t < full; ++t) {
+                const double2 mm = src[(size_t)t * 64];
+                const double2 uk = u2[t];
+                mu += mm.x * uk.x;
+                mu += mm.y * uk.y;
+            }
+            if (odd) mu += src[(size_t)full * 64].x * w.u[n - 1];
+        }
+        if (with_fval && blk == 0) {
+            for (int j = 0; j < n; ++j) { const double uj = w.u[j]; fv += uj * uj; }
+        }
+        if (r < w.m) {
+            const int sn = w.sense[r];
+            if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
+                const double bound = ep * w.scaling[r];
+                double cand = w.dupper[r] - mu;
+                if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 1; }
+                else {
+                    cand = mu - w.dlower[r];
+                    if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 0; }
+                }
+            }
+        }
+    }
+    if (with_fval) {
+        if (w.nblk == 0) fv = ordered_norm2(w, fv);
+        w.fval = fv;
+    }
+    wave_argmin(bv, bi, bup);
+    upper = bup;
+    return bi;
+}
+
+template <int C>
+__device__ __forceinline__ void commit_add(Wave<C> &w, int pick, int upper) // auxiliary.c:152-166
+{
+    if (lane_id() == 0) {
+        if (upper) w.sense[pick] &= ~DAQP_LOWER; else w.sense[pick] |= DAQP_LOWER;
+    }
+    double *t = w.lam; w.lam = w.lams; w.lams = t;
+    WSYNC();
+    add_constraint(w, pick, upper ? 1.0 : -1.0);
+}
+
+// one step of iterative refinement on the active rows (auxiliary.c:498-593)
+template <int C>
+__device__ __forceinline__ void refine_active(Wave<C> &w)
+{
+    const int lane = lane_id(), na = w.na, n = w.n;
+    w.reuse = 0;
+    double acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        acc[c] = 0;
+        if (i < na) {
+            const int id = w.ws[i];
+            const double *row = w.rowc + (size_t)i * w.ldr;
+            double mu = 0;
+            for (int j = (id < w.ms ? id : 0); j < n; ++j) mu += row[j] * w.u[j];
+            const double d = (w.sense[id] & DAQP_LOWER) ? w.dlower[id] : w.dupper[id];
+            acc[c] = mu - d;
+            if (w.sense[id] & DAQP_SOFT) acc[c] -= w.st.rho_soft * w.lams[i];
+        }
+    }
+    forward_rows<C>(w, acc, 0);
+    double b[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        b[c] = 0;
+        if (i < na) { w.xl[i] = acc[c]; b[c] = acc[c] / w.D[i]; w.zl[i] = b[c]; }
+    }
+    backward_rows<C>(w, b, na);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane + 64 * c;
+        if (i < na) { w.xl[i] = b[c]; w.lams[i] += b[c]; }
+    }
+    WSYNC();
+    double uu[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const int j = lane + 64 * c; uu[c] = (j < n) ? w.u[j] : 0.0; }
+    for (int i = 0; i < na; ++i) {
+        const double dl = w.xl[i];
+        const int id = w.ws[i];
+        const int j0 = id < w.ms ? id : 0;
+        const double *row = w.rowc + (size_t)i * w.ldr;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int j = lane + 64 * c;
+            if (j < n && j >= j0) uu[c] -= row[j] * dl;
+        }
+    }
+    WSYNC();
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const int j = lane + 64 * c; if (j < n) w.u[j] = uu[c]; }
+    WSYNC();
+    w.fval = ordered_norm2(w, w.soft);
+}
+
+// (re)build the working set from the ACTIVE bits, in index order (auxiliary.c:399-479)
+template <int C>
+__device__ __forceinline__ int activate_marked(Wave<C> &w)
+{
+    const int lane = lane_id();
+    for (int blk = 0; blk * 64 < w.m; ++blk) {
+        const int r = blk * 64 + lane;
+        unsigned long long msk = __ballot(r < w.m && (w.sense[r] & DAQP_ACTIVE));
+        while (msk) {
+            const int i = blk * 64 + __ffsll((long long)msk) - 1;
+            msk &= msk - 1;
+            add_constraint(w, i, (w.sense[i] & DAQP_LOWER) ? -1.0 : 1.0);
+            if (w.sing == kEmpty) continue;
+            const int last = w.ws[w.na - 1];
+            if (w.sense[last] & DAQP_IMMUTABLE) {
+                // a new equality depends on the active ones: consistent => ignore it
+                singular_direction(w);
+                double resid = 0.0, scale = 1.0;
+                for (int j = 0; j < w.na; ++j) {
+                    const int id = w.ws[j];
+                    const double bd = (w.sense[id] & DAQP_LOWER) ? w.dlower[id] : w.dupper[id];
+                    const double t = w.lams[j] * bd;
+                    resid += t;
+                    scale += t < 0 ? -t : t;
+                }
+                WSYNC();
+                if (lane == 0) w.sense[last] &= ~DAQP_ACTIVE;
+                w.na--;
+                w.sing = kEmpty;
+                if (w.reuse > w.na) w.reuse = w.na;
+                WSYNC();
+                if (resid <= w.st.primal_tol * scale && resid >= -w.st.primal_tol * scale) continue;
+                return DAQP_EXIT_OVERDETERMINED_INITIAL;
+            }
+            int flag = 1;
+            for (int q = i; q < w.m; q += 1) {
+                // rows after i: equalities that could not be activated are an error, the rest are cleaned
+                const int sn = w.sense[q];
+                if (sn & DAQP_ACTIVE) {
+                    if (sn & DAQP_IMMUTABLE) flag = DAQP_EXIT_OVERDETERMINED_INITIAL;
+                    else if (lane == 0) w.sense[q] = sn & ~DAQP_ACTIVE;
+                }
+            }
+            w.na--;
+            w.sing = kEmpty;
+            WSYNC();
+            return flag;
+        }
+    }
+    return 1;
+}
+
+template <int C>
+__device__ __forceinline__ void reset_ws(Wave<C> &w) { w.sing = kEmpty; w.na = 0; w.reuse = 0; }
+
+// ---------------------------------------------------------------------------------------
+// daqp_ldp (daqp.c:6-108)
+// ---------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ int ldp_loop(Wave<C> &w, int &iterations)
+{
+    const int lane = lane_id();
+    int flag = DAQP_EXIT_ITERLIMIT, it, repaired = 0, stall = 0;
+    double best = -1;
+    const double fbound = 2 * w.st.fval_bound;
+    for (it = 1; it < w.st.iter_limit; ++it) {
+        if (w.sing == kEmpty) {
+            solve_csp(w);
+            if (remove_blocking(w)) continue;
+            primal_u(w);
+            int upper = 0;
+            int pick = scan_rows(w, upper, true);
+            if (w.fval > fbound) { flag = DAQP_EXIT_INFEASIBLE; break; }
+            if (pick == kBig) {
+                double dmin = w.D[0];
+                for (int i = 1; i < w.na; ++i) { const double di = w.D[i]; if (di < dmin) dmin = di; }
+                if (w.na > 2 && repaired != 1 && dmin < w.st.refactor_tol) {
+                    repaired = 1;
+                    for (int i = lane; i < w.na; i += 64) {
+                        const int id = w.ws[i];
+                        if (w.lam[i] >= 0) w.sense[id] &= ~DAQP_LOWER; else w.sense[id] |= DAQP_LOWER;
+                    }
+                    WSYNC();
+                    reset_ws(w);
+                    activate_marked(w);
+                    continue;
+                }
+                if (w.na > 0 && dmin < w.st.pivot_tol) {
+                    refine_active(w);
+                    pick = scan_rows(w, upper, false);
+                    if (pick != kBig) { commit_add(w, pick, upper); continue; }
+                }
+                flag = (w.soft > w.st.primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
+                break;
+            }
+            commit_add(w, pick, upper);
+            if (w.fval - best < w.st.progress_tol) {
+                if (stall++ > w.st.cycle_tol) {
+                    if (repaired == 1) { flag = DAQP_EXIT_CYCLE; break; }
+                    repaired = 1;
+                    reset_ws(w);
+                    activate_marked(w);
+                    stall = 0;
+                    best = -1;
+                }
+            } else { best = w.fval; stall = 0; }
+        } else {
+            singular_direction(w);
+            if (!remove_blocking(w)) { flag = DAQP_EXIT_INFEASIBLE; break; }
+        }
+    }
+    iterations = it;
+    return flag;
+}
+
+} // namespace daqp_amd

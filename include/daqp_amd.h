@@ -1,0 +1,216 @@
+/*
+ * daqp_amd.h -- C ABI of the MI355X-native batched dual active-set QP path.
+ *
+ *   minimize   1/2 x'Hx + f'x      subject to   blower <= [x(1:ms); A x] <= bupper
+ *
+ * Two layers, both exported by libdaqp_amd.so (plain pointers and sizes only):
+ *
+ *  (1) The single-problem entry points of DAQP v0.9.1, same names, argument
+ *      meaning, struct layouts and exit flags, so that a binding written against
+ *      the reference's api.h links against this library unchanged.  Each call
+ *      is a batch of one on the GPU.
+ *        reference include/api.h:29-30   daqp_solve, daqp_quadprog
+ *        reference include/api.h:33-34   setup_daqp, setup_daqp_main
+ *        reference include/utils.h:11    daqp_update_ldp
+ *        reference include/api.h:40-52   allocate_/free_ helpers, daqp_default_settings
+ *        reference include/api.h:56-58   daqp_primal_init_active, daqp_dual_init_active
+ *
+ *  (2) The additive batch entry points (daqp_batch_* / daqp_quadprog_batch):
+ *      N independent problems of one shape (n, m, ms), stored back to back,
+ *      solved by one wavefront each with the working set and LDL' factors in LDS.
+ *
+ * Only the hot path is implemented: dense, strictly convex H; sense bits
+ * ACTIVE/LOWER/IMMUTABLE/SOFT.  Binary constraints, hierarchies, AVIs, LPs and
+ * singular Hessians (the reference's bnb/hiqp/avi/prox outer loops) return
+ * DAQP_EXIT_UNSUPPORTED.  There is NO CPU fallback: without a HIP device every
+ * entry point fails with DAQP_EXIT_UNSUPPORTED and daqp_amd_last_error() says why.
+ */
+#ifndef DAQP_AMD_H
+#define DAQP_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef double c_float; /* the path computes in fp64 only (reference types.h:8-12 default) */
+
+/* ---- exit flags (reference include/constants.h:42-51) ---- */
+#define DAQP_EXIT_SOFT_OPTIMAL 2
+#define DAQP_EXIT_OPTIMAL 1
+#define DAQP_EXIT_INFEASIBLE -1
+#define DAQP_EXIT_CYCLE -2
+#define DAQP_EXIT_UNBOUNDED -3
+#define DAQP_EXIT_ITERLIMIT -4
+#define DAQP_EXIT_NONCONVEX -5
+#define DAQP_EXIT_OVERDETERMINED_INITIAL -6
+#define DAQP_EXIT_TIMELIMIT -7
+#define DAQP_EXIT_UNSUPPORTED -8
+
+/* ---- daqp_update_ldp masks (reference include/constants.h:54-61) ---- */
+#define DAQP_UPDATE_Rinv 1
+#define DAQP_UPDATE_M 2
+#define DAQP_UPDATE_v 4
+#define DAQP_UPDATE_d 8
+#define DAQP_UPDATE_sense 16
+#define DAQP_UPDATE_hierarchy 32
+#define DAQP_UPDATE_unconstrained 64
+#define DAQP_UPDATE_eliminate 128
+
+/* ---- constraint sense bits (reference include/constants.h:64-96) ---- */
+#define DAQP_ACTIVE 1
+#define DAQP_LOWER 2
+#define DAQP_IMMUTABLE 4
+#define DAQP_SOFT 8
+#define DAQP_BINARY 16
+
+#define DAQP_EMPTY_IND -1
+#define DAQP_UNCONSTRAINED_OPTIMAL -2
+#define DAQP_INF ((c_float)1e30)
+
+/* Problem descriptor: layout of reference include/types.h:14-50 (80 bytes). */
+typedef struct {
+    int n, m, ms;            /* variables, constraints (simple first), simple bounds */
+    c_float *H;              /* n x n, row-major */
+    c_float *f;              /* n */
+    c_float *A;              /* (m-ms) x n, row-major */
+    c_float *bupper, *blower; /* m each: [simple; general] */
+    int *sense;              /* m, or NULL (= all 0) */
+    int *break_points;       /* must be NULL (hierarchies unsupported) */
+    int nh;                  /* 0 or 1 */
+    int problem_type;        /* must be 0 */
+} DAQPProblem;
+
+/* Settings: layout of reference include/types.h:52-74 (120 bytes). */
+typedef struct {
+    c_float primal_tol, dual_tol, zero_tol, pivot_tol, progress_tol;
+    int cycle_tol, iter_limit;
+    c_float fval_bound;
+    c_float eps_prox, eta_prox; /* accepted, unused: proximal loop is out of scope */
+    c_float rho_soft;
+    c_float rel_subopt, abs_subopt;
+    c_float sing_tol, refactor_tol;
+    c_float time_limit;         /* accepted, unused: bound work with iter_limit */
+} DAQPSettings;
+
+/* Result: layout of reference include/api.h:15-27 (64 bytes). x and lam are caller-owned. */
+typedef struct {
+    c_float *x, *lam;
+    c_float fval, soft_slack;
+    int exitflag, iter, nodes;
+    c_float solve_time, setup_time;
+} DAQPResult;
+
+/* Workspace: field order and offsets of reference include/types.h:187-264
+ * (288 bytes), so that sizeof/offsetof match for bindings that mirror it.
+ * In this implementation the numerical state lives on the GPU: the array
+ * members below are HOST MIRRORS refreshed by setup/solve (NULL where no
+ * mirror is kept); `timer` carries the opaque device handle. */
+typedef struct DAQPWorkspace {
+    DAQPProblem *qp;
+    int n, m, ms;
+    c_float *M, *dupper, *dlower, *Rinv, *v;   /* device-resident: NULL on the host */
+    int *sense;                                /* host mirror, m */
+    c_float *scaling, *RinvD;                  /* NULL */
+    c_float *x, *xold;                         /* x: host mirror of the last primal solution */
+    c_float *lam, *lam_star, *u;               /* lam_star: host mirror (n_active multipliers) */
+    c_float fval;
+    c_float *L, *D, *xldl, *zldl;              /* NULL */
+    int reuse_ind;
+    int *WS;                                   /* host mirror of the working set */
+    int n_active, iterations, sing_ind;
+    int *prox_mask;                            /* NULL */
+    int n_prox;                                /* always 0 */
+    c_float soft_slack;
+    DAQPSettings *settings;
+    void *bnb;                                 /* NULL */
+    int nh;
+    int *break_points;
+    void *avi, *eq;                            /* NULL */
+    void *timer;                               /* opaque: DAQPBatch* of size 1 */
+    c_float *Mu;                               /* NULL */
+} DAQPWorkspace;
+
+/* ------------------------------------------------------------------ */
+/* (1) single-problem drop-in entry points                             */
+/* ------------------------------------------------------------------ */
+void daqp_quadprog(DAQPResult *res, DAQPProblem *qp, DAQPSettings *settings); /* api.c:62-79 */
+void daqp_solve(DAQPResult *res, DAQPWorkspace *work);                         /* api.c:8-59 */
+int setup_daqp(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time);     /* api.c:88-90 */
+int setup_daqp_main(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time, int init_mask); /* api.c:93-160 */
+int daqp_update_ldp(const int mask, DAQPWorkspace *work, DAQPProblem *qp);     /* utils.c:58-221 */
+void daqp_default_settings(DAQPSettings *settings);                            /* api.c:505-527 */
+void allocate_daqp_settings(DAQPWorkspace *work);                              /* api.c:277-282 */
+void free_daqp_workspace(DAQPWorkspace *work);                                 /* api.c:393-420 */
+void free_daqp_ldp(DAQPWorkspace *work);                                       /* api.c:243-275 */
+void daqp_primal_init_active(DAQPProblem *qp, c_float *x);                     /* api.c:579-616 */
+void daqp_dual_init_active(DAQPProblem *qp, c_float *lam);                     /* api.c:620-633 */
+
+/* ------------------------------------------------------------------ */
+/* (2) batch entry points (additive; not in the reference)             */
+/* ------------------------------------------------------------------ */
+#define DAQP_MEM_HOST 0    /* pointers are host memory: the library stages them over PCIe */
+#define DAQP_MEM_DEVICE 1  /* pointers are device memory on the batch's GPU: used in place */
+
+/* N problems of one shape, each array the N per-problem arrays back to back
+ * (H: N*n*n, f: N*n, A: N*(m-ms)*n, bupper/blower/sense: N*m).  sense may be NULL. */
+typedef struct {
+    int N, n, m, ms;
+    const c_float *H, *f, *A, *bupper, *blower;
+    const int *sense;
+    int memory; /* DAQP_MEM_HOST or DAQP_MEM_DEVICE, applies to every pointer above */
+} DAQPBatchProblem;
+
+/* Per-problem outputs, back to back (x: N*n, lam: N*m, others: N).  Any pointer may be NULL. */
+typedef struct {
+    c_float *x, *lam, *fval, *soft_slack;
+    int *exitflag, *iter;
+    int memory;
+    c_float setup_time, solve_time; /* host wall clock of the last call, seconds (includes device sync) */
+} DAQPBatchResult;
+
+typedef struct DAQPBatch DAQPBatch; /* device-resident workspaces of N problems */
+
+/* Allocate device workspaces for N problems of shape (n, m, ms) with at most ns_max soft
+ * constraints each, on HIP device `device` (-1: current).  settings NULL = defaults.
+ * Returns 0 or a negative exit flag. */
+int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max,
+                      const DAQPSettings *settings, int device);
+void daqp_batch_free(DAQPBatch *b);
+/* hipStream_t the batch launches on (NULL: the legacy default stream). */
+void daqp_batch_set_stream(DAQPBatch *b, void *hip_stream);
+void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings);
+
+/* setup_daqp_main for every problem (QP -> LDP: Cholesky, R^-1, M = A R^-1, v, d, initial working
+ * set).  init_mask 0 = setup_daqp, DAQP_UPDATE_unconstrained = the daqp_quadprog variant.
+ * Returns 0 when launched; per-problem flags (1 ok, <0 exit flag) via daqp_batch_setup_flags. */
+int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask);
+/* daqp_update_ldp for every problem; supported masks: any combination of UPDATE_v, UPDATE_d
+ * (new f and/or bounds; factors and working sets are kept: warm start), or a full re-setup
+ * (UPDATE_Rinv|UPDATE_M|UPDATE_v|UPDATE_d|UPDATE_sense).  Pointers of `p` not covered by the
+ * mask may be NULL. */
+int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p);
+/* daqp_solve for every problem: dual active-set iteration from the current working sets, then
+ * x, lam, fval, exitflag, iter.  Blocks until results are in `r` unless r->memory is DEVICE
+ * (then they are ordered on the batch's stream). */
+int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r);
+/* copy out per-problem setup flags (host int[N]) */
+int daqp_batch_setup_flags(DAQPBatch *b, int *flags_host);
+/* copy out working sets: n_active (host int[N]) and WS (host int[N*(n+ns_max+1)], -1 padded); either may be NULL */
+int daqp_batch_working_sets(DAQPBatch *b, int *n_active_host, int *ws_host);
+/* one-shot: create + setup(DAQP_UPDATE_unconstrained) + solve + free == N x daqp_quadprog */
+int daqp_quadprog_batch(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQPSettings *settings);
+
+/* device-side timing of the last setup / solve launches (HIP events on the batch's stream), ms */
+int daqp_batch_kernel_ms(DAQPBatch *b, float *setup_ms, float *solve_ms);
+/* bytes of device memory held by the batch */
+unsigned long long daqp_batch_device_bytes(const DAQPBatch *b);
+
+/* diagnostics */
+const char *daqp_amd_last_error(void);
+int daqp_amd_device_count(void);
+const char *daqp_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAQP_AMD_H */

@@ -1,0 +1,131 @@
+"""CPU-only tests (-m "not gpu"): the oracle against committed golden vectors and analytic optima,
+host logic, and that the C-ABI library loads and exports every symbol include/daqp_amd.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_oracle_matches_generator_optimum(oracle):
+    for cfg in ("C1", "C2", "C3"):
+        n, m, ms, na, seed, _ = O.CONFIGS[cfg]
+        for k in range(20):
+            q = O.generate_qp(n, m, ms, na, rng=[seed, k])
+            x, lam, fval, flag, it = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+            assert flag == 1
+            assert np.abs(x - q["x"]).max() < 1e-8          # reference tests use 1e-4 (core_tests.jl:26-30)
+            assert (np.count_nonzero(lam) == na)
+            # KKT stationarity and objective identity (core_test.m:16-26)
+            Afull = np.vstack([np.eye(n)[:ms], q["A"]])
+            assert np.abs(q["H"] @ x + q["f"] + Afull.T @ lam).max() < 1e-7
+            assert abs(0.5 * x @ q["H"] @ x + q["f"] @ x - fval) < 1e-8
+
+
+def test_oracle_hand_examples(oracle):
+    # interfaces/daqp-python/test/example_test.py:175-237
+    H, f, A = np.eye(2), np.array([2.0, 2.0]), np.zeros((0, 2))
+    x, lam, fval, flag, it = oracle.quadprog(H, f, A, np.ones(2), -np.ones(2), np.zeros(2, np.int32))
+    assert flag == 1 and np.allclose(x, [-1, -1], atol=1e-6)
+    x, *_ = oracle.quadprog(H, -f, A, np.ones(2), -np.ones(2), np.zeros(2, np.int32))
+    assert np.allclose(x, [1, 1], atol=1e-6)
+    x, *_ = oracle.quadprog(H, f, A, 0.5 * np.ones(2), -0.5 * np.ones(2), np.zeros(2, np.int32))
+    assert np.allclose(x, [-0.5, -0.5], atol=1e-6)
+    # iter_limit = 1 -> -4 (core_tests.jl:33-35); crossed bounds -> -1 (core_test.m:212-221)
+    q = O.generate_qp(20, 40, 0, 8, rng=[1234, 0])
+    assert oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, O.default_settings(iter_limit=1))[3] == -4
+    bu = q["bupper"].copy(); bu[3] = q["blower"][3] - 1
+    assert oracle.quadprog(q["H"], q["f"], q["A"], bu, q["blower"])[3] == -1
+
+
+def test_oracle_warm_start_one_iteration(oracle):
+    """an exact dual warm start needs exactly 1 iteration (core_tests.jl:520-545)"""
+    n, m, ms, na, seed, _ = O.CONFIGS["C1"]
+    q = O.generate_qp(n, m, ms, na, rng=[seed, 3])
+    x, lam, *_ = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+    sense = np.zeros(m, np.int32)
+    sense[lam > 1e-12] |= O.ACTIVE
+    sense[lam < -1e-12] |= O.ACTIVE + O.LOWER
+    x2, lam2, fval2, flag, it = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], sense)
+    assert flag == 1 and it == 1 and np.abs(x - x2).max() < 1e-10
+
+
+def test_oracle_golden_vectors(oracle):
+    """fixtures written by tests/golden/make_golden.py from the REFERENCE library (strict build)"""
+    path = os.path.join(ROOT, "tests", "golden", "golden_quadprog.npz")
+    g = np.load(path, allow_pickle=False)
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) >= 40
+    for nm in names:
+        get = lambda f: g[f"{nm}/{f}"]
+        sense = get("sense") if f"{nm}/sense" in g.files else None
+        x, lam, fval, flag, it = oracle.quadprog(get("H"), get("f"), get("A"), get("bupper"), get("blower"), sense)
+        assert flag == int(get("exitflag")) and it == int(get("iter")), nm
+        if flag > 0:
+            assert np.array_equal(x.view(np.uint64), get("x").view(np.uint64)), nm
+            assert np.array_equal(lam.view(np.uint64), get("lam").view(np.uint64)), nm
+            assert fval == float(get("fval")), nm
+
+
+def test_oracle_golden_warm_sequence(oracle):
+    path = os.path.join(ROOT, "tests", "golden", "golden_warm.npz")
+    g = np.load(path, allow_pickle=False)
+    n, m, ms = int(g["n"]), int(g["m"]), int(g["ms"])
+    om = oracle.model(n, m, ms)
+    assert om.setup(g["H"], g["f0"], g["A"], g["bupper"], g["blower"], None) == 1
+    for t in range(g["fs"].shape[0]):
+        if t > 0:
+            assert om.update(O.UPDATE_v, f=g["fs"][t]) == 0
+        x, lam, fval, flag, it = om.solve()
+        assert flag == int(g["exitflag"][t]) and it == int(g["iter"][t])
+        assert np.array_equal(x.view(np.uint64), g["x"][t].view(np.uint64))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import daqp_amd
+    from daqp_amd._lib import EXPORTS
+    L = daqp_amd.lib()
+    hdr = open(os.path.join(ROOT, "include", "daqp_amd.h")).read()
+    declared = set(re.findall(r"\b((?:daqp|setup_daqp|allocate_daqp|free_daqp)\w*)\s*\(", hdr))
+    declared = {d for d in declared if not d.startswith("daqp_ldp")}
+    assert declared, "no declarations parsed"
+    for sym in declared | set(EXPORTS):
+        assert hasattr(L, sym), f"libdaqp_amd.so does not export {sym}"
+    assert b"daqp_amd" in L.daqp_amd_version()
+
+
+def test_struct_layouts_match_reference_abi():
+    """sizeof of the ctypes mirrors == the reference's x86-64 layouts"""
+    from daqp_amd._lib import DAQPProblem, DAQPResult, DAQPSettings, WORKSPACE_BYTES
+    assert C.sizeof(DAQPProblem) == 80 and C.sizeof(DAQPSettings) == 120 and C.sizeof(DAQPResult) == 64
+    assert WORKSPACE_BYTES == 288
+    assert DAQPSettings.cycle_tol.offset == 40 and DAQPSettings.fval_bound.offset == 48 and DAQPSettings.time_limit.offset == 112
+    assert DAQPResult.exitflag.offset == 32 and DAQPResult.setup_time.offset == 56
+
+
+def test_no_cpu_fallback_without_device():
+    """without a HIP device the product path refuses loudly instead of computing on the host"""
+    import daqp_amd
+    L = daqp_amd.lib()
+    if L.daqp_amd_device_count() > 0:
+        return
+    q = O.generate_qp(6, 12, 0, 2, rng=1)
+    x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+    assert flag == -8 and "no HIP device" in daqp_amd.last_error()
+    try:
+        daqp_amd.BatchModel(4, 6, 12, 0)
+        assert False, "BatchModel must raise without a device"
+    except RuntimeError as e:
+        assert "no HIP device" in str(e)
+
+
+def test_default_settings_match_reference_constants():
+    import daqp_amd
+    s = daqp_amd.default_settings()
+    o = O.default_settings()
+    for name, _ in s._fields_:
+        assert getattr(s, name) == getattr(o, name), name

@@ -1,0 +1,191 @@
+"""HIP path vs the oracle on the same seeded inputs (run with -m gpu on an MI355X).
+
+Bar (BASELINE.json north_star): active sets identical (index AND side, i.e. sign(lam)), identical
+iteration counts and exit flags, |x - x_ref|_inf < 1e-9.  Because the kernels keep the reference's
+operation order for every sum, the tests additionally demand bit-identical x / lam / fval.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+XTOL = 1e-9  # north_star tolerance on x*
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float64).view(np.uint64),
+                          np.ascontiguousarray(b, np.float64).view(np.uint64))
+
+
+def gpu_batch(q, **settings):
+    import daqp_amd
+    return daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q.get("sense"), ms=q["ms"], **settings)
+
+
+def check_batch(oracle, cfg, N, start=0, bitwise=True, **settings):
+    n, m, ms, na, seed, _ = O.CONFIGS[cfg]
+    q = O.generate_batch(N, n, m, ms, na, seed, start=start)
+    q["ms"] = ms
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms,
+                                settings=O.default_settings(**settings) if settings else None)
+    g = gpu_batch(q, **settings)
+    assert np.array_equal(g["exitflag"], ref[3]), f"exit flags differ: {np.nonzero(g['exitflag'] != ref[3])[0][:10]}"
+    assert np.array_equal(g["iter"], ref[4]), f"iteration counts differ at {np.nonzero(g['iter'] != ref[4])[0][:10]}"
+    assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1])), "active sets differ"
+    assert np.abs(g["x"] - ref[0]).max() < XTOL
+    ok = g["exitflag"] == 1
+    assert np.abs(g["x"][ok] - q["xref"][ok]).max(initial=0) < 1e-6   # generator's analytic optimum (core_tests.jl:26-30 uses 1e-4)
+    if bitwise:
+        assert bits_equal(g["x"], ref[0]) and bits_equal(g["lam"], ref[1]) and bits_equal(g["fval"], ref[2])
+    return g, ref
+
+
+def test_c1_single_qp(oracle, gpu_lib):
+    """config 1 shape (n=20, m=40) through the single-problem drop-in entry point daqp_quadprog"""
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS["C1"]
+    q = O.generate_qp(n, m, ms, na, rng=[seed, 0])
+    x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+    r = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+    assert flag == r[3] == 1 and info["iterations"] == r[4]
+    assert bits_equal(x, r[0]) and bits_equal(info["lam"], r[1]) and fval == r[2]
+    assert np.abs(x - q["x"]).max() < 1e-8
+
+
+@pytest.mark.parametrize("cfg,N", [("C1", 64), ("C2", 256), ("C3", 512)])
+def test_config_batches(oracle, gpu_lib, cfg, N):
+    check_batch(oracle, cfg, N)
+
+
+def test_c4_spill(oracle, gpu_lib):
+    """n=200: L and the active-row cache spill from LDS to HBM scratch"""
+    check_batch(oracle, "C4", 6)
+
+
+def test_iteration_limit(oracle, gpu_lib):
+    g, ref = check_batch(oracle, "C1", 8, bitwise=False, iter_limit=5)
+    assert (g["exitflag"] == -4).any()
+
+
+def test_ldp_setup_bitwise(oracle, gpu_lib):
+    """QP -> LDP transform (Cholesky, R^-1, M, v, d, scaling) against the oracle's, bit for bit"""
+    import daqp_amd
+    for cfg in ("C2", "C3"):
+        n, m, ms, na, seed, _ = O.CONFIGS[cfg]
+        N = 4
+        q = O.generate_batch(N, n, m, ms, na, seed)
+        bm = daqp_amd.BatchModel(N, n, m, ms)
+        bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+        assert (bm.setup_flags() == 1).all()
+        for k in range(N):
+            om = oracle.model(n, m, ms)
+            assert om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None) == 1
+            for name, a, b in zip(("M", "Rinv", "v", "dupper", "dlower", "scaling"), bm.read_ldp(k), om.ldp()):
+                assert bits_equal(a, b), f"{cfg}[{k}] {name}: max diff {np.abs(a - b).max():.3e}"
+        bm.close()
+
+
+def test_event_trace(oracle, gpu_lib):
+    """the sequence of constraint additions/removals is the reference's, step for step"""
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    N = 8
+    q = O.generate_batch(N, n, m, ms, na, seed, start=1000)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.enable_trace(2048)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+    bm.solve()
+    traces = bm.read_trace()
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.enable_trace()
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        om.solve()
+        assert np.array_equal(traces[k], om.get_trace())
+    bm.close()
+
+
+def test_degenerate_cases(oracle, gpu_lib):
+    """near-duplicate rows, dependent equalities, soft rows: pivoting / singular / refine / repair paths"""
+    import daqp_amd
+    mism = []
+    for trial in range(400):
+        rng = np.random.default_rng([99, trial])
+        eps = 10.0 ** rng.uniform(-13, -2)
+        n = int(rng.integers(4, 16)); m = int(rng.integers(n + 4, 4 * n)); ms = int(rng.integers(0, min(n, m // 3) + 1))
+        na = int(rng.integers(1, min(n, m - ms)))
+        q = O.generate_nasty(n, m, ms, na, eps, rng, n_dup=int(rng.integers(0, 5)), n_eq=int(rng.integers(0, 3)),
+                             n_soft=int(rng.integers(0, 3)), dep_eq=bool(rng.integers(0, 2)))
+        x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        r = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        ok = flag == r[3] and info["iterations"] == r[4]
+        if ok and flag > 0:
+            ok = bits_equal(x, r[0]) and bits_equal(info["lam"], r[1])
+        if not ok:
+            mism.append((trial, flag, r[3], info["iterations"], r[4]))
+    assert not mism, mism[:10]
+
+
+def test_warm_sequence(oracle, gpu_lib):
+    """config 5: setup + cold solve, then f <- f + 0.05 N(0,I): update(v) + solve reusing the LDL' on the device"""
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    N, T = 32, 5
+    q = O.generate_batch(N, n, m, ms, na, seed)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        models.append(om)
+    f = q["f"].copy()
+    warm_iters = []
+    for t in range(T + 1):
+        if t > 0:
+            for k in range(N):
+                f[k] = f[k] + 0.05 * np.random.default_rng([45, k, t - 1]).standard_normal(n)
+                assert models[k].update(O.UPDATE_v, f=f[k]) == 0
+            bm.update(f=f)
+        g = bm.solve()
+        for k in range(N):
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (t, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            assert bits_equal(g["x"][k], r[0]) and bits_equal(g["lam"][k], r[1])
+        if t > 0:
+            warm_iters.append(g["iter"].mean())
+    assert np.mean(warm_iters) < 15   # far fewer than the ~46 cold iterations
+    bm.close()
+
+
+def test_model_api(oracle, gpu_lib):
+    """reference python tests' Model flow (example_test.py:175-237): setup, solve, update f, update bounds"""
+    import daqp_amd
+    H, f = np.eye(2), np.array([2.0, 2.0])
+    A = np.zeros((0, 2))
+    d = daqp_amd.Model()
+    flag, _ = d.setup(H, f, A, np.ones(2), -np.ones(2), np.zeros(2, np.int32))
+    assert flag >= 0
+    x, fval, ef, info = d.solve()
+    assert ef == 1 and np.allclose(x, [-1, -1], atol=1e-6)
+    assert d.update(f=np.array([-2.0, -2.0])) == 0
+    x, _, ef, _ = d.solve()
+    assert ef == 1 and np.allclose(x, [1, 1], atol=1e-6)
+    d.update(bupper=np.array([0.5, 0.5]), blower=np.array([-0.5, -0.5]))
+    x, _, ef, _ = d.solve()
+    assert ef == 1 and np.allclose(x, [0.5, 0.5], atol=1e-6)
+
+
+def test_device_resident_io(oracle, gpu_lib):
+    """torch tensors already in HBM are used in place and results can stay on the device"""
+    import torch
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    N = 64
+    q = O.generate_batch(N, n, m, ms, na, seed, start=5000)
+    dev = {k: torch.from_numpy(q[k]).cuda() for k in ("H", "f", "A", "bupper", "blower")}
+    g = daqp_amd.solve_batch(dev["H"], dev["f"], dev["A"], dev["bupper"], dev["blower"], None, ms=ms, out="torch")
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert np.array_equal(g["iter"].cpu().numpy(), ref[4])
+    assert bits_equal(g["x"].cpu().numpy(), ref[0])

@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""bench.py -- QPs/sec (fp64) for batched random dense QPs n=50 m=150 on 1/2/4/8 MI355X.
+
+One "step" = the whole hot path (QP->LDP setup, dual active-set iteration, back-transform) over
+one batch of 100 000 synthetic QPs per GPU (config C2 of BASELINE.json / SURVEY.md section 8d),
+inputs already resident in HBM, results left in HBM.  One process per GPU; independent batches are
+sharded across ranks with no data-path collective (weak scaling); the only communication is the
+barrier + MAX of the elapsed time the contract asks for.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 2
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def algorithmic_bytes(n, m, ms, iters):
+    """per-QP  B = B_io + it * 8 (m-ms) n."""
+    mA = m - ms
+    b_in = 8 * (n * n + n + mA * n + 2 * m) + 4 * m
+    b_out = 8 * (n + m) + 8
+    stream = iters.astype(np.float64) * 8.0 * mA * n
+    return b_in, b_out, stream
+
+
+def cpu_baseline(q_host, ms, gpu_res):
+    """The same QPs solved one at a time by daqp_quadprog on ALL host cores: the reference library
+    itself (oracle/_ref, driven by oracle/ref_batch.c: one pthread per contiguous slice) when it
+    travelled with the repo, else this repo's C restatement built with the reference's flags."""
+    from oracle import oracle as O
+    S = q_host["f"].shape[0]
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    if O.reference_available():
+        kind = "reference"
+        dt, x, lam, fval, flag, it = O.timed_cpu_batch(os.path.join(O.HERE, "_ref", "libdaqp_ref.so"), cores,
+                                                       q_host["H"], q_host["f"], q_host["A"], q_host["bupper"],
+                                                       q_host["blower"], ms)
+    else:
+        kind = "port"
+        solver = O.Oracle(fast=True)
+        n, m = q_host["f"].shape[1], q_host["bupper"].shape[1]
+        x, lam = np.zeros((S, n)), np.zeros((S, m))
+        flag, it = np.zeros(S, np.int32), np.zeros(S, np.int32)
+
+        def work(lo, hi):   # one C call per slice; ctypes drops the GIL for its duration
+            r = solver.quadprog_batch(q_host["H"][lo:hi], q_host["f"][lo:hi], q_host["A"][lo:hi],
+                                      q_host["bupper"][lo:hi], q_host["blower"][lo:hi], None, ms=ms)
+            x[lo:hi], lam[lo:hi], flag[lo:hi], it[lo:hi] = r[0], r[1], r[3], r[4]
+
+        bounds = np.linspace(0, S, min(cores, S) + 1).astype(int)
+        th = [threading.Thread(target=work, args=(bounds[i], bounds[i + 1])) for i in range(len(bounds) - 1)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+    parity = dict(
+        sample=int(S),
+        identical_active_set=float(np.mean(np.all(np.sign(lam) == np.sign(gpu_res["lam"]), axis=1))),
+        identical_iter=float(np.mean(it == gpu_res["iter"])),
+        identical_exitflag=float(np.mean(flag == gpu_res["exitflag"])),
+        max_abs_dx=float(np.abs(x - gpu_res["x"]).max()),
+    )
+    return dict(value=S / dt, unit="QPs/s", cores=int(cores), kind=kind,
+                sample=f"first {S} QPs of the rank-0 batch, daqp_quadprog one QP at a time on {cores} host threads "
+                       f"({S * 1.0 / dt / cores:.0f} QPs/s per thread), wall {dt:.2f} s"), parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=100_000, help="QPs per GPU per step (config C2: 100k)")
+    ap.add_argument("--n", type=int, default=50)
+    ap.add_argument("--m", type=int, default=150)
+    ap.add_argument("--ms", type=int, default=0)
+    ap.add_argument("--n-active", type=int, default=20)
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="QPs for the CPU baseline (-1: auto, 0: skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import daqp_amd
+    from daqp_amd.synthetic import generate_batch_torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n, m, ms, N = args.n, args.m, args.ms, args.batch
+
+    # synthetic data of the reference's generator family; each rank owns an independent shard
+    q = generate_batch_torch(N, n, m, ms, args.n_active, seed=42 + 1000 * rank, device=f"cuda:{local_rank}")
+    bm = daqp_amd.BatchModel(N, n, m, ms, device=local_rank)
+    mask = daqp_amd.UPDATE_unconstrained | daqp_amd.UPDATE_eliminate   # daqp_quadprog semantics
+
+    def step():
+        bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=mask)
+        return bm.solve(out="torch")
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    sync()
+    setup_ms, solve_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        if rank == 0:
+            a, b = bm.kernel_ms()      # HIP events recorded on the launch stream around the kernels
+            setup_ms.append(a); solve_ms.append(b)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # whole-batch properties on every rank: optimal everywhere, analytic optimum reproduced
+    flags_ok = bool((res["exitflag"] == 1).all().item())
+    max_dx_analytic = float((res["x"] - q["xref"]).abs().max().item())
+    if rank == 0:
+        iters = res["iter"].cpu().numpy()
+        b_in, b_out, stream = algorithmic_bytes(n, m, ms, iters)
+        ldp_bytes = float(stream.sum() + b_out * N)          # what one k_ldp launch must move
+        all_bytes = float(stream.sum() + (b_in + b_out) * N)  # SURVEY 8(d) B summed over the batch
+        t_ldp = float(np.mean(solve_ms)) * 1e-3
+        t_setup = float(np.mean(setup_ms)) * 1e-3
+        ach = ldp_bytes / t_ldp / 1e9
+        out = {
+            "metric": "QPs/sec (fp64) for batched random dense QPs n=50 m=150",
+            "value": world * N * args.steps / elapsed, "unit": "QPs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C2: {N} random dense QPs per GPU, n={n} m={m} ms={ms}, {args.n_active} active at the "
+                                   "optimum, kappa=100 (reference generate_test_QP), daqp_quadprog semantics: setup + solve "
+                                   "per step, inputs and outputs resident in HBM", "batch_per_gpu": N,
+                       "mean_iterations": float(iters.mean()), "parallelism": f"independent shards x{world}, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_ldp (dual active-set iteration + back-transform)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_ms": t_ldp * 1e3,
+                         "algorithmic_bytes_per_launch": ldp_bytes,
+                         "pipeline": {"achieved": all_bytes / (t_ldp + t_setup) / 1e9, "frac": all_bytes / (t_ldp + t_setup) / 1e9 / HBM_PEAK_GBS,
+                                      "k_setup_ms": t_setup * 1e3, "k_ldp_ms": t_ldp * 1e3, "algorithmic_bytes_per_step": all_bytes}},
+            "checks": {"all_optimal": flags_ok, "max_abs_x_minus_analytic_optimum": max_dx_analytic},
+        }
+        sample = args.cpu_sample
+        if sample < 0:
+            sample = 0 if world > 1 else min(N, 65536)   # ~17 CPU-seconds of reference work at ~3.8k QPs/s/core
+        if sample > 0 and world == 1:
+            qh = {k: q[k][:sample].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}
+            gh = {k: res[k][:sample].cpu().numpy() for k in ("x", "lam", "iter", "exitflag")}
+            base, parity = cpu_baseline(qh, ms, gh)
+            out["cpu_baseline"] = base
+            out["parity_vs_cpu"] = parity
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    bm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,7 +48,8 @@ def build(force=False):
     need = force or not os.path.exists(os.path.join(HERE, "liboracle.so")) \
         or os.path.getmtime(os.path.join(HERE, "liboracle.so")) < os.path.getmtime(os.path.join(HERE, "daqp_oracle.c"))
     ref_missing = os.path.isdir("/root/reference/src") and not os.path.exists(os.path.join(HERE, "_ref", "libdaqp_ref.so"))
-    if need or ref_missing or not os.path.exists(os.path.join(HERE, "liboracle_fast.so")):
+    if need or ref_missing or not os.path.exists(os.path.join(HERE, "liboracle_fast.so")) \
+            or not os.path.exists(os.path.join(HERE, "librefbatch.so")):
         subprocess.check_call(["make", "-s", "-C", HERE, "all", os.path.join(HERE, "liboracle_fast.so")])
 
 
@@ -355,6 +356,25 @@ def generate_batch(N, n, m, ms, n_active, seed, kappa=100.0, start=0):
         out["H"][k], out["f"][k], out["A"][k] = q["H"], q["f"], q["A"]
         out["bupper"][k], out["blower"][k], out["xref"][k] = q["bupper"], q["blower"], q["x"]
     return out
+
+
+def timed_cpu_batch(libpath, threads, H, f, A, bupper, blower, ms=0):
+    """daqp_quadprog of `libpath` over a batch on `threads` host threads (oracle/ref_batch.c).
+    Returns (seconds, x, lam, fval, exitflag, iter)."""
+    build()
+    L = C.CDLL(os.path.join(HERE, "librefbatch.so"))
+    L.ref_batch_run.restype = C.c_double
+    L.ref_batch_run.argtypes = [C.c_char_p] + [C.c_int] * 5 + [c_double_p] * 8 + [c_int_p] * 2
+    H, f, A, bupper, blower = _f64(H), _f64(f), _f64(A), _f64(bupper), _f64(blower)
+    N, n = f.shape
+    m = bupper.shape[1]
+    x, lam, fval = np.zeros((N, n)), np.zeros((N, m)), np.zeros(N)
+    flag, it = np.zeros(N, np.int32), np.zeros(N, np.int32)
+    dt = L.ref_batch_run(libpath.encode(), threads, N, n, m, ms, _dp(H), _dp(f), _dp(A), _dp(bupper), _dp(blower),
+                         _dp(x), _dp(lam), _dp(fval), _ip(flag), _ip(it))
+    if dt < 0:
+        raise RuntimeError(f"could not load daqp_quadprog from {libpath}")
+    return dt, x, lam, fval, flag, it
 
 
 CONFIGS = {  # SURVEY.md section 8(d): name -> (n, m, ms, n_active, seed, full N)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIBPATH = os.path.join(LIBDIR, "libdaqp_amd.so")
-SOURCES = ["daqp_amd.hip", "kernels.hip.h", "wave_ldp.hip.h"]
+SOURCES = ["daqp_amd.hip", "kernels.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h", "setup_fast.hip.h"]
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -127,6 +127,8 @@ def lib():
     L.daqp_batch_enable_trace.argtypes = [vp, ci]
     L.daqp_batch_read_trace.argtypes = [vp, c_int_p]
     L.daqp_batch_read_ldp.argtypes = [vp, ci] + [c_double_p] * 6
+    L.daqp_batch_enable_profile.argtypes = [vp, ci]
+    L.daqp_batch_read_profile.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.daqp_quadprog.argtypes = [C.POINTER(DAQPResult), C.POINTER(DAQPProblem), C.POINTER(DAQPSettings)]
     L.daqp_quadprog.restype = None
     L.daqp_solve.argtypes = [C.POINTER(DAQPResult), vp]

@@ -290,6 +290,15 @@ class BatchModel:
         lib().daqp_batch_read_trace(self._h, _ip(t))
         return [t[q, : min(t[q, -1], self._trace_cap - 1)].copy() for q in range(self.N)]
 
+    def enable_profile(self, on=True):
+        lib().daqp_batch_enable_profile(self._h, 1 if on else 0)
+
+    def read_profile(self):
+        """(N, 8) int64 cycle sums per QP: csp, blocking test, primal, scan, add, remove, -, -"""
+        p = np.zeros((self.N, 8), np.int64)
+        lib().daqp_batch_read_profile(self._h, p.ctypes.data_as(C.POINTER(C.c_longlong)))
+        return p
+
     def read_ldp(self, q):
         n, m, ms = self.n, self.m, self.ms
         M, R, v = np.zeros((m - ms, n)), np.zeros(n * (n + 1) // 2), np.zeros(n)

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kernels.hip.h"
+#include "setup_fast.hip.h"
 
 using namespace daqp_amd;
 
@@ -61,8 +62,11 @@ struct DAQPBatch {
     // library-owned result buffers
     double *ox = nullptr, *olam = nullptr, *ofval = nullptr, *osoft = nullptr;
     int *oflag = nullptr, *oiter = nullptr;
+    DAQPSettings *st_dev = nullptr;
     int C = 1;
     bool spill = false;
+    int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
+    bool fast_setup = false;
     size_t lds_setup = 0, lds_ldp = 0, lds_update = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed_setup = false, timed_solve = false;
@@ -82,21 +86,44 @@ int dev_alloc(DAQPBatch *b, T **p, size_t count)
 }
 
 typedef void (*ldp_kernel_t)(BatchDev, int);
-ldp_kernel_t pick_ldp(int C, bool spill)
+// register-resident variants: (row blocks, k-pairs) held per lane; needs cap <= 64 and L/rows in LDS
+struct RegShape { int nb, np; };
+#ifdef DAQP_AMD_FEW_VARIANTS   // development builds: fewer instantiations, faster compile
+const RegShape kRegShapes[] = {{1, 8}, {3, 25}};
+#else
+const RegShape kRegShapes[] = {{1, 8}, {1, 16}, {2, 16}, {3, 25}, {2, 32}};
+#endif
+ldp_kernel_t pick_ldp(const DAQPBatch *b)
 {
-    if (!spill) {
-        if (C == 1) return k_ldp<1, false>;
-        if (C == 2) return k_ldp<2, false>;
-        return k_ldp<4, false>;
+    const int C = b->C;
+    const bool spill = b->spill;
+    if (b->NB > 0) {
+        if (b->NB == 1 && b->NP == 8) return k_ldp_reg<1, 8>;
+        if (b->NB == 3 && b->NP == 25) return k_ldp_reg<3, 25>;
+#ifndef DAQP_AMD_FEW_VARIANTS
+        if (b->NB == 1 && b->NP == 16) return k_ldp_reg<1, 16>;
+        if (b->NB == 2 && b->NP == 16) return k_ldp_reg<2, 16>;
+        if (b->NB == 2 && b->NP == 32) return k_ldp_reg<2, 32>;
+#endif
     }
-    if (C == 1) return k_ldp<1, true>;
-    if (C == 2) return k_ldp<2, true>;
-    return k_ldp<4, true>;
+#ifdef DAQP_AMD_FEW_VARIANTS
+    if (!spill) return k_ldp<4, false, 0, 0>;
+    return k_ldp<4, true, 0, 0>;
+#else
+    if (!spill) {
+        if (C == 1) return k_ldp<1, false, 0, 0>;
+        if (C == 2) return k_ldp<2, false, 0, 0>;
+        return k_ldp<4, false, 0, 0>;
+    }
+    if (C == 1) return k_ldp<1, true, 0, 0>;
+    if (C == 2) return k_ldp<2, true, 0, 0>;
+    return k_ldp<4, true, 0, 0>;
+#endif
 }
 
 int launch_ldp(DAQPBatch *b, int mode)
 {
-    ldp_kernel_t k = pick_ldp(b->C, b->spill);
+    ldp_kernel_t k = pick_ldp(b);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
     hipLaunchKernelGGL(k, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, b->d, mode);
     HIPCHK(hipGetLastError());
@@ -165,12 +192,19 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     d.ltri = cap * (cap + 1) / 2; d.rtri = n * (n + 1) / 2;
     if (settings) d.st = *settings; else default_settings(&d.st);
     b->C = cap <= 64 ? 1 : (cap <= 128 ? 2 : 4);
+#ifdef DAQP_AMD_FEW_VARIANTS
+    b->C = 4;
+#endif
     const char *env = getenv("DAQP_AMD_LDS_LIMIT");
     const int lds_limit = env ? atoi(env) : 80 * 1024;
     b->spill = ldp_lds(n, m, cap, false).total_bytes > lds_limit;
     if (getenv("DAQP_AMD_FORCE_SPILL")) b->spill = true;
+    if (!b->spill && cap <= 64 && !getenv("DAQP_AMD_STREAM_M"))
+        for (const RegShape &rs : kRegShapes)
+            if (d.nblk <= rs.nb && d.npair <= rs.np) { b->NB = rs.nb; b->NP = rs.np; break; }
     b->lds_ldp = (size_t)ldp_lds(n, m, cap, b->spill).total_bytes;
-    b->lds_setup = (size_t)setup_lds(n, m).total_bytes;
+    b->fast_setup = (n <= 64) && !getenv("DAQP_AMD_SLOW_SETUP");
+    b->lds_setup = b->fast_setup ? (size_t)fast_lds(n, m).total_bytes : (size_t)setup_lds(n, m).total_bytes;
     b->lds_update = (size_t)round_up(n, 2) * 16;
     if (b->lds_ldp > 160 * 1024 || b->lds_setup > 160 * 1024) {
         set_err("problem too large for the LDS-staged setup (needs %zu / %zu bytes)", b->lds_setup, b->lds_ldp);
@@ -198,6 +232,9 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &b->osoft, Nn);
     rc |= dev_alloc(b, &b->oflag, Nn);
     rc |= dev_alloc(b, &b->oiter, Nn);
+    rc |= dev_alloc(b, &b->st_dev, 1);
+    if (!rc && hipMemcpy(b->st_dev, &d.st, sizeof(DAQPSettings), hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+    d.st_dev = b->st_dev;
     if (rc) { daqp_batch_free(b); return DAQP_EXIT_UNSUPPORTED; }
     // padding rows/columns of the blocked M image are never written by the kernels: keep them defined
     if (hipMemset(d.Mblk, 0, Nn * d.nblk * d.npair * 128 * sizeof(double)) != hipSuccess ||
@@ -227,6 +264,8 @@ void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings)
 {
     if (!b) return;
     if (settings) b->d.st = *settings; else default_settings(&b->d.st);
+    (void)hipSetDevice(b->device);
+    (void)hipMemcpyAsync(b->st_dev, &b->d.st, sizeof(DAQPSettings), hipMemcpyHostToDevice, b->stream);
 }
 unsigned long long daqp_batch_device_bytes(const DAQPBatch *b) { return b ? b->bytes : 0; }
 
@@ -241,6 +280,27 @@ int daqp_batch_enable_trace(DAQPBatch *b, int cap)
     if (dev_alloc(b, &t, (size_t)b->d.N * cap)) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipMemset(t, 0, (size_t)b->d.N * cap * sizeof(int)));
     b->d.trace = t; b->d.trace_cap = cap;
+    return 0;
+}
+// debugging aid: per-problem cycle counters of the solve kernel's phases (8 x int64 per problem:
+// csp, blocking test, primal, scan, add, remove, -, -).  on=0 switches it off.
+int daqp_batch_enable_profile(DAQPBatch *b, int on)
+{
+    if (!b) return DAQP_EXIT_UNSUPPORTED;
+    (void)hipSetDevice(b->device);
+    if (!on) { b->d.prof = nullptr; return 0; }
+    long long *p = nullptr;
+    if (dev_alloc(b, &p, (size_t)b->d.N * 8)) return DAQP_EXIT_UNSUPPORTED;
+    HIPCHK(hipMemset(p, 0, (size_t)b->d.N * 8 * sizeof(long long)));
+    b->d.prof = p;
+    return 0;
+}
+int daqp_batch_read_profile(DAQPBatch *b, long long *host)
+{
+    if (!b || !b->d.prof) return DAQP_EXIT_UNSUPPORTED;
+    (void)hipSetDevice(b->device);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(host, b->d.prof, (size_t)b->d.N * 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 int daqp_batch_read_trace(DAQPBatch *b, int *host)
@@ -294,9 +354,12 @@ int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
     rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &d.sense_in);
     if (rc) return DAQP_EXIT_UNSUPPORTED;
     const int mask = init_mask | DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_setup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_setup));
+    typedef void (*setup_kernel_t)(BatchDev, int);
+    setup_kernel_t ks = k_setup;
+    if (b->fast_setup) ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : k_setup_fast<64>);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_setup));
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
-    hipLaunchKernelGGL(k_setup, dim3(d.N), dim3(64), b->lds_setup, b->stream, d, mask);
+    hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), b->lds_setup, b->stream, d, mask);
     HIPCHK(hipGetLastError());
     // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
     if (p->sense != nullptr || true) { rc = launch_ldp(b, 1); if (rc) return rc; }

@@ -5,6 +5,7 @@
 //   k_ldp     solve            (reference daqp_solve: daqp_ldp, ldp2qp_solution, daqp_extract_result)
 #pragma once
 #include "wave_ldp.hip.h"
+#include "wave_ldp_reg.hip.h"
 
 namespace daqp_amd {
 
@@ -32,6 +33,8 @@ struct BatchDev {
     int *exitflag, *iter;
     // debugging
     int *trace; int trace_cap;
+    long long *prof;   // [N][8] phase cycle sums, or NULL
+    const DAQPSettings *st_dev;   // device copy of st (scalar-load friendly)
     DAQPSettings st;
 };
 
@@ -63,7 +66,7 @@ __host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill)
     s.L = o; if (!spill) o += round_up(cap * (cap + 1) / 2, 2);
     s.rowc = o; if (!spill) o += round_up(cap * ldr, 2);
     s.D = o; o += cp; s.xl = o; o += cp; s.zl = o; o += cp; s.lamA = o; o += cp; s.lamB = o; o += cp;
-    s.u = o; o += round_up(n, 2) + 2;
+    s.u = o; o += round_up(n > 64 ? n : 64, 2) + 2;   // zero-padded to 64 for the register-resident scan
     s.pend_lam = o; o += cp;
     s.dbl = o;                       // ints start at double offset s.dbl
     int oi = 0;
@@ -409,7 +412,9 @@ __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
 // k_ldp: mode 0 = daqp_solve, mode 1 = only (re)build the working set from the ACTIVE bits
 // (the tail of daqp_update_ldp, utils.c:199-211)
 // ------------------------------------------------------------------------------------
-template <int C, bool SPILL>
+// LDS (L + active-row cache) already limits residency to one wave per SIMD, so the register
+// variants may take the whole unified 512-entry VGPR/AGPR file: waves_per_eu(1, NB > 0 ? 1 : 8)
+template <int C, bool SPILL, int NB, int NP>
 __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -424,7 +429,10 @@ __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
     }
     const LdpLds o = ldp_lds(n, m, cap, SPILL);
     int *ibase = reinterpret_cast<int *>(smem + o.dbl);
-    Wave<C> w;
+    Wave<C, NB, NP> w;
+    w.profiling = (b.prof != nullptr) && mode == 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w.prof[i] = 0;
     w.n = n; w.m = m; w.ms = b.ms; w.cap = cap; w.npair = b.npair; w.nblk = b.nblk; w.ldr = b.ldr;
     if (SPILL) {
         w.L = b.L + (size_t)q * b.ltri;
@@ -465,7 +473,17 @@ __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
             const double *gL = b.L + (size_t)q * b.ltri;
             for (int e = lane; e < used; e += 64) w.L[e] = gL[e];
         }
-        for (int e = lane; e < round_up(n, 2) + 2; e += 64) w.u[e] = 0;
+        for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) w.u[e] = 0;
+        if constexpr (NB > 0) {   // the QP's whole constraint matrix -> registers (read once from HBM)
+            const double2 *src = reinterpret_cast<const double2 *>(w.Mblk);
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+                for (int t = 0; t < NP; ++t) {
+                    double2 z; z.x = 0; z.y = 0;
+                    w.Mr[bb][t] = (bb < b.nblk && t < b.npair) ? src[((size_t)bb * b.npair + t) * 64 + lane] : z;
+                }
+        }
         WSYNC();
         for (int i = 0; i < w.na; ++i) fetch_row(w, w.ws[i], i);   // rebuild the active-row cache
     }
@@ -550,6 +568,182 @@ __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
         qs->lam_swapped = (w.lam == lamB) ? 1 : 0;
         qs->fval = w.fval; qs->soft_slack = w.soft;
         if (b.trace) b.trace[(size_t)q * b.trace_cap + b.trace_cap - 1] = w.trace_len;
+        if (w.profiling)
+            for (int i = 0; i < 8; ++i) b.prof[(size_t)q * 8 + i] = w.prof[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_ldp_reg: the register-centric solve kernel (wave_ldp_reg.hip.h) for n + n_soft + 1 <= 64 and
+// m <= 64*NB, n <= 2*NP.  Same global state layout as k_ldp, so the two are interchangeable.
+// ------------------------------------------------------------------------------------
+template <int NB, int NP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ldp_reg(BatchDev b, int mode)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int q = blockIdx.x, lane = lane_id();
+    const int n = b.n, m = b.m, cap = b.cap;
+    QState *qs = b.qs + q;
+    const int sflag = qs->setup_flag;
+    if (mode == 1) { if (sflag < 0 || !qs->need_activate) return; }
+    if (sflag < 0) {
+        if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
+        return;
+    }
+    const LdpLds o = ldp_lds(n, m, cap, false);
+    int *ibase = reinterpret_cast<int *>(smem + o.dbl);
+    RWave<NB, NP> w;
+    // phase counters live in the (otherwise unused) D/xl slots of the LDS carve-up
+    w.prof = ((b.prof != nullptr) && mode == 0) ? reinterpret_cast<long long *>(smem + o.D) : nullptr;
+    if (w.prof && lane < 8) w.prof[lane] = 0;
+    w.n = n; w.m = m; w.ms = b.ms; w.ldr = b.ldr;
+    w.L = smem + o.L; w.rowc = smem + o.rowc; w.u = smem + o.u; w.pend_lam = smem + o.pend_lam;
+    w.pend_id = ibase + o.pend_id;
+    w.stp = b.st_dev;
+    w.dual_tol = b.st.dual_tol; w.sing_tol = b.st.sing_tol; w.pivot_tol = b.st.pivot_tol; w.rho_soft = b.st.rho_soft;
+    w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
+    w.trace_cap = b.trace_cap; w.trace_len = 0;
+    w.na = qs->n_active; w.reuse = qs->reuse_ind; w.sing = qs->sing_ind;
+    w.fval = qs->fval; w.soft = qs->soft_slack;
+    const int swapped = qs->lam_swapped;
+    const double *gdu = b.dupper + (size_t)q * m, *gdl = b.dlower + (size_t)q * m, *gsc = b.scaling + (size_t)q * m;
+    int *gsense = b.sense + (size_t)q * m;
+    double *gv = b.vecs + (size_t)q * 5 * cap;
+    int *gws = b.WS + (size_t)q * cap;
+
+    if (w.sing == DAQP_UNCONSTRAINED_OPTIMAL && mode == 0) {   // api.c:40-45
+        const double *xu = b.xunc + (size_t)q * n, *vq = b.v + (size_t)q * n;
+        if (b.x) for (int i = lane; i < n; i += 64) b.x[(size_t)q * n + i] = xu[i];
+        if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = 0;
+        double fv = 0;
+        for (int i = 0; i < n; ++i) { const double vi = vq[i]; fv -= vi * vi; }
+        fv *= 0.5;
+        if (lane == 0) {
+            b.exitflag[q] = DAQP_EXIT_OPTIMAL; b.iter[q] = 1;
+            if (b.fval) b.fval[q] = fv;
+            if (b.soft) b.soft[q] = 0;
+            qs->iterations = 1; qs->fval = 0; qs->soft_slack = 0; qs->exitflag = DAQP_EXIT_OPTIMAL;
+        }
+        return;
+    }
+    // ---- row view: bounds, tolerance, sense and the rows of M themselves -> registers
+    const double ep = -w.stp->primal_tol;
+    int softbits = 0;
+    w.rs = 0;
+    const double2 *msrc = reinterpret_cast<const double2 *>(b.Mblk + (size_t)q * b.nblk * b.npair * 128);
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+        const int r = bb * 64 + lane;
+        const bool ok = r < m;
+        w.du[bb] = ok ? gdu[r] : 0.0;
+        w.dl[bb] = ok ? gdl[r] : 0.0;
+        w.bnd[bb] = ok ? ep * gsc[r] : 0.0;
+        const int sn = ok ? (gsense[r] & 0xff) : 0;
+        w.rs |= (unsigned)sn << (8 * bb);
+        softbits |= sn & DAQP_SOFT;
+        static_for<NP>([&](auto t) __attribute__((always_inline)) {
+            double vx = 0, vy = 0;
+            if (bb < b.nblk && t < b.npair) {
+                const double2 v = msrc[((size_t)bb * b.npair + t) * 64 + lane];
+                vx = v.x; vy = v.y;
+            }
+            w.Mx[bb][t] = vx; w.My[bb][t] = vy;
+            if constexpr ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 8 loads (32 VGPRs) in flight
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    w.has_soft = __any(softbits) ? 1 : 0;
+    // ---- working-set view
+    const bool act = lane < w.na;
+    w.wsid = act ? gws[lane] : 0;
+    w.slot = lane;
+    w.slotmask = (w.na >= 64) ? ~0ull : ((1ull << w.na) - 1ull);
+    w.D = (lane < cap) ? gv[lane] : 0.0;
+    w.xl = (lane < cap) ? gv[cap + lane] : 0.0;
+    w.zl = (lane < cap) ? gv[2 * cap + lane] : 0.0;
+    const double la = (lane < cap) ? gv[3 * cap + lane] : 0.0, lb = (lane < cap) ? gv[4 * cap + lane] : 0.0;
+    w.lam = swapped ? lb : la;
+    w.lams = swapped ? la : lb;
+    w.wflag = act ? gsense[w.wsid] : 0;
+    w.drhs = act ? -((w.wflag & DAQP_LOWER) ? gdl[w.wsid] : gdu[w.wsid]) : 0.0;
+    {
+        const int used = tri(w.na);
+        const double *gL = b.L + (size_t)q * b.ltri;
+        for (int e = lane; e < used; e += 64) w.L[e] = gL[e];
+        for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) w.u[e] = 0;
+    }
+    WSYNC();
+    for (int i = 0; i < w.na; ++i) {   // warm start: rebuild the active-row cache from the blocked HBM image
+        const int id = rli(w.wsid, i);
+        const double2 *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63);
+        double *dst = w.rowc + (size_t)i * w.ldr;
+        for (int t = lane; t < b.npair; t += 64) {
+            const double2 v = src[(size_t)t * 64];
+            dst[2 * t] = v.x;
+            if (2 * t + 1 < n) dst[2 * t + 1] = v.y;
+        }
+    }
+    WSYNC();
+
+    int iters = 0;
+    int flag = rrun(w, mode, qs->need_activate != 0, iters);
+    if (mode == 1) {
+        if (lane == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
+    } else {
+        const double *Rq = b.Rinv + (size_t)q * b.rtri, *vq = b.v + (size_t)q * n;
+        if (flag > 0) {   // ldp2qp_solution (daqp.c:111-139)
+            if (lane < n) w.u[lane] = w.u[lane] - vq[lane];
+            WSYNC();
+            if (lane < n) {
+                const double *row = Rq + roff(lane, n);
+                double xi = w.u[lane] * row[lane];
+                for (int j0 = lane + 1; j0 < n; j0 += kChunk) {
+                    double rr[kChunk];
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) rr[k] = (j0 + k < n) ? row[j0 + k] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) if (j0 + k < n) xi += rr[k] * w.u[j0 + k];
+                }
+                if (lane < b.ms) xi /= gsc[lane];
+                if (b.x) b.x[(size_t)q * n + lane] = xi;
+            }
+            if (lane < w.na) w.lams *= gsc[w.wsid];
+        } else if (b.x) {
+            if (lane < n) b.x[(size_t)q * n + lane] = w.u[lane];
+        }
+        if (b.lam) {   // daqp_extract_result (api.c:455-495)
+            for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = 0;
+            WSYNC();
+            if (lane < w.na) b.lam[(size_t)q * m + w.wsid] = w.lams;
+        }
+        double fv = w.fval;
+        for (int i = 0; i < n; ++i) { const double vi = vq[i]; fv -= vi * vi; }
+        fv *= 0.5;
+        if (lane == 0) {
+            b.exitflag[q] = flag; b.iter[q] = iters;
+            if (b.fval) b.fval[q] = fv;
+            if (b.soft) b.soft[q] = w.soft;
+            qs->iterations = iters; qs->exitflag = flag; qs->need_activate = 0;
+        }
+    }
+    // ---- store the persistent iterate (lam in buffer A, lam* in buffer B)
+    if (lane < cap) {
+        gv[lane] = w.D; gv[cap + lane] = w.xl; gv[2 * cap + lane] = w.zl;
+        gv[3 * cap + lane] = w.lam; gv[4 * cap + lane] = w.lams;
+        gws[lane] = (lane < w.na) ? w.wsid : -1;
+    }
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) { const int r = bb * 64 + lane; if (r < m) gsense[r] = rsense_get(w, bb); });
+    {
+        const int used = tri(w.na);
+        double *gL = b.L + (size_t)q * b.ltri;
+        for (int e = lane; e < used; e += 64) gL[e] = w.L[e];
+    }
+    if (lane == 0) {
+        qs->n_active = w.na; qs->reuse_ind = w.reuse; qs->sing_ind = w.sing;
+        qs->lam_swapped = 0;
+        qs->fval = w.fval; qs->soft_slack = w.soft;
+        if (b.trace) b.trace[(size_t)q * b.trace_cap + b.trace_cap - 1] = w.trace_len;
+        if (w.prof)
+            for (int i = 0; i < 8; ++i) b.prof[(size_t)q * 8 + i] = w.prof[i];
     }
 }
 

@@ -21,7 +21,11 @@ namespace daqp_amd {
 constexpr int kEmpty = DAQP_EMPTY_IND;
 constexpr int kBig = 0x7fffffff;
 
-#define WSYNC() __syncthreads()
+// One wavefront per workgroup: the LDS executes a wave's instructions in issue order, so a
+// cross-lane write -> read hand-off needs no s_waitcnt/s_barrier, only that the COMPILER keeps
+// the program order of the two LDS instructions (it reasons per thread and may otherwise swap a
+// store to a[tid] with a load of a[tid+1]).  A wavefront-scope fence is exactly that.
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 __device__ __forceinline__ int tri(int k) { return (k * (k + 1)) >> 1; }
 __device__ __forceinline__ int roff(int i, int n) { return ((2 * n - i - 1) * i) / 2; }
@@ -92,7 +96,7 @@ struct QState {   // per-problem scalars kept in HBM between launches
 
 // One wave's view of one LDP.  L and rowc are LDS (or HBM scratch when spilled); the small
 // vectors are always LDS; M and the bounds are read-only HBM.
-template <int C>
+template <int C, int NB, int NP>
 struct Wave {
     // sizes
     int n, m, ms, cap, npair, nblk, ldr;
@@ -109,10 +113,19 @@ struct Wave {
     DAQPSettings st;
     // optional event trace (+id+1 add, -(id+1) remove)
     int *trace; int trace_cap, trace_len;
+    // the whole constraint matrix of this QP, register-resident (NB row blocks x NP k-pairs per
+    // lane; NB == 0: streamed from HBM instead).  Padding pairs/rows are zero.
+    double2 Mr[NB > 0 ? NB : 1][NP > 0 ? NP : 1];
+    // optional phase cycle counters (s_memtime): csp, blocking, primal, scan, add, remove, other
+    long long prof[8];
+    bool profiling;
 };
 
-template <int C>
-__device__ __forceinline__ void trace_ev(Wave<C> &w, int ev)
+#define PROF_T0(w) long long prof_t0_ = (w).profiling ? (long long)__builtin_readcyclecounter() : 0
+#define PROF_ACC(w, slot) do { if ((w).profiling) { const long long t1_ = (long long)__builtin_readcyclecounter(); (w).prof[slot] += t1_ - prof_t0_; prof_t0_ = t1_; } } while (0)
+
+template <int C, int NB, int NP>
+__device__ __forceinline__ void trace_ev(Wave<C, NB, NP> &w, int ev)
 {
     if (w.trace) {
         if (lane_id() == 0 && w.trace_len < w.trace_cap) w.trace[w.trace_len] = ev;
@@ -120,18 +133,34 @@ __device__ __forceinline__ void trace_ev(Wave<C> &w, int ev)
     }
 }
 
-// rowc[slot][0..n) <- row `id` of the LDP constraint matrix (HBM, blocked layout
-// [row/64][k/2][row%64][k%2]); simple-bound rows are stored densely with a zero prefix
-template <int C>
-__device__ __forceinline__ void fetch_row(Wave<C> &w, int id, int slot)
+// rowc[slot][0..n) <- row `id` of the LDP constraint matrix.  Register-resident M: the owning
+// lane (id & 63) writes its registers to LDS; streamed M: gather from the blocked HBM layout
+// [row/64][k/2][row%64][k%2].  Simple-bound rows are stored densely with a zero prefix.
+template <int C, int NB, int NP>
+__device__ __forceinline__ void fetch_row(Wave<C, NB, NP> &w, int id, int slot)
 {
     const int lane = lane_id();
-    const double2 *src = reinterpret_cast<const double2 *>(w.Mblk) + ((size_t)(id >> 6) * w.npair) * 64 + (id & 63);
     double *dst = w.rowc + (size_t)slot * w.ldr;
-    for (int t = lane; t < w.npair; t += 64) {
-        const double2 v = src[(size_t)t * 64];
-        dst[2 * t] = v.x;
-        if (2 * t + 1 < w.n) dst[2 * t + 1] = v.y;
+    if constexpr (NB > 0) {
+        // uniform branch per row block: the owning lane stores its registers straight to LDS
+        const int b = id >> 6, l = id & 63;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            if (b == bb && lane == l) {
+#pragma unroll
+                for (int t = 0; t < NP; ++t) {
+                    if (2 * t < w.n) dst[2 * t] = w.Mr[bb][t].x;
+                    if (2 * t + 1 < w.n) dst[2 * t + 1] = w.Mr[bb][t].y;
+                }
+            }
+        }
+    } else {
+        const double2 *src = reinterpret_cast<const double2 *>(w.Mblk) + ((size_t)(id >> 6) * w.npair) * 64 + (id & 63);
+        for (int t = lane; t < w.npair; t += 64) {
+            const double2 v = src[(size_t)t * 64];
+            dst[2 * t] = v.x;
+            if (2 * t + 1 < w.n) dst[2 * t + 1] = v.y;
+        }
     }
     WSYNC();
 }
@@ -155,8 +184,8 @@ __device__ __forceinline__ double dot4(const double *a, const double *b, int len
 // LDL' row append (factorization.c:21-111): Gram column by lane<->active row, forward
 // substitution column by column, ordered Schur complement
 // ---------------------------------------------------------------------------------------
-template <int C>
-__device__ __forceinline__ void ldl_append(Wave<C> &w, int id)
+template <int C, int NB, int NP>
+__device__ __forceinline__ void ldl_append(Wave<C, NB, NP> &w, int id)
 {
     const int lane = lane_id(), na = w.na, n = w.n, base = tri(na);
     fetch_row(w, id, na);
@@ -220,8 +249,8 @@ __device__ __forceinline__ void ldl_append(Wave<C> &w, int id)
 // LDL' row delete (factorization.c:112-151): staged compaction of packed L, then the
 // Gill-Golub-Murray-Saunders C1 rank-one update with lane<->trailing row
 // ---------------------------------------------------------------------------------------
-template <int C>
-__device__ __forceinline__ void ldl_delete(Wave<C> &w, int r)
+template <int C, int NB, int NP>
+__device__ __forceinline__ void ldl_delete(Wave<C, NB, NP> &w, int r)
 {
     const int lane = lane_id(), na = w.na;
     if (na == r + 1) return;
@@ -282,8 +311,8 @@ __device__ __forceinline__ void ldl_delete(Wave<C> &w, int r)
 }
 
 // auxiliary.c:3-22 without the trailing pivot; returns 1 if the factor became singular
-template <int C>
-__device__ __forceinline__ int drop_core(Wave<C> &w, int r)
+template <int C, int NB, int NP>
+__device__ __forceinline__ int drop_core(Wave<C, NB, NP> &w, int r)
 {
     const int lane = lane_id();
     const int idr = w.ws[r];
@@ -324,8 +353,8 @@ __device__ __forceinline__ int drop_core(Wave<C> &w, int r)
     return took;
 }
 
-template <int C>
-__device__ __forceinline__ void push_core(Wave<C> &w, int id, double lamv) // auxiliary.c:27-40
+template <int C, int NB, int NP>
+__device__ __forceinline__ void push_core(Wave<C, NB, NP> &w, int id, double lamv) // auxiliary.c:27-40
 {
     const int lane = lane_id();
     trace_ev(w, id + 1);
@@ -339,8 +368,8 @@ __device__ __forceinline__ void push_core(Wave<C> &w, int id, double lamv) // au
 
 // daqp_pivot_last (auxiliary.c:379-396): its recursion through remove/add_constraint becomes
 // an explicit stack (in LDS) of constraints waiting to be re-inserted
-template <int C>
-__device__ __forceinline__ void pivot_tail(Wave<C> &w)
+template <int C, int NB, int NP>
+__device__ __forceinline__ void pivot_tail(Wave<C, NB, NP> &w)
 {
     const int lane = lane_id();
     int depth = 0;
@@ -367,13 +396,13 @@ __device__ __forceinline__ void pivot_tail(Wave<C> &w)
     }
 }
 
-template <int C>
-__device__ __forceinline__ void remove_constraint(Wave<C> &w, int r)
+template <int C, int NB, int NP>
+__device__ __forceinline__ void remove_constraint(Wave<C, NB, NP> &w, int r)
 {
     if (!drop_core(w, r)) pivot_tail(w);
 }
-template <int C>
-__device__ __forceinline__ void add_constraint(Wave<C> &w, int id, double lamv)
+template <int C, int NB, int NP>
+__device__ __forceinline__ void add_constraint(Wave<C, NB, NP> &w, int id, double lamv)
 {
     push_core(w, id, lamv);
     pivot_tail(w);
@@ -382,8 +411,8 @@ __device__ __forceinline__ void add_constraint(Wave<C> &w, int id, double lamv)
 // ---------------------------------------------------------------------------------------
 // constrained stationary point: L D L' lam* = -d_k  (auxiliary.c:314-354)
 // ---------------------------------------------------------------------------------------
-template <int C>
-__device__ __forceinline__ void forward_rows(Wave<C> &w, double (&acc)[C], int from)
+template <int C, int NB, int NP>
+__device__ __forceinline__ void forward_rows(Wave<C, NB, NP> &w, double (&acc)[C], int from)
 {
     // acc[c] holds the right-hand side of rows >= from; rows < from are final in xl
     const int lane = lane_id(), na = w.na;
@@ -405,8 +434,8 @@ __device__ __forceinline__ void forward_rows(Wave<C> &w, double (&acc)[C], int f
     }
 }
 // b <- L' \ b for the leading `cnt` rows; multiplication order as the reference: b_j * L[j][i]
-template <int C>
-__device__ __forceinline__ void backward_rows(Wave<C> &w, double (&b)[C], int cnt)
+template <int C, int NB, int NP>
+__device__ __forceinline__ void backward_rows(Wave<C, NB, NP> &w, double (&b)[C], int cnt)
 {
     const int lane = lane_id();
     for (int j = cnt - 1; j >= 1; --j) {
@@ -420,8 +449,8 @@ __device__ __forceinline__ void backward_rows(Wave<C> &w, double (&b)[C], int cn
     }
 }
 
-template <int C>
-__device__ __forceinline__ void solve_csp(Wave<C> &w)
+template <int C, int NB, int NP>
+__device__ __forceinline__ void solve_csp(Wave<C, NB, NP> &w)
 {
     const int lane = lane_id(), na = w.na, from = w.reuse;
     double acc[C];
@@ -458,8 +487,8 @@ __device__ __forceinline__ void solve_csp(Wave<C> &w)
     WSYNC();
 }
 
-template <int C>
-__device__ __forceinline__ void singular_direction(Wave<C> &w) // auxiliary.c:357-376
+template <int C, int NB, int NP>
+__device__ __forceinline__ void singular_direction(Wave<C, NB, NP> &w) // auxiliary.c:357-376
 {
     const int lane = lane_id(), s = w.sing, base = tri(s);
     double b[C];
@@ -482,8 +511,8 @@ __device__ __forceinline__ void singular_direction(Wave<C> &w) // auxiliary.c:35
 }
 
 // auxiliary.c:277-311 (SOFT_WEIGHTS off): ratio test over the working set, drop the argmin
-template <int C>
-__device__ __forceinline__ int remove_blocking(Wave<C> &w)
+template <int C, int NB, int NP>
+__device__ __forceinline__ int remove_blocking(Wave<C, NB, NP> &w)
 {
     const int lane = lane_id(), na = w.na;
     const double dtol = w.st.dual_tol;
@@ -523,8 +552,8 @@ __device__ __forceinline__ int remove_blocking(Wave<C> &w)
 
 // u = -M_k' lam*, fval = rho*sum_soft lam*^2 + |u|^2 (auxiliary.c:46-88); every sum is in
 // the reference's order: over the working set for u, over j for |u|^2
-template <int C>
-__device__ __forceinline__ void primal_u(Wave<C> &w)
+template <int C, int NB, int NP>
+__device__ __forceinline__ void primal_u(Wave<C, NB, NP> &w)
 {
     const int lane = lane_id(), na = w.na, n = w.n;
     double uu[C];
@@ -553,8 +582,8 @@ __device__ __forceinline__ void primal_u(Wave<C> &w)
     w.soft = fv;
     WSYNC();
 }
-template <int C>
-__device__ __forceinline__ double ordered_norm2(Wave<C> &w, double start)
+template <int C, int NB, int NP>
+__device__ __forceinline__ double ordered_norm2(Wave<C, NB, NP> &w, double start)
 {
     double fv = start;
     for (int j = 0; j < w.n; ++j) { const double uj = w.u[j]; fv += uj * uj; }
@@ -562,59 +591,92 @@ __device__ __forceinline__ double ordered_norm2(Wave<C> &w, double start)
 }
 
 // feasibility scan + most-violated pick (auxiliary.c:89-198).  Returns the row (or kBig) and
-// sets `upper`.  When `with_fval`, |u|^2 is accumulated in the first row block's k loop.
-template <int C>
-__device__ __forceinline__ int scan_rows(Wave<C> &w, int &upper, bool with_fval)
+// sets `upper`.  When `with_fval`, |u|^2 (j-ordered) is accumulated alongside.
+template <int C, int NB, int NP>
+__device__ __forceinline__ int scan_rows(Wave<C, NB, NP> &w, int &upper, bool with_fval)
 {
     const int lane = lane_id(), n = w.n;
     const double ep = -w.st.primal_tol;
     double bv = 0.0;
     int bi = kBig, bup = 0;
     double fv = w.soft;
-    const bool odd = (n & 1) != 0;
     const double2 *u2 = reinterpret_cast<const double2 *>(w.u);
-    for (int blk = 0; blk < w.nblk; ++blk) {
-        const int r = blk * 64 + lane;
-        const double2 *src = reinterpret_cast<const double2 *>(w.Mblk) + ((size_t)blk * w.npair) * 64 + lane;
-        double mu = 0;
-        const int full = odd ? w.npair - 1 : w.npair;
-        if (r < w.m) {
-#pragma unroll 5
-            for (int t = 0; t < full; ++t) {
-                const double2 mm = src[(size_t)t * 64];
-                const double2 uk = u2[t];
-                mu += mm.x * uk.x;
-                mu += mm.y * uk.y;
+    if constexpr (NB > 0) {
+        // M is in registers: NB independent k-ordered chains per lane, u broadcast from LDS.
+        // Zero padding (pairs >= npair, u beyond n) adds +0.0 and leaves every sum unchanged.
+        double mu[NB];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) mu[bb] = 0;
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
+            const double2 uk = u2[t];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                mu[bb] += w.Mr[bb][t].x * uk.x;
+                mu[bb] += w.Mr[bb][t].y * uk.y;
             }
-            if (odd) mu += src[(size_t)full * 64].x * w.u[n - 1];
+            if (with_fval) { fv += uk.x * uk.x; fv += uk.y * uk.y; }   // j-ordered |u|^2 (auxiliary.c:85-86)
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the LDS broadcasts from being hoisted en bloc
         }
-        if (with_fval && blk == 0) {
-            for (int j = 0; j < n; ++j) { const double uj = w.u[j]; fv += uj * uj; }
-        }
-        if (r < w.m) {
-            const int sn = w.sense[r];
-            if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
-                const double bound = ep * w.scaling[r];
-                double cand = w.dupper[r] - mu;
-                if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 1; }
-                else {
-                    cand = mu - w.dlower[r];
-                    if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 0; }
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            const int r = bb * 64 + lane;
+            if (r < w.m) {
+                const int sn = w.sense[r];
+                if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
+                    const double bound = ep * w.scaling[r];
+                    double cand = w.dupper[r] - mu[bb];
+                    if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 1; }
+                    else {
+                        cand = mu[bb] - w.dlower[r];
+                        if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 0; }
+                    }
                 }
             }
         }
+    } else {
+        const bool odd = (n & 1) != 0;
+        for (int blk = 0; blk < w.nblk; ++blk) {
+            const int r = blk * 64 + lane;
+            const double2 *src = reinterpret_cast<const double2 *>(w.Mblk) + ((size_t)blk * w.npair) * 64 + lane;
+            double mu = 0;
+            const int full = odd ? w.npair - 1 : w.npair;
+            if (r < w.m) {
+#pragma unroll 5
+                for (int t = 0; t < full; ++t) {
+                    const double2 mm = src[(size_t)t * 64];
+                    const double2 uk = u2[t];
+                    mu += mm.x * uk.x;
+                    mu += mm.y * uk.y;
+                }
+                if (odd) mu += src[(size_t)full * 64].x * w.u[n - 1];
+            }
+            if (with_fval && blk == 0) {
+                for (int j = 0; j < n; ++j) { const double uj = w.u[j]; fv += uj * uj; }
+            }
+            if (r < w.m) {
+                const int sn = w.sense[r];
+                if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
+                    const double bound = ep * w.scaling[r];
+                    double cand = w.dupper[r] - mu;
+                    if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 1; }
+                    else {
+                        cand = mu - w.dlower[r];
+                        if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 0; }
+                    }
+                }
+            }
+        }
+        if (with_fval && w.nblk == 0) fv = ordered_norm2(w, fv);
     }
-    if (with_fval) {
-        if (w.nblk == 0) fv = ordered_norm2(w, fv);
-        w.fval = fv;
-    }
+    if (with_fval) w.fval = fv;
     wave_argmin(bv, bi, bup);
     upper = bup;
     return bi;
 }
 
-template <int C>
-__device__ __forceinline__ void commit_add(Wave<C> &w, int pick, int upper) // auxiliary.c:152-166
+template <int C, int NB, int NP>
+__device__ __forceinline__ void commit_add(Wave<C, NB, NP> &w, int pick, int upper) // auxiliary.c:152-166
 {
     if (lane_id() == 0) {
         if (upper) w.sense[pick] &= ~DAQP_LOWER; else w.sense[pick] |= DAQP_LOWER;
@@ -625,8 +687,8 @@ __device__ __forceinline__ void commit_add(Wave<C> &w, int pick, int upper) // a
 }
 
 // one step of iterative refinement on the active rows (auxiliary.c:498-593)
-template <int C>
-__device__ __forceinline__ void refine_active(Wave<C> &w)
+template <int C, int NB, int NP>
+__device__ __forceinline__ void refine_active(Wave<C, NB, NP> &w)
 {
     const int lane = lane_id(), na = w.na, n = w.n;
     w.reuse = 0;
@@ -682,8 +744,8 @@ __device__ __forceinline__ void refine_active(Wave<C> &w)
 }
 
 // (re)build the working set from the ACTIVE bits, in index order (auxiliary.c:399-479)
-template <int C>
-__device__ __forceinline__ int activate_marked(Wave<C> &w)
+template <int C, int NB, int NP>
+__device__ __forceinline__ int activate_marked(Wave<C, NB, NP> &w)
 {
     const int lane = lane_id();
     for (int blk = 0; blk * 64 < w.m; ++blk) {
@@ -733,26 +795,32 @@ __device__ __forceinline__ int activate_marked(Wave<C> &w)
     return 1;
 }
 
-template <int C>
-__device__ __forceinline__ void reset_ws(Wave<C> &w) { w.sing = kEmpty; w.na = 0; w.reuse = 0; }
+template <int C, int NB, int NP>
+__device__ __forceinline__ void reset_ws(Wave<C, NB, NP> &w) { w.sing = kEmpty; w.na = 0; w.reuse = 0; }
 
 // ---------------------------------------------------------------------------------------
 // daqp_ldp (daqp.c:6-108)
 // ---------------------------------------------------------------------------------------
-template <int C>
-__device__ __forceinline__ int ldp_loop(Wave<C> &w, int &iterations)
+template <int C, int NB, int NP>
+__device__ __forceinline__ int ldp_loop(Wave<C, NB, NP> &w, int &iterations)
 {
     const int lane = lane_id();
     int flag = DAQP_EXIT_ITERLIMIT, it, repaired = 0, stall = 0;
     double best = -1;
     const double fbound = 2 * w.st.fval_bound;
     for (it = 1; it < w.st.iter_limit; ++it) {
+        PROF_T0(w);
         if (w.sing == kEmpty) {
             solve_csp(w);
-            if (remove_blocking(w)) continue;
+            PROF_ACC(w, 0);
+            const int blocked = remove_blocking(w);
+            if (blocked) PROF_ACC(w, 5); else PROF_ACC(w, 1);
+            if (blocked) continue;
             primal_u(w);
+            PROF_ACC(w, 2);
             int upper = 0;
             int pick = scan_rows(w, upper, true);
+            PROF_ACC(w, 3);
             if (w.fval > fbound) { flag = DAQP_EXIT_INFEASIBLE; break; }
             if (pick == kBig) {
                 double dmin = w.D[0];
@@ -777,6 +845,7 @@ __device__ __forceinline__ int ldp_loop(Wave<C> &w, int &iterations)
                 break;
             }
             commit_add(w, pick, upper);
+            PROF_ACC(w, 4);
             if (w.fval - best < w.st.progress_tol) {
                 if (stall++ > w.st.cycle_tol) {
                     if (repaired == 1) { flag = DAQP_EXIT_CYCLE; break; }

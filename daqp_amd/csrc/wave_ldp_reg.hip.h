@@ -1,0 +1,731 @@
+// wave_ldp_reg.hip.h -- register-centric variant of the one-wavefront LDP iteration, for
+// working sets of at most 64 rows (n + n_soft + 1 <= 64).  Same algorithm and the same
+// floating-point operation order as wave_ldp.hip.h (reference src/daqp.c, src/auxiliary.c,
+// src/factorization.c); what changes is where the state lives:
+//
+//   lane i  <-> position i of the working set : constraint id, row-cache slot, sense flags,
+//               lam, lam*, D_i, x_i/z_i of the LDL' solve, right-hand side  -- all VGPRs
+//   lane r  <-> constraint rows r, r+64, ...  : the rows of M themselves (NB x NP double2),
+//               d_upper, d_lower, -primal_tol*scaling, sense                -- all VGPRs/AGPRs
+//   LDS                                         : packed L, the active-row cache (slot-indexed,
+//               so a removal moves no row), u
+//
+// One wave per SIMD is all the LDS budget allows, so nothing hides an LDS round trip: every
+// substitution loop therefore preloads its L entries eight steps at a time BEFORE entering the
+// dependency chain, and cross-lane traffic is v_readlane / DPP, never LDS.
+#pragma once
+#include <utility>
+#include "wave_ldp.hip.h"
+
+namespace daqp_amd {
+
+constexpr int kChunk = 8;
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  Register
+// arrays are only ever indexed through these, so an index is a constant by construction (a
+// `#pragma unroll` that the optimizer declines turns the whole array into scratch memory).
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int NB, int NP>
+struct RWave {
+    int n, m, ms, ldr;
+    double *L, *rowc, *u, *pend_lam;   // LDS
+    int *pend_id;                      // LDS
+    // working-set view (lane i = position i)
+    int wsid, slot, wflag;
+    double lam, lams, D, xl, zl, drhs;
+    // row view (lane r + 64*bb = constraint row).  At one wave per SIMD the kernel owns the
+    // whole unified 512-entry register file; the compiler parks what exceeds the 256
+    // architectural VGPRs in AGPRs (v_accvgpr_read on use).
+    double Mx[NB][NP], My[NB][NP];   // M[row][2t], M[row][2t+1]
+    double du[NB], dl[NB], bnd[NB];
+    unsigned rs;   // sense bits of this lane's rows, 8 bits per row block (a register, never an array)
+    // uniform
+    int na, reuse, sing, has_soft;
+    unsigned long long slotmask;
+    double fval, soft;
+    const DAQPSettings *stp;            // device copy of the settings (cold fields)
+    double dual_tol, sing_tol, pivot_tol, rho_soft;   // hot tolerances, loaded once
+    int *trace; int trace_cap, trace_len;
+    long long *prof;                    // LDS, 8 phase counters (NULL: off)
+};
+
+#define RPROF_T0(w) long long prof_t0_ = (w).prof ? (long long)__builtin_readcyclecounter() : 0
+#define RPROF_ACC(w, slot) do { if ((w).prof) { const long long t1_ = (long long)__builtin_readcyclecounter(); if (lane_id() == 0) (w).prof[slot] += t1_ - prof_t0_; prof_t0_ = t1_; } } while (0)
+
+__device__ __forceinline__ int rli(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+template <int NB, int NP>
+__device__ __forceinline__ void rtrace(RWave<NB, NP> &w, int ev)
+{
+    if (w.trace) {
+        if (lane_id() == 0 && w.trace_len < w.trace_cap) w.trace[w.trace_len] = ev;
+        w.trace_len++;
+    }
+}
+
+// --- row-view accessors ----------------------------------------------------------------------
+// sense words are < 256 (bits ACTIVE..SLACK_FIXED): block bb of this lane sits in byte bb of w.rs
+template <int NB, int NP>
+__device__ __forceinline__ int rsense_get(const RWave<NB, NP> &w, int bb) { return (int)((w.rs >> (8 * bb)) & 0xffu); }
+template <int NB, int NP>
+__device__ __forceinline__ int sense_of(const RWave<NB, NP> &w, int id)   // id wave-uniform
+{
+    return rli(rsense_get(w, id >> 6), id & 63);
+}
+template <int NB, int NP>
+__device__ __forceinline__ void sense_set(RWave<NB, NP> &w, int id, int set_bits, int clear_bits)
+{
+    if (lane_id() == (id & 63)) {
+        const int sh = 8 * (id >> 6);
+        w.rs = (w.rs | ((unsigned)set_bits << sh)) & ~((unsigned)clear_bits << sh);
+    }
+}
+// bound of constraint id: broadcast every block's candidate first, THEN pick (selecting between
+// array elements before the readlane gets folded into a dynamic index => scratch)
+template <int NB, int NP>
+__device__ __forceinline__ double bound_of(const RWave<NB, NP> &w, int id, bool lower)
+{
+    double v = 0;
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+        const double bu = rl(w.du[bb], id & 63), bl = rl(w.dl[bb], id & 63);
+        if ((id >> 6) == bb) v = lower ? bl : bu;
+    });
+    return v;
+}
+
+// rowc[slot] <- row id: the owning lane stores its registers
+template <int NB, int NP>
+__device__ __forceinline__ void rfetch_row(RWave<NB, NP> &w, int id, int slot)
+{
+    const int lane = lane_id();
+    double *dst = w.rowc + (size_t)slot * w.ldr;
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+        if ((id >> 6) == bb && lane == (id & 63)) {
+            static_for<NP>([&](auto t) __attribute__((always_inline)) {
+                if (2 * t < w.n) dst[2 * t] = w.Mx[bb][t];
+                if (2 * t + 1 < w.n) dst[2 * t + 1] = w.My[bb][t];
+            });
+        }
+    });
+    WSYNC();
+}
+
+// factorization.c:4-15 with the loads of each group of 8 issued before its arithmetic
+__device__ __forceinline__ double dot4_pipelined(const double *a, const double *b, int len)
+{
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int i = 0;
+    for (; i + 7 < len; i += 8) {
+        double x[8], y[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { x[q] = a[i + q]; y[q] = b[i + q]; }
+        s0 += x[0] * y[0]; s1 += x[1] * y[1]; s2 += x[2] * y[2]; s3 += x[3] * y[3];
+        s0 += x[4] * y[4]; s1 += x[5] * y[5]; s2 += x[6] * y[6]; s3 += x[7] * y[7];
+    }
+    for (; i + 3 < len; i += 4) {
+        double x[4], y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { x[q] = a[i + q]; y[q] = b[i + q]; }
+        s0 += x[0] * y[0]; s1 += x[1] * y[1]; s2 += x[2] * y[2]; s3 += x[3] * y[3];
+    }
+    for (; i < len; i++) s0 += a[i] * b[i];
+    return (s0 + s1) + (s2 + s3);
+}
+
+// b <- L' \ b over the leading cnt positions (column-oriented; product order b_j * L[j][i])
+template <int NB, int NP>
+__device__ __forceinline__ double rbackward(RWave<NB, NP> &w, double b, int cnt)
+{
+    const int lane = lane_id();
+    for (int j0 = cnt - 1; j0 >= 1; j0 -= kChunk) {
+        double Lb[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int j = j0 - q;
+            Lb[q] = (j >= 1 && lane < j) ? w.L[tri(j) + lane] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int j = j0 - q;
+            if (j >= 1) {
+                const double bj = rl(b, j);
+                if (lane < j) b -= bj * Lb[q];
+            }
+        }
+    }
+    return b;
+}
+// x_i = rhs_i - sum_{j<i} L[i][j] x_j for rows i >= from, j ascending (row-oriented: products in
+// parallel, then the ordered subtraction chain over v_readlane).  x, rhs: one per lane.
+template <int NB, int NP>
+__device__ __forceinline__ double rforward(RWave<NB, NP> &w, double x, double rhs, int from)
+{
+    const int lane = lane_id();
+    for (int i = from; i < w.na; ++i) {
+        const double p = (lane < i) ? w.L[tri(i) + lane] * x : 0.0;
+        double acc = rl(rhs, i);
+        for (int j = 0; j < i; ++j) acc -= rl(p, j);
+        if (lane == i) x = acc;
+    }
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------
+// LDL' row append (factorization.c:21-111); returns the new pivot D[na]
+// ---------------------------------------------------------------------------------------
+template <int NB, int NP>
+__device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int newslot, int sn_id)
+{
+    const int lane = lane_id(), na = w.na, n = w.n, base = tri(na);
+    rfetch_row(w, id, newslot);
+    const int c0 = id < w.ms ? id : 0;
+    w.sing = kEmpty;
+    const double *Mi = w.rowc + (size_t)newslot * w.ldr;
+    double g = 0;
+    if (lane <= na) {
+        const int idk = (lane < na) ? w.wsid : id;
+        const int sk = (lane < na) ? w.slot : newslot;
+        const int j = (lane < na && idk < w.ms) ? (c0 > idk ? c0 : idk) : c0;
+        g = dot4_pipelined(w.rowc + (size_t)sk * w.ldr + j, Mi + j, n - j);
+    }
+    int ns_act = 0;
+    if (w.has_soft) ns_act = __popcll(__ballot(lane < na && (w.wflag & DAQP_SOFT))) + ((sn_id & DAQP_SOFT) ? 1 : 0);
+    double dnew = rl(g, na);
+    if (sn_id & DAQP_SOFT) dnew += w.rho_soft;
+    if (na == 0) return dnew;
+    // forward substitution with L, column by column; each lane preloads its own row of L 8 columns ahead
+    for (int j0 = 0; j0 < na - 1; j0 += kChunk) {
+        double Lk[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int j = j0 + q;
+            Lk[q] = (lane > j && lane < na) ? w.L[tri(lane) + j] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int j = j0 + q;
+            if (j < na - 1) {
+                const double lj = rl(g, j);
+                if (lane > j && lane < na) g -= Lk[q] * lj;
+            }
+        }
+    }
+    double p = 0;
+    if (lane < na) {
+        const double t = g;
+        const double lk = t / w.D;
+        w.L[base + lane] = lk;
+        p = t * lk;
+    }
+    double acc = dnew;
+    for (int k = 0; k < na; ++k) acc -= rl(p, k);
+    if (acc < w.sing_tol || na >= n + ns_act) { w.sing = na; acc = 0; }
+    WSYNC();
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// LDL' row delete (factorization.c:112-151)
+// ---------------------------------------------------------------------------------------
+template <int NB, int NP>
+__device__ __forceinline__ void rldl_delete(RWave<NB, NP> &w, int r)
+{
+    const int lane = lane_id(), na = w.na;
+    if (na == r + 1) return;
+    const int nupd = na - r - 1;
+    double wv = (lane < nupd) ? w.L[tri(r + 1 + lane) + r] : 0.0;
+    const int e0 = tri(r), e1 = tri(na - 1);
+    constexpr int U = 4;
+    for (int cb = e0; cb < e1; cb += 64 * U) {
+        double tmp[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int e = cb + q * 64 + lane;
+            tmp[q] = 0;
+            if (e < e1) {
+                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while (tri(i + 1) <= e) ++i;
+                while (tri(i) > e) --i;
+                const int j = e - tri(i);
+                tmp[q] = w.L[tri(i + 1) + j + (j >= r ? 1 : 0)];
+            }
+        }
+        WSYNC();
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int e = cb + q * 64 + lane;
+            if (e < e1) w.L[e] = tmp[q];
+        }
+        WSYNC();
+    }
+    // Gill-Golub-Murray-Saunders C1 update: lane t <-> trailing row r+t (new numbering); its L
+    // entries for 8 consecutive columns are read before, and written back after, the chain
+    double alpha = rl(w.D, r);
+    double Dn = w.D;
+    const int rowbase = tri(r + lane) + r;
+    for (int j0 = 0; j0 < nupd; j0 += kChunk) {
+        double Lc[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int j = j0 + q;
+            Lc[q] = (lane > j && lane < nupd) ? w.L[rowbase + j] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int j = j0 + q;
+            if (j < nupd) {
+                const int i = r + 1 + j;
+                const double p = rl(wv, j);
+                const double Di = rl(w.D, i);
+                const double dbar = Di + alpha * p * p;
+                const double beta = p * alpha / dbar;
+                alpha = Di * alpha / dbar;
+                if (lane == i - 1) Dn = dbar;
+                if (lane > j && lane < nupd) {
+                    wv -= p * Lc[q];
+                    Lc[q] = Lc[q] + beta * wv;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int j = j0 + q;
+            if (lane > j && lane < nupd) w.L[rowbase + j] = Lc[q];
+        }
+    }
+    w.D = Dn;
+    WSYNC();
+}
+
+template <class T>
+__device__ __forceinline__ T shift_from(T v, int r)
+{
+    const T up = __shfl_down(v, 1);
+    return lane_id() >= r ? up : v;
+}
+
+template <int NB, int NP>
+__device__ __forceinline__ int rdrop_core(RWave<NB, NP> &w, int r) // auxiliary.c:3-22
+{
+    const int lane = lane_id();
+    const int idr = rli(w.wsid, r);
+    rtrace(w, -(idr + 1));
+    sense_set(w, idr, 0, DAQP_ACTIVE);
+    w.slotmask &= ~(1ull << rli(w.slot, r));
+    rldl_delete(w, r);
+    w.na--;
+    w.wsid = shift_from(w.wsid, r);
+    w.slot = shift_from(w.slot, r);
+    w.wflag = shift_from(w.wflag, r);
+    w.lam = shift_from(w.lam, r);
+    w.drhs = shift_from(w.drhs, r);
+    if (r < w.reuse) w.reuse = r;
+    if (w.na > 0 && rl(w.D, w.na - 1) < w.sing_tol) {
+        w.sing = w.na - 1;
+        if (lane == w.na - 1) w.D = 0;
+        return 1;
+    }
+    return 0;
+}
+
+template <int NB, int NP>
+__device__ __forceinline__ void rpush_core(RWave<NB, NP> &w, int id, double lamv) // auxiliary.c:27-40
+{
+    const int lane = lane_id();
+    rtrace(w, id + 1);
+    sense_set(w, id, DAQP_ACTIVE, 0);
+    const int sn = sense_of(w, id);
+    const int newslot = __ffsll((long long)~w.slotmask) - 1;
+    w.slotmask |= 1ull << newslot;
+    const double dnew = rldl_append(w, id, newslot, sn);
+    const bool lower = (sn & DAQP_LOWER) != 0;
+    const double bd = bound_of(w, id, lower);
+    if (lane == w.na) {
+        w.wsid = id; w.slot = newslot; w.wflag = sn; w.lam = lamv; w.D = dnew; w.drhs = -bd;
+    }
+    w.na++;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-iteration kernels
+// ---------------------------------------------------------------------------------------
+template <int NB, int NP>
+__device__ __forceinline__ void rsolve_csp(RWave<NB, NP> &w) // auxiliary.c:314-354
+{
+    const int lane = lane_id(), na = w.na, from = w.reuse;
+    w.xl = rforward(w, w.xl, w.drhs, from);
+    if (lane >= from && lane < na) w.zl = w.xl / w.D;
+    const double b = rbackward(w, (lane < na) ? w.zl : 0.0, na);
+    if (lane < na) w.lams = b;
+    w.reuse = na;
+}
+
+template <int NB, int NP>
+__device__ __forceinline__ void rsingular_direction(RWave<NB, NP> &w) // auxiliary.c:357-376
+{
+    const int lane = lane_id(), s = w.sing;
+    double b = (lane < s) ? -w.L[tri(s) + lane] : 0.0;
+    b = rbackward(w, b, s);
+    const bool flip = (rli(w.wflag, s) & DAQP_LOWER) != 0;
+    if (lane <= s) {
+        const double v = (lane == s) ? 1.0 : b;
+        w.lams = flip ? -v : v;
+    }
+}
+
+// ratio test of auxiliary.c:277-311 (SOFT_WEIGHTS off): returns the position to drop (or kBig)
+// after stepping lam towards lam*; the removal itself is the caller's single DROP site
+template <int NB, int NP>
+__device__ __forceinline__ int rblocking_test(RWave<NB, NP> &w)
+{
+    const int lane = lane_id(), na = w.na;
+    const double dtol = w.dual_tol;
+    const bool regular = (w.sing == kEmpty);
+    double bv = DAQP_INF;
+    int bi = kBig, aux = 0;
+    if (lane < na) {
+        bool blocking = !(w.wflag & DAQP_IMMUTABLE);
+        if (w.wflag & DAQP_LOWER) { if (w.lams < dtol) blocking = false; }
+        else if (w.lams > -dtol) blocking = false;
+        if (blocking) {
+            const double cand = regular ? -w.lam / (w.lams - w.lam) : -w.lam / w.lams;
+            if (cand < bv) { bv = cand; bi = lane; }
+        }
+    }
+    wave_argmin(bv, bi, aux);
+    if (bi == kBig) return kBig;
+    const double alpha = bv;
+    if (lane < na) w.lam = regular ? w.lam + alpha * (w.lams - w.lam) : w.lam + alpha * w.lams;
+    w.sing = kEmpty;
+    return bi;
+}
+
+// u = -M_k' lam*  (auxiliary.c:46-88): lane <-> component j, working-set order, rows preloaded 8 ahead
+template <int NB, int NP>
+__device__ __forceinline__ void rprimal_u(RWave<NB, NP> &w)
+{
+    const int lane = lane_id(), na = w.na, n = w.n;
+    double uu = 0;
+    for (int i0 = 0; i0 < na; i0 += kChunk) {
+        double rv[kChunk], li[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int i = i0 + q;
+            rv[q] = 0; li[q] = 0;
+            if (i < na) {
+                const int s = rli(w.slot, i);
+                li[q] = rl(w.lams, i);
+                if (lane < n) rv[q] = w.rowc[(size_t)s * w.ldr + lane];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q)
+            if (i0 + q < na) uu -= rv[q] * li[q];
+    }
+    WSYNC();
+    if (lane < n) w.u[lane] = uu;
+    double fv = 0;
+    if (w.has_soft) {
+        const double sq = (lane < na && (w.wflag & DAQP_SOFT)) ? w.lams * w.lams : 0.0;
+        const unsigned long long sm = __ballot(lane < na && (w.wflag & DAQP_SOFT));
+        for (int i = 0; i < na; ++i) if ((sm >> i) & 1) fv += rl(sq, i);
+    }
+    fv = fv * w.rho_soft;
+    w.soft = fv;
+    WSYNC();
+}
+
+// feasibility scan + most-violated pick (auxiliary.c:89-198), everything but u from registers
+template <int NB, int NP>
+__device__ __forceinline__ int rscan_rows(RWave<NB, NP> &w, int &upper, bool with_fval)
+{
+    const int lane = lane_id();
+    double bv = 0.0;
+    int bi = kBig, bup = 0;
+    double fv = w.soft;
+    const double2 *u2 = reinterpret_cast<const double2 *>(w.u);
+    double mu[NB];
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) { mu[bb] = 0; });
+    // NB independent k-ordered chains per lane; u broadcast from LDS.  Zero padding (pairs beyond
+    // n/2) adds +0.0 and leaves every sum unchanged.
+    static_for<NP>([&](auto t) __attribute__((always_inline)) {
+        const double2 uk = u2[t];
+        const double ux = uk.x, uy = uk.y;
+        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+            mu[bb] += w.Mx[bb][t] * ux;
+            mu[bb] += w.My[bb][t] * uy;
+        });
+        if (with_fval) { fv += ux * ux; fv += uy * uy; }   // j-ordered |u|^2 (auxiliary.c:85-86)
+        if constexpr ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+        const int r = bb * 64 + lane;
+        if (r < w.m && !(rsense_get(w, bb) & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
+            double cand = w.du[bb] - mu[bb];
+            if (cand < bv && cand < w.bnd[bb]) { bv = cand; bi = r; bup = 1; }
+            else {
+                cand = mu[bb] - w.dl[bb];
+                if (cand < bv && cand < w.bnd[bb]) { bv = cand; bi = r; bup = 0; }
+            }
+        }
+    });
+    if (with_fval) w.fval = fv;
+    wave_argmin(bv, bi, bup);
+    upper = bup;
+    return bi;
+}
+
+template <int NB, int NP>
+__device__ __forceinline__ void rrefine_active(RWave<NB, NP> &w) // auxiliary.c:498-593
+{
+    const int lane = lane_id(), na = w.na, n = w.n;
+    w.reuse = 0;
+    double rhs = 0;
+    if (lane < na) {
+        const double *row = w.rowc + (size_t)w.slot * w.ldr;
+        double mu = 0;
+        for (int j = (w.wsid < w.ms ? w.wsid : 0); j < n; ++j) mu += row[j] * w.u[j];
+        rhs = mu - (-w.drhs);                     // d = -drhs exactly
+        if (w.wflag & DAQP_SOFT) rhs -= w.rho_soft * w.lams;
+    }
+    w.xl = rforward(w, w.xl, rhs, 0);
+    if (lane < na) w.zl = w.xl / w.D;
+    const double dlt = rbackward(w, (lane < na) ? w.zl : 0.0, na);
+    if (lane < na) { w.xl = dlt; w.lams += dlt; }
+    double uu = (lane < n) ? w.u[lane] : 0.0;
+    for (int i = 0; i < na; ++i) {
+        const double di = rl(w.xl, i);
+        const int id = rli(w.wsid, i), s = rli(w.slot, i);
+        const int j0 = id < w.ms ? id : 0;
+        if (lane < n && lane >= j0) uu -= w.rowc[(size_t)s * w.ldr + lane] * di;
+    }
+    WSYNC();
+    if (lane < n) w.u[lane] = uu;
+    WSYNC();
+    double fv = w.soft;
+    for (int j = 0; j < n; ++j) { const double uj = w.u[j]; fv += uj * uj; }
+    w.fval = fv;
+}
+
+template <int NB, int NP>
+__device__ __forceinline__ void rreset_ws(RWave<NB, NP> &w) { w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0; }
+
+template <int NB, int NP>
+__device__ __forceinline__ unsigned long long active_mask(const RWave<NB, NP> &w, int bb)
+{
+    return __ballot(bb * 64 + lane_id() < w.m && (rsense_get(w, bb) & DAQP_ACTIVE));
+}
+
+// ---------------------------------------------------------------------------------------
+// daqp_ldp (daqp.c:6-108) + daqp_activate_constraints (auxiliary.c:399-479) + daqp_pivot_last
+// (auxiliary.c:379-396) as ONE explicit state machine.  The reference reaches add_constraint /
+// remove_constraint from a dozen places and recurses through pivot_last; inlining that call
+// tree multiplied the code of every primitive (and its register pressure) tenfold, so here each
+// primitive has exactly one call site and "who asked" is a continuation code.
+//   mode 1: only rebuild the working set from the ACTIVE bits (tail of daqp_update_ldp).
+// Returns the exit flag (mode 0) or the activation flag (mode 1).
+// ---------------------------------------------------------------------------------------
+enum : int { PC_START_LOOP, PC_ITER, PC_ITER_NEXT, PC_SCAN, PC_AFTER_SCAN_MAIN, PC_AFTER_SCAN_REFINE, PC_CYCLE,
+             PC_CYCLE_REPAIRED, PC_ADD, PC_DROP, PC_PIVOT, PC_ACT_BEGIN, PC_ACT_NEXT, PC_ACT_POST, PC_DONE };
+
+template <int NB, int NP>
+__device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activate, int &iterations)
+{
+    const int lane = lane_id();
+    int flag = DAQP_EXIT_ITERLIMIT, it = 1, repaired = 0, stall = 0;
+    double best = -1;
+    const double fbound = 2 * w.stp->fval_bound;
+    const int iter_limit = w.stp->iter_limit;
+    // edit requests (ADD / DROP + the pivot stack) and continuations
+    int depth = 0, req_id = 0, req_r = 0, edit_ret = PC_DONE;
+    double req_lam = 0;
+    // activation cursor
+    int act_ret = PC_DONE, act_bb = 0, act_i = 0, act_flag = 1;
+    unsigned long long act_msk = 0;
+    // scan request
+    int scan_ret = PC_DONE, scan_fval = 1, pick = kBig, upper = 0;
+    int pc;
+    if (mode == 1 || need_activate) { rreset_ws(w); act_ret = (mode == 1) ? PC_DONE : PC_START_LOOP; pc = PC_ACT_BEGIN; }
+    else pc = PC_START_LOOP;
+    RPROF_T0(w);
+    while (pc != PC_DONE) {
+        switch (pc) {
+        case PC_START_LOOP:
+            if (act_flag < 0) { flag = act_flag; pc = PC_DONE; break; }
+            it = 1;
+            pc = (it < iter_limit) ? PC_ITER : PC_DONE;
+            break;
+        case PC_ITER_NEXT:
+            ++it;
+            pc = (it < iter_limit) ? PC_ITER : PC_DONE;   // falling out of the loop: flag stays ITERLIMIT
+            break;
+        case PC_ITER: {
+            const bool was_singular = (w.sing != kEmpty);
+            if (!was_singular) rsolve_csp(w); else rsingular_direction(w);
+            RPROF_ACC(w, 0);
+            const int blk = rblocking_test(w);
+            RPROF_ACC(w, 1);
+            if (blk != kBig) { req_r = blk; depth = 0; edit_ret = PC_ITER_NEXT; pc = PC_DROP; break; }
+            if (was_singular) { flag = DAQP_EXIT_INFEASIBLE; pc = PC_DONE; break; }
+            rprimal_u(w);
+            RPROF_ACC(w, 2);
+            scan_fval = 1; scan_ret = PC_AFTER_SCAN_MAIN; pc = PC_SCAN;
+            break;
+        }
+        case PC_SCAN:
+            pick = rscan_rows(w, upper, scan_fval != 0);
+            RPROF_ACC(w, 3);
+            pc = scan_ret;
+            break;
+        case PC_AFTER_SCAN_MAIN: {
+            if (w.fval > fbound) { flag = DAQP_EXIT_INFEASIBLE; pc = PC_DONE; break; }
+            if (pick == kBig) {
+                const double dmin = (w.na > 0) ? wave_min(lane < w.na ? w.D : (double)DAQP_INF) : (double)DAQP_INF;
+                if (w.na > 2 && repaired != 1 && dmin < w.stp->refactor_tol) {
+                    repaired = 1;
+                    for (int i = 0; i < w.na; ++i) {
+                        const int id = rli(w.wsid, i);
+                        if (rl(w.lam, i) >= 0) sense_set(w, id, 0, DAQP_LOWER); else sense_set(w, id, DAQP_LOWER, 0);
+                    }
+                    rreset_ws(w);
+                    act_ret = PC_ITER_NEXT; pc = PC_ACT_BEGIN;
+                    break;
+                }
+                if (w.na > 0 && dmin < w.pivot_tol) {
+                    rrefine_active(w);
+                    scan_fval = 0; scan_ret = PC_AFTER_SCAN_REFINE; pc = PC_SCAN;
+                    break;
+                }
+                flag = (w.soft > w.stp->primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
+                pc = PC_DONE;
+                break;
+            }
+            edit_ret = PC_CYCLE;
+            goto commit;
+        }
+        case PC_AFTER_SCAN_REFINE:
+            if (pick == kBig) {
+                flag = (w.soft > w.stp->primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
+                pc = PC_DONE;
+                break;
+            }
+            edit_ret = PC_ITER_NEXT;
+        commit: {   // auxiliary.c:152-166: fix the side, lam <-> lam*, then add with multiplier +-1
+            if (upper) sense_set(w, pick, 0, DAQP_LOWER); else sense_set(w, pick, DAQP_LOWER, 0);
+            const double t = w.lam; w.lam = w.lams; w.lams = t;
+            req_id = pick; req_lam = upper ? 1.0 : -1.0; depth = 0; pc = PC_ADD;
+            break;
+        }
+        case PC_CYCLE:   // daqp.c:66-85
+            pc = PC_ITER_NEXT;
+            if (w.fval - best < w.stp->progress_tol) {
+                if (stall++ > w.stp->cycle_tol) {
+                    if (repaired == 1) { flag = DAQP_EXIT_CYCLE; pc = PC_DONE; break; }
+                    repaired = 1;
+                    rreset_ws(w);
+                    act_ret = PC_CYCLE_REPAIRED; pc = PC_ACT_BEGIN;
+                }
+            } else { best = w.fval; stall = 0; }
+            break;
+        case PC_CYCLE_REPAIRED:
+            stall = 0; best = -1; pc = PC_ITER_NEXT;
+            break;
+        // ---- working-set edits: add_constraint / remove_constraint / pivot_last
+        case PC_ADD:
+            rpush_core(w, req_id, req_lam);
+            RPROF_ACC(w, 4);
+            pc = PC_PIVOT;
+            break;
+        case PC_DROP: {
+            const int took = rdrop_core(w, req_r);
+            RPROF_ACC(w, 5);
+            pc = took ? edit_ret : PC_PIVOT;
+            break;
+        }
+        case PC_PIVOT: {
+            const int r = w.na - 2;
+            bool piv = false;
+            if (w.na > 1) {
+                const double dr = rl(w.D, r), dlast = rl(w.D, w.na - 1);
+                piv = dr < w.pivot_tol && dr < dlast;
+            }
+            if (piv) {
+                const int idp = rli(w.wsid, r);
+                const double lp = rl(w.lam, r);
+                if (lane == 0) { w.pend_id[depth] = idp; w.pend_lam[depth] = lp; }
+                depth++;
+                WSYNC();
+                req_r = r; pc = PC_DROP;
+                break;
+            }
+            if (depth == 0 || w.sing != kEmpty) { pc = edit_ret; break; }
+            depth--;
+            req_id = w.pend_id[depth]; req_lam = w.pend_lam[depth];
+            pc = PC_ADD;
+            break;
+        }
+        // ---- daqp_activate_constraints: ACTIVE rows in index order
+        case PC_ACT_BEGIN:
+            act_bb = 0; act_flag = 1;
+            act_msk = active_mask(w, 0);
+            pc = PC_ACT_NEXT;
+            break;
+        case PC_ACT_NEXT: {
+            while (act_msk == 0 && act_bb + 1 < NB) { act_bb++; act_msk = active_mask(w, act_bb); }
+            if (act_msk == 0) { pc = act_ret; break; }
+            act_i = act_bb * 64 + __ffsll((long long)act_msk) - 1;
+            act_msk &= act_msk - 1;
+            req_id = act_i; req_lam = (sense_of(w, act_i) & DAQP_LOWER) ? -1.0 : 1.0;
+            depth = 0; edit_ret = PC_ACT_POST; pc = PC_ADD;
+            break;
+        }
+        case PC_ACT_POST: {
+            if (w.sing == kEmpty) { pc = PC_ACT_NEXT; break; }
+            const int lastflag = rli(w.wflag, w.na - 1);
+            const int last = rli(w.wsid, w.na - 1);
+            if (lastflag & DAQP_IMMUTABLE) {   // a new equality depends on the active ones
+                rsingular_direction(w);
+                double resid = 0.0, scale = 1.0;
+                const double term = (lane < w.na) ? w.lams * (-w.drhs) : 0.0;
+                for (int j = 0; j < w.na; ++j) {
+                    const double t = rl(term, j);
+                    resid += t;
+                    scale += t < 0 ? -t : t;
+                }
+                sense_set(w, last, 0, DAQP_ACTIVE);
+                w.slotmask &= ~(1ull << rli(w.slot, w.na - 1));
+                w.na--;
+                w.sing = kEmpty;
+                if (w.reuse > w.na) w.reuse = w.na;
+                if (resid <= w.stp->primal_tol * scale && resid >= -w.stp->primal_tol * scale) { pc = PC_ACT_NEXT; break; }
+                act_flag = DAQP_EXIT_OVERDETERMINED_INITIAL; pc = act_ret;
+                break;
+            }
+            int fl = 1;
+            static_for<NB>([&](auto b2) __attribute__((always_inline)) {   // rows >= i: unactivated equalities are an error, the rest are cleaned
+                const int r = b2 * 64 + lane;
+                const int sn = rsense_get(w, b2);
+                const bool later = r >= act_i && r < w.m && (sn & DAQP_ACTIVE);
+                if (__any(later && (sn & DAQP_IMMUTABLE))) fl = DAQP_EXIT_OVERDETERMINED_INITIAL;
+                if (later && !(sn & DAQP_IMMUTABLE)) w.rs &= ~((unsigned)DAQP_ACTIVE << (8 * b2));
+            });
+            w.slotmask &= ~(1ull << rli(w.slot, w.na - 1));
+            w.na--;
+            w.sing = kEmpty;
+            act_flag = fl; pc = act_ret;
+            break;
+        }
+        default:
+            pc = PC_DONE;
+            break;
+        }
+    }
+    iterations = it;
+    return (mode == 1) ? act_flag : flag;
+}
+
+} // namespace daqp_amd

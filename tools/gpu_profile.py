@@ -1,0 +1,36 @@
+"""Phase breakdown of the solve kernel (cycle counters) + kernel times on a mid-size batch."""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import daqp_amd
+from daqp_amd.synthetic import generate_batch_torch
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+n, m, ms, na = 50, 150, 0, 20
+q = generate_batch_torch(N, n, m, ms, na, seed=42)
+for prof in (False, True):
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    if prof:
+        bm.enable_profile(True)
+    for rep in range(3):
+        bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=64)
+        torch.cuda.synchronize()
+        if prof and rep == 2:
+            ps = bm.read_profile().astype(np.float64).mean(axis=0)
+            print("  setup cycles per QP: chol %d, inverse+v %d, xunc %d, M %d, norm/d/store %d, tail %d, total %d"
+                  % (ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[:6].sum()))
+        res = bm.solve(out="torch")
+        torch.cuda.synchronize()
+    su, so = bm.kernel_ms()
+    it = res["iter"].cpu().numpy()
+    print(f"profiling={prof}: N={N} k_setup {su:.2f} ms, k_ldp {so:.2f} ms, mean iter {it.mean():.1f}, "
+          f"all optimal {(res['exitflag'] == 1).all().item()}, max|x-xref| {(res['x'] - q['xref']).abs().max().item():.2e}")
+    if prof:
+        p = bm.read_profile().astype(np.float64)
+        names = ["csp", "blocking", "primal_u", "scan", "add", "remove", "-", "-"]
+        tot = p.sum()
+        per_it = p.sum(axis=0) / it.sum()
+        print("  cycles per iteration by phase:", {k: round(v) for k, v in zip(names, per_it) if v > 0},
+              "total/iter", round(tot / it.sum()))
+    bm.close()

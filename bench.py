@@ -135,10 +135,8 @@ def main():
             setup_ms.append(a); solve_ms.append(b)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from daqp_amd.parallel import max_over_ranks
+    elapsed = max_over_ranks(elapsed, device="cuda")
 
     # whole-batch properties on every rank: optimal everywhere, analytic optimum reproduced
     flags_ok = bool((res["exitflag"] == 1).all().item())

@@ -66,7 +66,7 @@ struct DAQPBatch {
     int C = 1;
     bool spill = false;
     int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
-    bool fast_setup = false;
+    bool fast_setup = false, setup_spill = false;
     size_t lds_setup = 0, lds_ldp = 0, lds_update = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed_setup = false, timed_solve = false;
@@ -204,7 +204,8 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
             if (d.nblk <= rs.nb && d.npair <= rs.np) { b->NB = rs.nb; b->NP = rs.np; break; }
     b->lds_ldp = (size_t)ldp_lds(n, m, cap, b->spill).total_bytes;
     b->fast_setup = (n <= 64) && !getenv("DAQP_AMD_SLOW_SETUP");
-    b->lds_setup = b->fast_setup ? (size_t)fast_lds(n, m).total_bytes : (size_t)setup_lds(n, m).total_bytes;
+    b->setup_spill = !b->fast_setup && (setup_lds(n, m).total_bytes > 150 * 1024 || getenv("DAQP_AMD_FORCE_SPILL"));
+    b->lds_setup = b->fast_setup ? (size_t)fast_lds(n, m).total_bytes : (size_t)setup_lds(n, m, b->setup_spill).total_bytes;
     b->lds_update = (size_t)round_up(n, 2) * 16;
     if (b->lds_ldp > 160 * 1024 || b->lds_setup > 160 * 1024) {
         set_err("problem too large for the LDS-staged setup (needs %zu / %zu bytes)", b->lds_setup, b->lds_ldp);
@@ -226,6 +227,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &d.WS, Nn * cap);
     rc |= dev_alloc(b, &d.qs, Nn);
     if (b->spill) rc |= dev_alloc(b, &d.rowc_g, Nn * cap * d.ldr);
+    if (b->setup_spill) rc |= dev_alloc(b, &d.setup_g, Nn * (2 * (size_t)round_up(d.rtri, 2) + round_up(64 * d.ldr, 2)));
     rc |= dev_alloc(b, &b->ox, Nn * n);
     rc |= dev_alloc(b, &b->olam, Nn * m);
     rc |= dev_alloc(b, &b->ofval, Nn);
@@ -355,7 +357,7 @@ int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
     if (rc) return DAQP_EXIT_UNSUPPORTED;
     const int mask = init_mask | DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
     typedef void (*setup_kernel_t)(BatchDev, int);
-    setup_kernel_t ks = k_setup;
+    setup_kernel_t ks = b->setup_spill ? k_setup<true> : k_setup<false>;
     if (b->fast_setup) ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : k_setup_fast<64>);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_setup));
     HIPCHK(hipEventRecord(b->ev[0], b->stream));

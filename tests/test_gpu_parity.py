@@ -189,3 +189,28 @@ def test_device_resident_io(oracle, gpu_lib):
     ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
     assert np.array_equal(g["iter"].cpu().numpy(), ref[4])
     assert bits_equal(g["x"].cpu().numpy(), ref[0])
+
+
+def test_full_size_properties(gpu_lib):
+    """BASELINE configs at full size, checked through size-independent properties of the generator:
+    every QP optimal, the analytic optimum reproduced, exactly n_active multipliers non-zero,
+    KKT stationarity and primal feasibility."""
+    import torch
+    import daqp_amd
+    from daqp_amd.synthetic import generate_batch_torch
+    for (N, n, m, ms, na) in ((100_000, 50, 150, 0, 20), (250_000, 12, 48, 12, 6)):
+        q = generate_batch_torch(N, n, m, ms, na, seed=7)
+        g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms, out="torch")
+        assert bool((g["exitflag"] == 1).all())
+        # tolerances of the reference's own generator tests (core_test.m:16-26: 1e-5): a drawn multiplier
+        # ~0 leaves its constraint violated by < primal_tol and therefore (correctly) inactive
+        assert float((g["x"] - q["xref"]).abs().max()) < 1e-5
+        nact = (g["lam"] != 0).sum(dim=1)
+        assert bool((nact <= na).all()) and float((nact != na).double().mean()) < 1e-3
+        Afull = torch.cat([torch.eye(n, dtype=torch.float64, device="cuda")[:ms].expand(N, ms, n), q["A"]], dim=1)
+        kkt = (q["H"] @ g["x"][:, :, None])[:, :, 0] + q["f"] + (Afull.transpose(1, 2) @ g["lam"][:, :, None])[:, :, 0]
+        assert float(kkt.abs().max()) < 1e-5
+        ax = (Afull @ g["x"][:, :, None])[:, :, 0]
+        assert bool((ax <= q["bupper"] + 1e-5).all()) and bool((ax >= q["blower"] - 1e-5).all())
+        del q, g, Afull, kkt, ax
+        torch.cuda.empty_cache()

@@ -294,8 +294,9 @@ class BatchModel:
         lib().daqp_batch_enable_profile(self._h, 1 if on else 0)
 
     def read_profile(self):
-        """(N, 8) int64 cycle sums per QP: csp, blocking test, primal, scan, add, remove, -, -"""
-        p = np.zeros((self.N, 8), np.int64)
+        """(N, 32) int64 per QP.  Solve kernel (register variant): cycles per state machine state [0:16] and
+        visits [16:32]; setup kernel: cycles per phase [0:6]."""
+        p = np.zeros((self.N, 32), np.int64)
         lib().daqp_batch_read_profile(self._h, p.ctypes.data_as(C.POINTER(C.c_longlong)))
         return p
 

@@ -63,6 +63,7 @@ struct DAQPBatch {
     double *ox = nullptr, *olam = nullptr, *ofval = nullptr, *osoft = nullptr;
     int *oflag = nullptr, *oiter = nullptr;
     DAQPSettings *st_dev = nullptr;
+    BatchDev *d_dev = nullptr;
     int C = 1;
     bool spill = false;
     int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
@@ -86,6 +87,7 @@ int dev_alloc(DAQPBatch *b, T **p, size_t count)
 }
 
 typedef void (*ldp_kernel_t)(BatchDev, int);
+typedef void (*ldp_reg_kernel_t)(const BatchDev *, int);
 // register-resident variants: (row blocks, k-pairs) held per lane; needs cap <= 64 and L/rows in LDS
 struct RegShape { int nb, np; };
 #ifdef DAQP_AMD_FEW_VARIANTS   // development builds: fewer instantiations, faster compile
@@ -93,19 +95,21 @@ const RegShape kRegShapes[] = {{1, 8}, {3, 25}};
 #else
 const RegShape kRegShapes[] = {{1, 8}, {1, 16}, {2, 16}, {3, 25}, {2, 32}};
 #endif
+ldp_reg_kernel_t pick_ldp_reg(const DAQPBatch *b)
+{
+    if (b->NB == 1 && b->NP == 8) return k_ldp_reg<1, 8>;
+    if (b->NB == 3 && b->NP == 25) return k_ldp_reg<3, 25>;
+#ifndef DAQP_AMD_FEW_VARIANTS
+    if (b->NB == 1 && b->NP == 16) return k_ldp_reg<1, 16>;
+    if (b->NB == 2 && b->NP == 16) return k_ldp_reg<2, 16>;
+    if (b->NB == 2 && b->NP == 32) return k_ldp_reg<2, 32>;
+#endif
+    return nullptr;
+}
 ldp_kernel_t pick_ldp(const DAQPBatch *b)
 {
     const int C = b->C;
     const bool spill = b->spill;
-    if (b->NB > 0) {
-        if (b->NB == 1 && b->NP == 8) return k_ldp_reg<1, 8>;
-        if (b->NB == 3 && b->NP == 25) return k_ldp_reg<3, 25>;
-#ifndef DAQP_AMD_FEW_VARIANTS
-        if (b->NB == 1 && b->NP == 16) return k_ldp_reg<1, 16>;
-        if (b->NB == 2 && b->NP == 16) return k_ldp_reg<2, 16>;
-        if (b->NB == 2 && b->NP == 32) return k_ldp_reg<2, 32>;
-#endif
-    }
 #ifdef DAQP_AMD_FEW_VARIANTS
     if (!spill) return k_ldp<4, false, 0, 0>;
     return k_ldp<4, true, 0, 0>;
@@ -123,6 +127,15 @@ ldp_kernel_t pick_ldp(const DAQPBatch *b)
 
 int launch_ldp(DAQPBatch *b, int mode)
 {
+    if (b->NB > 0) {
+        ldp_reg_kernel_t kr = pick_ldp_reg(b);
+        // the descriptor travels through device memory: stream-ordered copy, then the launch
+        HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
+        hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     ldp_kernel_t k = pick_ldp(b);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
     hipLaunchKernelGGL(k, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, b->d, mode);
@@ -204,6 +217,10 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
             if (d.nblk <= rs.nb && d.npair <= rs.np) { b->NB = rs.nb; b->NP = rs.np; break; }
     b->lds_ldp = (size_t)ldp_lds(n, m, cap, b->spill).total_bytes;
     b->fast_setup = (n <= 64) && !getenv("DAQP_AMD_SLOW_SETUP");
+    {   // DAQP_AMD_EXACT=1: keep the reference's summation order in M = A R^-1 (bit-exact LDP); default: MFMA
+        const char *ex = getenv("DAQP_AMD_EXACT");
+        d.exact_setup = (ex && atoi(ex) != 0) ? 1 : 0;
+    }
     b->setup_spill = !b->fast_setup && (setup_lds(n, m).total_bytes > 150 * 1024 || getenv("DAQP_AMD_FORCE_SPILL"));
     b->lds_setup = b->fast_setup ? (size_t)fast_lds(n, m).total_bytes : (size_t)setup_lds(n, m, b->setup_spill).total_bytes;
     b->lds_update = (size_t)round_up(n, 2) * 16;
@@ -235,6 +252,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &b->oflag, Nn);
     rc |= dev_alloc(b, &b->oiter, Nn);
     rc |= dev_alloc(b, &b->st_dev, 1);
+    rc |= dev_alloc(b, &b->d_dev, 1);
     if (!rc && hipMemcpy(b->st_dev, &d.st, sizeof(DAQPSettings), hipMemcpyHostToDevice) != hipSuccess) rc = 1;
     d.st_dev = b->st_dev;
     if (rc) { daqp_batch_free(b); return DAQP_EXIT_UNSUPPORTED; }
@@ -261,6 +279,7 @@ void daqp_batch_free(DAQPBatch *b)
     delete b;
 }
 
+void daqp_batch_set_exact(DAQPBatch *b, int exact) { if (b) b->d.exact_setup = exact ? 1 : 0; }
 void daqp_batch_set_stream(DAQPBatch *b, void *hip_stream) { if (b) b->stream = reinterpret_cast<hipStream_t>(hip_stream); }
 void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings)
 {
@@ -292,8 +311,8 @@ int daqp_batch_enable_profile(DAQPBatch *b, int on)
     (void)hipSetDevice(b->device);
     if (!on) { b->d.prof = nullptr; return 0; }
     long long *p = nullptr;
-    if (dev_alloc(b, &p, (size_t)b->d.N * 8)) return DAQP_EXIT_UNSUPPORTED;
-    HIPCHK(hipMemset(p, 0, (size_t)b->d.N * 8 * sizeof(long long)));
+    if (dev_alloc(b, &p, (size_t)b->d.N * 32)) return DAQP_EXIT_UNSUPPORTED;
+    HIPCHK(hipMemset(p, 0, (size_t)b->d.N * 32 * sizeof(long long)));
     b->d.prof = p;
     return 0;
 }
@@ -302,7 +321,7 @@ int daqp_batch_read_profile(DAQPBatch *b, long long *host)
     if (!b || !b->d.prof) return DAQP_EXIT_UNSUPPORTED;
     (void)hipSetDevice(b->device);
     HIPCHK(hipStreamSynchronize(b->stream));
-    HIPCHK(hipMemcpy(host, b->d.prof, (size_t)b->d.N * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(host, b->d.prof, (size_t)b->d.N * 32 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 int daqp_batch_read_trace(DAQPBatch *b, int *host)

@@ -36,6 +36,7 @@ struct BatchDev {
     int *trace; int trace_cap;
     long long *prof;   // [N][8] phase cycle sums, or NULL
     const DAQPSettings *st_dev;   // device copy of st (scalar-load friendly)
+    int exact_setup;              // 1: M = A R^-1 in the reference's operation order (VALU); 0: MFMA f64
     DAQPSettings st;
 };
 
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
         qs->fval = w.fval; qs->soft_slack = w.soft;
         if (b.trace) b.trace[(size_t)q * b.trace_cap + b.trace_cap - 1] = w.trace_len;
         if (w.profiling)
-            for (int i = 0; i < 8; ++i) b.prof[(size_t)q * 8 + i] = w.prof[i];
+            for (int i = 0; i < 8; ++i) b.prof[(size_t)q * 32 + i] = w.prof[i];
     }
 }
 
@@ -588,14 +589,21 @@ __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
 // m <= 64*NB, n <= 2*NP.  Same global state layout as k_ldp, so the two are interchangeable.
 // ------------------------------------------------------------------------------------
 template <int NB, int NP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ldp_reg(BatchDev b, int mode)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ldp_reg(const BatchDev *bp, int mode)
 {
+    // The descriptor is read through a pointer (scalar loads at the point of use) instead of being a
+    // by-value kernel argument: ~60 SGPRs of pointers would otherwise stay live across the whole state
+    // machine and push its uniform state into VGPR-lane spills.
+    const BatchDev &b = *bp;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = lane_id();
     const int n = b.n, m = b.m, cap = b.cap;
     QState *qs = b.qs + q;
-    const int sflag = qs->setup_flag;
-    if (mode == 1) { if (sflag < 0 || !qs->need_activate) return; }
+    // everything read from the per-QP record is wave-uniform; say so, or every loop bounded by
+    // n_active becomes a divergent (exec-masked) loop with readfirstlane waterfalls around v_readlane
+    const int sflag = __builtin_amdgcn_readfirstlane(qs->setup_flag);
+    const int q_need_act = __builtin_amdgcn_readfirstlane(qs->need_activate);
+    if (mode == 1) { if (sflag < 0 || !q_need_act) return; }
     if (sflag < 0) {
         if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
         return;
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     RWave<NB, NP> w;
     // phase counters live in the (otherwise unused) D/xl slots of the LDS carve-up
     w.prof = ((b.prof != nullptr) && mode == 0) ? reinterpret_cast<long long *>(smem + o.D) : nullptr;
-    if (w.prof && lane < 8) w.prof[lane] = 0;
+    if (w.prof && lane < 32) w.prof[lane] = 0;
     w.n = n; w.m = m; w.ms = b.ms; w.ldr = b.ldr;
     w.L = smem + o.L; w.rowc = smem + o.rowc; w.u = smem + o.u; w.pend_lam = smem + o.pend_lam;
     w.pend_id = ibase + o.pend_id;
@@ -613,9 +621,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     w.dual_tol = b.st.dual_tol; w.sing_tol = b.st.sing_tol; w.pivot_tol = b.st.pivot_tol; w.rho_soft = b.st.rho_soft;
     w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
     w.trace_cap = b.trace_cap; w.trace_len = 0;
-    w.na = qs->n_active; w.reuse = qs->reuse_ind; w.sing = qs->sing_ind;
-    w.fval = qs->fval; w.soft = qs->soft_slack;
-    const int swapped = qs->lam_swapped;
+    w.na = __builtin_amdgcn_readfirstlane(qs->n_active);
+    w.reuse = __builtin_amdgcn_readfirstlane(qs->reuse_ind);
+    w.sing = __builtin_amdgcn_readfirstlane(qs->sing_ind);
+    w.fval = rl(qs->fval, 0); w.soft = rl(qs->soft_slack, 0);
+    const int swapped = __builtin_amdgcn_readfirstlane(qs->lam_swapped);
     const double *gdu = b.dupper + (size_t)q * m, *gdl = b.dlower + (size_t)q * m, *gsc = b.scaling + (size_t)q * m;
     int *gsense = b.sense + (size_t)q * m;
     double *gv = b.vecs + (size_t)q * 5 * cap;
@@ -695,7 +705,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     WSYNC();
 
     int iters = 0;
-    int flag = rrun(w, mode, qs->need_activate != 0, iters);
+    int flag = rrun(w, mode, q_need_act != 0, iters);
     if (mode == 1) {
         if (lane == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
     } else {
@@ -753,7 +763,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         qs->fval = w.fval; qs->soft_slack = w.soft;
         if (b.trace) b.trace[(size_t)q * b.trace_cap + b.trace_cap - 1] = w.trace_len;
         if (w.prof)
-            for (int i = 0; i < 8; ++i) b.prof[(size_t)q * 8 + i] = w.prof[i];
+            for (int i = 0; i < 32; ++i) b.prof[(size_t)q * 32 + i] = w.prof[i];
     }
 }
 

@@ -58,6 +58,30 @@ __device__ __forceinline__ double chain_add8(double acc, int cnt, FA A, FB B)
     return acc;
 }
 
+// dst[r*ld + c] = src[r*n + c] for r < rows, c < n: every lane walks the contiguous source with stride 64,
+// keeps (row, col) incrementally (no division) and has 8 loads in flight before the first LDS store --
+// at <= 3 waves per CU nothing else would hide the HBM latency of a load-store-load-store loop.
+__device__ __forceinline__ void stage_rows(double *dst, const double *src, int rows, int n, int ld)
+{
+    const int lane = lane_id(), total = rows * n;
+    int r = 0, c = lane;
+    while (c >= n) { c -= n; ++r; }
+    for (int e0 = lane; e0 < total; e0 += 64 * 8) {
+        double v[8];
+        int off[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + 64 * q;
+            v[q] = (e < total) ? src[e] : 0.0;
+            off[q] = r * ld + c;
+            c += 64;
+            while (c >= n) { c -= n; ++r; }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (e0 + 64 * q < total) dst[off[q]] = v[q];
+    }
+}
+
 // LDS: [ Rsq: n x nsq zero-padded square R^-1, overlaying the packed Cholesky factor once that is
 // dead | f v xu | scaling dupper dlower | tile (64 x ldr: inverse scratch, then the A tiles) | sense ]
 struct FastLds { int R, fv, vv, xu, sc, du, dl, tile, sens, total_bytes; };
@@ -113,12 +137,15 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     else if (bad & 1) flag = DAQP_EXIT_INFEASIBLE;
     if (st.eps_prox > 0.0) flag = DAQP_EXIT_UNSUPPORTED;
     if (lane < n) fl[lane] = f[lane];
-    // pack 1/2 (H + H') (utils.c:318-324)
-    if (flag > 0)
-        for (int e = lane; e < n * n; e += 64) {
-            const int i = e / n, j = e - i * n;
-            if (j >= i) R[roff(i, n) + j] = (i == j) ? H[e] : 0.5 * (H[e] + H[(size_t)j * n + i]);
+    // pack 1/2 (H + H') (utils.c:318-324): H is staged through the (still unused) tile area
+    if (flag > 0) {
+        stage_rows(tile, H, n, n, ldr);
+        WSYNC();
+        for (int i = 0; i < n; ++i) {
+            const int j = i + lane;
+            if (j < n) R[roff(i, n) + j] = (j == i) ? tile[i * ldr + i] : 0.5 * (tile[i * ldr + j] + tile[j * ldr + i]);
         }
+    }
     WSYNC();
 
     // --- Cholesky (utils.c:335-352)
@@ -212,10 +239,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
         for (int tb = 0; tb < mA && flag > 0; tb += 64) {
             const int rows = (mA - tb) < 64 ? (mA - tb) : 64;
             WSYNC();
-            for (int e = lane; e < rows * n; e += 64) {
-                const int rr = e / n, cc = e - rr * n;
-                tile[rr * ldr + cc] = A[(size_t)tb * n + e];
-            }
+            stage_rows(tile, A + (size_t)tb * n, rows, n, ldr);
             WSYNC();
             const int k = tb + lane;
             const bool own = lane < rows;
@@ -223,23 +247,62 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             const int gi = ms + (own ? k : tb);
             double sunc = 0;
             if (unc) sunc = chain_add8(0.0, n, [&](int j) { return a[j]; }, [&](int j) { return xu[j]; });
-            // M row: r-outer, accumulators in registers (utils.c:441-453: diagonal term first, then decreasing r)
             double acc[NMAX];
-            static_for<NMAX>([&](auto c) __attribute__((always_inline)) { acc[c] = 0.0; });
-            for (int r = n - 1; r >= 0; --r) {
-                const double ar = a[r];
-                const double2 *Rr = reinterpret_cast<const double2 *>(Rsq + r * nsq);
-                // groups of 8 columns, branch-free inside: entries left of the diagonal are stored zeros,
-                // so they add +0.0; only groups that reach the diagonal or beyond are executed
-                static_for<NMAX / 8>([&](auto g) __attribute__((always_inline)) {
-                    if (8 * g + 7 >= r && 8 * g < n) {
-                        static_for<4>([&](auto h) __attribute__((always_inline)) {
-                            const double2 rv = Rr[4 * g + h];
-                            acc[8 * g + 2 * h] += rv.x * ar;
-                            acc[8 * g + 2 * h + 1] += rv.y * ar;
+            if (b.exact_setup) {
+                // M row: r-outer, accumulators in registers (utils.c:441-453: diagonal term first, then decreasing r)
+                static_for<NMAX>([&](auto c) __attribute__((always_inline)) { acc[c] = 0.0; });
+                for (int r = n - 1; r >= 0; --r) {
+                    const double ar = a[r];
+                    const double2 *Rr = reinterpret_cast<const double2 *>(Rsq + r * nsq);
+                    // groups of 8 columns, branch-free inside: entries left of the diagonal are stored zeros,
+                    // so they add +0.0; only groups that reach the diagonal or beyond are executed
+                    static_for<NMAX / 8>([&](auto g) __attribute__((always_inline)) {
+                        if (8 * g + 7 >= r && 8 * g < n) {
+                            static_for<4>([&](auto h) __attribute__((always_inline)) {
+                                const double2 rv = Rr[4 * g + h];
+                                acc[8 * g + 2 * h] += rv.x * ar;
+                                acc[8 * g + 2 * h + 1] += rv.y * ar;
+                            });
+                        }
+                    });
+                }
+            } else {
+                // M = A R^-1 on the matrix cores: v_mfma_f64_16x16x4_f64, one 16-row tile of A against the
+                // (upper-triangular: K only up to the column tile's last column) 16-column tiles of R^-1.
+                // A: lane l supplies A[l&15][l>>4], B: R^-1[l>>4][l&15], D: col = l&15, row = (l>>4) + 4*reg.
+                // The summation order differs from the reference's (fp64, fused): M agrees to ~1e-16 relative.
+                typedef double v4d __attribute__((ext_vector_type(4)));
+                const int lr = lane & 15, lk = lane >> 4, ktn = (n + 3) >> 2;
+                for (int rt = 0; rt * 16 < rows; ++rt) {
+                    v4d acc4[4];
+                    static_for<4>([&](auto ct) __attribute__((always_inline)) { acc4[ct] = (v4d){0.0, 0.0, 0.0, 0.0}; });
+                    const int arow = rt * 16 + lr;
+                    const bool rowok = arow < rows;
+                    const double *arowp = tile + (rowok ? arow : 0) * ldr;
+                    for (int kt = 0; kt < ktn; ++kt) {
+                        const int kk = 4 * kt + lk;
+                        const bool kok = kk < n;
+                        const double aload = arowp[kok ? kk : 0];
+                        const double av = (rowok && kok) ? aload : 0.0;
+                        static_for<4>([&](auto ct) __attribute__((always_inline)) {
+                            if (16 * ct < n && kt <= 4 * ct + 3) {
+                                const int cc = 16 * ct + lr;
+                                const bool ok = kok && cc < n;
+                                const double bload = Rsq[(kok ? kk : 0) * nsq + (cc < n ? cc : 0)];
+                                acc4[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, ok ? bload : 0.0, acc4[ct], 0, 0, 0);
+                            }
                         });
                     }
-                });
+                    WSYNC();   // every lane's reads of this row tile precede the in-place overwrite below
+                    static_for<4>([&](auto ct) __attribute__((always_inline)) {
+                        static_for<4>([&](auto r) __attribute__((always_inline)) {
+                            const int row = rt * 16 + lk + 4 * r, col = 16 * ct + lr;
+                            if (col < n && row < rows) tile[row * ldr + col] = acc4[ct][(int)r];
+                        });
+                    });
+                }
+                WSYNC();
+                static_for<NMAX>([&](auto c) __attribute__((always_inline)) { acc[c] = (c < n) ? a[c < n ? c : 0] : 0.0; });
             }
             SPROF(3);
             // normalise (utils.c:586-613), d (utils.c:499-544 / 664-676 + 151-159), blocked store
@@ -334,7 +397,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0;
-        if (b.prof) for (int i = 0; i < 6; ++i) b.prof[(size_t)q * 8 + i] = pt[i];
+        if (b.prof) for (int i = 0; i < 6; ++i) b.prof[(size_t)q * 32 + i] = pt[i];
     }
 #undef SPROF
 }

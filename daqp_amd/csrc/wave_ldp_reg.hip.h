@@ -136,7 +136,13 @@ __device__ __forceinline__ double dot4_pipelined(const double *a, const double *
     return (s0 + s1) + (s2 + s3);
 }
 
-// b <- L' \ b over the leading cnt positions (column-oriented; product order b_j * L[j][i])
+// Measured on gfx950 at one wave per SIMD (tools/ubench.hip): a ROLLED loop step costs ~67 cycles
+// against ~23 unrolled (taken branch ~40), a uniform branch ~18, any LDS instruction 25-40 cycles of
+// issue time.  Hence: chains run in straight-line groups of 8 with the loads of the group issued
+// first, and steps beyond the end are padded with exact zeros (x - 0*y == x) instead of guarded.
+
+// b <- L' \ b over the leading cnt positions (column-oriented; product order b_j * L[j][i]).
+// Lanes >= cnt must hold b == 0.
 template <int NB, int NP>
 __device__ __forceinline__ double rbackward(RWave<NB, NP> &w, double b, int cnt)
 {
@@ -146,30 +152,44 @@ __device__ __forceinline__ double rbackward(RWave<NB, NP> &w, double b, int cnt)
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
             const int j = j0 - q;
-            Lb[q] = (j >= 1 && lane < j) ? w.L[tri(j) + lane] : 0.0;
+            Lb[q] = (j >= 1 && lane < j) ? w.L[tri(j > 0 ? j : 0) + lane] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
-            const int j = j0 - q;
-            if (j >= 1) {
-                const double bj = rl(b, j);
-                if (lane < j) b -= bj * Lb[q];
-            }
+            const double bj = rl(b, (j0 - q) & 63);     // padding steps read some finite lane and multiply it by 0
+            b -= bj * Lb[q];
         }
     }
     return b;
 }
-// x_i = rhs_i - sum_{j<i} L[i][j] x_j for rows i >= from, j ascending (row-oriented: products in
-// parallel, then the ordered subtraction chain over v_readlane).  x, rhs: one per lane.
+// ordered sum: acc - p_0 - p_1 - ... - p_{cnt-1} (p must be 0 in lanes >= cnt)
+__device__ __forceinline__ double ordered_sub(double acc, double p, int cnt)
+{
+    for (int k0 = 0; k0 < cnt; k0 += kChunk) {
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) acc -= rl(p, (k0 + q) & 63);
+    }
+    return acc;
+}
+// x_i = rhs_i - sum_{j<i} L[i][j] x_j for rows i >= from (j ascending), column-oriented: lane <-> row, the
+// lane's own L entries for 8 columns preloaded, x_j broadcast by v_readlane once final.
+// In: x = final values for lanes < from; rhs for lanes in [from, na); 0 beyond.
 template <int NB, int NP>
 __device__ __forceinline__ double rforward(RWave<NB, NP> &w, double x, double rhs, int from)
 {
-    const int lane = lane_id();
-    for (int i = from; i < w.na; ++i) {
-        const double p = (lane < i) ? w.L[tri(i) + lane] * x : 0.0;
-        double acc = rl(rhs, i);
-        for (int j = 0; j < i; ++j) acc -= rl(p, j);
-        if (lane == i) x = acc;
+    const int lane = lane_id(), na = w.na;
+    const bool pending = lane >= from && lane < na;
+    x = pending ? rhs : (lane < na ? x : 0.0);
+    const int rowbase = tri(lane);
+    for (int j0 = 0; j0 < na - 1; j0 += kChunk) {
+        double Lk[kChunk];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) Lk[q] = (pending && lane > j0 + q) ? w.L[rowbase + j0 + q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const double xj = rl(x, (j0 + q) & 63);
+            x -= Lk[q] * xj;
+        }
     }
     return x;
 }
@@ -207,11 +227,8 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
         }
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
-            const int j = j0 + q;
-            if (j < na - 1) {
-                const double lj = rl(g, j);
-                if (lane > j && lane < na) g -= Lk[q] * lj;
-            }
+            const double lj = rl(g, (j0 + q) & 63);
+            g -= Lk[q] * lj;                        // Lk == 0 where the step does not apply
         }
     }
     double p = 0;
@@ -221,8 +238,7 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
         w.L[base + lane] = lk;
         p = t * lk;
     }
-    double acc = dnew;
-    for (int k = 0; k < na; ++k) acc -= rl(p, k);
+    double acc = ordered_sub(dnew, p, na);
     if (acc < w.sing_tol || na >= n + ns_act) { w.sing = na; acc = 0; }
     WSYNC();
     return acc;
@@ -357,9 +373,12 @@ template <int NB, int NP>
 __device__ __forceinline__ void rsolve_csp(RWave<NB, NP> &w) // auxiliary.c:314-354
 {
     const int lane = lane_id(), na = w.na, from = w.reuse;
+    long long tq = w.prof ? (long long)__builtin_readcyclecounter() : 0;
     w.xl = rforward(w, w.xl, w.drhs, from);
     if (lane >= from && lane < na) w.zl = w.xl / w.D;
+    if (w.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) w.prof[11] += t1 - tq; tq = t1; }
     const double b = rbackward(w, (lane < na) ? w.zl : 0.0, na);
+    if (w.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) w.prof[12] += t1 - tq; tq = t1; }
     if (lane < na) w.lams = b;
     w.reuse = na;
 }
@@ -415,16 +434,14 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP> &w)
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
             const int i = i0 + q;
-            rv[q] = 0; li[q] = 0;
-            if (i < na) {
-                const int s = rli(w.slot, i);
-                li[q] = rl(w.lams, i);
-                if (lane < n) rv[q] = w.rowc[(size_t)s * w.ldr + lane];
-            }
+            const bool in = i < na;                              // wave-uniform
+            const int s = in ? rli(w.slot, i & 63) : 0;
+            const double l = rl(w.lams, i & 63);
+            li[q] = in ? l : 0.0;
+            rv[q] = (in && lane < n) ? w.rowc[(size_t)s * w.ldr + lane] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < kChunk; ++q)
-            if (i0 + q < na) uu -= rv[q] * li[q];
+        for (int q = 0; q < kChunk; ++q) uu -= rv[q] * li[q];   // padding: 0*0, exact
     }
     WSYNC();
     if (lane < n) w.u[lane] = uu;
@@ -539,7 +556,7 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
     int flag = DAQP_EXIT_ITERLIMIT, it = 1, repaired = 0, stall = 0;
     double best = -1;
     const double fbound = 2 * w.stp->fval_bound;
-    const int iter_limit = w.stp->iter_limit;
+    const int iter_limit = __builtin_amdgcn_readfirstlane(w.stp->iter_limit);
     // edit requests (ADD / DROP + the pivot stack) and continuations
     int depth = 0, req_id = 0, req_r = 0, edit_ret = PC_DONE;
     double req_lam = 0;
@@ -551,8 +568,9 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
     int pc;
     if (mode == 1 || need_activate) { rreset_ws(w); act_ret = (mode == 1) ? PC_DONE : PC_START_LOOP; pc = PC_ACT_BEGIN; }
     else pc = PC_START_LOOP;
-    RPROF_T0(w);
     while (pc != PC_DONE) {
+        const int pc_now = pc;
+        const long long t_in = w.prof ? (long long)__builtin_readcyclecounter() : 0;
         switch (pc) {
         case PC_START_LOOP:
             if (act_flag < 0) { flag = act_flag; pc = PC_DONE; break; }
@@ -566,19 +584,18 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
         case PC_ITER: {
             const bool was_singular = (w.sing != kEmpty);
             if (!was_singular) rsolve_csp(w); else rsingular_direction(w);
-            RPROF_ACC(w, 0);
+            long long tq = w.prof ? (long long)__builtin_readcyclecounter() : 0;
             const int blk = rblocking_test(w);
-            RPROF_ACC(w, 1);
+            if (w.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) w.prof[13] += t1 - tq; tq = t1; }
             if (blk != kBig) { req_r = blk; depth = 0; edit_ret = PC_ITER_NEXT; pc = PC_DROP; break; }
             if (was_singular) { flag = DAQP_EXIT_INFEASIBLE; pc = PC_DONE; break; }
             rprimal_u(w);
-            RPROF_ACC(w, 2);
+            if (w.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) w.prof[14] += t1 - tq; tq = t1; }
             scan_fval = 1; scan_ret = PC_AFTER_SCAN_MAIN; pc = PC_SCAN;
             break;
         }
         case PC_SCAN:
             pick = rscan_rows(w, upper, scan_fval != 0);
-            RPROF_ACC(w, 3);
             pc = scan_ret;
             break;
         case PC_AFTER_SCAN_MAIN: {
@@ -637,12 +654,10 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
         // ---- working-set edits: add_constraint / remove_constraint / pivot_last
         case PC_ADD:
             rpush_core(w, req_id, req_lam);
-            RPROF_ACC(w, 4);
             pc = PC_PIVOT;
             break;
         case PC_DROP: {
             const int took = rdrop_core(w, req_r);
-            RPROF_ACC(w, 5);
             pc = took ? edit_ret : PC_PIVOT;
             break;
         }
@@ -664,7 +679,7 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
             }
             if (depth == 0 || w.sing != kEmpty) { pc = edit_ret; break; }
             depth--;
-            req_id = w.pend_id[depth]; req_lam = w.pend_lam[depth];
+            req_id = __builtin_amdgcn_readfirstlane(w.pend_id[depth]); req_lam = rl(w.pend_lam[depth], 0);
             pc = PC_ADD;
             break;
         }
@@ -722,6 +737,10 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
         default:
             pc = PC_DONE;
             break;
+        }
+        if (w.prof) {   // cycles and visits per state (debug builds of the profile only)
+            const long long t_out = (long long)__builtin_readcyclecounter();
+            if (lane == 0) { w.prof[pc_now] += t_out - t_in; w.prof[16 + pc_now] += 1; }
         }
     }
     iterations = it;

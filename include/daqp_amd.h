@@ -179,6 +179,10 @@ void daqp_batch_free(DAQPBatch *b);
 /* hipStream_t the batch launches on (NULL: the legacy default stream). */
 void daqp_batch_set_stream(DAQPBatch *b, void *hip_stream);
 void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings);
+/* exact != 0: form M = A R^-1 in the reference's operation order (VALU; the whole LDP is then bit-identical
+ * to the reference's strict-IEEE build).  0 (default, or env DAQP_AMD_EXACT unset): MFMA f64 matrix cores,
+ * M equal to ~1e-16 relative; active sets/iterations identical, x within 1e-9 (tests/test_gpu_fast_mode.py). */
+void daqp_batch_set_exact(DAQPBatch *b, int exact);
 
 /* setup_daqp_main for every problem (QP -> LDP: Cholesky, R^-1, M = A R^-1, v, d, initial working
  * set).  init_mask 0 = setup_daqp, DAQP_UPDATE_unconstrained = the daqp_quadprog variant.

@@ -1,0 +1,75 @@
+"""Default mode of the library: M = A R^-1 on the MFMA f64 matrix cores (summation order differs from the
+reference, M equal to ~1e-16 relative).  Bar = BASELINE.json north_star: active sets (index and side),
+iteration counts and exit flags identical to the reference algorithm, |x - x_ref|_inf < 1e-9."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+XTOL = 1e-9
+
+
+@pytest.fixture(autouse=True)
+def fast_mode(monkeypatch):
+    monkeypatch.delenv("DAQP_AMD_EXACT", raising=False)
+
+
+@pytest.mark.parametrize("cfg,N", [("C1", 256), ("C2", 2048), ("C3", 4096)])
+def test_fast_mode_parity(oracle, gpu_lib, cfg, N):
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS[cfg]
+    q = O.generate_batch(N, n, m, ms, na, seed, start=20000)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert np.array_equal(g["exitflag"], ref[3])
+    assert np.array_equal(g["iter"], ref[4])
+    assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1]))
+    assert np.abs(g["x"] - ref[0]).max() < XTOL
+    assert np.abs(g["lam"] - ref[1]).max() < 1e-8
+    assert np.abs(g["fval"] - ref[2]).max() < 1e-8 * max(1.0, np.abs(ref[2]).max())
+
+
+def test_fast_mode_ldp_close(oracle, gpu_lib):
+    """the MFMA-formed M matches the reference's to rounding; everything upstream of it stays bit-identical"""
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    q = O.generate_batch(4, n, m, ms, na, seed)
+    bm = daqp_amd.BatchModel(4, n, m, ms)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+    for k in range(4):
+        om = oracle.model(n, m, ms)
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        M, R, v, du, dl, sc = bm.read_ldp(k)
+        Mo, Ro, vo, duo, dlo, sco = om.ldp()
+        assert np.array_equal(R.view(np.uint64), Ro.view(np.uint64)) and np.array_equal(v.view(np.uint64), vo.view(np.uint64))
+        assert np.abs(M - Mo).max() < 1e-14 and np.abs(sc - sco).max() < 1e-13 * np.abs(sco).max()
+        assert np.abs(du - duo).max() < 1e-12 and np.abs(dl - dlo).max() < 1e-12
+    bm.close()
+
+
+def test_fast_mode_warm_sequence(oracle, gpu_lib):
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    N, T = 64, 4
+    q = O.generate_batch(N, n, m, ms, na, seed, start=777)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        models.append(om)
+    f = q["f"].copy()
+    for t in range(T + 1):
+        if t > 0:
+            for k in range(N):
+                f[k] = f[k] + 0.05 * np.random.default_rng([45, k, t - 1]).standard_normal(n)
+                models[k].update(O.UPDATE_v, f=f[k])
+            bm.update(f=f)
+        g = bm.solve()
+        for k in range(N):
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4]
+            assert np.array_equal(np.sign(g["lam"][k]), np.sign(r[1])) and np.abs(g["x"][k] - r[0]).max() < XTOL
+    bm.close()

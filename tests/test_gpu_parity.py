@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 XTOL = 1e-9  # north_star tolerance on x*
 
 
+@pytest.fixture(autouse=True)
+def exact_mode(monkeypatch):
+    """This file asserts BIT-identical results, which needs the reference's summation order in
+    M = A R^-1 (DAQP_AMD_EXACT=1: VALU path).  The default MFMA path is covered by
+    tests/test_gpu_fast_mode.py at the north_star bar (identical active sets, |dx| < 1e-9)."""
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+
+
 def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a, np.float64).view(np.uint64),
                           np.ascontiguousarray(b, np.float64).view(np.uint64))

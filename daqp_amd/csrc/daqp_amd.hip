@@ -215,7 +215,13 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     if (!b->spill && cap <= 64 && !getenv("DAQP_AMD_STREAM_M"))
         for (const RegShape &rs : kRegShapes)
             if (d.nblk <= rs.nb && d.npair <= rs.np) { b->NB = rs.nb; b->NP = rs.np; break; }
-    b->lds_ldp = (size_t)ldp_lds(n, m, cap, b->spill).total_bytes;
+    d.ldrc = 0;
+    if (b->NB > 0) {   // stride == 2 (mod 4): rows 16-byte aligned and 16 consecutive rows hit 16 distinct 4-bank groups
+        int l = n > 2 * b->NP ? n : 2 * b->NP;
+        while ((l & 3) != 2) ++l;
+        d.ldrc = l;
+    }
+    b->lds_ldp = (size_t)ldp_lds(n, m, cap, b->spill, d.ldrc).total_bytes;
     b->fast_setup = (n <= 64) && !getenv("DAQP_AMD_SLOW_SETUP");
     {   // DAQP_AMD_EXACT=1: keep the reference's summation order in M = A R^-1 (bit-exact LDP); default: MFMA
         const char *ex = getenv("DAQP_AMD_EXACT");

@@ -12,6 +12,7 @@ namespace daqp_amd {
 struct BatchDev {
     int N, n, m, ms, cap, mA;
     int npair, nblk, ldr, ltri, rtri;
+    int ldrc;   // row stride of the register kernel's active-row cache: == 2 (mod 4) doubles, >= 2*NP (16-B rows, conflict-free)
     // problem data (device pointers; owned by the caller or by the batch's staging buffers)
     const double *H, *f, *A, *bu, *bl;
     const int *sense_in;
@@ -60,10 +61,10 @@ __host__ __device__ inline SetupLds setup_lds(int n, int m, bool gs = false)
     return s;
 }
 struct LdpLds { int L, rowc, D, xl, zl, lamA, lamB, u, pend_lam, dbl; int ws, sense, pend_id, ints; int total_bytes; };
-__host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill)
+__host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill, int ldrc = 0)
 {
     LdpLds s;
-    const int ldr = n | 1, cp = round_up(cap, 2);
+    const int ldr = ldrc > 0 ? ldrc : (n | 1), cp = round_up(cap, 2);
     int o = 0;
     s.L = o; if (!spill) o += round_up(cap * (cap + 1) / 2, 2);
     s.rowc = o; if (!spill) o += round_up(cap * ldr, 2);
@@ -608,13 +609,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
         return;
     }
-    const LdpLds o = ldp_lds(n, m, cap, false);
+    const LdpLds o = ldp_lds(n, m, cap, false, b.ldrc);
     int *ibase = reinterpret_cast<int *>(smem + o.dbl);
     RWave<NB, NP> w;
     // phase counters live in the (otherwise unused) D/xl slots of the LDS carve-up
     w.prof = ((b.prof != nullptr) && mode == 0) ? reinterpret_cast<long long *>(smem + o.D) : nullptr;
     if (w.prof && lane < 32) w.prof[lane] = 0;
-    w.n = n; w.m = m; w.ms = b.ms; w.ldr = b.ldr;
+    w.n = n; w.m = m; w.ms = b.ms; w.ldr = b.ldrc;
     w.L = smem + o.L; w.rowc = smem + o.rowc; w.u = smem + o.u; w.pend_lam = smem + o.pend_lam;
     w.pend_id = ibase + o.pend_id;
     w.stp = b.st_dev;

@@ -97,21 +97,44 @@ __device__ __forceinline__ double bound_of(const RWave<NB, NP> &w, int id, bool 
     return v;
 }
 
-// rowc[slot] <- row id: the owning lane stores its registers
+// rowc[slot] <- row id: the owning lane stores its registers, NP unconditional 16-byte writes (the row
+// stride is >= 2*NP and rows are 16-byte aligned; entries beyond n are the zero padding of M)
 template <int NB, int NP>
 __device__ __forceinline__ void rfetch_row(RWave<NB, NP> &w, int id, int slot)
 {
     const int lane = lane_id();
-    double *dst = w.rowc + (size_t)slot * w.ldr;
+    double2 *dst = reinterpret_cast<double2 *>(w.rowc + (size_t)slot * w.ldr);
     static_for<NB>([&](auto bb) __attribute__((always_inline)) {
         if ((id >> 6) == bb && lane == (id & 63)) {
             static_for<NP>([&](auto t) __attribute__((always_inline)) {
-                if (2 * t < w.n) dst[2 * t] = w.Mx[bb][t];
-                if (2 * t + 1 < w.n) dst[2 * t + 1] = w.My[bb][t];
+                double2 v; v.x = w.Mx[bb][t]; v.y = w.My[bb][t];
+                dst[t] = v;
             });
         }
     });
     WSYNC();
+}
+
+// factorization.c:4-15 for rows that both start at column 0 (no simple bounds involved): 16-byte loads, groups of
+// 8 products with their loads issued first; (s0,s1,s2,s3) rotate over the columns exactly as the reference's
+__device__ __forceinline__ double dot4_pairs(const double *a, const double *b, int len)
+{
+    const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int i = 0;
+    for (; i + 7 < len; i += 8) {
+        double2 x[4], y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { x[q] = a2[(i >> 1) + q]; y[q] = b2[(i >> 1) + q]; }
+        s0 += x[0].x * y[0].x; s1 += x[0].y * y[0].y; s2 += x[1].x * y[1].x; s3 += x[1].y * y[1].y;
+        s0 += x[2].x * y[2].x; s1 += x[2].y * y[2].y; s2 += x[3].x * y[3].x; s3 += x[3].y * y[3].y;
+    }
+    for (; i + 3 < len; i += 4) {
+        const double2 x0 = a2[i >> 1], x1 = a2[(i >> 1) + 1], y0 = b2[i >> 1], y1 = b2[(i >> 1) + 1];
+        s0 += x0.x * y0.x; s1 += x0.y * y0.y; s2 += x1.x * y1.x; s3 += x1.y * y1.y;
+    }
+    for (; i < len; i++) s0 += a[i] * b[i];
+    return (s0 + s1) + (s2 + s3);
 }
 
 // factorization.c:4-15 with the loads of each group of 8 issued before its arithmetic
@@ -150,14 +173,16 @@ __device__ __forceinline__ double rbackward(RWave<NB, NP> &w, double b, int cnt)
     for (int j0 = cnt - 1; j0 >= 1; j0 -= kChunk) {
         double Lb[kChunk];
 #pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
+        for (int q = 0; q < kChunk; ++q) {   // unconditional loads (any address inside the LDS allocation is fine)
             const int j = j0 - q;
-            Lb[q] = (j >= 1 && lane < j) ? w.L[tri(j > 0 ? j : 0) + lane] : 0.0;
+            Lb[q] = w.L[tri(j > 0 ? j : 0) + lane];
         }
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
-            const double bj = rl(b, (j0 - q) & 63);     // padding steps read some finite lane and multiply it by 0
-            b -= bj * Lb[q];
+            const int j = j0 - q;
+            const double bj = rl(b, j & 63);
+            const double t = b - bj * Lb[q];
+            b = (j >= 1 && lane < j) ? t : b;   // the select discards whatever the padding lanes computed
         }
     }
     return b;
@@ -184,11 +209,12 @@ __device__ __forceinline__ double rforward(RWave<NB, NP> &w, double x, double rh
     for (int j0 = 0; j0 < na - 1; j0 += kChunk) {
         double Lk[kChunk];
 #pragma unroll
-        for (int q = 0; q < kChunk; ++q) Lk[q] = (pending && lane > j0 + q) ? w.L[rowbase + j0 + q] : 0.0;
+        for (int q = 0; q < kChunk; ++q) Lk[q] = w.L[rowbase + j0 + q];
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
             const double xj = rl(x, (j0 + q) & 63);
-            x -= Lk[q] * xj;
+            const double t = x - Lk[q] * xj;
+            x = (pending && lane > j0 + q) ? t : x;
         }
     }
     return x;
@@ -210,7 +236,8 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
         const int idk = (lane < na) ? w.wsid : id;
         const int sk = (lane < na) ? w.slot : newslot;
         const int j = (lane < na && idk < w.ms) ? (c0 > idk ? c0 : idk) : c0;
-        g = dot4_pipelined(w.rowc + (size_t)sk * w.ldr + j, Mi + j, n - j);
+        g = (w.ms == 0) ? dot4_pairs(w.rowc + (size_t)sk * w.ldr, Mi, n)
+                        : dot4_pipelined(w.rowc + (size_t)sk * w.ldr + j, Mi + j, n - j);
     }
     int ns_act = 0;
     if (w.has_soft) ns_act = __popcll(__ballot(lane < na && (w.wflag & DAQP_SOFT))) + ((sn_id & DAQP_SOFT) ? 1 : 0);
@@ -221,14 +248,12 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
     for (int j0 = 0; j0 < na - 1; j0 += kChunk) {
         double Lk[kChunk];
 #pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
-            const int j = j0 + q;
-            Lk[q] = (lane > j && lane < na) ? w.L[tri(lane) + j] : 0.0;
-        }
+        for (int q = 0; q < kChunk; ++q) Lk[q] = w.L[tri(lane) + j0 + q];
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
             const double lj = rl(g, (j0 + q) & 63);
-            g -= Lk[q] * lj;                        // Lk == 0 where the step does not apply
+            const double t = g - Lk[q] * lj;
+            g = (lane > j0 + q && lane < na) ? t : g;
         }
     }
     double p = 0;
@@ -438,7 +463,7 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP> &w)
             const int s = in ? rli(w.slot, i & 63) : 0;
             const double l = rl(w.lams, i & 63);
             li[q] = in ? l : 0.0;
-            rv[q] = (in && lane < n) ? w.rowc[(size_t)s * w.ldr + lane] : 0.0;
+            rv[q] = w.rowc[(size_t)s * w.ldr + lane];           // padding steps read slot 0 (finite) and multiply by 0
         }
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) uu -= rv[q] * li[q];   // padding: 0*0, exact
@@ -546,8 +571,9 @@ __device__ __forceinline__ unsigned long long active_mask(const RWave<NB, NP> &w
 //   mode 1: only rebuild the working set from the ACTIVE bits (tail of daqp_update_ldp).
 // Returns the exit flag (mode 0) or the activation flag (mode 1).
 // ---------------------------------------------------------------------------------------
-enum : int { PC_START_LOOP, PC_ITER, PC_ITER_NEXT, PC_SCAN, PC_AFTER_SCAN_MAIN, PC_AFTER_SCAN_REFINE, PC_CYCLE,
-             PC_CYCLE_REPAIRED, PC_ADD, PC_DROP, PC_PIVOT, PC_ACT_BEGIN, PC_ACT_NEXT, PC_ACT_POST, PC_DONE };
+enum : int { PC_START_LOOP, PC_ITER, PC_EDIT, PC_ACT_BEGIN, PC_ACT_NEXT, PC_ACT_POST, PC_DONE };
+enum : int { AFTER_NEXT_ITER, AFTER_CYCLE_GUARD, AFTER_ACT_POST };   // what follows a completed working-set edit
+enum : int { ACT_THEN_DONE, ACT_THEN_LOOP, ACT_THEN_NEXT_ITER, ACT_THEN_CYCLE_RESET };
 
 template <int NB, int NP>
 __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activate, int &iterations)
@@ -557,16 +583,14 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
     double best = -1;
     const double fbound = 2 * w.stp->fval_bound;
     const int iter_limit = __builtin_amdgcn_readfirstlane(w.stp->iter_limit);
-    // edit requests (ADD / DROP + the pivot stack) and continuations
-    int depth = 0, req_id = 0, req_r = 0, edit_ret = PC_DONE;
+    // edit request (add / drop, then the pivot_last cascade) and its continuation
+    int depth = 0, req_add = 1, req_id = 0, req_r = 0, after_edit = AFTER_NEXT_ITER;
     double req_lam = 0;
     // activation cursor
-    int act_ret = PC_DONE, act_bb = 0, act_i = 0, act_flag = 1;
+    int act_then = ACT_THEN_DONE, act_bb = 0, act_i = 0, act_flag = 1;
     unsigned long long act_msk = 0;
-    // scan request
-    int scan_ret = PC_DONE, scan_fval = 1, pick = kBig, upper = 0;
     int pc;
-    if (mode == 1 || need_activate) { rreset_ws(w); act_ret = (mode == 1) ? PC_DONE : PC_START_LOOP; pc = PC_ACT_BEGIN; }
+    if (mode == 1 || need_activate) { rreset_ws(w); act_then = (mode == 1) ? ACT_THEN_DONE : ACT_THEN_LOOP; pc = PC_ACT_BEGIN; }
     else pc = PC_START_LOOP;
     while (pc != PC_DONE) {
         const int pc_now = pc;
@@ -577,29 +601,18 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
             it = 1;
             pc = (it < iter_limit) ? PC_ITER : PC_DONE;
             break;
-        case PC_ITER_NEXT:
-            ++it;
-            pc = (it < iter_limit) ? PC_ITER : PC_DONE;   // falling out of the loop: flag stays ITERLIMIT
-            break;
+        // ---- one iteration of daqp_ldp up to its working-set edit (daqp.c:12-64, 86-93)
         case PC_ITER: {
             const bool was_singular = (w.sing != kEmpty);
             if (!was_singular) rsolve_csp(w); else rsingular_direction(w);
-            long long tq = w.prof ? (long long)__builtin_readcyclecounter() : 0;
             const int blk = rblocking_test(w);
-            if (w.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) w.prof[13] += t1 - tq; tq = t1; }
-            if (blk != kBig) { req_r = blk; depth = 0; edit_ret = PC_ITER_NEXT; pc = PC_DROP; break; }
+            if (blk != kBig) { req_add = 0; req_r = blk; depth = 0; after_edit = AFTER_NEXT_ITER; pc = PC_EDIT; break; }
             if (was_singular) { flag = DAQP_EXIT_INFEASIBLE; pc = PC_DONE; break; }
             rprimal_u(w);
-            if (w.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) w.prof[14] += t1 - tq; tq = t1; }
-            scan_fval = 1; scan_ret = PC_AFTER_SCAN_MAIN; pc = PC_SCAN;
-            break;
-        }
-        case PC_SCAN:
-            pick = rscan_rows(w, upper, scan_fval != 0);
-            pc = scan_ret;
-            break;
-        case PC_AFTER_SCAN_MAIN: {
+            int upper = 0;
+            int pick = rscan_rows(w, upper, true);
             if (w.fval > fbound) { flag = DAQP_EXIT_INFEASIBLE; pc = PC_DONE; break; }
+            after_edit = AFTER_CYCLE_GUARD;
             if (pick == kBig) {
                 const double dmin = (w.na > 0) ? wave_min(lane < w.na ? w.D : (double)DAQP_INF) : (double)DAQP_INF;
                 if (w.na > 2 && repaired != 1 && dmin < w.stp->refactor_tol) {
@@ -609,81 +622,75 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
                         if (rl(w.lam, i) >= 0) sense_set(w, id, 0, DAQP_LOWER); else sense_set(w, id, DAQP_LOWER, 0);
                     }
                     rreset_ws(w);
-                    act_ret = PC_ITER_NEXT; pc = PC_ACT_BEGIN;
+                    act_then = ACT_THEN_NEXT_ITER; pc = PC_ACT_BEGIN;
                     break;
                 }
                 if (w.na > 0 && dmin < w.pivot_tol) {
                     rrefine_active(w);
-                    scan_fval = 0; scan_ret = PC_AFTER_SCAN_REFINE; pc = PC_SCAN;
+                    pick = rscan_rows(w, upper, false);
+                    after_edit = AFTER_NEXT_ITER;
+                }
+                if (pick == kBig) {
+                    flag = (w.soft > w.stp->primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
+                    pc = PC_DONE;
                     break;
                 }
-                flag = (w.soft > w.stp->primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
-                pc = PC_DONE;
-                break;
             }
-            edit_ret = PC_CYCLE;
-            goto commit;
-        }
-        case PC_AFTER_SCAN_REFINE:
-            if (pick == kBig) {
-                flag = (w.soft > w.stp->primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
-                pc = PC_DONE;
-                break;
-            }
-            edit_ret = PC_ITER_NEXT;
-        commit: {   // auxiliary.c:152-166: fix the side, lam <-> lam*, then add with multiplier +-1
+            // auxiliary.c:152-166: fix the side, lam <-> lam*, then add with multiplier +-1
             if (upper) sense_set(w, pick, 0, DAQP_LOWER); else sense_set(w, pick, DAQP_LOWER, 0);
-            const double t = w.lam; w.lam = w.lams; w.lams = t;
-            req_id = pick; req_lam = upper ? 1.0 : -1.0; depth = 0; pc = PC_ADD;
+            { const double t = w.lam; w.lam = w.lams; w.lams = t; }
+            req_add = 1; req_id = pick; req_lam = upper ? 1.0 : -1.0; depth = 0; pc = PC_EDIT;
             break;
         }
-        case PC_CYCLE:   // daqp.c:66-85
-            pc = PC_ITER_NEXT;
-            if (w.fval - best < w.stp->progress_tol) {
-                if (stall++ > w.stp->cycle_tol) {
-                    if (repaired == 1) { flag = DAQP_EXIT_CYCLE; pc = PC_DONE; break; }
-                    repaired = 1;
-                    rreset_ws(w);
-                    act_ret = PC_CYCLE_REPAIRED; pc = PC_ACT_BEGIN;
+        // ---- add_constraint / remove_constraint with the pivot_last cascade (auxiliary.c:3-44, 379-396),
+        // each primitive instantiated once; then the caller's continuation
+        case PC_EDIT: {
+            for (;;) {
+                bool settled = false;
+                if (req_add) rpush_core(w, req_id, req_lam);
+                else settled = rdrop_core(w, req_r) != 0;      // a removal that left a singular factor does not pivot
+                if (!settled) {
+                    const int r = w.na - 2;
+                    bool piv = false;
+                    if (w.na > 1) {
+                        const double dr = rl(w.D, r), dlast = rl(w.D, w.na - 1);
+                        piv = dr < w.pivot_tol && dr < dlast;
+                    }
+                    if (piv) {
+                        const int idp = rli(w.wsid, r);
+                        const double lp = rl(w.lam, r);
+                        if (lane == 0) { w.pend_id[depth] = idp; w.pend_lam[depth] = lp; }
+                        depth++;
+                        WSYNC();
+                        req_add = 0; req_r = r;
+                        continue;
+                    }
+                    if (depth > 0 && w.sing == kEmpty) {
+                        depth--;
+                        req_id = __builtin_amdgcn_readfirstlane(w.pend_id[depth]); req_lam = rl(w.pend_lam[depth], 0);
+                        req_add = 1;
+                        continue;
+                    }
                 }
-            } else { best = w.fval; stall = 0; }
-            break;
-        case PC_CYCLE_REPAIRED:
-            stall = 0; best = -1; pc = PC_ITER_NEXT;
-            break;
-        // ---- working-set edits: add_constraint / remove_constraint / pivot_last
-        case PC_ADD:
-            rpush_core(w, req_id, req_lam);
-            pc = PC_PIVOT;
-            break;
-        case PC_DROP: {
-            const int took = rdrop_core(w, req_r);
-            pc = took ? edit_ret : PC_PIVOT;
-            break;
-        }
-        case PC_PIVOT: {
-            const int r = w.na - 2;
-            bool piv = false;
-            if (w.na > 1) {
-                const double dr = rl(w.D, r), dlast = rl(w.D, w.na - 1);
-                piv = dr < w.pivot_tol && dr < dlast;
-            }
-            if (piv) {
-                const int idp = rli(w.wsid, r);
-                const double lp = rl(w.lam, r);
-                if (lane == 0) { w.pend_id[depth] = idp; w.pend_lam[depth] = lp; }
-                depth++;
-                WSYNC();
-                req_r = r; pc = PC_DROP;
                 break;
             }
-            if (depth == 0 || w.sing != kEmpty) { pc = edit_ret; break; }
-            depth--;
-            req_id = __builtin_amdgcn_readfirstlane(w.pend_id[depth]); req_lam = rl(w.pend_lam[depth], 0);
-            pc = PC_ADD;
+            if (after_edit == AFTER_ACT_POST) { pc = PC_ACT_POST; break; }
+            if (after_edit == AFTER_CYCLE_GUARD) {   // daqp.c:66-85
+                if (w.fval - best < w.stp->progress_tol) {
+                    if (stall++ > w.stp->cycle_tol) {
+                        if (repaired == 1) { flag = DAQP_EXIT_CYCLE; pc = PC_DONE; break; }
+                        repaired = 1;
+                        rreset_ws(w);
+                        act_then = ACT_THEN_CYCLE_RESET; pc = PC_ACT_BEGIN;
+                        break;
+                    }
+                } else { best = w.fval; stall = 0; }
+            }
+            ++it;
+            pc = (it < iter_limit) ? PC_ITER : PC_DONE;   // falling out of the loop: flag stays ITERLIMIT
             break;
         }
-        // ---- daqp_activate_constraints: ACTIVE rows in index order
+        // ---- daqp_activate_constraints: ACTIVE rows in index order (auxiliary.c:399-479)
         case PC_ACT_BEGIN:
             act_bb = 0; act_flag = 1;
             act_msk = active_mask(w, 0);
@@ -691,17 +698,27 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
             break;
         case PC_ACT_NEXT: {
             while (act_msk == 0 && act_bb + 1 < NB) { act_bb++; act_msk = active_mask(w, act_bb); }
-            if (act_msk == 0) { pc = act_ret; break; }
+            if (act_msk == 0) {   // done: continue where the activation was requested from
+                if (act_then == ACT_THEN_DONE) pc = PC_DONE;
+                else if (act_then == ACT_THEN_LOOP) pc = PC_START_LOOP;
+                else {
+                    if (act_then == ACT_THEN_CYCLE_RESET) { stall = 0; best = -1; }
+                    ++it;
+                    pc = (it < iter_limit) ? PC_ITER : PC_DONE;
+                }
+                break;
+            }
             act_i = act_bb * 64 + __ffsll((long long)act_msk) - 1;
             act_msk &= act_msk - 1;
-            req_id = act_i; req_lam = (sense_of(w, act_i) & DAQP_LOWER) ? -1.0 : 1.0;
-            depth = 0; edit_ret = PC_ACT_POST; pc = PC_ADD;
+            req_add = 1; req_id = act_i; req_lam = (sense_of(w, act_i) & DAQP_LOWER) ? -1.0 : 1.0;
+            depth = 0; after_edit = AFTER_ACT_POST; pc = PC_EDIT;
             break;
         }
         case PC_ACT_POST: {
             if (w.sing == kEmpty) { pc = PC_ACT_NEXT; break; }
             const int lastflag = rli(w.wflag, w.na - 1);
             const int last = rli(w.wsid, w.na - 1);
+            bool stop = true;
             if (lastflag & DAQP_IMMUTABLE) {   // a new equality depends on the active ones
                 rsingular_direction(w);
                 double resid = 0.0, scale = 1.0;
@@ -717,28 +734,32 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
                 w.sing = kEmpty;
                 if (w.reuse > w.na) w.reuse = w.na;
                 if (resid <= w.stp->primal_tol * scale && resid >= -w.stp->primal_tol * scale) { pc = PC_ACT_NEXT; break; }
-                act_flag = DAQP_EXIT_OVERDETERMINED_INITIAL; pc = act_ret;
-                break;
+                act_flag = DAQP_EXIT_OVERDETERMINED_INITIAL;
+            } else {
+                int fl = 1;
+                static_for<NB>([&](auto b2) __attribute__((always_inline)) {   // rows >= i: unactivated equalities are an error, the rest are cleaned
+                    const int r = b2 * 64 + lane;
+                    const int sn = rsense_get(w, b2);
+                    const bool later = r >= act_i && r < w.m && (sn & DAQP_ACTIVE);
+                    if (__any(later && (sn & DAQP_IMMUTABLE))) fl = DAQP_EXIT_OVERDETERMINED_INITIAL;
+                    if (later && !(sn & DAQP_IMMUTABLE)) w.rs &= ~((unsigned)DAQP_ACTIVE << (8 * b2));
+                });
+                w.slotmask &= ~(1ull << rli(w.slot, w.na - 1));
+                w.na--;
+                w.sing = kEmpty;
+                act_flag = fl;
             }
-            int fl = 1;
-            static_for<NB>([&](auto b2) __attribute__((always_inline)) {   // rows >= i: unactivated equalities are an error, the rest are cleaned
-                const int r = b2 * 64 + lane;
-                const int sn = rsense_get(w, b2);
-                const bool later = r >= act_i && r < w.m && (sn & DAQP_ACTIVE);
-                if (__any(later && (sn & DAQP_IMMUTABLE))) fl = DAQP_EXIT_OVERDETERMINED_INITIAL;
-                if (later && !(sn & DAQP_IMMUTABLE)) w.rs &= ~((unsigned)DAQP_ACTIVE << (8 * b2));
-            });
-            w.slotmask &= ~(1ull << rli(w.slot, w.na - 1));
-            w.na--;
-            w.sing = kEmpty;
-            act_flag = fl; pc = act_ret;
+            if (stop) {   // activation ends here (with act_flag); same continuations as a completed scan of the rows
+                act_msk = 0; act_bb = NB;
+                pc = PC_ACT_NEXT;
+            }
             break;
         }
         default:
             pc = PC_DONE;
             break;
         }
-        if (w.prof) {   // cycles and visits per state (debug builds of the profile only)
+        if (w.prof) {   // cycles and visits per state
             const long long t_out = (long long)__builtin_readcyclecounter();
             if (lane == 0) { w.prof[pc_now] += t_out - t_in; w.prof[16 + pc_now] += 1; }
         }

@@ -28,13 +28,12 @@ for prof in (False, True):
           f"all optimal {(res['exitflag'] == 1).all().item()}, max|x-xref| {(res['x'] - q['xref']).abs().max().item():.2e}")
     if prof:
         p = bm.read_profile().astype(np.float64)
-        names = ["START", "ITER(csp+block+primal)", "ITER_NEXT", "SCAN", "AFTER_SCAN", "AFTER_REFINE", "CYCLE", "CYC_REP",
-                 "ADD", "DROP", "PIVOT", "ACT_BEGIN", "ACT_NEXT", "ACT_POST", "DONE", "-"]
+        names = ["START", "ITER(csp..scan..commit)", "EDIT(add/drop+pivot+guard)", "ACT_BEGIN", "ACT_NEXT", "ACT_POST", "DONE"] + ["-"] * 9
         cyc, vis = p[:, :16].sum(axis=0), p[:, 16:].sum(axis=0)
         nit = it.sum()
         print("  state: cycles/iteration (cycles/visit, visits/iteration)")
         for k in range(16):
             if vis[k] > 0:
                 print(f"    {names[k]:24s} {cyc[k] / nit:9.0f}  ({cyc[k] / vis[k]:8.0f}, {vis[k] / nit:5.2f})")
-        print("    total/iter", round(cyc[:11].sum() / nit), " | inside ITER: fwd %d bwd %d blocking %d primal %d (cycles/iter)" % tuple(cyc[11:15] / nit))
+        print("    total/iter", round(cyc[:7].sum() / nit), " | csp fwd %d bwd %d (cycles/iter)" % tuple(cyc[11:13] / nit))
     bm.close()

@@ -279,29 +279,32 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP> &w, int r)
     if (na == r + 1) return;
     const int nupd = na - r - 1;
     double wv = (lane < nupd) ? w.L[tri(r + 1 + lane) + r] : 0.0;
-    const int e0 = tri(r), e1 = tri(na - 1);
-    constexpr int U = 4;
-    for (int cb = e0; cb < e1; cb += 64 * U) {
-        double tmp[U];
+    // move rows r+1.. up by one and drop column r, element-parallel over the packed destination range
+    // [tri(r), tri(na-1)).  Destination e always reads from a higher address, so ascending chunks with
+    // "read all, then write all" never clobber a live source.  Row of e: float sqrt + one branch-free
+    // correction each way (|error| < 1 for e < 2^21).
+    {
+        const int e0 = tri(r), e1 = tri(na - 1);
+        constexpr int U = 2;
+        for (int cb = e0; cb < e1; cb += 64 * U) {
+            double tmp[U];
 #pragma unroll
-        for (int q = 0; q < U; ++q) {
-            const int e = cb + q * 64 + lane;
-            tmp[q] = 0;
-            if (e < e1) {
-                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-                while (tri(i + 1) <= e) ++i;
-                while (tri(i) > e) --i;
+            for (int q = 0; q < U; ++q) {
+                const int e = cb + q * 64 + lane;
+                int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                i += (tri(i + 1) <= e) ? 1 : 0;
+                i -= (tri(i) > e) ? 1 : 0;
                 const int j = e - tri(i);
-                tmp[q] = w.L[tri(i + 1) + j + (j >= r ? 1 : 0)];
+                tmp[q] = w.L[(e < e1) ? tri(i + 1) + j + (j >= r ? 1 : 0) : 0];
             }
-        }
-        WSYNC();
+            WSYNC();
 #pragma unroll
-        for (int q = 0; q < U; ++q) {
-            const int e = cb + q * 64 + lane;
-            if (e < e1) w.L[e] = tmp[q];
+            for (int q = 0; q < U; ++q) {
+                const int e = cb + q * 64 + lane;
+                if (e < e1) w.L[e] = tmp[q];
+            }
+            WSYNC();
         }
-        WSYNC();
     }
     // Gill-Golub-Murray-Saunders C1 update: lane t <-> trailing row r+t (new numbering); its L
     // entries for 8 consecutive columns are read before, and written back after, the chain
@@ -342,11 +345,14 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP> &w, int r)
     WSYNC();
 }
 
-template <class T>
-__device__ __forceinline__ T shift_from(T v, int r)
+// lane i <- lane i+1 for lanes >= r (closing the gap a removed working-set position leaves): one DPP move per
+// dword (wave_shl:1, whole-wave shift on GFX9-family CDNA) instead of a ds_bpermute round trip through the LDS
+__device__ __forceinline__ int shl1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xF, 0xF, false); }
+__device__ __forceinline__ int shift_from(int v, int r) { const int up = shl1(v); return lane_id() >= r ? up : v; }
+__device__ __forceinline__ double shift_from(double v, int r)
 {
-    const T up = __shfl_down(v, 1);
-    return lane_id() >= r ? up : v;
+    const int lo = shl1(__double2loint(v)), hi = shl1(__double2hiint(v));
+    return lane_id() >= r ? __hiloint2double(hi, lo) : v;
 }
 
 template <int NB, int NP>

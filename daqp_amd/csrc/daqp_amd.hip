@@ -228,7 +228,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.exact_setup = (ex && atoi(ex) != 0) ? 1 : 0;
     }
     b->setup_spill = !b->fast_setup && (setup_lds(n, m).total_bytes > 150 * 1024 || getenv("DAQP_AMD_FORCE_SPILL"));
-    b->lds_setup = b->fast_setup ? (size_t)fast_lds(n, m).total_bytes : (size_t)setup_lds(n, m, b->setup_spill).total_bytes;
+    b->lds_setup = b->fast_setup ? (size_t)fast_lds(n, m, 1).total_bytes : (size_t)setup_lds(n, m, b->setup_spill).total_bytes;
     b->lds_update = (size_t)round_up(n, 2) * 16;
     if (b->lds_ldp > 160 * 1024 || b->lds_setup > 160 * 1024) {
         set_err("problem too large for the LDS-staged setup (needs %zu / %zu bytes)", b->lds_setup, b->lds_ldp);
@@ -383,10 +383,14 @@ int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
     const int mask = init_mask | DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
     typedef void (*setup_kernel_t)(BatchDev, int);
     setup_kernel_t ks = b->setup_spill ? k_setup<true> : k_setup<false>;
-    if (b->fast_setup) ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : k_setup_fast<64>);
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_setup));
+    size_t lds_setup = b->lds_setup;
+    if (b->fast_setup) {
+        ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : (d.n <= 56 ? k_setup_fast<56> : k_setup_fast<64>));
+        lds_setup = (size_t)fast_lds(d.n, d.m, d.exact_setup).total_bytes;   // the MFMA path overlays the A tile on R^-1
+    }
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
-    hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), b->lds_setup, b->stream, d, mask);
+    hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask);
     HIPCHK(hipGetLastError());
     // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
     if (p->sense != nullptr || true) { rc = launch_ldp(b, 1); if (rc) return rc; }

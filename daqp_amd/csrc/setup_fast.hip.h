@@ -1,16 +1,16 @@
-// setup_fast.hip.h -- QP -> LDP for n <= NMAX <= 64, one wavefront per QP, restructured around
-// the one thing that matters at one-to-three waves per SIMD: never wait for LDS inside a
-// dependency chain.  Arithmetic (operation ORDER included) is exactly that of k_setup /
-// reference src/utils.c:223-687; only the schedule differs:
-//   * Cholesky row i (utils.c:335-352): lane <-> column j; the k-ordered chain
-//       r_ij -= r_ki * r_kj   runs on register operands loaded eight steps ahead;
-//   * R -> R^-1 (utils.c:380-389): lane <-> row k, LEFT-looking: t_j = (r_kj*(-1/r_kk)
-//       - sum_{i<j} r_ij t_i) / r_jj with the row's own partial results in a conflict-free
-//       per-lane LDS column (no read-modify-write of shared rows);
-//   * M = A R^-1 (utils.c:434-472): lane <-> row of A, r-OUTER: all n accumulators of the row
-//       live in registers and every step  m_c += rinv_rc * a_r  (c >= r) is independent of its
-//       neighbours, so the wave runs at VALU rate instead of LDS latency.  Per output the
-//       terms still arrive diagonal first, then decreasing r.
+// setup_fast.hip.h -- QP -> LDP for n <= NMAX <= 64, one wavefront per QP.  Arithmetic (operation
+// ORDER included) is exactly that of k_setup / reference src/utils.c:223-687; only the schedule differs:
+//   * Cholesky (utils.c:335-352) and R -> R^-1 (utils.c:380-389) are FUSED and RIGHT-looking, entirely in
+//     registers: lane j holds column j of the trailing Schur complement (c[]) and lane k holds row k of the
+//     running inverse accumulators (a[]).  Step k finishes row k of R, broadcasts its entries with
+//     v_readlane and applies   c_ij -= r_ki r_kj   and   a_kj -= r_ij t_i   to every later column.  Each
+//     element still receives its subtractions in ascending k, i.e. the reference's left-looking chains
+//     bit for bit, but no step waits for LDS and the two updates share the broadcasts.  Writing the result
+//     of step k one register lower (c[i] = c[i+1] - ...) keeps "row k" in register 0, so the loop over k
+//     stays rolled with compile-time register indices.
+//   * M = A R^-1 (utils.c:434-472): default on the matrix cores (v_mfma_f64_16x16x4_f64) with the R^-1
+//     fragments register-resident for the whole problem; with exact_setup lane <-> row of A, r-OUTER with
+//     all n accumulators of the row in registers (terms arrive diagonal first, then decreasing r).
 #pragma once
 #include "wave_ldp_reg.hip.h"
 #include "kernels.hip.h"
@@ -59,18 +59,19 @@ __device__ __forceinline__ double chain_add8(double acc, int cnt, FA A, FB B)
 }
 
 // dst[r*ld + c] = src[r*n + c] for r < rows, c < n: every lane walks the contiguous source with stride 64,
-// keeps (row, col) incrementally (no division) and has 8 loads in flight before the first LDS store --
+// keeps (row, col) incrementally (no division) and has 16 loads in flight before the first LDS store --
 // at <= 3 waves per CU nothing else would hide the HBM latency of a load-store-load-store loop.
 __device__ __forceinline__ void stage_rows(double *dst, const double *src, int rows, int n, int ld)
 {
     const int lane = lane_id(), total = rows * n;
     int r = 0, c = lane;
     while (c >= n) { c -= n; ++r; }
-    for (int e0 = lane; e0 < total; e0 += 64 * 8) {
-        double v[8];
-        int off[8];
+    constexpr int DEPTH = 16;
+    for (int e0 = lane; e0 < total; e0 += 64 * DEPTH) {
+        double v[DEPTH];
+        int off[DEPTH];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < DEPTH; ++q) {
             const int e = e0 + 64 * q;
             v[q] = (e < total) ? src[e] : 0.0;
             off[q] = r * ld + c;
@@ -78,22 +79,26 @@ __device__ __forceinline__ void stage_rows(double *dst, const double *src, int r
             while (c >= n) { c -= n; ++r; }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) if (e0 + 64 * q < total) dst[off[q]] = v[q];
+        for (int q = 0; q < DEPTH; ++q) if (e0 + 64 * q < total) dst[off[q]] = v[q];
     }
 }
 
-// LDS: [ Rsq: n x nsq zero-padded square R^-1, overlaying the packed Cholesky factor once that is
-// dead | f v xu | scaling dupper dlower | tile (64 x ldr: inverse scratch, then the A tiles) | sense ]
-struct FastLds { int R, fv, vv, xu, sc, du, dl, tile, sens, total_bytes; };
-__host__ __device__ inline FastLds fast_lds(int n, int m)
+// LDS: [ Rsq: n x nsq square R^-1 (zeros left of the diagonal; first the staged H) | tile (64 x ldr: A rows,
+// overwritten by their M rows) | f v xu | scaling dupper dlower | sense ].  Without exact_setup the R^-1
+// fragments live in registers during the M phase, so the tile aliases Rsq and four workgroups fit a CU.
+struct FastLds { int R, fv, vv, xu, sc, du, dl, tile, sens, nsq, total_bytes; };
+__host__ __device__ inline int fast_nsq(int n) { int q = n < 2 ? 2 : n; while ((q & 3) != 2) ++q; return q; }
+__host__ __device__ inline FastLds fast_lds(int n, int m, int exact)
 {
     FastLds s;
-    const int nsq = round_up(n, 8), rt = round_up(n * (n + 1) / 2, 2), np = round_up(n, 2), mp = round_up(m, 2), ldr = n | 1;
+    const int nsq = fast_nsq(n), np = round_up(n, 2), mp = round_up(m, 2), ldr = n | 1;
+    const int rsz = round_up(n * nsq + 8, 2), tsz = round_up(64 * ldr, 2);
     int o = 0;
-    s.R = o; o += (n * nsq > rt ? n * nsq : rt) + 8;
+    s.nsq = nsq;
+    s.R = 0;
+    if (exact) { s.tile = rsz; o = rsz + tsz; } else { s.tile = 0; o = rsz > tsz ? rsz : tsz; }
     s.fv = o; o += np; s.vv = o; o += np; s.xu = o; o += np;
     s.sc = o; o += mp; s.du = o; o += mp; s.dl = o; o += mp;
-    s.tile = o; o += round_up(64 * ldr, 2);
     s.sens = o;
     s.total_bytes = o * 8 + round_up(m, 4) * 4;
     return s;
@@ -104,9 +109,10 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = lane_id();
-    const int n = b.n, m = b.m, ms = b.ms, mA = b.mA, ldr = b.ldr, nsq = round_up(n, 8);
-    const FastLds o = fast_lds(n, m);
-    double *R = smem + o.R, *Rsq = smem + o.R, *fl = smem + o.fv, *vv = smem + o.vv, *xu = smem + o.xu;
+    const int n = b.n, m = b.m, ms = b.ms, mA = b.mA, ldr = b.ldr;
+    const FastLds o = fast_lds(n, m, b.exact_setup);
+    const int nsq = o.nsq;
+    double *Rsq = smem + o.R, *fl = smem + o.fv, *vv = smem + o.vv, *xu = smem + o.xu;
     double *sc = smem + o.sc, *du = smem + o.du, *dl = smem + o.dl, *tile = smem + o.tile;
     int *sens = reinterpret_cast<int *>(smem + o.sens);
     const double *H = b.H + (size_t)q * n * n, *f = b.f + (size_t)q * n, *A = b.A + (size_t)q * mA * n;
@@ -137,65 +143,74 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     else if (bad & 1) flag = DAQP_EXIT_INFEASIBLE;
     if (st.eps_prox > 0.0) flag = DAQP_EXIT_UNSUPPORTED;
     if (lane < n) fl[lane] = f[lane];
-    // pack 1/2 (H + H') (utils.c:318-324): H is staged through the (still unused) tile area
-    if (flag > 0) {
-        stage_rows(tile, H, n, n, ldr);
-        WSYNC();
-        for (int i = 0; i < n; ++i) {
-            const int j = i + lane;
-            if (j < n) R[roff(i, n) + j] = (j == i) ? tile[i * ldr + i] : 0.5 * (tile[i * ldr + j] + tile[j * ldr + i]);
-        }
-    }
-    WSYNC();
-
-    // --- Cholesky (utils.c:335-352)
+    // --- 1/2 (H + H') (utils.c:318-324) into registers: lane j <-> column j, c[i] = row i
     double pmin = DAQP_INF, pmax = 0.0;
     if (flag > 0) {
-        for (int i = 0; i < n && flag > 0; ++i) {
-            const int pi = roff(i, n);
-            const int j = i + lane;
-            const bool own = j < n;
-            const int jj = own ? j : i;                 // clamp: inactive lanes recompute the diagonal chain
-            double acc = R[pi + jj];
-            acc = chain_sub8(acc, i, [&](int k) { return R[roff(k, n) + i]; }, [&](int k) { return R[roff(k, n) + jj]; });
-            const double dg = rl(acc, 0);
-            if (dg <= st.zero_tol) { flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED; break; }
-            if (dg < pmin) pmin = dg;
-            if (dg > pmax) pmax = dg;
-            const double dgi = 1 / sqrt(dg);
-            if (own) R[pi + j] = (lane == 0) ? dgi : acc * dgi;
-            WSYNC();
+        double c[NMAX], a[NMAX];
+        stage_rows(Rsq, H, n, n, nsq);
+        WSYNC();
+        {
+            const int jj = lane < n ? lane : 0;
+            static_for<NMAX / 8>([&](auto g) __attribute__((always_inline)) {
+                if (8 * g < n) {
+                    static_for<8>([&](auto h) __attribute__((always_inline)) {
+                        constexpr int i = 8 * g + h;
+                        const int ii = i < n ? i : 0;
+                        const double hij = Rsq[ii * nsq + jj], hji = Rsq[jj * nsq + ii];
+                        const double val = (jj == ii) ? hij : 0.5 * (hij + hji);
+                        c[i] = (lane < n && i < n) ? val : 0.0;
+                        a[i] = 0.0;
+                    });
+                } else {
+                    static_for<8>([&](auto h) __attribute__((always_inline)) { c[8 * g + h] = 0.0; a[8 * g + h] = 0.0; });
+                }
+            });
         }
+        WSYNC();
+        if (lane < 8) Rsq[n * nsq + lane] = 0.0;   // padding behind the last row (read, never used, by the 8-column groups)
+        // --- fused Cholesky (utils.c:335-352) and R -> R^-1 (utils.c:380-389).  Entering step k, c[i] is row
+        // k+i of the Schur complement (lane <-> column) and, in lanes < k, a[i] is the accumulator of
+        // (R^-1)[lane][k+i]; lanes >= k hold +-0 there.
+        // Phase P covers the steps k that still have 8(P-1) < n-1-k <= 8P later rows: its body updates exactly
+        // 8P registers with no branch inside (rows >= n only ever hold zeros or unused values).
+        static_for<NMAX / 8 + 1>([&](auto pp) __attribute__((always_inline)) {
+            constexpr int P = NMAX / 8 - pp;
+            int k = n - 1 - 8 * P;
+            if (k < 0) k = 0;
+            const int kend = (P == 0) ? n : n - 1 - 8 * (P - 1);
+            for (; k < kend && flag > 0; ++k) {
+                const double dg = rl(c[0], k);
+                if (dg <= st.zero_tol) { flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED; break; }
+                if (dg < pmin) pmin = dg;
+                if (dg > pmax) pmax = dg;
+                const double dgi = 1 / sqrt(dg);
+                const double rk = (lane > k) ? c[0] * dgi : 0.0;                   // r_kj, j > k
+                const double tk = a[0] * dgi;                                      // t_k *= 1/r_kk for the rows above
+                const double col = (lane < k) ? tk : ((lane == k) ? dgi : 0.0);    // column k of R^-1 (zeros below the diagonal)
+                if (lane < n) Rsq[lane * nsq + k] = col;
+                // lane k starts its own row now: -0.0 - r_kj*(1/r_kk) == r_kj * -(1/r_kk) bit for bit, so the start is
+                // the common update applied to a forced -0.0 (lanes >= k only ever hold +-0: low word 0, OR the sign in)
+                const unsigned sgn = (lane >= k) ? 0x80000000u : 0u;
+                // rotate row k so that r_{k,k+1+i} sits in lane i: a v_readlane with an immediate lane costs half of
+                // one with a computed lane (s_add + SGPR-index hazard), and there are ~n^2/2 of them
+                const double rot = __shfl(rk, (lane + k + 1) & 63);
+                static_for<8 * P>([&](auto ii) __attribute__((always_inline)) {
+                    constexpr int i = ii;
+                    if constexpr (i + 1 < NMAX) {
+                        const double s = rl(rot, i);                               // r_{k,k+1+i}, wave-uniform
+                        c[i] = c[i + 1] - s * rk;
+                        const double ap = __hiloint2double(__double2hiint(a[i + 1]) | sgn, __double2loint(a[i + 1]));
+                        a[i] = ap - s * col;
+                    }
+                });
+            }
+        });
         if (flag > 0 && pmin <= st.zero_tol * pmax)
             flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED;
+        WSYNC();
     }
     SPROF(0);
-    // --- R -> R^-1 (utils.c:380-389), lane <-> row k.  T[i*64 + lane] = t_i of this lane's row (0 for i <= k),
-    // kept in the tile area; the finished row is written to Ro.
-    double *T = tile;
     if (flag > 0) {
-        const int k = lane;
-        const bool own = k < n;
-        const int pk = own ? roff(k, n) : 0;
-        const double rkk = own ? R[pk + k] : 0.0;
-        T[lane] = 0.0;   // i = 0 is never a t_i of any row (i > k >= 0)
-        for (int j = 1; j < n; ++j) {
-            const int jc = (own && j > k) ? j : (own ? k : 0);          // in-range address for idle lanes
-            double acc = R[pk + jc] * -rkk;                             // r_kj *= -(1/r_kk)
-            acc = chain_sub8(acc, j - 1, [&](int ii) { return R[roff(ii + 1, n) + j]; },
-                             [&](int ii) { return T[(ii + 1) * 64 + lane]; });
-            const double tj = acc * R[roff(j, n) + j];                   // t_j *= 1/r_jj
-            T[j * 64 + lane] = (own && j > k) ? tj : 0.0;
-        }
-        WSYNC();
-        // the Cholesky factor is dead: expand R^-1 into the zero-padded square Rsq[r*nsq + c]
-        for (int e = lane; e < n * nsq; e += 64) Rsq[e] = 0.0;
-        WSYNC();
-        if (own) {
-            Rsq[k * nsq + k] = rkk;
-            for (int j = k + 1; j < n; ++j) Rsq[k * nsq + j] = T[j * 64 + lane];
-        }
-        WSYNC();
         // --- v = R^-T f (utils.c:474-497)
         if (lane < n) {
             const int i = lane;
@@ -232,9 +247,67 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     }
     SPROF(2);
 
-    // --- general rows, 64 at a time through the LDS tile; lane <-> row
+    // --- simple bounds: rows < ms of R^-1 normalised (utils.c:569-585), their d, their dense image in M.
+    // Rsq itself stays unscaled (the general rows below multiply by the unscaled inverse, as the
+    // reference does at that point); every consumer applies the one multiplication by s itself.
     int feasible = 1;
     double *Mq = b.Mblk + (size_t)q * b.nblk * b.npair * 128;
+    if (flag > 0) {
+        if (lane < ms) {
+            const int i = lane;
+            const double *Ri = Rsq + i * nsq;
+            double s = 0;
+            for (int j = i; j < n; ++j) s += Ri[j] * Ri[j];
+            s = 1 / sqrt(s);
+            sc[i] = s;
+            if (unc) {
+                const double u0 = bu[i] - xu[i], l0 = bl[i] - xu[i];
+                if (u0 < -st.primal_tol || l0 > st.primal_tol) feasible = 0;
+                du[i] = u0 * s; dl[i] = l0 * s;
+            } else {
+                double t = 0;
+                for (int j = i; j < n; ++j) t += (Ri[j] * s) * vv[j];
+                du[i] = bu[i] * s + t;
+                dl[i] = bl[i] * s + t;
+            }
+            double2 *dst = reinterpret_cast<double2 *>(Mq) + ((size_t)(i >> 6) * b.npair) * 64 + (i & 63);
+            for (int t = 0; t < b.npair; ++t) {
+                double2 vpair;
+                vpair.x = (2 * t >= i) ? Ri[2 * t] * s : 0.0;
+                vpair.y = (2 * t + 1 >= i && 2 * t + 1 < n) ? Ri[2 * t + 1] * s : 0.0;
+                dst[(size_t)t * 64] = vpair;
+            }
+        }
+        WSYNC();
+        // packed upper image for the solve kernel / warm updates (rows < ms normalised)
+        double *Rp = b.Rinv + (size_t)q * b.rtri;
+        for (int i = 0; i < n; ++i) {
+            const int j = i + lane;
+            if (j < n) {
+                double val = Rsq[i * nsq + j];
+                if (i < ms) val *= sc[i];
+                Rp[roff(i, n) + j] = val;
+            }
+        }
+    }
+    // R^-1 fragments of the MFMA path: Bf[kt][ct] = R^-1[4kt + (lane>>4)][16ct + (lane&15)], upper triangular
+    // (k tiles only up to the column tile's last column), zero outside n x n
+    constexpr int KT = NMAX / 4, CT = (NMAX + 15) / 16;
+    double Bf[KT][CT];
+    if (flag > 0 && !b.exact_setup) {
+        const int lr = lane & 15, lk = lane >> 4;
+        static_for<KT>([&](auto kt) __attribute__((always_inline)) {
+            static_for<CT>([&](auto ct) __attribute__((always_inline)) {
+                if constexpr (kt <= 4 * ct + 3) {
+                    const int kk = 4 * kt + lk, cc = 16 * ct + lr;
+                    const bool ok = kk < n && cc < n;
+                    const double bload = Rsq[(kk < n ? kk : 0) * nsq + (cc < n ? cc : 0)];
+                    Bf[kt][ct] = ok ? bload : 0.0;
+                } else Bf[kt][ct] = 0.0;
+            });
+        });
+    }
+    // --- general rows, 64 at a time through the LDS tile; lane <-> row
     if (flag > 0) {
         for (int tb = 0; tb < mA && flag > 0; tb += 64) {
             const int rows = (mA - tb) < 64 ? (mA - tb) : 64;
@@ -268,33 +341,32 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                 }
             } else {
                 // M = A R^-1 on the matrix cores: v_mfma_f64_16x16x4_f64, one 16-row tile of A against the
-                // (upper-triangular: K only up to the column tile's last column) 16-column tiles of R^-1.
-                // A: lane l supplies A[l&15][l>>4], B: R^-1[l>>4][l&15], D: col = l&15, row = (l>>4) + 4*reg.
+                // register-resident fragments of R^-1.  A: lane l supplies A[l&15][4kt + (l>>4)], B: R^-1[4kt + (l>>4)][16ct + (l&15)],
+                // D: col = l&15, row = (l>>4) + 4*reg.  No run-time guards inside: fragments beyond n are zeros.
                 // The summation order differs from the reference's (fp64, fused): M agrees to ~1e-16 relative.
                 typedef double v4d __attribute__((ext_vector_type(4)));
-                const int lr = lane & 15, lk = lane >> 4, ktn = (n + 3) >> 2;
+                const int lr = lane & 15, lk = lane >> 4;
                 for (int rt = 0; rt * 16 < rows; ++rt) {
-                    v4d acc4[4];
-                    static_for<4>([&](auto ct) __attribute__((always_inline)) { acc4[ct] = (v4d){0.0, 0.0, 0.0, 0.0}; });
+                    v4d acc4[CT];
+                    static_for<CT>([&](auto ct) __attribute__((always_inline)) { acc4[ct] = (v4d){0.0, 0.0, 0.0, 0.0}; });
                     const int arow = rt * 16 + lr;
                     const bool rowok = arow < rows;
                     const double *arowp = tile + (rowok ? arow : 0) * ldr;
-                    for (int kt = 0; kt < ktn; ++kt) {
+                    double av[KT];
+                    static_for<KT>([&](auto kt) __attribute__((always_inline)) {
                         const int kk = 4 * kt + lk;
                         const bool kok = kk < n;
                         const double aload = arowp[kok ? kk : 0];
-                        const double av = (rowok && kok) ? aload : 0.0;
-                        static_for<4>([&](auto ct) __attribute__((always_inline)) {
-                            if (16 * ct < n && kt <= 4 * ct + 3) {
-                                const int cc = 16 * ct + lr;
-                                const bool ok = kok && cc < n;
-                                const double bload = Rsq[(kok ? kk : 0) * nsq + (cc < n ? cc : 0)];
-                                acc4[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, ok ? bload : 0.0, acc4[ct], 0, 0, 0);
-                            }
+                        av[kt] = (rowok && kok) ? aload : 0.0;
+                    });
+                    static_for<KT>([&](auto kt) __attribute__((always_inline)) {
+                        static_for<CT>([&](auto ct) __attribute__((always_inline)) {
+                            if constexpr (kt <= 4 * ct + 3)
+                                acc4[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], Bf[kt][ct], acc4[ct], 0, 0, 0);
                         });
-                    }
+                    });
                     WSYNC();   // every lane's reads of this row tile precede the in-place overwrite below
-                    static_for<4>([&](auto ct) __attribute__((always_inline)) {
+                    static_for<CT>([&](auto ct) __attribute__((always_inline)) {
                         static_for<4>([&](auto r) __attribute__((always_inline)) {
                             const int row = rt * 16 + lk + 4 * r, col = 16 * ct + lr;
                             if (col < n && row < rows) tile[row * ldr + col] = acc4[ct][(int)r];
@@ -345,45 +417,10 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             SPROF(4);
         }
     }
-    // --- simple bounds: normalise rows < ms of R^-1 (utils.c:569-585), their d, their dense image in M
-    if (flag > 0) {
-        WSYNC();
-        if (lane < ms) {
-            const int i = lane;
-            double *Ri = Rsq + i * nsq;
-            double s = 0;
-            for (int j = i; j < n; ++j) s += Ri[j] * Ri[j];
-            s = 1 / sqrt(s);
-            sc[i] = s;
-            for (int j = i; j < n; ++j) Ri[j] *= s;
-            if (unc) {
-                const double u0 = bu[i] - xu[i], l0 = bl[i] - xu[i];
-                if (u0 < -st.primal_tol || l0 > st.primal_tol) feasible = 0;
-                du[i] = u0 * s; dl[i] = l0 * s;
-            } else {
-                double t = 0;
-                for (int j = i; j < n; ++j) t += Ri[j] * vv[j];
-                du[i] = bu[i] * s + t;
-                dl[i] = bl[i] * s + t;
-            }
-            double2 *dst = reinterpret_cast<double2 *>(Mq) + ((size_t)(i >> 6) * b.npair) * 64 + (i & 63);
-            for (int t = 0; t < b.npair; ++t) {
-                double2 vpair;
-                vpair.x = (2 * t >= i) ? Ri[2 * t] : 0.0;
-                vpair.y = (2 * t + 1 >= i && 2 * t + 1 < n) ? Ri[2 * t + 1] : 0.0;
-                dst[(size_t)t * 64] = vpair;
-            }
-        }
-        WSYNC();
-    }
     const int all_feasible = __all(feasible);
     int sing = kEmpty;
     if (flag > 0 && unc && all_feasible) { sing = DAQP_UNCONSTRAINED_OPTIMAL; activate = 0; }
     if (flag > 0) {
-        for (int e = lane; e < n * n; e += 64) {   // packed upper image for the solve kernel / warm updates
-            const int i = e / n, j = e - i * n;
-            if (j >= i) b.Rinv[(size_t)q * b.rtri + roff(i, n) + j] = Rsq[i * nsq + j];
-        }
         if (lane < n) { b.v[(size_t)q * n + lane] = vv[lane]; if (unc) b.xunc[(size_t)q * n + lane] = xu[lane]; }
         for (int i = lane; i < m; i += 64) {
             b.scaling[(size_t)q * m + i] = sc[i];

@@ -610,13 +610,18 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
         // ---- one iteration of daqp_ldp up to its working-set edit (daqp.c:12-64, 86-93)
         case PC_ITER: {
             const bool was_singular = (w.sing != kEmpty);
+            RPROF_T0(w);
             if (!was_singular) rsolve_csp(w); else rsingular_direction(w);
+            RPROF_ACC(w, 7);
             const int blk = rblocking_test(w);
+            RPROF_ACC(w, 8);
             if (blk != kBig) { req_add = 0; req_r = blk; depth = 0; after_edit = AFTER_NEXT_ITER; pc = PC_EDIT; break; }
             if (was_singular) { flag = DAQP_EXIT_INFEASIBLE; pc = PC_DONE; break; }
             rprimal_u(w);
+            RPROF_ACC(w, 9);
             int upper = 0;
             int pick = rscan_rows(w, upper, true);
+            RPROF_ACC(w, 10);
             if (w.fval > fbound) { flag = DAQP_EXIT_INFEASIBLE; pc = PC_DONE; break; }
             after_edit = AFTER_CYCLE_GUARD;
             if (pick == kBig) {
@@ -653,8 +658,9 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
         case PC_EDIT: {
             for (;;) {
                 bool settled = false;
-                if (req_add) rpush_core(w, req_id, req_lam);
-                else settled = rdrop_core(w, req_r) != 0;      // a removal that left a singular factor does not pivot
+                RPROF_T0(w);
+                if (req_add) { rpush_core(w, req_id, req_lam); RPROF_ACC(w, 13); }
+                else { settled = rdrop_core(w, req_r) != 0; RPROF_ACC(w, 14); }     // a removal that left a singular factor does not pivot
                 if (!settled) {
                     const int r = w.na - 2;
                     bool piv = false;

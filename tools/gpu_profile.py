@@ -36,4 +36,6 @@ for prof in (False, True):
             if vis[k] > 0:
                 print(f"    {names[k]:24s} {cyc[k] / nit:9.0f}  ({cyc[k] / vis[k]:8.0f}, {vis[k] / nit:5.2f})")
         print("    total/iter", round(cyc[:7].sum() / nit), " | csp fwd %d bwd %d (cycles/iter)" % tuple(cyc[11:13] / nit))
+        print("    ITER parts/iter: csp %d, blocking %d, primal %d, scan %d | EDIT parts/iter: push %d, drop %d"
+              % (cyc[7] / nit, cyc[8] / nit, cyc[9] / nit, cyc[10] / nit, cyc[13] / nit, cyc[14] / nit))
     bm.close()

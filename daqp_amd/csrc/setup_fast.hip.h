@@ -83,6 +83,19 @@ __device__ __forceinline__ void stage_rows(double *dst, const double *src, int r
     }
 }
 
+// Contiguous HBM -> LDS copy that bypasses the VGPRs: global_load_lds_dwordx4 (gfx950), 16 bytes per lane per
+// instruction, every instruction of the copy in flight at once (one HBM round trip per tile instead of one
+// per eight loads).  cnt even, src and dst 16-byte aligned; completion = vmcnt (copy_wait).
+__device__ __forceinline__ void copy_async(double *dst, const double *src, int cnt)
+{
+    const int lane = lane_id(), pairs = cnt >> 1;
+    for (int c = 0; c < pairs; c += 64)
+        if (c + lane < pairs)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2 * (c + lane)),
+                                             (__attribute__((address_space(3))) void *)(dst + 2 * c), 16, 0, 0);
+}
+__device__ __forceinline__ void copy_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */ }
+
 // LDS: [ Rsq: n x nsq square R^-1 (zeros left of the diagonal; first the staged H) | tile (64 x ldr: A rows,
 // overwritten by their M rows) | f v xu | scaling dupper dlower | sense ].  Without exact_setup the R^-1
 // fragments live in registers during the M phase, so the tile aliases Rsq and four workgroups fit a CU.
@@ -91,7 +104,7 @@ __host__ __device__ inline int fast_nsq(int n) { int q = n < 2 ? 2 : n; while ((
 __host__ __device__ inline FastLds fast_lds(int n, int m, int exact)
 {
     FastLds s;
-    const int nsq = fast_nsq(n), np = round_up(n, 2), mp = round_up(m, 2), ldr = n | 1;
+    const int nsq = fast_nsq(n), np = round_up(n, 2), mp = round_up(m, 2), ldr = n | 1;   // tile stride: n | 1 (staged) or n (direct copy)
     const int rsz = round_up(n * nsq + 8, 2), tsz = round_up(64 * ldr, 2);
     int o = 0;
     s.nsq = nsq;
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = lane_id();
-    const int n = b.n, m = b.m, ms = b.ms, mA = b.mA, ldr = b.ldr;
+    const int n = b.n, m = b.m, ms = b.ms, mA = b.mA;
     const FastLds o = fast_lds(n, m, b.exact_setup);
     const int nsq = o.nsq;
     double *Rsq = smem + o.R, *fl = smem + o.fv, *vv = smem + o.vv, *xu = smem + o.xu;
@@ -119,11 +132,16 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
     const DAQPSettings &st = b.st;
     QState *qs = b.qs + q;
+    // rows of even length (and not a multiple of 32 doubles, which would put every row of the tile on the same
+    // LDS banks) are copied HBM -> LDS directly, unpadded; everything else is staged through registers with an odd stride
+    const bool direct = !(n & 1) && (n & 31) && !(((size_t)H | (size_t)A) & 15);
+    const int ldr = direct ? n : (n | 1);
     int flag = 1, activate = 0;
-    long long pt[6] = {0, 0, 0, 0, 0, 0};
+    long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t0 = b.prof ? (long long)__builtin_readcyclecounter() : 0;
 #define SPROF(slot) do { if (b.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[slot] += t1 - t0; t0 = t1; } } while (0)
 
+    if (direct) copy_async(Rsq, H, n * n);     // in flight while the bounds are checked
     // --- sense (utils.c:84-91) and early bound check (utils.c:546-567)
     int bad = 0;
     for (int i = lane; i < m; i += 64) {
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     double pmin = DAQP_INF, pmax = 0.0;
     if (flag > 0) {
         double c[NMAX], a[NMAX];
-        stage_rows(Rsq, H, n, n, nsq);
+        if (direct) copy_wait(); else stage_rows(Rsq, H, n, n, n);
         WSYNC();
         {
             const int jj = lane < n ? lane : 0;
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                     static_for<8>([&](auto h) __attribute__((always_inline)) {
                         constexpr int i = 8 * g + h;
                         const int ii = i < n ? i : 0;
-                        const double hij = Rsq[ii * nsq + jj], hji = Rsq[jj * nsq + ii];
+                        const double hij = Rsq[ii * n + jj], hji = Rsq[jj * n + ii];
                         const double val = (jj == ii) ? hij : 0.5 * (hij + hji);
                         c[i] = (lane < n && i < n) ? val : 0.0;
                         a[i] = 0.0;
@@ -307,13 +325,17 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             });
         });
     }
+    SPROF(6);
     // --- general rows, 64 at a time through the LDS tile; lane <-> row
     if (flag > 0) {
+        WSYNC();   // Rsq (under the tile unless exact_setup) has no readers left
+        if (direct && mA > 0) copy_async(tile, A, (mA < 64 ? mA : 64) * n);
         for (int tb = 0; tb < mA && flag > 0; tb += 64) {
             const int rows = (mA - tb) < 64 ? (mA - tb) : 64;
+            if (direct) copy_wait();
+            else { WSYNC(); stage_rows(tile, A + (size_t)tb * n, rows, n, ldr); }
             WSYNC();
-            stage_rows(tile, A + (size_t)tb * n, rows, n, ldr);
-            WSYNC();
+            SPROF(7);
             const int k = tb + lane;
             const bool own = lane < rows;
             const double *a = tile + (own ? lane : 0) * ldr;
@@ -374,9 +396,14 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                     });
                 }
                 WSYNC();
+                SPROF(8);
                 static_for<NMAX>([&](auto c) __attribute__((always_inline)) { acc[c] = (c < n) ? a[c < n ? c : 0] : 0.0; });
             }
             SPROF(3);
+            if (direct && tb + 64 < mA) {   // this tile lives in registers now: the next one loads during the normalisation
+                WSYNC();
+                copy_async(tile, A + (size_t)(tb + 64) * n, ((mA - tb - 64) < 64 ? (mA - tb - 64) : 64) * n);
+            }
             // normalise (utils.c:586-613), d (utils.c:499-544 / 664-676 + 151-159), blocked store
             double s = 0;
             static_for<NMAX>([&](auto c) __attribute__((always_inline)) { if (c < n) s += acc[c] * acc[c]; });
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0;
-        if (b.prof) for (int i = 0; i < 6; ++i) b.prof[(size_t)q * 32 + i] = pt[i];
+        if (b.prof) for (int i = 0; i < 10; ++i) b.prof[(size_t)q * 32 + i] = pt[i];
     }
 #undef SPROF
 }

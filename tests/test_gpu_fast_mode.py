@@ -30,6 +30,20 @@ def test_fast_mode_parity(oracle, gpu_lib, cfg, N):
     assert np.abs(g["fval"] - ref[2]).max() < 1e-8 * max(1.0, np.abs(ref[2]).max())
 
 
+@pytest.mark.parametrize("shape", [(7, 20, 3, 3), (16, 40, 4, 6), (31, 64, 0, 10), (32, 64, 0, 12), (33, 70, 5, 12),
+                                   (48, 100, 0, 16), (56, 120, 0, 20), (57, 120, 0, 20), (64, 128, 0, 24)])
+def test_fast_mode_shapes(oracle, gpu_lib, shape):
+    """the MFMA fragment guards of every setup variant (partial k / column tiles) at the north_star bar"""
+    import daqp_amd
+    n, m, ms, na = shape
+    q = O.generate_batch(64, n, m, ms, na, 900 + n)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4])
+    assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1]))
+    assert np.abs(g["x"] - ref[0]).max() < XTOL
+
+
 def test_fast_mode_ldp_close(oracle, gpu_lib):
     """the MFMA-formed M matches the reference's to rounding; everything upstream of it stays bit-identical"""
     import daqp_amd

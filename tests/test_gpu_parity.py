@@ -32,7 +32,7 @@ def gpu_batch(q, **settings):
 
 
 def check_batch(oracle, cfg, N, start=0, bitwise=True, **settings):
-    n, m, ms, na, seed, _ = O.CONFIGS[cfg]
+    n, m, ms, na, seed, _ = O.CONFIGS[cfg] if isinstance(cfg, str) else cfg
     q = O.generate_batch(N, n, m, ms, na, seed, start=start)
     q["ms"] = ms
     ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms,
@@ -64,6 +64,15 @@ def test_c1_single_qp(oracle, gpu_lib):
 @pytest.mark.parametrize("cfg,N", [("C1", 64), ("C2", 256), ("C3", 512)])
 def test_config_batches(oracle, gpu_lib, cfg, N):
     check_batch(oracle, cfg, N)
+
+
+@pytest.mark.parametrize("shape", [(7, 20, 3, 3), (16, 40, 4, 6), (31, 64, 0, 10), (32, 64, 0, 12), (33, 70, 5, 12),
+                                   (48, 100, 0, 16), (56, 120, 0, 20), (57, 120, 0, 20), (64, 128, 0, 24)])
+def test_setup_shapes(oracle, gpu_lib, shape):
+    """every variant of the register setup kernel (NMAX 16/32/56/64), both tile paths: direct HBM->LDS copy (n even,
+    not a multiple of 32) and register staging (odd n, n = 32, 64), partial column groups, simple bounds"""
+    n, m, ms, na = shape
+    check_batch(oracle, (n, m, ms, na, 900 + n, 0), 48)
 
 
 def test_c4_spill(oracle, gpu_lib):

@@ -149,6 +149,7 @@ def main():
         t_ldp = float(np.mean(solve_ms)) * 1e-3
         t_setup = float(np.mean(setup_ms)) * 1e-3
         ach = ldp_bytes / t_ldp / 1e9
+        traffic, traffic_src = pmc_traffic(N, n, m)
         out = {
             "metric": "QPs/sec (fp64) for batched random dense QPs n=50 m=150",
             "value": world * N * args.steps / elapsed, "unit": "QPs/s", "n_gpus": world, "steps": args.steps,
@@ -160,7 +161,7 @@ def main():
                        "mean_iterations": float(iters.mean()), "parallelism": f"independent shards x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": "k_ldp (dual active-set iteration + back-transform)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": t_ldp * 1e3,
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": t_ldp * 1e3,
                          "algorithmic_bytes_per_launch": ldp_bytes,
                          "pipeline": {"achieved": all_bytes / (t_ldp + t_setup) / 1e9, "frac": all_bytes / (t_ldp + t_setup) / 1e9 / HBM_PEAK_GBS,
                                       "k_setup_ms": t_setup * 1e3, "k_ldp_ms": t_ldp * 1e3, "algorithmic_bytes_per_step": all_bytes}},
@@ -180,6 +181,23 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     bm.close()
+
+
+def pmc_traffic(N, n, m):
+    """HBM bytes per solve launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE each in its
+    own run, corrected as MI355X_MICROARCH.md prescribes; see profiles/README.md).  Counters cannot be collected
+    from inside this process, so the figure is the one measured with this same command line, and only quoted
+    for the workload it was measured on."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_hbm.json")))
+    if not files or (N, n, m) != (100000, 50, 150):
+        return None, None
+    d = json.load(open(files[-1]))
+    for k, v in d.items():
+        if k.startswith("k_ldp_reg") and isinstance(v, dict) and "traffic_bytes_per_launch" in v:
+            return v["traffic_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
+    return None, None
 
 
 if __name__ == "__main__":

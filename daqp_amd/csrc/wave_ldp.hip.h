@@ -27,7 +27,7 @@ constexpr int kBig = 0x7fffffff;
 // store to a[tid] with a load of a[tid+1]).  A wavefront-scope fence is exactly that.
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-__device__ __forceinline__ int tri(int k) { return (k * (k + 1)) >> 1; }
+__host__ __device__ constexpr __forceinline__ int tri(int k) { return (k * (k + 1)) >> 1; }
 __device__ __forceinline__ int roff(int i, int n) { return ((2 * n - i - 1) * i) / 2; }
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
 

@@ -164,36 +164,49 @@ __device__ __forceinline__ double dot4_pipelined(const double *a, const double *
 // issue time.  Hence: chains run in straight-line groups of 8 with the loads of the group issued
 // first, and steps beyond the end are padded with exact zeros (x - 0*y == x) instead of guarded.
 
+// Lane numbers of the chains below are COMPILE-TIME constants (static chunks of 8 lanes, a chunk skipped by one
+// uniform branch once past the end): v_readlane with an immediate lane costs ~8 cycles, with a computed lane ~15
+// (s_add + SGPR-index hazard, tools/ubench2.hip), and a constant column turns every L address into
+// "lane base + immediate offset".
+
 // b <- L' \ b over the leading cnt positions (column-oriented; product order b_j * L[j][i]).
 // Lanes >= cnt must hold b == 0.
 template <int NB, int NP>
 __device__ __forceinline__ double rbackward(RWave<NB, NP> &w, double b, int cnt)
 {
     const int lane = lane_id();
-    for (int j0 = cnt - 1; j0 >= 1; j0 -= kChunk) {
-        double Lb[kChunk];
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) {   // unconditional loads (any address inside the LDS allocation is fine)
-            const int j = j0 - q;
-            Lb[q] = w.L[tri(j > 0 ? j : 0) + lane];
+    const double *Ll = w.L + lane;
+    // step j updates lanes with lane < j < cnt  <=>  (unsigned)(j - 1 - lane) < (unsigned)(cnt - 1 - lane) for lane < cnt:
+    // one add and one compare per step on per-lane registers, no wave-uniform mask per step (those end up as
+    // spilled SGPR pairs).  Lanes >= cnt may pick up unused values; nothing reads them.
+    const unsigned room = (unsigned)(cnt - 1 - lane);
+    const int nlane = -1 - lane;
+    static_for<8>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = 7 - cc;
+        if (8 * c < cnt && cnt > 1) {
+            double Lb[8];
+            static_for<8>([&](auto q) __attribute__((always_inline)) {   // unconditional loads (any address inside the LDS allocation is fine)
+                constexpr int j = 8 * c + 7 - q;
+                Lb[q] = Ll[tri(j)];
+            });
+            static_for<8>([&](auto q) __attribute__((always_inline)) {
+                constexpr int j = 8 * c + 7 - q;
+                if constexpr (j >= 1) {
+                    const double bj = rl(b, j);
+                    const double t = b - bj * Lb[q];
+                    b = ((unsigned)(j + nlane) < room) ? t : b;
+                }
+            });
         }
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
-            const int j = j0 - q;
-            const double bj = rl(b, j & 63);
-            const double t = b - bj * Lb[q];
-            b = (j >= 1 && lane < j) ? t : b;   // the select discards whatever the padding lanes computed
-        }
-    }
+    });
     return b;
 }
 // ordered sum: acc - p_0 - p_1 - ... - p_{cnt-1} (p must be 0 in lanes >= cnt)
 __device__ __forceinline__ double ordered_sub(double acc, double p, int cnt)
 {
-    for (int k0 = 0; k0 < cnt; k0 += kChunk) {
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) acc -= rl(p, (k0 + q) & 63);
-    }
+    static_for<8>([&](auto c) __attribute__((always_inline)) {
+        if (8 * c < cnt) static_for<8>([&](auto q) __attribute__((always_inline)) { acc -= rl(p, 8 * c + q); });
+    });
     return acc;
 }
 // x_i = rhs_i - sum_{j<i} L[i][j] x_j for rows i >= from (j ascending), column-oriented: lane <-> row, the
@@ -205,18 +218,27 @@ __device__ __forceinline__ double rforward(RWave<NB, NP> &w, double x, double rh
     const int lane = lane_id(), na = w.na;
     const bool pending = lane >= from && lane < na;
     x = pending ? rhs : (lane < na ? x : 0.0);
-    const int rowbase = tri(lane);
-    for (int j0 = 0; j0 < na - 1; j0 += kChunk) {
-        double Lk[kChunk];
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) Lk[q] = w.L[rowbase + j0 + q];
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
-            const double xj = rl(x, (j0 + q) & 63);
-            const double t = x - Lk[q] * xj;
-            x = (pending && lane > j0 + q) ? t : x;
-        }
+    if (from == na - 1 && na > 1) {
+        // the usual case after an add: only the last row is open.  Its products in parallel, then the j-ordered
+        // chain of subtractions on broadcast operands -- the same operations as the sweep below for that row
+        const double p = (lane < na - 1) ? w.L[tri(na - 1) + lane] * x : 0.0;
+        const double last = ordered_sub(rl(rhs, na - 1), p, na - 1);
+        return (lane == na - 1) ? last : x;
     }
+    const int pl = pending ? lane : -1;
+    const double *Lr = w.L + tri(lane);
+    static_for<8>([&](auto c) __attribute__((always_inline)) {
+        if (8 * c < na - 1) {
+            double Lk[8];
+            static_for<8>([&](auto q) __attribute__((always_inline)) { Lk[q] = Lr[8 * c + q]; });
+            static_for<8>([&](auto q) __attribute__((always_inline)) {
+                constexpr int j = 8 * c + q;
+                const double xj = rl(x, j);
+                const double t = x - Lk[q] * xj;
+                x = (pl > j) ? t : x;     // rows > j that are still open; steps j >= na-1 select nothing (pl < na)
+            });
+        }
+    });
     return x;
 }
 
@@ -245,16 +267,21 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
     if (sn_id & DAQP_SOFT) dnew += w.rho_soft;
     if (na == 0) return dnew;
     // forward substitution with L, column by column; each lane preloads its own row of L 8 columns ahead
-    for (int j0 = 0; j0 < na - 1; j0 += kChunk) {
-        double Lk[kChunk];
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) Lk[q] = w.L[tri(lane) + j0 + q];
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
-            const double lj = rl(g, (j0 + q) & 63);
-            const double t = g - Lk[q] * lj;
-            g = (lane > j0 + q && lane < na) ? t : g;
-        }
+    {
+        const int pl = lane < na ? lane : -1;
+        const double *Lr = w.L + tri(lane);
+        static_for<8>([&](auto c) __attribute__((always_inline)) {
+            if (8 * c < na - 1) {
+                double Lk[8];
+                static_for<8>([&](auto q) __attribute__((always_inline)) { Lk[q] = Lr[8 * c + q]; });
+                static_for<8>([&](auto q) __attribute__((always_inline)) {
+                    constexpr int j = 8 * c + q;
+                    const double lj = rl(g, j);
+                    const double t = g - Lk[q] * lj;
+                    g = (pl > j) ? t : g;
+                });
+            }
+        });
     }
     double p = 0;
     if (lane < na) {
@@ -310,37 +337,37 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP> &w, int r)
     // entries for 8 consecutive columns are read before, and written back after, the chain
     double alpha = rl(w.D, r);
     double Dn = w.D;
-    const int rowbase = tri(r + lane) + r;
-    for (int j0 = 0; j0 < nupd; j0 += kChunk) {
-        double Lc[kChunk];
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
-            const int j = j0 + q;
-            Lc[q] = (lane > j && lane < nupd) ? w.L[rowbase + j] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
-            const int j = j0 + q;
-            if (j < nupd) {
-                const int i = r + 1 + j;
-                const double p = rl(wv, j);
-                const double Di = rl(w.D, i);
-                const double dbar = Di + alpha * p * p;
-                const double beta = p * alpha / dbar;
-                alpha = Di * alpha / dbar;
-                if (lane == i - 1) Dn = dbar;
-                if (lane > j && lane < nupd) {
-                    wv -= p * Lc[q];
-                    Lc[q] = Lc[q] + beta * wv;
+    const double Drot = __shfl(w.D, (lane + r + 1) & 63);     // D_{r+1+j} in lane j: compile-time lane numbers below
+    const int pl = lane < nupd ? lane : -1;
+    double *Lr = w.L + tri(r + lane) + r;
+    static_for<8>([&](auto c) __attribute__((always_inline)) {
+        if (8 * c < nupd) {
+            double Lc[8];
+            static_for<8>([&](auto q) __attribute__((always_inline)) {
+                constexpr int j = 8 * c + q;
+                Lc[q] = (pl > j) ? Lr[j] : 0.0;
+            });
+            static_for<8>([&](auto q) __attribute__((always_inline)) {
+                constexpr int j = 8 * c + q;
+                if (j < nupd) {
+                    const double p = rl(wv, j);
+                    const double Di = rl(Drot, j);
+                    const double dbar = Di + alpha * p * p;
+                    const double beta = p * alpha / dbar;
+                    alpha = Di * alpha / dbar;
+                    if (lane == r + j) Dn = dbar;
+                    if (pl > j) {
+                        wv -= p * Lc[q];
+                        Lc[q] = Lc[q] + beta * wv;
+                    }
                 }
-            }
+            });
+            static_for<8>([&](auto q) __attribute__((always_inline)) {
+                constexpr int j = 8 * c + q;
+                if (pl > j) Lr[j] = Lc[q];
+            });
         }
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
-            const int j = j0 + q;
-            if (lane > j && lane < nupd) w.L[rowbase + j] = Lc[q];
-        }
-    }
+    });
     w.D = Dn;
     WSYNC();
 }
@@ -460,20 +487,22 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP> &w)
 {
     const int lane = lane_id(), na = w.na, n = w.n;
     double uu = 0;
-    for (int i0 = 0; i0 < na; i0 += kChunk) {
-        double rv[kChunk], li[kChunk];
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
-            const int i = i0 + q;
-            const bool in = i < na;                              // wave-uniform
-            const int s = in ? rli(w.slot, i & 63) : 0;
-            const double l = rl(w.lams, i & 63);
-            li[q] = in ? l : 0.0;
-            rv[q] = w.rowc[(size_t)s * w.ldr + lane];           // padding steps read slot 0 (finite) and multiply by 0
+    // per working-set position (in its lane): element offset of its cached row (0 beyond na: a finite row) and
+    // its multiplier (0 beyond na: the padding steps subtract 0 * finite, exact)
+    const int soff = (lane < na) ? w.slot * w.ldr : 0;
+    const double lz = (lane < na) ? w.lams : 0.0;
+    const double *rc = w.rowc + lane;
+    static_for<8>([&](auto c) __attribute__((always_inline)) {
+        if (8 * c < na) {
+            double rv[8], li[8];
+            static_for<8>([&](auto q) __attribute__((always_inline)) {
+                constexpr int i = 8 * c + q;
+                li[q] = rl(lz, i);
+                rv[q] = rc[rli(soff, i)];
+            });
+            static_for<8>([&](auto q) __attribute__((always_inline)) { uu -= rv[q] * li[q]; });
         }
-#pragma unroll
-        for (int q = 0; q < kChunk; ++q) uu -= rv[q] * li[q];   // padding: 0*0, exact
-    }
+    });
     WSYNC();
     if (lane < n) w.u[lane] = uu;
     double fv = 0;

@@ -242,6 +242,50 @@ __device__ __forceinline__ double rforward(RWave<NB, NP> &w, double x, double rh
     return x;
 }
 
+// factorization.c:4-15 for all rows of the working set at once when no simple bounds are involved: TWO lanes per row
+// (lane 2k+h: row k, h = 0 carries the reference's partial sums (s0,s1), h = 1 carries (s2,s3)), so a lane reads
+// every other 16-byte pair of its row and of the new row: half the LDS instructions and a quarter of the VALU work
+// of one lane per row.  Element e < 4*(n/4) goes to chain e%4 in ascending order, the n%4 tail elements go to s0 one
+// after the other, and the result is (s0+s1)+(s2+s3) -- exactly the reference's dot_row.  Row na is the new row itself.
+template <int NB, int NP>
+__device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP> &w, int newslot, const double *Mi)
+{
+    const int lane = lane_id(), na = w.na, n = w.n, nq = n >> 2, h = lane & 1;
+    const double2 *rb = reinterpret_cast<const double2 *>(Mi) + h;
+    double g = 0;
+    for (int p0 = 0; p0 <= na; p0 += 32) {
+        const int k = p0 + (lane >> 1);
+        const int sl = __shfl(w.slot, k & 63);
+        const int sk = (k < na) ? sl : newslot;                  // rows beyond na: the new row again (finite, unused)
+        const double *rowk = w.rowc + (size_t)sk * w.ldr;
+        const double2 *ra = reinterpret_cast<const double2 *>(rowk) + h;
+        double sa = 0, sb = 0;
+        static_for<(NP / 2 + 3) / 4>([&](auto G) __attribute__((always_inline)) {
+            if (4 * G + 3 < nq) {
+                double2 x[4], y[4];
+                static_for<4>([&](auto q) __attribute__((always_inline)) { x[q] = ra[2 * (4 * G + q)]; y[q] = rb[2 * (4 * G + q)]; });
+                static_for<4>([&](auto q) __attribute__((always_inline)) { sa += x[q].x * y[q].x; sb += x[q].y * y[q].y; });
+            } else if (4 * G < nq) {
+                static_for<4>([&](auto q) __attribute__((always_inline)) {
+                    if (4 * G + q < nq) {
+                        const double2 x = ra[2 * (4 * G + q)], y = rb[2 * (4 * G + q)];
+                        sa += x.x * y.x; sb += x.y * y.y;
+                    }
+                });
+            }
+        });
+        for (int e = 4 * nq; e < n; ++e) {                       // tail: all of it on s0
+            const double t = sa + rowk[e] * Mi[e];
+            sa = (h == 0) ? t : sa;
+        }
+        const double part = sa + sb;
+        const double tot = part + __shfl_xor(part, 1);           // (s0+s1)+(s2+s3), the same bits in both lanes
+        const double gk = __shfl(tot, (2 * (lane - p0)) & 63);
+        if (lane >= p0 && lane < p0 + 32) g = gk;
+    }
+    return g;
+}
+
 // ---------------------------------------------------------------------------------------
 // LDL' row append (factorization.c:21-111); returns the new pivot D[na]
 // ---------------------------------------------------------------------------------------
@@ -249,7 +293,9 @@ template <int NB, int NP>
 __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int newslot, int sn_id)
 {
     const int lane = lane_id(), na = w.na, n = w.n, base = tri(na);
+    RPROF_T0(w);
     rfetch_row(w, id, newslot);
+    RPROF_ACC(w, 24);
     const int c0 = id < w.ms ? id : 0;
     w.sing = kEmpty;
     const double *Mi = w.rowc + (size_t)newslot * w.ldr;
@@ -258,13 +304,14 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
         const int idk = (lane < na) ? w.wsid : id;
         const int sk = (lane < na) ? w.slot : newslot;
         const int j = (lane < na && idk < w.ms) ? (c0 > idk ? c0 : idk) : c0;
-        g = (w.ms == 0) ? dot4_pairs(w.rowc + (size_t)sk * w.ldr, Mi, n)
-                        : dot4_pipelined(w.rowc + (size_t)sk * w.ldr + j, Mi + j, n - j);
+        if (w.ms != 0) g = dot4_pipelined(w.rowc + (size_t)sk * w.ldr + j, Mi + j, n - j);
     }
+    if (w.ms == 0) g = rdots_two_lanes(w, newslot, Mi);
     int ns_act = 0;
     if (w.has_soft) ns_act = __popcll(__ballot(lane < na && (w.wflag & DAQP_SOFT))) + ((sn_id & DAQP_SOFT) ? 1 : 0);
     double dnew = rl(g, na);
     if (sn_id & DAQP_SOFT) dnew += w.rho_soft;
+    RPROF_ACC(w, 25);
     if (na == 0) return dnew;
     // forward substitution with L, column by column; each lane preloads its own row of L 8 columns ahead
     {
@@ -283,6 +330,7 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
             }
         });
     }
+    RPROF_ACC(w, 26);
     double p = 0;
     if (lane < na) {
         const double t = g;
@@ -293,6 +341,7 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
     double acc = ordered_sub(dnew, p, na);
     if (acc < w.sing_tol || na >= n + ns_act) { w.sing = na; acc = 0; }
     WSYNC();
+    RPROF_ACC(w, 27);
     return acc;
 }
 
@@ -517,6 +566,9 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP> &w)
 }
 
 // feasibility scan + most-violated pick (auxiliary.c:89-198), everything but u from registers
+// the value is materialised in a VGPR at this point of the program (an optimisation barrier for that value only)
+__device__ __forceinline__ void pin_vgpr(double &x) { asm volatile("" : "+v"(x)); }
+
 template <int NB, int NP>
 __device__ __forceinline__ int rscan_rows(RWave<NB, NP> &w, int &upper, bool with_fval)
 {
@@ -527,28 +579,43 @@ __device__ __forceinline__ int rscan_rows(RWave<NB, NP> &w, int &upper, bool wit
     const double2 *u2 = reinterpret_cast<const double2 *>(w.u);
     double mu[NB];
     static_for<NB>([&](auto bb) __attribute__((always_inline)) { mu[bb] = 0; });
-    // NB independent k-ordered chains per lane; u broadcast from LDS.  Zero padding (pairs beyond
-    // n/2) adds +0.0 and leaves every sum unchanged.
-    static_for<NP>([&](auto t) __attribute__((always_inline)) {
-        const double2 uk = u2[t];
-        const double ux = uk.x, uy = uk.y;
-        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-            mu[bb] += w.Mx[bb][t] * ux;
-            mu[bb] += w.My[bb][t] * uy;
+    // NB independent k-ordered chains per lane; u broadcast from LDS four pairs at a time, the next group's loads
+    // issued before this group's arithmetic (two 16-register buffers: a whole-row preload would push that many
+    // more rows of M out to the AGPRs, and every AGPR operand costs two v_accvgpr_read per scan).  Zero padding
+    // (pairs beyond n/2) adds +0.0 and leaves every sum unchanged.
+    constexpr int NG = (NP + 3) / 4;
+    double2 ub[2][4];
+    static_for<4>([&](auto h) __attribute__((always_inline)) { if constexpr (h < NP) ub[0][h] = u2[h]; });
+    static_for<NG>([&](auto g) __attribute__((always_inline)) {
+        if constexpr (g + 1 < NG)
+            static_for<4>([&](auto h) __attribute__((always_inline)) { if constexpr (4 * (g + 1) + h < NP) ub[(g + 1) & 1][h] = u2[4 * (g + 1) + h]; });
+        __builtin_amdgcn_sched_barrier(0);   // the next group's loads stay ahead of this group's arithmetic
+        static_for<4>([&](auto h) __attribute__((always_inline)) {
+            constexpr int t = 4 * g + h;
+            if constexpr (t < NP) {
+                const double ux = ub[g & 1][h].x, uy = ub[g & 1][h].y;
+                static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+                    mu[bb] += w.Mx[bb][t] * ux;
+                    mu[bb] += w.My[bb][t] * uy;
+                });
+                if (with_fval) { fv += ux * ux; fv += uy * uy; }   // j-ordered |u|^2 (auxiliary.c:85-86)
+            }
         });
-        if (with_fval) { fv += ux * ux; fv += uy * uy; }   // j-ordered |u|^2 (auxiliary.c:85-86)
-        if constexpr ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        // pin this group's partial sums here: without it the optimizer sinks whole chains below the loop (towards
+        // their only use), which keeps every u pair alive at once
+        static_for<NB>([&](auto bb) __attribute__((always_inline)) { pin_vgpr(mu[bb]); });
+        pin_vgpr(fv);
     });
+    // selection without branches (a branch lets the compiler sink a whole block's chain into it, serialising the blocks)
     static_for<NB>([&](auto bb) __attribute__((always_inline)) {
         const int r = bb * 64 + lane;
-        if (r < w.m && !(rsense_get(w, bb) & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
-            double cand = w.du[bb] - mu[bb];
-            if (cand < bv && cand < w.bnd[bb]) { bv = cand; bi = r; bup = 1; }
-            else {
-                cand = mu[bb] - w.dl[bb];
-                if (cand < bv && cand < w.bnd[bb]) { bv = cand; bi = r; bup = 0; }
-            }
-        }
+        const bool open = r < w.m && !(rsense_get(w, bb) & (DAQP_ACTIVE + DAQP_IMMUTABLE));
+        const double cu = w.du[bb] - mu[bb], cl = mu[bb] - w.dl[bb];
+        const bool up = open && cu < bv && cu < w.bnd[bb];
+        const bool lo = open && !up && cl < bv && cl < w.bnd[bb];
+        bv = up ? cu : (lo ? cl : bv);
+        bi = (up || lo) ? r : bi;
+        bup = up ? 1 : (lo ? 0 : bup);
     });
     if (with_fval) w.fval = fv;
     wave_argmin(bv, bi, bup);

@@ -318,6 +318,12 @@ def solve_batch(H, f, A, bupper, blower=None, sense=None, ms=None, out="numpy", 
     ms = m - mA if ms is None else ms
     if blower is None:
         blower = (torch.full_like(bupper, -INF) if _is_torch(bupper) else np.full(bupper.shape, -INF))
+    if N == 0:   # an empty batch is a valid (empty) answer, as it is for daqp_quadprog_batch
+        if out == "torch" and _is_torch(f):
+            z = lambda *sh, dt=torch.float64: torch.zeros(sh, dtype=dt, device=f.device)
+            return dict(x=z(0, n), lam=z(0, m), fval=z(0), soft_slack=z(0), exitflag=z(0, dt=torch.int32), iter=z(0, dt=torch.int32))
+        return dict(x=np.zeros((0, n)), lam=np.zeros((0, m)), fval=np.zeros(0), soft_slack=np.zeros(0),
+                    exitflag=np.zeros(0, np.int32), iter=np.zeros(0, np.int32))
     ns = 0
     if sense is not None:
         s = sense.cpu().numpy() if _is_torch(sense) else np.asarray(sense)

@@ -517,6 +517,7 @@ int daqp_batch_kernel_ms(DAQPBatch *b, float *setup_ms, float *solve_ms)
 int daqp_quadprog_batch(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQPSettings *settings)
 {
     if (!r || !p) { set_err("null argument"); return DAQP_EXIT_UNSUPPORTED; }
+    if (p->N == 0) { r->setup_time = r->solve_time = 0; return 0; }   // empty batch: nothing to do, not an error
     int ns = 0;
     if (p->sense && p->memory == DAQP_MEM_HOST) {
         for (int q = 0; q < p->N; ++q) {

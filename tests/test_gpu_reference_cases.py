@@ -1,0 +1,124 @@
+"""The reference's own known-answer tests, run on the HIP path through the drop-in C ABI
+(daqp_quadprog / setup_daqp / daqp_solve / daqp_update_ldp), each cross-checked against the oracle:
+  * hand examples of the Python binding's tests            interfaces/daqp-python/test/example_test.py:17-26,175-237
+  * generator QPs with analytic optimum, KKT and fval      interfaces/daqp-julia/test/core_tests.jl:26-30, core_test.m:16-26
+  * iter_limit = 1 -> -4                                    core_tests.jl:33-35
+  * exact warm start -> exactly one iteration               core_tests.jl:520-545
+  * unconstrained optimum inside the bounds (shortcut)      core_tests.jl:825-839
+  * crossed bounds -> -1                                    core_test.m:212-221
+plus the edge cases of the batch boundary (empty batch, one QP, no general rows, only equalities, soft rows)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def exact_mode(monkeypatch):
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+
+
+def same(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float64).view(np.uint64), np.ascontiguousarray(b, np.float64).view(np.uint64))
+
+
+def test_hand_examples(oracle, gpu_lib):
+    import daqp_amd
+    H, f, A = np.eye(2), np.array([2.0, 2.0]), np.zeros((0, 2))
+    for ff, bu, want in ((f, 1.0, [-1, -1]), (-f, 1.0, [1, 1]), (f, 0.5, [-0.5, -0.5])):
+        x, fval, flag, info = daqp_amd.solve(H, ff, A, bu * np.ones(2), -bu * np.ones(2), np.zeros(2, np.int32))
+        r = oracle.quadprog(H, ff, A, bu * np.ones(2), -bu * np.ones(2), np.zeros(2, np.int32))
+        assert flag == 1 and np.allclose(x, want, atol=1e-6) and same(x, r[0]) and info["iterations"] == r[4]
+    # example_test.py:17-26: H = [[1,0],[0,1]], f = [1,1], A = [[1,2],[1,-1]], bupper = [1,2,3,4], blower = [-1,-2,-3,-4]
+    H = np.eye(2); f = np.ones(2); A = np.array([[1.0, 2.0], [1.0, -1.0]])
+    bu = np.array([1.0, 2, 3, 4]); bl = -bu
+    x, fval, flag, info = daqp_amd.solve(H, f, A, bu, bl, np.zeros(4, np.int32))
+    r = oracle.quadprog(H, f, A, bu, bl, np.zeros(4, np.int32))
+    assert flag == r[3] == 1 and same(x, r[0]) and fval == r[2] and np.allclose(x, [-1, -1], atol=1e-9)
+
+
+def test_generator_optimum_kkt_fval(oracle, gpu_lib):
+    import daqp_amd
+    for cfg in ("C1", "C3"):
+        n, m, ms, na, seed, _ = O.CONFIGS[cfg]
+        for k in range(10):
+            q = O.generate_qp(n, m, ms, na, rng=[seed, 100 + k])
+            x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+            lam = info["lam"]
+            assert flag == 1 and np.abs(x - q["x"]).max() < 1e-8 and np.count_nonzero(lam) == na
+            Afull = np.vstack([np.eye(n)[:ms], q["A"]])
+            assert np.abs(q["H"] @ x + q["f"] + Afull.T @ lam).max() < 1e-7
+            assert abs(0.5 * x @ q["H"] @ x + q["f"] @ x - fval) < 1e-8
+            Ax = Afull @ x
+            assert (Ax <= q["bupper"] + 1e-6).all() and (Ax >= q["blower"] - 1e-6).all()
+            assert (lam[Ax < q["bupper"] - 1e-6] <= 0).all() and (lam[Ax > q["blower"] + 1e-6] >= 0).all()
+
+
+def test_iteration_limit_and_crossed_bounds(oracle, gpu_lib):
+    import daqp_amd
+    q = O.generate_qp(20, 40, 0, 8, rng=[1234, 0])
+    x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, iter_limit=1)
+    assert flag == -4
+    bu = q["bupper"].copy(); bu[3] = q["blower"][3] - 1
+    x0 = np.full(20, 7.0)
+    x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], bu, q["blower"], None)
+    assert flag == -1 == oracle.quadprog(q["H"], q["f"], q["A"], bu, q["blower"])[3]
+
+
+def test_exact_warm_start_needs_one_iteration(oracle, gpu_lib):
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS["C1"]
+    q = O.generate_qp(n, m, ms, na, rng=[seed, 3])
+    x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+    lam = info["lam"]
+    sense = np.zeros(m, np.int32)
+    sense[lam > 1e-12] |= O.ACTIVE
+    sense[lam < -1e-12] |= O.ACTIVE + O.LOWER
+    x2, fval2, flag2, info2 = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], sense)
+    r = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], sense)
+    assert flag2 == 1 and info2["iterations"] == 1 == r[4] and same(x2, r[0]) and np.abs(x - x2).max() < 1e-10
+
+
+def test_unconstrained_shortcut(oracle, gpu_lib):
+    """bounds far from the unconstrained optimum: solved in setup (daqp_check_unconstrained), iter = 1, lam = 0"""
+    import daqp_amd
+    q = O.generate_qp(12, 30, 4, 5, rng=[7, 7])
+    bu, bl = np.full(30, 1e3), np.full(30, -1e3)
+    x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], bu, bl, None)
+    r = oracle.quadprog(q["H"], q["f"], q["A"], bu, bl, None)
+    assert flag == r[3] == 1 and info["iterations"] == r[4] == 1 and not info["lam"].any() and same(x, r[0])
+    assert np.abs(x + np.linalg.solve(q["H"], q["f"])).max() < 1e-9
+    H = np.eye(3)
+    x, fval, flag, info = daqp_amd.solve(H, np.zeros(3), np.zeros((0, 3)), np.ones(3), -np.ones(3), None)
+    assert flag == 1 and not x.any()      # core_tests.jl:825-839: x = 0
+
+
+def test_boundary_edge_cases(oracle, gpu_lib):
+    import daqp_amd
+    # empty batch
+    g = daqp_amd.solve_batch(np.zeros((0, 4, 4)), np.zeros((0, 4)), np.zeros((0, 3, 4)), np.zeros((0, 5)), np.zeros((0, 5)), None, ms=2)
+    assert g["x"].shape == (0, 4) and g["exitflag"].shape == (0,)
+    # a batch of one, only simple bounds (no general rows at all)
+    q = O.generate_qp(6, 6, 6, 3, rng=[5, 1])
+    g = daqp_amd.solve_batch(q["H"][None], q["f"][None], np.zeros((1, 0, 6)), q["bupper"][None], q["blower"][None], None, ms=6)
+    r = oracle.quadprog(q["H"], q["f"], np.zeros((0, 6)), q["bupper"], q["blower"], None)
+    assert g["exitflag"][0] == r[3] and g["iter"][0] == r[4] and same(g["x"][0], r[0]) and same(g["lam"][0], r[1])
+    # equalities (sense 5) and soft rows (sense 8): exit flag 1 / 2 as the reference decides
+    for trial in range(20):
+        rng = np.random.default_rng([31, trial])
+        q = O.generate_nasty(8, 20, 2, 3, 1e-3, rng, n_dup=0, n_eq=2, n_soft=2)
+        x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        r = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        assert flag == r[3] and info["iterations"] == r[4]
+        if flag > 0:
+            assert same(x, r[0]) and same(info["lam"], r[1])
+    # infeasible: two parallel rows that exclude each other
+    H = np.eye(2); A = np.array([[1.0, 0.0], [1.0, 0.0]])
+    x, fval, flag, info = daqp_amd.solve(H, np.zeros(2), A, np.array([1.0, -2.0]), np.array([0.5, -3.0]), np.zeros(2, np.int32))
+    assert flag == -1 == oracle.quadprog(H, np.zeros(2), A, np.array([1.0, -2.0]), np.array([0.5, -3.0]), np.zeros(2, np.int32))[3]
+    # non-convex Hessian -> -5 with eps_prox = 0 (api.c / utils.c:356-377)
+    Hn = np.array([[1.0, 2.0], [2.0, 1.0]])
+    x, fval, flag, info = daqp_amd.solve(Hn, np.zeros(2), np.zeros((0, 2)), np.ones(2), -np.ones(2), None, eps_prox=0.0)
+    assert flag == -5

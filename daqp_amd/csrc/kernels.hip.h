@@ -589,8 +589,15 @@ __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
 // k_ldp_reg: the register-centric solve kernel (wave_ldp_reg.hip.h) for n + n_soft + 1 <= 64 and
 // m <= 64*NB, n <= 2*NP.  Same global state layout as k_ldp, so the two are interchangeable.
 // ------------------------------------------------------------------------------------
+// Waves per SIMD: M alone takes 4*NB*NP registers per lane.  The large shapes own the whole unified 512-entry file (one
+// wave per SIMD); the small ones are held to a budget that lets 2 or 4 waves share a SIMD, where the other waves'
+// instructions fill this wave's issue gaps and LDS waits.
+#ifndef DAQP_AMD_SMALL_WAVES
+#define DAQP_AMD_SMALL_WAVES 3
+#endif
+constexpr int ldp_reg_waves(int NB, int NP) { return NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 32 ? 2 : 1); }
 template <int NB, int NP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ldp_reg(const BatchDev *bp, int mode)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_waves(NB, NP), ldp_reg_waves(NB, NP)))) void k_ldp_reg(const BatchDev *bp, int mode)
 {
     // The descriptor is read through a pointer (scalar loads at the point of use) instead of being a
     // by-value kernel argument: ~60 SGPRs of pointers would otherwise stay live across the whole state

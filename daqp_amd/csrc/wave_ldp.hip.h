@@ -642,12 +642,24 @@ __device__ __forceinline__ int scan_rows(Wave<C, NB, NP> &w, int &upper, bool wi
             double mu = 0;
             const int full = odd ? w.npair - 1 : w.npair;
             if (r < w.m) {
-#pragma unroll 5
-                for (int t = 0; t < full; ++t) {
-                    const double2 mm = src[(size_t)t * 64];
-                    const double2 uk = u2[t];
-                    mu += mm.x * uk.x;
-                    mu += mm.y * uk.y;
+                // the stream of M: 16 x 16-byte loads per lane in flight (16 KiB per wave) before the k-ordered chain
+                // consumes them -- with a handful in flight the scan is pure HBM latency at large n
+                int t = 0;
+                for (; t + 16 <= full; t += 16) {
+                    double2 mm[16], uk[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) mm[q] = src[(size_t)(t + q) * 64];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) uk[q] = u2[t + q];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { mu += mm[q].x * uk[q].x; mu += mm[q].y * uk[q].y; }
+                }
+                if (t < full) {
+                    double2 mm[16], uk[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { const int tt = (t + q < full) ? t + q : full - 1; mm[q] = src[(size_t)tt * 64]; uk[q] = u2[tt]; }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) if (t + q < full) { mu += mm[q].x * uk[q].x; mu += mm[q].y * uk[q].y; }
                 }
                 if (odd) mu += src[(size_t)full * 64].x * w.u[n - 1];
             }

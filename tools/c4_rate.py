@@ -1,0 +1,20 @@
+"""C4 throughput (n=200, m=600) on a reduced batch + parity sample: python tools/c4_rate.py [N]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, daqp_amd
+from oracle import oracle as O
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+n, m, ms, na, seed, _ = O.CONFIGS["C4"]
+qn = O.generate_batch(N, n, m, ms, na, seed)
+q = {k: torch.from_numpy(np.ascontiguousarray(qn[k])).cuda() for k in ("H", "f", "A", "bupper", "blower", "xref")}
+bm = daqp_amd.BatchModel(N, n, m, ms)
+if len(sys.argv) > 2: bm.enable_profile(True)
+def step():
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=64 | 128)
+    return bm.solve(out="torch")
+step(); torch.cuda.synchronize()
+t0 = time.perf_counter(); r = step(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+ref = O.Oracle().quadprog_batch(qn["H"][:16], qn["f"][:16], qn["A"][:16], qn["bupper"][:16], qn["blower"][:16], None, ms=ms)
+ok = (np.sign(r["lam"][:16].cpu().numpy()) == np.sign(ref[1])).all() and (r["iter"][:16].cpu().numpy() == ref[4]).all()
+print(f"C4 N={N}: {N / dt:.0f} QPs/s, kernels setup/solve ms {bm.kernel_ms()}, mean iter {r['iter'].double().mean().item():.1f}, optimal {(r['exitflag'] == 1).all().item()}, parity(16) {ok}, max|dx| {np.abs(r['x'][:16].cpu().numpy() - ref[0]).max():.1e}")

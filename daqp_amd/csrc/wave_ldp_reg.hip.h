@@ -115,28 +115,6 @@ __device__ __forceinline__ void rfetch_row(RWave<NB, NP> &w, int id, int slot)
     WSYNC();
 }
 
-// factorization.c:4-15 for rows that both start at column 0 (no simple bounds involved): 16-byte loads, groups of
-// 8 products with their loads issued first; (s0,s1,s2,s3) rotate over the columns exactly as the reference's
-__device__ __forceinline__ double dot4_pairs(const double *a, const double *b, int len)
-{
-    const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int i = 0;
-    for (; i + 7 < len; i += 8) {
-        double2 x[4], y[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { x[q] = a2[(i >> 1) + q]; y[q] = b2[(i >> 1) + q]; }
-        s0 += x[0].x * y[0].x; s1 += x[0].y * y[0].y; s2 += x[1].x * y[1].x; s3 += x[1].y * y[1].y;
-        s0 += x[2].x * y[2].x; s1 += x[2].y * y[2].y; s2 += x[3].x * y[3].x; s3 += x[3].y * y[3].y;
-    }
-    for (; i + 3 < len; i += 4) {
-        const double2 x0 = a2[i >> 1], x1 = a2[(i >> 1) + 1], y0 = b2[i >> 1], y1 = b2[(i >> 1) + 1];
-        s0 += x0.x * y0.x; s1 += x0.y * y0.y; s2 += x1.x * y1.x; s3 += x1.y * y1.y;
-    }
-    for (; i < len; i++) s0 += a[i] * b[i];
-    return (s0 + s1) + (s2 + s3);
-}
-
 // factorization.c:4-15 with the loads of each group of 8 issued before its arithmetic
 __device__ __forceinline__ double dot4_pipelined(const double *a, const double *b, int len)
 {

@@ -122,3 +122,29 @@ def test_boundary_edge_cases(oracle, gpu_lib):
     Hn = np.array([[1.0, 2.0], [2.0, 1.0]])
     x, fval, flag, info = daqp_amd.solve(Hn, np.zeros(2), np.zeros((0, 2)), np.ones(2), -np.ones(2), None, eps_prox=0.0)
     assert flag == -5
+
+
+def test_concurrent_host_threads(oracle, gpu_lib):
+    """the reference is re-entrant per workspace (SURVEY 8b "Threading"): four host threads, each with its own batch
+    (own HIP stream), must get the answers of a serial run"""
+    import threading
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS["C1"]
+    qs = [O.generate_batch(96, n, m, ms, na, seed, start=1000 * t) for t in range(4)]
+    out = [None] * 4
+
+    def work(t):
+        q = qs[t]
+        for _ in range(3):
+            out[t] = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for t in range(4):
+        q = qs[t]
+        r = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+        assert np.array_equal(out[t]["exitflag"], r[3]) and np.array_equal(out[t]["iter"], r[4])
+        assert same(out[t]["x"], r[0]) and same(out[t]["lam"], r[1])

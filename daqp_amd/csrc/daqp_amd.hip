@@ -202,7 +202,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     BatchDev &d = b->d;
     d.N = N; d.n = n; d.m = m; d.ms = ms; d.cap = cap; d.mA = m - ms;
     d.npair = (n + 1) / 2; d.nblk = (m + 63) / 64; d.ldr = n | 1;
-    d.ltri = cap * (cap + 1) / 2; d.rtri = n * (n + 1) / 2;
+    d.ltri = round_up(cap * (cap + 1) / 2, 2); d.rtri = n * (n + 1) / 2;   // even stride: 16-byte aligned rows for the direct HBM->LDS copy
     if (settings) d.st = *settings; else default_settings(&d.st);
     b->C = cap <= 64 ? 1 : (cap <= 128 ? 2 : 4);
 #ifdef DAQP_AMD_FEW_VARIANTS

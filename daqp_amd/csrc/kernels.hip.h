@@ -60,17 +60,25 @@ __host__ __device__ inline SetupLds setup_lds(int n, int m, bool gs = false)
     s.total_bytes = o * 8 + round_up(m, 4) * 4;
     return s;
 }
-struct LdpLds { int L, rowc, D, xl, zl, lamA, lamB, u, pend_lam, dbl; int ws, sense, pend_id, ints; int total_bytes; };
+struct LdpLds { int L, rowc, rowc_size, D, xl, zl, lamA, lamB, u, pend_lam, vq, sc, dbl; int ws, sense, pend_id, ints; int total_bytes; };
 __host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill, int ldrc = 0)
 {
     LdpLds s;
     const int ldr = ldrc > 0 ? ldrc : (n | 1), cp = round_up(cap, 2);
     int o = 0;
     s.L = o; if (!spill) o += round_up(cap * (cap + 1) / 2, 2);
-    s.rowc = o; if (!spill) o += round_up(cap * ldr, 2);
+    s.rowc = o;
+    if (!spill) {
+        int rc = round_up(cap * ldr, 2);
+        const int fin = round_up(n * (n + 1) / 2, 2) + 2 + round_up(m, 2);   // register kernel's epilogue: staged R^-1 + lam
+        if (ldrc > 0 && rc < fin) rc = fin;
+        s.rowc_size = rc;
+        o += rc;
+    } else s.rowc_size = 0;
     s.D = o; o += cp; s.xl = o; o += cp; s.zl = o; o += cp; s.lamA = o; o += cp; s.lamB = o; o += cp;
     s.u = o; o += round_up(n > 64 ? n : 64, 2) + 2;   // zero-padded to 64 for the register-resident scan
     s.pend_lam = o; o += cp;
+    s.vq = o; s.sc = o;
     s.dbl = o;                       // ints start at double offset s.dbl
     int oi = 0;
     s.ws = oi; oi += round_up(cap, 4);
@@ -604,6 +612,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     // machine and push its uniform state into VGPR-lane spills.
     const BatchDev &b = *bp;
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    const long long t_start = (long long)__builtin_readcyclecounter();
     const int q = blockIdx.x, lane = lane_id();
     const int n = b.n, m = b.m, cap = b.cap;
     QState *qs = b.qs + q;
@@ -674,10 +683,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
                 const double2 v = msrc[((size_t)bb * b.npair + t) * 64 + lane];
                 vx = v.x; vy = v.y;
             }
-            w.Mx[bb][t] = vx; w.My[bb][t] = vy;
-            if constexpr ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 8 loads (32 VGPRs) in flight
+            w.Mx[bb][t] = vx; w.My[bb][t] = vy;     // every load lands in its final register: all of them may be in flight
         });
-        __builtin_amdgcn_sched_barrier(0);
     });
     w.has_soft = __any(softbits) ? 1 : 0;
     // ---- working-set view
@@ -685,66 +692,102 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     w.wsid = act ? gws[lane] : 0;
     w.slot = lane;
     w.slotmask = (w.na >= 64) ? ~0ull : ((1ull << w.na) - 1ull);
+    w.hi_slot = w.na - 1;
+    const int rinv_off = o.rowc_size - round_up(b.rtri, 2) - 2;
     w.D = (lane < cap) ? gv[lane] : 0.0;
     w.xl = (lane < cap) ? gv[cap + lane] : 0.0;
     w.zl = (lane < cap) ? gv[2 * cap + lane] : 0.0;
     const double la = (lane < cap) ? gv[3 * cap + lane] : 0.0, lb = (lane < cap) ? gv[4 * cap + lane] : 0.0;
     w.lam = swapped ? lb : la;
     w.lams = swapped ? la : lb;
-    w.wflag = act ? gsense[w.wsid] : 0;
-    w.drhs = act ? -((w.wflag & DAQP_LOWER) ? gdl[w.wsid] : gdu[w.wsid]) : 0.0;
-    {
-        const int used = tri(w.na);
-        const double *gL = b.L + (size_t)q * b.ltri;
-        for (int e = lane; e < used; e += 64) w.L[e] = gL[e];
-        for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) w.u[e] = 0;
+    {   // sense and bound of each working-set row are already in the row registers: fetch them across lanes
+        // (ds_bpermute) instead of a second, dependent trip to HBM
+        const int src = w.wsid & 63, blk = w.wsid >> 6;
+        int fl = 0;
+        double bu = 0, bl = 0;
+        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+            const int s8 = (int)((__shfl((int)w.rs, src) >> (8 * bb)) & 0xff);
+            const double u_ = __shfl(w.du[bb], src), l_ = __shfl(w.dl[bb], src);
+            if (blk == bb) { fl = s8; bu = u_; bl = l_; }
+        });
+        w.wflag = act ? fl : 0;
+        w.drhs = act ? -((fl & DAQP_LOWER) ? bl : bu) : 0.0;
     }
-    WSYNC();
-    for (int i = 0; i < w.na; ++i) {   // warm start: rebuild the active-row cache from the blocked HBM image
-        const int id = rli(w.wsid, i);
-        const double2 *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63);
-        double *dst = w.rowc + (size_t)i * w.ldr;
-        for (int t = lane; t < b.npair; t += 64) {
-            const double2 v = src[(size_t)t * 64];
-            dst[2 * t] = v.x;
-            if (2 * t + 1 < n) dst[2 * t + 1] = v.y;
+    {
+        // warm start: packed L and the active-row cache come straight from HBM into LDS (global_load_lds, no VGPRs),
+        // every instruction in flight at once -- one memory round trip instead of one per row
+        const double *gL = b.L + (size_t)q * b.ltri;
+        copy_async(w.L, gL, round_up(tri(w.na), 2));
+        for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) w.u[e] = 0;
+        for (int i = 0; i < w.na; ++i) {
+            const int id = rli(w.wsid, i);
+            const double2 *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63) + (size_t)lane * 64;
+            if (lane < b.npair)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(w.rowc + (size_t)i * w.ldr), 16, 0, 0);
         }
+        copy_wait();
     }
     WSYNC();
 
     int iters = 0;
+    const long long t_loop = (long long)__builtin_readcyclecounter();
     int flag = rrun(w, mode, q_need_act != 0, iters);
+    const long long t_done = (long long)__builtin_readcyclecounter();
     if (mode == 1) {
         if (lane == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
     } else {
-        const double *Rq = b.Rinv + (size_t)q * b.rtri, *vq = b.v + (size_t)q * n;
+        const double *Rq = b.Rinv + (size_t)q * b.rtri;
+        // Everything that needs LDS hand-offs (x from the staged R^-1, lam assembled by working-set scatter) comes
+        // first; the stores to HBM are issued together at the very end, so no fence ever waits for a store.
+        // Packed R^-1 comes into the top of the (now dead) active-row cache in one HBM round trip; v and the scalings ride along.
+        // (16 bytes per lane; the packed rows of odd QPs start 8 bytes off a 16-byte boundary, so the LDS image is
+        // shifted by one double for them and that first double goes separately)
+        const int odd8 = (int)(((size_t)Rq >> 3) & 1);
+        double *Rl = w.rowc + rinv_off + odd8;
+        if (flag > 0) {
+            if (odd8) copy_async_dwords(Rl, Rq, 1);
+            const int body = (b.rtri - odd8) & ~1;
+            copy_async(Rl + odd8, Rq + odd8, body);
+            if (odd8 + body < b.rtri) copy_async_dwords(Rl + odd8 + body, Rq + odd8 + body, 1);
+        }
+        const double *vq = b.v + (size_t)q * n;
+        const double vl = (lane < n) ? vq[lane] : 0.0;
+        const double sc_ws = (flag > 0 && lane < w.na) ? gsc[w.wsid] : 1.0;
+        const double sc_sb = (flag > 0 && lane < b.ms) ? gsc[lane] : 1.0;
+        double *lamq = w.rowc;                                          // m doubles at the (dead) bottom of the row cache
+        double xi = (lane < n) ? w.u[lane] : 0.0;
+        if (b.lam) for (int i = lane; i < m; i += 64) lamq[i] = 0;     // daqp_extract_result (api.c:455-495): zero ...
+        const long long te1 = (long long)__builtin_readcyclecounter();
+        copy_wait();
         if (flag > 0) {   // ldp2qp_solution (daqp.c:111-139)
-            if (lane < n) w.u[lane] = w.u[lane] - vq[lane];
-            WSYNC();
-            if (lane < n) {
-                const double *row = Rq + roff(lane, n);
-                double xi = w.u[lane] * row[lane];
-                for (int j0 = lane + 1; j0 < n; j0 += kChunk) {
-                    double rr[kChunk];
+            if (lane < n) w.u[lane] = w.u[lane] - vl;
+            if (lane < w.na) w.lams *= sc_ws;
+        }
+        WSYNC();
+        const long long te2 = (long long)__builtin_readcyclecounter();
+        if (b.lam && lane < w.na) lamq[w.wsid] = w.lams;                // ... then scatter by WS
+        if (flag > 0 && lane < n) {
+            const double *row = Rl + roff(lane, n);
+            xi = w.u[lane] * row[lane];
+            for (int j0 = lane + 1; j0 < n; j0 += kChunk) {
+                double rr[kChunk], uu[kChunk];
 #pragma unroll
-                    for (int k = 0; k < kChunk; ++k) rr[k] = (j0 + k < n) ? row[j0 + k] : 0.0;
+                for (int k = 0; k < kChunk; ++k) { const int j = (j0 + k < n) ? j0 + k : n - 1; rr[k] = row[j]; uu[k] = w.u[j]; }
 #pragma unroll
-                    for (int k = 0; k < kChunk; ++k) if (j0 + k < n) xi += rr[k] * w.u[j0 + k];
-                }
-                if (lane < b.ms) xi /= gsc[lane];
-                if (b.x) b.x[(size_t)q * n + lane] = xi;
+                for (int k = 0; k < kChunk; ++k) if (j0 + k < n) xi += rr[k] * uu[k];
             }
-            if (lane < w.na) w.lams *= gsc[w.wsid];
-        } else if (b.x) {
-            if (lane < n) b.x[(size_t)q * n + lane] = w.u[lane];
+            if (lane < b.ms) xi /= sc_sb;
         }
-        if (b.lam) {   // daqp_extract_result (api.c:455-495)
-            for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = 0;
-            WSYNC();
-            if (lane < w.na) b.lam[(size_t)q * m + w.wsid] = w.lams;
-        }
-        double fv = w.fval;
-        for (int i = 0; i < n; ++i) { const double vi = vq[i]; fv -= vi * vi; }
+        WSYNC();
+        const long long te3 = (long long)__builtin_readcyclecounter();
+        if (w.prof && lane == 0) { w.prof[20] = te1 - t_done; w.prof[21] = te2 - te1; w.prof[22] = te3 - te2; }
+        if (b.x && lane < n) b.x[(size_t)q * n + lane] = xi;
+        if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = lamq[i];
+        double fv = w.fval;                      // fval - |v|^2 in index order, v_i broadcast from its lane
+        static_for<8>([&](auto c) __attribute__((always_inline)) {
+            if (8 * c < n) static_for<8>([&](auto k) __attribute__((always_inline)) { const double vi = rl(vl, 8 * c + k); fv -= vi * vi; });
+        });
         fv *= 0.5;
         if (lane == 0) {
             b.exitflag[q] = flag; b.iter[q] = iters;
@@ -770,8 +813,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         qs->lam_swapped = 0;
         qs->fval = w.fval; qs->soft_slack = w.soft;
         if (b.trace) b.trace[(size_t)q * b.trace_cap + b.trace_cap - 1] = w.trace_len;
-        if (w.prof)
+        if (w.prof) {
+            const long long te4 = (long long)__builtin_readcyclecounter();
+            w.prof[23] = te4 - t_done;
             for (int i = 0; i < 32; ++i) b.prof[(size_t)q * 32 + i] = w.prof[i];
+            b.prof[(size_t)q * 32 + 28] = t_loop - t_start;                                    // prologue
+            b.prof[(size_t)q * 32 + 29] = (long long)__builtin_readcyclecounter() - t_done;   // epilogue
+            b.prof[(size_t)q * 32 + 30] = t_done - t_loop;                                     // the loop
+        }
     }
 }
 

@@ -83,19 +83,6 @@ __device__ __forceinline__ void stage_rows(double *dst, const double *src, int r
     }
 }
 
-// Contiguous HBM -> LDS copy that bypasses the VGPRs: global_load_lds_dwordx4 (gfx950), 16 bytes per lane per
-// instruction, every instruction of the copy in flight at once (one HBM round trip per tile instead of one
-// per eight loads).  cnt even, src and dst 16-byte aligned; completion = vmcnt (copy_wait).
-__device__ __forceinline__ void copy_async(double *dst, const double *src, int cnt)
-{
-    const int lane = lane_id(), pairs = cnt >> 1;
-    for (int c = 0; c < pairs; c += 64)
-        if (c + lane < pairs)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2 * (c + lane)),
-                                             (__attribute__((address_space(3))) void *)(dst + 2 * c), 16, 0, 0);
-}
-__device__ __forceinline__ void copy_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */ }
-
 // LDS: [ Rsq: n x nsq square R^-1 (zeros left of the diagonal; first the staged H) | tile (64 x ldr: A rows,
 // overwritten by their M rows) | f v xu | scaling dupper dlower | sense ].  Without exact_setup the R^-1
 // fragments live in registers during the M phase, so the tile aliases Rsq and four workgroups fit a CU.

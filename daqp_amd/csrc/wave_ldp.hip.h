@@ -31,6 +31,30 @@ __host__ __device__ constexpr __forceinline__ int tri(int k) { return (k * (k + 
 __device__ __forceinline__ int roff(int i, int n) { return ((2 * n - i - 1) * i) / 2; }
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
 
+// Contiguous HBM -> LDS copy that bypasses the VGPRs: global_load_lds_dwordx4 (gfx950), 16 bytes per lane per
+// instruction, every instruction of the copy in flight at once (one HBM round trip per tile instead of one
+// per eight loads).  cnt even, src and dst 16-byte aligned; completion = vmcnt (copy_wait).
+__device__ __forceinline__ void copy_async(double *dst, const double *src, int cnt)
+{
+    const int lane = lane_id(), pairs = cnt >> 1;
+    for (int c = 0; c < pairs; c += 64)
+        if (c + lane < pairs)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2 * (c + lane)),
+                                             (__attribute__((address_space(3))) void *)(dst + 2 * c), 16, 0, 0);
+}
+// the same with 4 bytes per lane (256 B per instruction): for sources that are only 8-byte aligned
+__device__ __forceinline__ void copy_async_dwords(double *dst, const double *src, int cnt)
+{
+    const int lane = lane_id(), nd = 2 * cnt;
+    const unsigned *s32 = reinterpret_cast<const unsigned *>(src);
+    unsigned *d32 = reinterpret_cast<unsigned *>(dst);
+    for (int c = 0; c < nd; c += 64)
+        if (c + lane < nd)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s32 + c + lane),
+                                             (__attribute__((address_space(3))) void *)(d32 + c), 4, 0, 0);
+}
+__device__ __forceinline__ void copy_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */ }
+
 // broadcast lane `src` (wave-uniform) of v to every lane: two v_readlane_b32
 __device__ __forceinline__ double rl(double v, int src)
 {

@@ -45,6 +45,7 @@ struct RWave {
     unsigned rs;   // sense bits of this lane's rows, 8 bits per row block (a register, never an array)
     // uniform
     int na, reuse, sing, has_soft;
+    int hi_slot;                        // highest row-cache slot ever used (the top of the cache doubles as a prefetch buffer)
     unsigned long long slotmask;
     double fval, soft;
     const DAQPSettings *stp;            // device copy of the settings (cold fields)
@@ -442,6 +443,7 @@ __device__ __forceinline__ void rpush_core(RWave<NB, NP> &w, int id, double lamv
     const int sn = sense_of(w, id);
     const int newslot = __ffsll((long long)~w.slotmask) - 1;
     w.slotmask |= 1ull << newslot;
+    if (newslot > w.hi_slot) w.hi_slot = newslot;
     const double dnew = rldl_append(w, id, newslot, sn);
     const bool lower = (sn & DAQP_LOWER) != 0;
     const double bd = bound_of(w, id, lower);

@@ -68,6 +68,7 @@ struct DAQPBatch {
     bool spill = false;
     int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
     bool fast_setup = false, setup_spill = false;
+    int pending_mask = 0;   // daqp_batch_update(UPDATE_v|UPDATE_d) not yet applied: the next solve launch does it (k_ldp_reg mode 2)
     size_t lds_setup = 0, lds_ldp = 0, lds_update = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed_setup = false, timed_solve = false;
@@ -141,6 +142,17 @@ int launch_ldp(DAQPBatch *b, int mode)
     hipLaunchKernelGGL(k, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, b->d, mode);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// a deferred daqp_batch_update is applied now by the stand-alone kernel (someone wants to see the state before a solve)
+int flush_update(DAQPBatch *b)
+{
+    if (!b->pending_mask) return 0;
+    const int mask = b->pending_mask;
+    b->pending_mask = 0;
+    hipLaunchKernelGGL(k_update, dim3(b->d.N), dim3(64), b->lds_update, b->stream, b->d, mask);
+    HIPCHK(hipGetLastError());
+    return launch_ldp(b, 1);
 }
 
 // copy (host) or adopt (device) one input array
@@ -344,6 +356,7 @@ int daqp_batch_read_ldp(DAQPBatch *b, int q, double *M, double *R, double *v, do
 {
     if (!b || q < 0 || q >= b->d.N) return DAQP_EXIT_UNSUPPORTED;
     (void)hipSetDevice(b->device);
+    if (flush_update(b)) return DAQP_EXIT_UNSUPPORTED;
     const BatchDev &d = b->d;
     HIPCHK(hipStreamSynchronize(b->stream));
     if (M) {
@@ -370,6 +383,7 @@ int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
         set_err("H, f, A, bupper, blower are required (LPs / missing linear term are outside this path)");
         return DAQP_EXIT_UNSUPPORTED;
     }
+    b->pending_mask = 0;   // a full setup supersedes any deferred update
     HIPCHK(hipSetDevice(b->device));
     BatchDev &d = b->d;
     const size_t N = d.N;
@@ -424,13 +438,26 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
     BatchDev &d = b->d;
     const size_t N = d.N;
     const double *tmp = nullptr;
+    // The register solve kernel applies the update itself at its next launch (it has the rows of M in registers anyway:
+    // one pass over M per MPC step instead of two).  Because that reads f / the bounds later than this call, device
+    // arrays are copied into the batch's own buffers (stream-ordered, a few tens of microseconds) instead of adopted.
+    const bool lazy = b->NB > 0 && !getenv("DAQP_AMD_EAGER_UPDATE");
+    const int mem = p->memory;
+    auto take = [&](const double *src, size_t count, double **slot, const double **out) -> int {
+        if (!lazy || mem != DAQP_MEM_DEVICE) return stage(b, src, mem, count, slot, out);
+        if (*slot == nullptr) { if (dev_alloc(b, slot, count)) return DAQP_EXIT_UNSUPPORTED; }
+        if (src != *slot) HIPCHK(hipMemcpyAsync(*slot, src, count * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+        *out = *slot;
+        return 0;
+    };
     if (mask & DAQP_UPDATE_v) {
         if (!p->f) { set_err("DAQP_UPDATE_v needs f"); return DAQP_EXIT_UNSUPPORTED; }
-        rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &tmp); d.f = tmp;
+        rc |= take(p->f, N * d.n, &b->sf, &tmp); d.f = tmp;
     }
-    if (p->bupper) { rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &tmp); d.bu = tmp; }
-    if (p->blower) { rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &tmp); d.bl = tmp; }
+    if (p->bupper) { rc |= take(p->bupper, N * d.m, &b->sbu, &tmp); d.bu = tmp; }
+    if (p->blower) { rc |= take(p->blower, N * d.m, &b->sbl, &tmp); d.bl = tmp; }
     if (rc) return DAQP_EXIT_UNSUPPORTED;
+    if (lazy) { b->pending_mask |= mask; b->timed_setup = false; return 0; }
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
     hipLaunchKernelGGL(k_update, dim3(d.N), dim3(64), b->lds_update, b->stream, d, mask);
     HIPCHK(hipGetLastError());
@@ -456,7 +483,9 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
     d.iter = (dev && r->iter) ? r->iter : b->oiter;
     const double t0 = now_s();
     HIPCHK(hipEventRecord(b->ev[2], b->stream));
-    int rc = launch_ldp(b, 0);
+    const int mode = b->pending_mask ? (2 | (b->pending_mask << 4)) : 0;
+    b->pending_mask = 0;
+    int rc = launch_ldp(b, mode);
     if (rc) return rc;
     HIPCHK(hipEventRecord(b->ev[3], b->stream));
     b->timed_solve = true;
@@ -478,6 +507,7 @@ int daqp_batch_setup_flags(DAQPBatch *b, int *flags_host)
 {
     if (!b || !flags_host) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipSetDevice(b->device));
+    if (flush_update(b)) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipStreamSynchronize(b->stream));
     std::vector<QState> qs(b->d.N);
     HIPCHK(hipMemcpy(qs.data(), b->d.qs, sizeof(QState) * b->d.N, hipMemcpyDeviceToHost));
@@ -489,6 +519,7 @@ int daqp_batch_working_sets(DAQPBatch *b, int *n_active_host, int *ws_host)
 {
     if (!b) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipSetDevice(b->device));
+    if (flush_update(b)) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipStreamSynchronize(b->stream));
     if (n_active_host) {
         std::vector<QState> qs(b->d.N);

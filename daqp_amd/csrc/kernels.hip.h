@@ -605,8 +605,13 @@ __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
 #endif
 constexpr int ldp_reg_waves(int NB, int NP) { return NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 32 ? 2 : 1); }
 template <int NB, int NP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_waves(NB, NP), ldp_reg_waves(NB, NP)))) void k_ldp_reg(const BatchDev *bp, int mode)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_waves(NB, NP), ldp_reg_waves(NB, NP)))) void k_ldp_reg(const BatchDev *bp, int mode_in)
 {
+    // mode 0: daqp_solve; 1: only (re)build the working set from the ACTIVE bits; 2 | mask << 4: daqp_update_ldp(mask)
+    // for mask within UPDATE_v|UPDATE_d applied here, then daqp_solve -- the rows of M are in registers anyway, so the
+    // warm path of an MPC step reads them from HBM once instead of twice (k_update + solve)
+    const int upd = (mode_in & 3) == 2 ? (mode_in >> 4) : 0;
+    const int mode = (mode_in & 3) == 2 ? 0 : (mode_in & 3);
     // The descriptor is read through a pointer (scalar loads at the point of use) instead of being a
     // by-value kernel argument: ~60 SGPRs of pointers would otherwise stay live across the whole state
     // machine and push its uniform state into VGPR-lane spills.
@@ -619,7 +624,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     // everything read from the per-QP record is wave-uniform; say so, or every loop bounded by
     // n_active becomes a divergent (exec-masked) loop with readfirstlane waterfalls around v_readlane
     const int sflag = __builtin_amdgcn_readfirstlane(qs->setup_flag);
-    const int q_need_act = __builtin_amdgcn_readfirstlane(qs->need_activate);
+    int q_need_act = __builtin_amdgcn_readfirstlane(qs->need_activate);
     if (mode == 1) { if (sflag < 0 || !q_need_act) return; }
     if (sflag < 0) {
         if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
@@ -648,7 +653,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     double *gv = b.vecs + (size_t)q * 5 * cap;
     int *gws = b.WS + (size_t)q * cap;
 
-    if (w.sing == DAQP_UNCONSTRAINED_OPTIMAL && mode == 0) {   // api.c:40-45
+    if (w.sing == DAQP_UNCONSTRAINED_OPTIMAL && mode == 0 && !upd) {   // api.c:40-45 (an update resets sing_ind first)
         const double *xu = b.xunc + (size_t)q * n, *vq = b.v + (size_t)q * n;
         if (b.x) for (int i = lane; i < n; i += 64) b.x[(size_t)q * n + i] = xu[i];
         if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = 0;
@@ -663,8 +668,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         }
         return;
     }
+    // a pending UPDATE_v needs R^-1 and f: their loads go out first and arrive together with the rows of M
+    const int rinv0 = o.rowc_size - round_up(b.rtri, 2) - 2;
+    double *Rl0 = w.rowc + rinv0;
+    double f_in = 0;
+    if (upd & DAQP_UPDATE_v) {
+        const double *Rq = b.Rinv + (size_t)q * b.rtri, *f = b.f + (size_t)q * n;
+        const int odd8 = (int)(((size_t)Rq >> 3) & 1);
+        Rl0 += odd8;
+        if (odd8) copy_async_dwords(Rl0, Rq, 1);
+        const int body = (b.rtri - odd8) & ~1;
+        copy_async(Rl0 + odd8, Rq + odd8, body);
+        if (odd8 + body < b.rtri) copy_async_dwords(Rl0 + odd8 + body, Rq + odd8 + body, 1);
+        if (lane < n) f_in = (lane < b.ms) ? f[lane] / gsc[lane] : f[lane];
+    }
     // ---- row view: bounds, tolerance, sense and the rows of M themselves -> registers
     const double ep = -w.stp->primal_tol;
+    double scr[NB];
     int softbits = 0;
     w.rs = 0;
     const double2 *msrc = reinterpret_cast<const double2 *>(b.Mblk + (size_t)q * b.nblk * b.npair * 128);
@@ -673,7 +693,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         const bool ok = r < m;
         w.du[bb] = ok ? gdu[r] : 0.0;
         w.dl[bb] = ok ? gdl[r] : 0.0;
-        w.bnd[bb] = ok ? ep * gsc[r] : 0.0;
+        scr[bb] = ok ? gsc[r] : 0.0;
+        w.bnd[bb] = ep * scr[bb];
         const int sn = ok ? (gsense[r] & 0xff) : 0;
         w.rs |= (unsigned)sn << (8 * bb);
         softbits |= sn & DAQP_SOFT;
@@ -687,6 +708,78 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         });
     });
     w.has_soft = __any(softbits) ? 1 : 0;
+    if (upd) {
+        // ---- daqp_update_ldp(UPDATE_v|UPDATE_d) on the resident factors (utils.c:58-221 without Rinv/M), cf. k_update
+        const double *nbu = b.bu + (size_t)q * m, *nbl = b.bl + (size_t)q * m;
+        double bur[NB], blr[NB];
+        int bad = 0;
+        static_for<NB>([&](auto bb) __attribute__((always_inline)) {   // check_bounds (utils.c:546-567) on the stored sense
+            const int r = bb * 64 + lane;
+            const bool ok = r < m;
+            bur[bb] = ok ? nbu[r] : 0.0;
+            blr[bb] = ok ? nbl[r] : 0.0;
+            const int sn = rsense_get(w, bb);
+            if (ok && !(sn & DAQP_IMMUTABLE)) {
+                const double diff = bur[bb] - blr[bb];
+                if (diff < -w.stp->primal_tol) bad |= 1;
+                else if (diff < w.stp->zero_tol && !(sn & DAQP_SOFT)) { w.rs |= (unsigned)(DAQP_ACTIVE | DAQP_IMMUTABLE) << (8 * bb); bad |= 4; }
+            }
+        });
+        if (__any(bad & 1)) {
+            if (lane == 0) {
+                qs->exitflag = DAQP_EXIT_INFEASIBLE; qs->setup_flag = DAQP_EXIT_INFEASIBLE;
+                b.exitflag[q] = DAQP_EXIT_INFEASIBLE; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0;
+            }
+            return;
+        }
+        if (__any(bad & 4)) q_need_act = 1;
+        double *vv = w.u, *fl = w.pend_lam;       // both regions are free until the loop starts (u is zeroed below)
+        for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) vv[e] = 0;
+        if (upd & DAQP_UPDATE_v) {   // v = R^-T f (utils.c:474-497), rows < ms of R^-1 are the normalised ones
+            const double *Rl = Rl0;
+            if (lane < n) fl[lane] = f_in;
+            copy_wait();
+            WSYNC();
+            if (lane < n) {
+                const int i = lane;
+                double acc = Rl[roff(i, n) + i] * fl[i];
+                for (int j0 = i - 1; j0 >= 0; j0 -= kChunk) {
+                    double rr[kChunk], ff[kChunk];
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) { const int j = (j0 - k >= 0) ? j0 - k : 0; rr[k] = Rl[roff(j, n) + i]; ff[k] = fl[j]; }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) if (j0 - k >= 0) acc += rr[k] * ff[k];
+                }
+                vv[i] = acc;
+                b.v[(size_t)q * n + i] = acc;
+            }
+        } else if (lane < n) vv[lane] = b.v[(size_t)q * n + lane];
+        WSYNC();
+        // d = b*scaling + (row . v) for every row of the dense image (utils.c:499-544); rows stay in registers
+        {
+            const double2 *v2 = reinterpret_cast<const double2 *>(vv);
+            double sm[NB];
+            static_for<NB>([&](auto bb) __attribute__((always_inline)) { sm[bb] = 0; });
+            static_for<NP>([&](auto tt) __attribute__((always_inline)) {
+                const double2 vk = v2[tt];
+                static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+                    sm[bb] += w.Mx[bb][tt] * vk.x;
+                    sm[bb] += w.My[bb][tt] * vk.y;     // odd n: the last pair's partner is 0 * 0 (both zero padding), an exact no-op
+                });
+            });
+            static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+                const int r = bb * 64 + lane;
+                if (r < m) {
+                    w.du[bb] = bur[bb] * scr[bb] + sm[bb];
+                    w.dl[bb] = blr[bb] * scr[bb] + sm[bb];
+                    b.dupper[(size_t)q * m + r] = w.du[bb];
+                    b.dlower[(size_t)q * m + r] = w.dl[bb];
+                }
+            });
+        }
+        w.reuse = 0; w.sing = kEmpty;     // utils.c:80-81
+        WSYNC();
+    }
     // ---- working-set view
     const bool act = lane < w.na;
     w.wsid = act ? gws[lane] : 0;

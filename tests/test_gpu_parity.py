@@ -176,6 +176,49 @@ def test_warm_sequence(oracle, gpu_lib):
     bm.close()
 
 
+@pytest.mark.parametrize("eager", [False, True])
+@pytest.mark.parametrize("shape", [(13, 40, 5, 5), (12, 48, 12, 6), (20, 40, 0, 8)])
+def test_warm_sequence_shapes(oracle, gpu_lib, monkeypatch, shape, eager):
+    """update(v) and update(d) (new f, new bounds) on shapes with simple bounds and an odd n; the update is applied inside
+    the next solve launch by default (k_ldp_reg mode 2) or by the stand-alone kernel (DAQP_AMD_EAGER_UPDATE=1)"""
+    import daqp_amd
+    if eager:
+        monkeypatch.setenv("DAQP_AMD_EAGER_UPDATE", "1")
+    n, m, ms, na = shape
+    N, T = 24, 4
+    q = O.generate_batch(N, n, m, ms, na, 700 + n)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        models.append(om)
+    f, bu, bl = q["f"].copy(), q["bupper"].copy(), q["blower"].copy()
+    for t in range(T + 1):
+        if t > 0:
+            for k in range(N):
+                rng = np.random.default_rng([46, k, t])
+                f[k] = f[k] + 0.05 * rng.standard_normal(n)
+                if t % 2 == 0:      # every other step the bounds move too (UPDATE_v | UPDATE_d)
+                    shift = 0.02 * rng.standard_normal(m)
+                    bu[k] = bu[k] + shift; bl[k] = bl[k] + shift
+                    assert models[k].update(O.UPDATE_v | O.UPDATE_d, f=f[k], bupper=bu[k], blower=bl[k]) == 0
+                else:
+                    assert models[k].update(O.UPDATE_v, f=f[k]) == 0
+            if t % 2 == 0:
+                bm.update(f=f, bupper=bu, blower=bl)
+            else:
+                bm.update(f=f)
+        g = bm.solve()
+        for k in range(N):
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (t, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            if r[3] > 0:
+                assert bits_equal(g["x"][k], r[0]) and bits_equal(g["lam"][k], r[1])
+    bm.close()
+
+
 def test_model_api(oracle, gpu_lib):
     """reference python tests' Model flow (example_test.py:175-237): setup, solve, update f, update bounds"""
     import daqp_amd

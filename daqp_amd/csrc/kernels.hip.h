@@ -494,16 +494,6 @@ __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
             for (int e = lane; e < used; e += 64) w.L[e] = gL[e];
         }
         for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) w.u[e] = 0;
-        if constexpr (NB > 0) {   // the QP's whole constraint matrix -> registers (read once from HBM)
-            const double2 *src = reinterpret_cast<const double2 *>(w.Mblk);
-#pragma unroll
-            for (int bb = 0; bb < NB; ++bb)
-#pragma unroll
-                for (int t = 0; t < NP; ++t) {
-                    double2 z; z.x = 0; z.y = 0;
-                    w.Mr[bb][t] = (bb < b.nblk && t < b.npair) ? src[((size_t)bb * b.npair + t) * 64 + lane] : z;
-                }
-        }
         WSYNC();
         for (int i = 0; i < w.na; ++i) fetch_row(w, w.ws[i], i);   // rebuild the active-row cache
     }

@@ -139,7 +139,6 @@ struct Wave {
     int *trace; int trace_cap, trace_len;
     // the whole constraint matrix of this QP, register-resident (NB row blocks x NP k-pairs per
     // lane; NB == 0: streamed from HBM instead).  Padding pairs/rows are zero.
-    double2 Mr[NB > 0 ? NB : 1][NP > 0 ? NP : 1];
     // optional phase cycle counters (s_memtime): csp, blocking, primal, scan, add, remove, other
     long long prof[8];
     bool profiling;
@@ -157,34 +156,19 @@ __device__ __forceinline__ void trace_ev(Wave<C, NB, NP> &w, int ev)
     }
 }
 
-// rowc[slot][0..n) <- row `id` of the LDP constraint matrix.  Register-resident M: the owning
-// lane (id & 63) writes its registers to LDS; streamed M: gather from the blocked HBM layout
-// [row/64][k/2][row%64][k%2].  Simple-bound rows are stored densely with a zero prefix.
+// rowc[slot][0..n) <- row `id` of the LDP constraint matrix, gathered from the blocked HBM layout
+// [row/64][k/2][row%64][k%2] (the register-resident variant is k_ldp_reg / wave_ldp_reg.hip.h).
+// Simple-bound rows are stored densely with a zero prefix.
 template <int C, int NB, int NP>
 __device__ __forceinline__ void fetch_row(Wave<C, NB, NP> &w, int id, int slot)
 {
     const int lane = lane_id();
     double *dst = w.rowc + (size_t)slot * w.ldr;
-    if constexpr (NB > 0) {
-        // uniform branch per row block: the owning lane stores its registers straight to LDS
-        const int b = id >> 6, l = id & 63;
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb) {
-            if (b == bb && lane == l) {
-#pragma unroll
-                for (int t = 0; t < NP; ++t) {
-                    if (2 * t < w.n) dst[2 * t] = w.Mr[bb][t].x;
-                    if (2 * t + 1 < w.n) dst[2 * t + 1] = w.Mr[bb][t].y;
-                }
-            }
-        }
-    } else {
-        const double2 *src = reinterpret_cast<const double2 *>(w.Mblk) + ((size_t)(id >> 6) * w.npair) * 64 + (id & 63);
-        for (int t = lane; t < w.npair; t += 64) {
-            const double2 v = src[(size_t)t * 64];
-            dst[2 * t] = v.x;
-            if (2 * t + 1 < w.n) dst[2 * t + 1] = v.y;
-        }
+    const double2 *src = reinterpret_cast<const double2 *>(w.Mblk) + ((size_t)(id >> 6) * w.npair) * 64 + (id & 63);
+    for (int t = lane; t < w.npair; t += 64) {
+        const double2 v = src[(size_t)t * 64];
+        dst[2 * t] = v.x;
+        if (2 * t + 1 < w.n) dst[2 * t + 1] = v.y;
     }
     WSYNC();
 }
@@ -625,86 +609,52 @@ __device__ __forceinline__ int scan_rows(Wave<C, NB, NP> &w, int &upper, bool wi
     int bi = kBig, bup = 0;
     double fv = w.soft;
     const double2 *u2 = reinterpret_cast<const double2 *>(w.u);
-    if constexpr (NB > 0) {
-        // M is in registers: NB independent k-ordered chains per lane, u broadcast from LDS.
-        // Zero padding (pairs >= npair, u beyond n) adds +0.0 and leaves every sum unchanged.
-        double mu[NB];
+    const bool odd = (n & 1) != 0;
+    for (int blk = 0; blk < w.nblk; ++blk) {
+        const int r = blk * 64 + lane;
+        const double2 *src = reinterpret_cast<const double2 *>(w.Mblk) + ((size_t)blk * w.npair) * 64 + lane;
+        double mu = 0;
+        const int full = odd ? w.npair - 1 : w.npair;
+        if (r < w.m) {
+            // the stream of M: 16 x 16-byte loads per lane in flight (16 KiB per wave) before the k-ordered chain
+            // consumes them -- with a handful in flight the scan is pure HBM latency at large n
+            int t = 0;
+            for (; t + 16 <= full; t += 16) {
+                double2 mm[16], uk[16];
 #pragma unroll
-        for (int bb = 0; bb < NB; ++bb) mu[bb] = 0;
+                for (int q = 0; q < 16; ++q) mm[q] = src[(size_t)(t + q) * 64];
 #pragma unroll
-        for (int t = 0; t < NP; ++t) {
-            const double2 uk = u2[t];
+                for (int q = 0; q < 16; ++q) uk[q] = u2[t + q];
 #pragma unroll
-            for (int bb = 0; bb < NB; ++bb) {
-                mu[bb] += w.Mr[bb][t].x * uk.x;
-                mu[bb] += w.Mr[bb][t].y * uk.y;
+                for (int q = 0; q < 16; ++q) { mu += mm[q].x * uk[q].x; mu += mm[q].y * uk[q].y; }
             }
-            if (with_fval) { fv += uk.x * uk.x; fv += uk.y * uk.y; }   // j-ordered |u|^2 (auxiliary.c:85-86)
-            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the LDS broadcasts from being hoisted en bloc
+            if (t < full) {
+                double2 mm[16], uk[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { const int tt = (t + q < full) ? t + q : full - 1; mm[q] = src[(size_t)tt * 64]; uk[q] = u2[tt]; }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) if (t + q < full) { mu += mm[q].x * uk[q].x; mu += mm[q].y * uk[q].y; }
+            }
+            if (odd) mu += src[(size_t)full * 64].x * w.u[n - 1];
         }
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb) {
-            const int r = bb * 64 + lane;
-            if (r < w.m) {
-                const int sn = w.sense[r];
-                if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
-                    const double bound = ep * w.scaling[r];
-                    double cand = w.dupper[r] - mu[bb];
-                    if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 1; }
-                    else {
-                        cand = mu[bb] - w.dlower[r];
-                        if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 0; }
-                    }
-                }
-            }
+        if (with_fval && blk == 0) {
+            for (int j = 0; j < n; ++j) { const double uj = w.u[j]; fv += uj * uj; }
         }
-    } else {
-        const bool odd = (n & 1) != 0;
-        for (int blk = 0; blk < w.nblk; ++blk) {
-            const int r = blk * 64 + lane;
-            const double2 *src = reinterpret_cast<const double2 *>(w.Mblk) + ((size_t)blk * w.npair) * 64 + lane;
-            double mu = 0;
-            const int full = odd ? w.npair - 1 : w.npair;
-            if (r < w.m) {
-                // the stream of M: 16 x 16-byte loads per lane in flight (16 KiB per wave) before the k-ordered chain
-                // consumes them -- with a handful in flight the scan is pure HBM latency at large n
-                int t = 0;
-                for (; t + 16 <= full; t += 16) {
-                    double2 mm[16], uk[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) mm[q] = src[(size_t)(t + q) * 64];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) uk[q] = u2[t + q];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) { mu += mm[q].x * uk[q].x; mu += mm[q].y * uk[q].y; }
-                }
-                if (t < full) {
-                    double2 mm[16], uk[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) { const int tt = (t + q < full) ? t + q : full - 1; mm[q] = src[(size_t)tt * 64]; uk[q] = u2[tt]; }
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) if (t + q < full) { mu += mm[q].x * uk[q].x; mu += mm[q].y * uk[q].y; }
-                }
-                if (odd) mu += src[(size_t)full * 64].x * w.u[n - 1];
-            }
-            if (with_fval && blk == 0) {
-                for (int j = 0; j < n; ++j) { const double uj = w.u[j]; fv += uj * uj; }
-            }
-            if (r < w.m) {
-                const int sn = w.sense[r];
-                if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
-                    const double bound = ep * w.scaling[r];
-                    double cand = w.dupper[r] - mu;
-                    if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 1; }
-                    else {
-                        cand = mu - w.dlower[r];
-                        if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 0; }
-                    }
+        if (r < w.m) {
+            const int sn = w.sense[r];
+            if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
+                const double bound = ep * w.scaling[r];
+                double cand = w.dupper[r] - mu;
+                if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 1; }
+                else {
+                    cand = mu - w.dlower[r];
+                    if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 0; }
                 }
             }
         }
-        if (with_fval && w.nblk == 0) fv = ordered_norm2(w, fv);
     }
+    if (with_fval && w.nblk == 0) fv = ordered_norm2(w, fv);
+
     if (with_fval) w.fval = fv;
     wave_argmin(bv, bi, bup);
     upper = bup;

@@ -233,7 +233,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         while ((l & 3) != 2) ++l;
         d.ldrc = l;
     }
-    b->lds_ldp = (size_t)ldp_lds(n, m, cap, b->spill, d.ldrc).total_bytes;
+    b->lds_ldp = b->NB > 0 ? (size_t)reg_lds_bytes(b->NB, n, m, cap, d.ldrc) : (size_t)ldp_lds(n, m, cap, b->spill, d.ldrc).total_bytes;
     b->fast_setup = (n <= 64) && !getenv("DAQP_AMD_SLOW_SETUP");
     {   // DAQP_AMD_EXACT=1: keep the reference's summation order in M = A R^-1 (bit-exact LDP); default: MFMA
         const char *ex = getenv("DAQP_AMD_EXACT");
@@ -328,6 +328,7 @@ int daqp_batch_enable_profile(DAQPBatch *b, int on)
     if (!b) return DAQP_EXIT_UNSUPPORTED;
     (void)hipSetDevice(b->device);
     if (!on) { b->d.prof = nullptr; return 0; }
+    if (!kProfile) { set_err("cycle-counter probes are not compiled in (build with -DDAQP_AMD_PROFILE)"); return DAQP_EXIT_UNSUPPORTED; }
     long long *p = nullptr;
     if (dev_alloc(b, &p, (size_t)b->d.N * 32)) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipMemset(p, 0, (size_t)b->d.N * 32 * sizeof(long long)));

@@ -60,7 +60,7 @@ __host__ __device__ inline SetupLds setup_lds(int n, int m, bool gs = false)
     s.total_bytes = o * 8 + round_up(m, 4) * 4;
     return s;
 }
-struct LdpLds { int L, rowc, rowc_size, D, xl, zl, lamA, lamB, u, pend_lam, vq, sc, dbl; int ws, sense, pend_id, ints; int total_bytes; };
+struct LdpLds { int L, rowc, rowc_size, D, xl, zl, lamA, lamB, u, pend_lam, rowv, dbl; int ws, sense, pend_id, ints; int total_bytes; };
 __host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill, int ldrc = 0)
 {
     LdpLds s;
@@ -78,7 +78,7 @@ __host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill, int
     s.D = o; o += cp; s.xl = o; o += cp; s.zl = o; o += cp; s.lamA = o; o += cp; s.lamB = o; o += cp;
     s.u = o; o += round_up(n > 64 ? n : 64, 2) + 2;   // zero-padded to 64 for the register-resident scan
     s.pend_lam = o; o += cp;
-    s.vq = o; s.sc = o;
+    s.rowv = o;
     s.dbl = o;                       // ints start at double offset s.dbl
     int oi = 0;
     s.ws = oi; oi += round_up(cap, 4);
@@ -583,6 +583,22 @@ __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
     }
 }
 
+// LDS of the register-centric solve kernel.  Everything small sits at COMPILE-TIME offsets in front (u, the pivot
+// stack, the per-row bounds, packed L): their addresses are "immediate + 8*lane", nothing to keep in a register across
+// the state-machine loop (every loop-invariant base pointer is one more value that the full register file spills to
+// scratch).  Only the active-row cache, behind the run-time sized L, has a run-time base.
+template <int NB>
+struct RegLds {
+    static constexpr int u = 0, pend_lam = 68, pend_id = 132, prof = 164, rowv = 196, L = 196 + 192 * NB;   // doubles
+};
+__host__ __device__ inline int reg_lds_rowc_size(int n, int m, int cap, int ldrc)
+{
+    const int rows = round_up(cap * ldrc, 2), fin = round_up(n * (n + 1) / 2, 2) + 2 + round_up(m, 2);   // epilogue: staged R^-1 + lam
+    return rows > fin ? rows : fin;
+}
+__host__ __device__ inline int reg_lds_rowc(int NB, int cap) { return 196 + 192 * NB + round_up(cap * (cap + 1) / 2, 2); }
+__host__ __device__ inline int reg_lds_bytes(int NB, int n, int m, int cap, int ldrc) { return 8 * (reg_lds_rowc(NB, cap) + reg_lds_rowc_size(n, m, cap, ldrc)); }
+
 // ------------------------------------------------------------------------------------
 // k_ldp_reg: the register-centric solve kernel (wave_ldp_reg.hip.h) for n + n_soft + 1 <= 64 and
 // m <= 64*NB, n <= 2*NP.  Same global state layout as k_ldp, so the two are interchangeable.
@@ -595,7 +611,7 @@ __global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
 #endif
 constexpr int ldp_reg_waves(int NB, int NP) { return NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 32 ? 2 : 1); }
 template <int NB, int NP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_waves(NB, NP), ldp_reg_waves(NB, NP)))) void k_ldp_reg(const BatchDev *bp, int mode_in)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_waves(NB, NP), ldp_reg_waves(NB, NP)))) void k_ldp_reg(const BatchDev *__restrict__ bp, int mode_in)
 {
     // mode 0: daqp_solve; 1: only (re)build the working set from the ACTIVE bits; 2 | mask << 4: daqp_update_ldp(mask)
     // for mask within UPDATE_v|UPDATE_d applied here, then daqp_solve -- the rows of M are in registers anyway, so the
@@ -620,15 +636,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
         return;
     }
-    const LdpLds o = ldp_lds(n, m, cap, false, b.ldrc);
-    int *ibase = reinterpret_cast<int *>(smem + o.dbl);
+    typedef RegLds<NB> o;
+    const int rowc_size = reg_lds_rowc_size(n, m, cap, b.ldrc);
     RWave<NB, NP> w;
     // phase counters live in the (otherwise unused) D/xl slots of the LDS carve-up
-    w.prof = ((b.prof != nullptr) && mode == 0) ? reinterpret_cast<long long *>(smem + o.D) : nullptr;
-    if (w.prof && lane < 32) w.prof[lane] = 0;
+    w.prof = (kProfile && (b.prof != nullptr) && mode == 0) ? reinterpret_cast<long long *>(smem + o::prof) : nullptr;
+    if (kProfile && w.prof && lane < 32) w.prof[lane] = 0;
     w.n = n; w.m = m; w.ms = b.ms; w.ldr = b.ldrc;
-    w.L = smem + o.L; w.rowc = smem + o.rowc; w.u = smem + o.u; w.pend_lam = smem + o.pend_lam;
-    w.pend_id = ibase + o.pend_id;
+    w.L = smem + o::L; w.rowc = smem + reg_lds_rowc(NB, cap); w.u = smem + o::u; w.pend_lam = smem + o::pend_lam;
+    w.rowv = smem + o::rowv;
+    w.pend_id = reinterpret_cast<int *>(smem + o::pend_id);
     w.stp = b.st_dev;
     w.dual_tol = b.st.dual_tol; w.sing_tol = b.st.sing_tol; w.pivot_tol = b.st.pivot_tol; w.rho_soft = b.st.rho_soft;
     w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
@@ -659,7 +676,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         return;
     }
     // a pending UPDATE_v needs R^-1 and f: their loads go out first and arrive together with the rows of M
-    const int rinv0 = o.rowc_size - round_up(b.rtri, 2) - 2;
+    const int rinv0 = rowc_size - round_up(b.rtri, 2) - 2;
     double *Rl0 = w.rowc + rinv0;
     double f_in = 0;
     if (upd & DAQP_UPDATE_v) {
@@ -678,26 +695,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     int softbits = 0;
     w.rs = 0;
     const double2 *msrc = reinterpret_cast<const double2 *>(b.Mblk + (size_t)q * b.nblk * b.npair * 128);
+    const int npair_u = __builtin_amdgcn_readfirstlane(b.npair), nblk_u = __builtin_amdgcn_readfirstlane(b.nblk);
+    // the small per-row loads go out first: in-order return means whoever waits for them would otherwise wait for
+    // every row of M issued before them
+    double dur[NB], dlr[NB];
+    int snr[NB];
     static_for<NB>([&](auto bb) __attribute__((always_inline)) {
         const int r = bb * 64 + lane;
         const bool ok = r < m;
-        w.du[bb] = ok ? gdu[r] : 0.0;
-        w.dl[bb] = ok ? gdl[r] : 0.0;
         scr[bb] = ok ? gsc[r] : 0.0;
-        w.bnd[bb] = ep * scr[bb];
-        const int sn = ok ? (gsense[r] & 0xff) : 0;
-        w.rs |= (unsigned)sn << (8 * bb);
-        softbits |= sn & DAQP_SOFT;
-        static_for<NP>([&](auto t) __attribute__((always_inline)) {
-            double vx = 0, vy = 0;
-            if (bb < b.nblk && t < b.npair) {
-                const double2 v = msrc[((size_t)bb * b.npair + t) * 64 + lane];
-                vx = v.x; vy = v.y;
-            }
-            w.Mx[bb][t] = vx; w.My[bb][t] = vy;     // every load lands in its final register: all of them may be in flight
+        dur[bb] = ok ? gdu[r] : 0.0;
+        dlr[bb] = ok ? gdl[r] : 0.0;
+        snr[bb] = ok ? (gsense[r] & 0xff) : 0;
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    if (nblk_u == NB && npair_u == NP) {
+        // the shape fills the template exactly (the benchmark's case): NB*NP unconditional loads in ONE basic block, each
+        // straight into its final (mostly accumulation) register -- all in flight, one wait at the first use
+        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+            static_for<NP>([&](auto t) __attribute__((always_inline)) {
+                const double2 v = msrc[((size_t)bb * NP + t) * 64 + lane];
+                w.Mx[bb][t] = v.x; w.My[bb][t] = v.y;
+            });
         });
+    } else {
+        // smaller problems in the same register shape: lines beyond the problem's are zeros (a select per load keeps
+        // only a few of them in flight; these shapes are far from bandwidth-critical)
+        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+            static_for<NP>([&](auto t) __attribute__((always_inline)) {
+                const bool ok = bb < nblk_u && t < npair_u;
+                const double2 v = msrc[(ok ? ((size_t)bb * npair_u + t) : (size_t)0) * 64 + lane];
+                w.Mx[bb][t] = ok ? v.x : 0.0; w.My[bb][t] = ok ? v.y : 0.0;
+            });
+        });
+    }
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+        const int r = bb * 64 + lane;
+        w.rowv[r] = dur[bb];
+        w.rowv[(64 * NB) + r] = dlr[bb];
+        w.rowv[2 * (64 * NB) + r] = ep * scr[bb];
+        w.rs |= (unsigned)snr[bb] << (8 * bb);
+        softbits |= snr[bb] & DAQP_SOFT;
     });
     w.has_soft = __any(softbits) ? 1 : 0;
+    const long long tp1 = kProfile ? (long long)__builtin_readcyclecounter() : 0;
     if (upd) {
         // ---- daqp_update_ldp(UPDATE_v|UPDATE_d) on the resident factors (utils.c:58-221 without Rinv/M), cf. k_update
         const double *nbu = b.bu + (size_t)q * m, *nbl = b.bl + (size_t)q * m;
@@ -760,10 +801,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
             static_for<NB>([&](auto bb) __attribute__((always_inline)) {
                 const int r = bb * 64 + lane;
                 if (r < m) {
-                    w.du[bb] = bur[bb] * scr[bb] + sm[bb];
-                    w.dl[bb] = blr[bb] * scr[bb] + sm[bb];
-                    b.dupper[(size_t)q * m + r] = w.du[bb];
-                    b.dlower[(size_t)q * m + r] = w.dl[bb];
+                    const double nu = bur[bb] * scr[bb] + sm[bb], nl = blr[bb] * scr[bb] + sm[bb];
+                    dur[bb] = nu; dlr[bb] = nl;
+                    w.rowv[r] = nu; w.rowv[(64 * NB) + r] = nl;
+                    b.dupper[(size_t)q * m + r] = nu;
+                    b.dlower[(size_t)q * m + r] = nl;
                 }
             });
         }
@@ -776,21 +818,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     w.slot = lane;
     w.slotmask = (w.na >= 64) ? ~0ull : ((1ull << w.na) - 1ull);
     w.hi_slot = w.na - 1;
-    const int rinv_off = o.rowc_size - round_up(b.rtri, 2) - 2;
+    const int rinv_off = rowc_size - round_up(b.rtri, 2) - 2;
     w.D = (lane < cap) ? gv[lane] : 0.0;
     w.xl = (lane < cap) ? gv[cap + lane] : 0.0;
     w.zl = (lane < cap) ? gv[2 * cap + lane] : 0.0;
     const double la = (lane < cap) ? gv[3 * cap + lane] : 0.0, lb = (lane < cap) ? gv[4 * cap + lane] : 0.0;
     w.lam = swapped ? lb : la;
     w.lams = swapped ? la : lb;
-    {   // sense and bound of each working-set row are already in the row registers: fetch them across lanes
+    {   // sense and bound of each working-set row are already in registers (row view): fetch them across lanes
         // (ds_bpermute) instead of a second, dependent trip to HBM
         const int src = w.wsid & 63, blk = w.wsid >> 6;
         int fl = 0;
         double bu = 0, bl = 0;
         static_for<NB>([&](auto bb) __attribute__((always_inline)) {
             const int s8 = (int)((__shfl((int)w.rs, src) >> (8 * bb)) & 0xff);
-            const double u_ = __shfl(w.du[bb], src), l_ = __shfl(w.dl[bb], src);
+            const double u_ = __shfl(dur[bb], src), l_ = __shfl(dlr[bb], src);
             if (blk == bb) { fl = s8; bu = u_; bl = l_; }
         });
         w.wflag = act ? fl : 0;
@@ -809,7 +851,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(w.rowc + (size_t)i * w.ldr), 16, 0, 0);
         }
+        if (kProfile && w.prof && lane == 0) { w.prof[16] = tp1 - t_start; w.prof[17] = (long long)__builtin_readcyclecounter() - tp1; }
         copy_wait();
+        if (kProfile && w.prof && lane == 0) w.prof[18] = (long long)__builtin_readcyclecounter() - tp1;
     }
     WSYNC();
 
@@ -864,7 +908,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         }
         WSYNC();
         const long long te3 = (long long)__builtin_readcyclecounter();
-        if (w.prof && lane == 0) { w.prof[20] = te1 - t_done; w.prof[21] = te2 - te1; w.prof[22] = te3 - te2; }
+        if (kProfile && w.prof && lane == 0) { w.prof[20] = te1 - t_done; w.prof[21] = te2 - te1; w.prof[22] = te3 - te2; }
         if (b.x && lane < n) b.x[(size_t)q * n + lane] = xi;
         if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = lamq[i];
         double fv = w.fval;                      // fval - |v|^2 in index order, v_i broadcast from its lane
@@ -896,7 +940,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         qs->lam_swapped = 0;
         qs->fval = w.fval; qs->soft_slack = w.soft;
         if (b.trace) b.trace[(size_t)q * b.trace_cap + b.trace_cap - 1] = w.trace_len;
-        if (w.prof) {
+        if (kProfile && w.prof) {
             const long long te4 = (long long)__builtin_readcyclecounter();
             w.prof[23] = te4 - t_done;
             for (int i = 0; i < 32; ++i) b.prof[(size_t)q * 32 + i] = w.prof[i];

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     const int ldr = direct ? n : (n | 1);
     int flag = 1, activate = 0;
     long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long t0 = b.prof ? (long long)__builtin_readcyclecounter() : 0;
-#define SPROF(slot) do { if (b.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[slot] += t1 - t0; t0 = t1; } } while (0)
+    long long t0 = (kProfile && b.prof) ? (long long)__builtin_readcyclecounter() : 0;
+#define SPROF(slot) do { if (kProfile && b.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); pt[slot] += t1 - t0; t0 = t1; } } while (0)
 
     if (direct) copy_async(Rsq, H, n * n);     // in flight while the bounds are checked
     // --- sense (utils.c:84-91) and early bound check (utils.c:546-567)
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0;
-        if (b.prof) for (int i = 0; i < 10; ++i) b.prof[(size_t)q * 32 + i] = pt[i];
+        if (kProfile && b.prof) for (int i = 0; i < 10; ++i) b.prof[(size_t)q * 32 + i] = pt[i];
     }
 #undef SPROF
 }

@@ -41,7 +41,9 @@ struct RWave {
     // whole unified 512-entry register file; the compiler parks what exceeds the 256
     // architectural VGPRs in AGPRs (v_accvgpr_read on use).
     double Mx[NB][NP], My[NB][NP];   // M[row][2t], M[row][2t+1]
-    double du[NB], dl[NB], bnd[NB];
+    // d_upper, d_lower and -primal_tol*scaling of every row live in LDS (rowv[r], rowv[R + r], rowv[2R + r], R = 64*NB): they are read once per iteration at the end of the scan, and 18 more registers held across the whole
+    // loop push the allocator into scratch spills (the register file is full: 300 registers of M + the working set)
+    double *rowv;
     unsigned rs;   // sense bits of this lane's rows, 8 bits per row block (a register, never an array)
     // uniform
     int na, reuse, sing, has_soft;
@@ -54,8 +56,24 @@ struct RWave {
     long long *prof;                    // LDS, 8 phase counters (NULL: off)
 };
 
-#define RPROF_T0(w) long long prof_t0_ = (w).prof ? (long long)__builtin_readcyclecounter() : 0
-#define RPROF_ACC(w, slot) do { if ((w).prof) { const long long t1_ = (long long)__builtin_readcyclecounter(); if (lane_id() == 0) (w).prof[slot] += t1_ - prof_t0_; prof_t0_ = t1_; } } while (0)
+// The lane number as a value the optimizer cannot see through: LDS addresses of the form "base + 8*lane" are loop
+// invariant, so LICM hoists them out of the state-machine loop, the register file (full: M alone is 300 registers)
+// cannot hold them, and they come back as scratch reloads -- a trip to memory to save one v_lshl_add.  Addresses
+// built from lane_now() are recomputed where they are used.
+__device__ __forceinline__ int lane_now() { int l = lane_id(); asm volatile("" : "+v"(l)); return l; }
+
+// Cycle-counter probes (per-state / per-phase, tools/gpu_profile.py).  They are compiled in by default and switched on
+// per batch at run time (daqp_batch_enable_profile): measured on gfx950, the build WITH the (disabled) probes is the
+// faster one -- k_ldp_reg 7.53 ms vs 7.95 ms per 20 k QPs of config C2 -- because the probe branches split the giant
+// basic blocks of the state machine and the register allocator, working on a completely full register file, does
+// better on the pieces.  -DDAQP_AMD_NO_PROFILE removes them.
+#ifndef DAQP_AMD_NO_PROFILE
+constexpr bool kProfile = true;
+#else
+constexpr bool kProfile = false;
+#endif
+#define RPROF_T0(w) long long prof_t0_ = (kProfile && (w).prof) ? (long long)__builtin_readcyclecounter() : 0
+#define RPROF_ACC(w, slot) do { if (kProfile && (w).prof) { const long long t1_ = (long long)__builtin_readcyclecounter(); if (lane_id() == 0) (w).prof[slot] += t1_ - prof_t0_; prof_t0_ = t1_; } } while (0)
 
 __device__ __forceinline__ int rli(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
@@ -90,12 +108,7 @@ __device__ __forceinline__ void sense_set(RWave<NB, NP> &w, int id, int set_bits
 template <int NB, int NP>
 __device__ __forceinline__ double bound_of(const RWave<NB, NP> &w, int id, bool lower)
 {
-    double v = 0;
-    static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-        const double bu = rl(w.du[bb], id & 63), bl = rl(w.dl[bb], id & 63);
-        if ((id >> 6) == bb) v = lower ? bl : bu;
-    });
-    return v;
+    return w.rowv[(lower ? (64 * NB) : 0) + id];     // wave-uniform address: an LDS broadcast
 }
 
 // rowc[slot] <- row id: the owning lane stores its registers, NP unconditional 16-byte writes (the row
@@ -154,7 +167,7 @@ template <int NB, int NP>
 __device__ __forceinline__ double rbackward(RWave<NB, NP> &w, double b, int cnt)
 {
     const int lane = lane_id();
-    const double *Ll = w.L + lane;
+    const double *Ll = w.L + lane_now();
     // step j updates lanes with lane < j < cnt  <=>  (unsigned)(j - 1 - lane) < (unsigned)(cnt - 1 - lane) for lane < cnt:
     // one add and one compare per step on per-lane registers, no wave-uniform mask per step (those end up as
     // spilled SGPR pairs).  Lanes >= cnt may pick up unused values; nothing reads them.
@@ -200,12 +213,12 @@ __device__ __forceinline__ double rforward(RWave<NB, NP> &w, double x, double rh
     if (from == na - 1 && na > 1) {
         // the usual case after an add: only the last row is open.  Its products in parallel, then the j-ordered
         // chain of subtractions on broadcast operands -- the same operations as the sweep below for that row
-        const double p = (lane < na - 1) ? w.L[tri(na - 1) + lane] * x : 0.0;
+        const double p = (lane < na - 1) ? w.L[tri(na - 1) + lane_now()] * x : 0.0;
         const double last = ordered_sub(rl(rhs, na - 1), p, na - 1);
         return (lane == na - 1) ? last : x;
     }
     const int pl = pending ? lane : -1;
-    const double *Lr = w.L + tri(lane);
+    const double *Lr = w.L + tri(lane_now());
     static_for<8>([&](auto c) __attribute__((always_inline)) {
         if (8 * c < na - 1) {
             double Lk[8];
@@ -272,9 +285,7 @@ template <int NB, int NP>
 __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int newslot, int sn_id)
 {
     const int lane = lane_id(), na = w.na, n = w.n, base = tri(na);
-    RPROF_T0(w);
     rfetch_row(w, id, newslot);
-    RPROF_ACC(w, 24);
     const int c0 = id < w.ms ? id : 0;
     w.sing = kEmpty;
     const double *Mi = w.rowc + (size_t)newslot * w.ldr;
@@ -290,12 +301,11 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
     if (w.has_soft) ns_act = __popcll(__ballot(lane < na && (w.wflag & DAQP_SOFT))) + ((sn_id & DAQP_SOFT) ? 1 : 0);
     double dnew = rl(g, na);
     if (sn_id & DAQP_SOFT) dnew += w.rho_soft;
-    RPROF_ACC(w, 25);
     if (na == 0) return dnew;
     // forward substitution with L, column by column; each lane preloads its own row of L 8 columns ahead
     {
         const int pl = lane < na ? lane : -1;
-        const double *Lr = w.L + tri(lane);
+        const double *Lr = w.L + tri(lane_now());
         static_for<8>([&](auto c) __attribute__((always_inline)) {
             if (8 * c < na - 1) {
                 double Lk[8];
@@ -309,18 +319,16 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
             }
         });
     }
-    RPROF_ACC(w, 26);
     double p = 0;
     if (lane < na) {
         const double t = g;
         const double lk = t / w.D;
-        w.L[base + lane] = lk;
+        w.L[base + lane_now()] = lk;
         p = t * lk;
     }
     double acc = ordered_sub(dnew, p, na);
     if (acc < w.sing_tol || na >= n + ns_act) { w.sing = na; acc = 0; }
     WSYNC();
-    RPROF_ACC(w, 27);
     return acc;
 }
 
@@ -333,7 +341,8 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP> &w, int r)
     const int lane = lane_id(), na = w.na;
     if (na == r + 1) return;
     const int nupd = na - r - 1;
-    double wv = (lane < nupd) ? w.L[tri(r + 1 + lane) + r] : 0.0;
+    RPROF_T0(w);
+    double wv = (lane < nupd) ? w.L[tri(r + 1 + lane_now()) + r] : 0.0;
     // move rows r+1.. up by one and drop column r, element-parallel over the packed destination range
     // [tri(r), tri(na-1)).  Destination e always reads from a higher address, so ascending chunks with
     // "read all, then write all" never clobber a live source.  Row of e: float sqrt + one branch-free
@@ -363,11 +372,12 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP> &w, int r)
     }
     // Gill-Golub-Murray-Saunders C1 update: lane t <-> trailing row r+t (new numbering); its L
     // entries for 8 consecutive columns are read before, and written back after, the chain
+    RPROF_ACC(w, 24);
     double alpha = rl(w.D, r);
     double Dn = w.D;
     const double Drot = __shfl(w.D, (lane + r + 1) & 63);     // D_{r+1+j} in lane j: compile-time lane numbers below
     const int pl = lane < nupd ? lane : -1;
-    double *Lr = w.L + tri(r + lane) + r;
+    double *Lr = w.L + tri(r + lane_now()) + r;
     static_for<8>([&](auto c) __attribute__((always_inline)) {
         if (8 * c < nupd) {
             double Lc[8];
@@ -398,6 +408,7 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP> &w, int r)
     });
     w.D = Dn;
     WSYNC();
+    RPROF_ACC(w, 25);
 }
 
 // lane i <- lane i+1 for lanes >= r (closing the gap a removed working-set position leaves): one DPP move per
@@ -460,12 +471,12 @@ template <int NB, int NP>
 __device__ __forceinline__ void rsolve_csp(RWave<NB, NP> &w) // auxiliary.c:314-354
 {
     const int lane = lane_id(), na = w.na, from = w.reuse;
-    long long tq = w.prof ? (long long)__builtin_readcyclecounter() : 0;
+    long long tq = (kProfile && w.prof) ? (long long)__builtin_readcyclecounter() : 0;
     w.xl = rforward(w, w.xl, w.drhs, from);
     if (lane >= from && lane < na) w.zl = w.xl / w.D;
-    if (w.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) w.prof[11] += t1 - tq; tq = t1; }
+    if (kProfile && w.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) w.prof[11] += t1 - tq; tq = t1; }
     const double b = rbackward(w, (lane < na) ? w.zl : 0.0, na);
-    if (w.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) w.prof[12] += t1 - tq; tq = t1; }
+    if (kProfile && w.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) w.prof[12] += t1 - tq; tq = t1; }
     if (lane < na) w.lams = b;
     w.reuse = na;
 }
@@ -520,7 +531,7 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP> &w)
     // its multiplier (0 beyond na: the padding steps subtract 0 * finite, exact)
     const int soff = (lane < na) ? w.slot * w.ldr : 0;
     const double lz = (lane < na) ? w.lams : 0.0;
-    const double *rc = w.rowc + lane;
+    const double *rc = w.rowc + lane_now();
     static_for<8>([&](auto c) __attribute__((always_inline)) {
         if (8 * c < na) {
             double rv[8], li[8];
@@ -533,7 +544,7 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP> &w)
         }
     });
     WSYNC();
-    if (lane < n) w.u[lane] = uu;
+    if (lane < n) w.u[lane_now()] = uu;
     double fv = 0;
     if (w.has_soft) {
         const double sq = (lane < na && (w.wflag & DAQP_SOFT)) ? w.lams * w.lams : 0.0;
@@ -586,13 +597,18 @@ __device__ __forceinline__ int rscan_rows(RWave<NB, NP> &w, int &upper, bool wit
         static_for<NB>([&](auto bb) __attribute__((always_inline)) { pin_vgpr(mu[bb]); });
         pin_vgpr(fv);
     });
+    double du_[NB], dl_[NB], bn_[NB];
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+        const int r = bb * 64 + lane_now();
+        du_[bb] = w.rowv[r]; dl_[bb] = w.rowv[(64 * NB) + r]; bn_[bb] = w.rowv[2 * (64 * NB) + r];
+    });
     // selection without branches (a branch lets the compiler sink a whole block's chain into it, serialising the blocks)
     static_for<NB>([&](auto bb) __attribute__((always_inline)) {
         const int r = bb * 64 + lane;
         const bool open = r < w.m && !(rsense_get(w, bb) & (DAQP_ACTIVE + DAQP_IMMUTABLE));
-        const double cu = w.du[bb] - mu[bb], cl = mu[bb] - w.dl[bb];
-        const bool up = open && cu < bv && cu < w.bnd[bb];
-        const bool lo = open && !up && cl < bv && cl < w.bnd[bb];
+        const double cu = du_[bb] - mu[bb], cl = mu[bb] - dl_[bb];
+        const bool up = open && cu < bv && cu < bn_[bb];
+        const bool lo = open && !up && cl < bv && cl < bn_[bb];
         bv = up ? cu : (lo ? cl : bv);
         bi = (up || lo) ? r : bi;
         bup = up ? 1 : (lo ? 0 : bup);
@@ -628,7 +644,7 @@ __device__ __forceinline__ void rrefine_active(RWave<NB, NP> &w) // auxiliary.c:
         if (lane < n && lane >= j0) uu -= w.rowc[(size_t)s * w.ldr + lane] * di;
     }
     WSYNC();
-    if (lane < n) w.u[lane] = uu;
+    if (lane < n) w.u[lane_now()] = uu;
     WSYNC();
     double fv = w.soft;
     for (int j = 0; j < n; ++j) { const double uj = w.u[j]; fv += uj * uj; }
@@ -665,6 +681,10 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
     double best = -1;
     const double fbound = 2 * w.stp->fval_bound;
     const int iter_limit = __builtin_amdgcn_readfirstlane(w.stp->iter_limit);
+    // read once: inside the loop these would be two dependent trips to memory per iteration (the stores in the loop keep
+    // the compiler from hoisting them itself)
+    const double progress_tol = rl(w.stp->progress_tol, 0);
+    const int cycle_tol = __builtin_amdgcn_readfirstlane(w.stp->cycle_tol);
     // edit request (add / drop, then the pivot_last cascade) and its continuation
     int depth = 0, req_add = 1, req_id = 0, req_r = 0, after_edit = AFTER_NEXT_ITER;
     double req_lam = 0;
@@ -676,7 +696,7 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
     else pc = PC_START_LOOP;
     while (pc != PC_DONE) {
         const int pc_now = pc;
-        const long long t_in = w.prof ? (long long)__builtin_readcyclecounter() : 0;
+        const long long t_in = (kProfile && w.prof) ? (long long)__builtin_readcyclecounter() : 0;
         switch (pc) {
         case PC_START_LOOP:
             if (act_flag < 0) { flag = act_flag; pc = PC_DONE; break; }
@@ -764,8 +784,8 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
             }
             if (after_edit == AFTER_ACT_POST) { pc = PC_ACT_POST; break; }
             if (after_edit == AFTER_CYCLE_GUARD) {   // daqp.c:66-85
-                if (w.fval - best < w.stp->progress_tol) {
-                    if (stall++ > w.stp->cycle_tol) {
+                if (w.fval - best < progress_tol) {
+                    if (stall++ > cycle_tol) {
                         if (repaired == 1) { flag = DAQP_EXIT_CYCLE; pc = PC_DONE; break; }
                         repaired = 1;
                         rreset_ws(w);
@@ -847,7 +867,7 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
             pc = PC_DONE;
             break;
         }
-        if (w.prof) {   // cycles and visits per state
+        if (kProfile && w.prof) {   // cycles and visits per state
             const long long t_out = (long long)__builtin_readcyclecounter();
             if (lane == 0) { w.prof[pc_now] += t_out - t_in; w.prof[16 + pc_now] += 1; }
         }

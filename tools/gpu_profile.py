@@ -40,7 +40,8 @@ for prof in (False, True):
         print("    ITER parts/iter: csp %d, blocking %d, primal %d, scan %d | EDIT parts/iter: push %d, drop %d"
               % (cyc[7] / nit, cyc[8] / nit, cyc[9] / nit, cyc[10] / nit, cyc[13] / nit, cyc[14] / nit))
         print("    per QP: prologue %d, loop %d, epilogue %d cycles" % tuple(p[:, 28:31].mean(axis=0)))
+        print("    prologue: to end of row loads %d, +to copy issue %d, +to copy done %d" % tuple(p[:, 16:19].mean(axis=0)))
         print("    epilogue: issue %d, wait copy %d, x+lam in LDS %d, up to final stores %d" % tuple(p[:, 20:24].mean(axis=0)))
         pc = p[:, 24:28].sum(axis=0) / nit
-        print("    push parts/iter: fetch row %d, dots %d, forward %d, divide+D+store %d" % tuple(pc))
+        print("    drop parts/iter: compaction %d, C1 update %d (of drop total above)" % tuple(pc[:2]))
     bm.close()

@@ -73,7 +73,14 @@ def _stale():
         return True
     t = os.path.getmtime(LIBPATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(ROOT, "include", "daqp_amd.h")]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    if any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps):
+        return True
+    try:   # a development build (tools/devbuild.sh: fewer kernel variants) is never what build() should leave behind
+        v = C.CDLL(LIBPATH).daqp_amd_version
+        v.restype = C.c_char_p
+        return b"dev build" in v()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):

@@ -183,7 +183,11 @@ int check_problem(const DAQPBatch *b, const DAQPBatchProblem *p)
 extern "C" {
 
 const char *daqp_amd_last_error(void) { return g_err; }
+#ifdef DAQP_AMD_FEW_VARIANTS
+const char *daqp_amd_version(void) { return "daqp_amd 0.1 (gfx950, fp64, one wavefront per QP) [dev build: few template instantiations]"; }
+#else
 const char *daqp_amd_version(void) { return "daqp_amd 0.1 (gfx950, fp64, one wavefront per QP)"; }
+#endif
 int daqp_amd_device_count(void)
 {
     int c = 0;

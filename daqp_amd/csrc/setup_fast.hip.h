@@ -327,6 +327,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             const bool own = lane < rows;
             const double *a = tile + (own ? lane : 0) * ldr;
             const int gi = ms + (own ? k : tb);
+            const double bu_gi = bu[gi], bl_gi = bl[gi];   // issued now, used after the tile's arithmetic: no exposed trip to HBM
             double sunc = 0;
             if (unc) sunc = chain_add8(0.0, n, [&](int j) { return a[j]; }, [&](int j) { return xu[j]; });
             double acc[NMAX];
@@ -384,7 +385,16 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                 }
                 WSYNC();
                 SPROF(8);
-                static_for<NMAX>([&](auto c) __attribute__((always_inline)) { acc[c] = (c < n) ? a[c < n ? c : 0] : 0.0; });
+                if (direct) {   // even row length, 16-byte aligned rows: two columns per LDS read
+                    const double2 *a2 = reinterpret_cast<const double2 *>(a);
+                    static_for<NMAX / 2>([&](auto t) __attribute__((always_inline)) {
+                        const double2 v = a2[(2 * t < n) ? t : 0];
+                        acc[2 * t] = (2 * t < n) ? v.x : 0.0;
+                        acc[2 * t + 1] = (2 * t + 1 < n) ? v.y : 0.0;
+                    });
+                } else {
+                    static_for<NMAX>([&](auto c) __attribute__((always_inline)) { acc[c] = (c < n) ? a[c < n ? c : 0] : 0.0; });
+                }
             }
             SPROF(3);
             if (direct && tb + 64 < mA) {   // this tile lives in registers now: the next one loads during the normalisation
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             int rowbad = 0;
             if (own) {
                 if (s < st.zero_tol) {
-                    if (bu[gi] < -st.zero_tol || bl[gi] > st.zero_tol)
+                    if (bu_gi < -st.zero_tol || bl_gi > st.zero_tol)
                         if (!(sens[gi] & DAQP_IMMUTABLE) && !(sens[gi] & DAQP_SOFT)) rowbad = 1;
                     sens[gi] = DAQP_IMMUTABLE;
                 } else scal = 1 / sqrt(s);
@@ -410,12 +420,12 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             if (own) {
                 sc[gi] = scal;
                 if (unc) {
-                    const double u0 = bu[gi] - sunc, l0 = bl[gi] - sunc;
+                    const double u0 = bu_gi - sunc, l0 = bl_gi - sunc;
                     if (u0 < -st.primal_tol || l0 > st.primal_tol) feasible = 0;
                     du[gi] = u0 * scal; dl[gi] = l0 * scal;
                 } else {
-                    du[gi] = bu[gi] * scal + dsum;
-                    dl[gi] = bl[gi] * scal + dsum;
+                    du[gi] = bu_gi * scal + dsum;
+                    dl[gi] = bl_gi * scal + dsum;
                 }
                 double2 *dst = reinterpret_cast<double2 *>(Mq) + ((size_t)(gi >> 6) * b.npair) * 64 + (gi & 63);
                 static_for<NMAX / 2>([&](auto t) __attribute__((always_inline)) {

@@ -17,4 +17,9 @@ step(); torch.cuda.synchronize()
 t0 = time.perf_counter(); r = step(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 ref = O.Oracle().quadprog_batch(qn["H"][:16], qn["f"][:16], qn["A"][:16], qn["bupper"][:16], qn["blower"][:16], None, ms=ms)
 ok = (np.sign(r["lam"][:16].cpu().numpy()) == np.sign(ref[1])).all() and (r["iter"][:16].cpu().numpy() == ref[4]).all()
+if len(sys.argv) > 2:
+    pr = bm.read_profile().astype(float)
+    it = r["iter"].double().sum().item()
+    names = ["csp", "ratio test(no block)", "primal", "scan", "add (incl. guard)", "ratio test + drop", "-", "-"]
+    print("  cycles/iteration:", ", ".join(f"{names[k]} {pr[:, k].sum() / it:.0f}" for k in range(6)), f"| total {pr[:, :6].sum() / it:.0f}")
 print(f"C4 N={N}: {N / dt:.0f} QPs/s, kernels setup/solve ms {bm.kernel_ms()}, mean iter {r['iter'].double().mean().item():.1f}, optimal {(r['exitflag'] == 1).all().item()}, parity(16) {ok}, max|dx| {np.abs(r['x'][:16].cpu().numpy() - ref[0]).max():.1e}")

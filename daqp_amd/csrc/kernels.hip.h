@@ -851,9 +851,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(w.rowc + (size_t)i * w.ldr), 16, 0, 0);
         }
-        if (kProfile && w.prof && lane == 0) { w.prof[16] = tp1 - t_start; w.prof[17] = (long long)__builtin_readcyclecounter() - tp1; }
+        if (kProfile && w.prof && lane == 0) { w.prof[26] = tp1 - t_start; w.prof[27] = (long long)__builtin_readcyclecounter() - tp1; }
         copy_wait();
-        if (kProfile && w.prof && lane == 0) w.prof[18] = (long long)__builtin_readcyclecounter() - tp1;
+        if (kProfile && w.prof && lane == 0) w.prof[31] = (long long)__builtin_readcyclecounter() - tp1;
     }
     WSYNC();
 

@@ -29,18 +29,21 @@ for prof in (False, True):
           f"all optimal {(res['exitflag'] == 1).all().item()}, max|x-xref| {(res['x'] - q['xref']).abs().max().item():.2e}")
     if prof:
         p = bm.read_profile().astype(np.float64)
-        names = ["START", "ITER(csp..scan..commit)", "EDIT(add/drop+pivot+guard)", "ACT_BEGIN", "ACT_NEXT", "ACT_POST", "DONE"] + ["-"] * 9
+        # profile slots per QP: [0:7] cycles per state, [7:11] ITER parts, [11:13] csp fwd/bwd, [13:15] add/remove,
+        # [16:23] visits per state, [20:24] epilogue parts (overlaying the never-visited ACT states' visit slots),
+        # [24:26] remove parts, [26],[27],[31] prologue parts, [28:31] prologue/epilogue/loop totals
+        names = ["START", "ITER(csp..scan..commit)", "EDIT(add/drop+pivot+guard)", "ACT_BEGIN", "ACT_NEXT", "ACT_POST", "DONE"]
         cyc, vis = p[:, :16].sum(axis=0), p[:, 16:].sum(axis=0)
         nit = it.sum()
         print("  state: cycles/iteration (cycles/visit, visits/iteration)")
-        for k in range(16):
+        for k in range(3):
             if vis[k] > 0:
                 print(f"    {names[k]:24s} {cyc[k] / nit:9.0f}  ({cyc[k] / vis[k]:8.0f}, {vis[k] / nit:5.2f})")
         print("    total/iter", round(cyc[:7].sum() / nit), " | csp fwd %d bwd %d (cycles/iter)" % tuple(cyc[11:13] / nit))
         print("    ITER parts/iter: csp %d, blocking %d, primal %d, scan %d | EDIT parts/iter: push %d, drop %d"
               % (cyc[7] / nit, cyc[8] / nit, cyc[9] / nit, cyc[10] / nit, cyc[13] / nit, cyc[14] / nit))
-        print("    per QP: prologue %d, loop %d, epilogue %d cycles" % tuple(p[:, 28:31].mean(axis=0)))
-        print("    prologue: to end of row loads %d, +to copy issue %d, +to copy done %d" % tuple(p[:, 16:19].mean(axis=0)))
+        print("    per QP: prologue %d, epilogue %d, loop %d cycles" % tuple(p[:, 28:31].mean(axis=0)))
+        print("    prologue: to end of row loads %d, +to copy issue %d, +to copy done %d" % (p[:, 26].mean(), p[:, 27].mean(), p[:, 31].mean()))
         print("    epilogue: issue %d, wait copy %d, x+lam in LDS %d, up to final stores %d" % tuple(p[:, 20:24].mean(axis=0)))
         pc = p[:, 24:28].sum(axis=0) / nit
         print("    drop parts/iter: compaction %d, C1 update %d (of drop total above)" % tuple(pc[:2]))

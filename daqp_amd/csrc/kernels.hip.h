@@ -434,8 +434,14 @@ __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
 // ------------------------------------------------------------------------------------
 // LDS (L + active-row cache) already limits residency to one wave per SIMD, so the register
 // variants may take the whole unified 512-entry VGPR/AGPR file: waves_per_eu(1, NB > 0 ? 1 : 8)
+#ifndef DAQP_AMD_SPILL_WAVES
+#define DAQP_AMD_SPILL_WAVES 2
+#endif
+// The spilled variant (L and the active-row cache in HBM, n = 200 class): 2 waves per SIMD measured best (3, 4 and 5 waves
+// cost more in scratch spills than they hide in latency: 604 / 613 / 635 ms per 8 192 QPs of config C4).
 template <int C, bool SPILL, int NB, int NP>
-__global__ __launch_bounds__(64) void k_ldp(BatchDev b, int mode)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPILL ? DAQP_AMD_SPILL_WAVES : 1, SPILL ? DAQP_AMD_SPILL_WAVES : 8)))
+void k_ldp(BatchDev b, int mode)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = lane_id();

@@ -173,11 +173,22 @@ __device__ __forceinline__ void fetch_row(Wave<C, NB, NP> &w, int id, int slot)
     WSYNC();
 }
 
+constexpr int kPre = 8;   // columns / rows fetched ahead of each dependency chain in this (LDS- or HBM-resident) variant
+
 // factorization.c:4-15 (4 interleaved partial sums, then (s0+s1)+(s2+s3))
 __device__ __forceinline__ double dot4(const double *a, const double *b, int len)
 {
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int i = 0;
+    for (; i + 15 < len; i += 16) {   // 32 loads in flight before the four chains consume them: when the rows live in HBM
+        double x[16], y[16];          // (L / row cache spilled, n = 200) a trip per four elements is pure latency
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { x[q] = a[i + q]; y[q] = b[i + q]; }
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+            s0 += x[q] * y[q]; s1 += x[q + 1] * y[q + 1]; s2 += x[q + 2] * y[q + 2]; s3 += x[q + 3] * y[q + 3];
+        }
+    }
     for (; i + 3 < len; i += 4) {
         s0 += a[i] * b[i];
         s1 += a[i + 1] * b[i + 1];
@@ -223,12 +234,26 @@ __device__ __forceinline__ void ldl_append(Wave<C, NB, NP> &w, int id)
         return;
     }
     // forward substitution  l <- L \ g   (factorization.c:81-88)
-    for (int j = 0; j < na - 1; ++j) {
-        const double lj = rlc<C>(g, j);
+    for (int j0 = 0; j0 < na - 1; j0 += kPre) {   // the lane's own L entries of kPre columns are loaded before their chain
+        double Lv[kPre][C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int k = lane + 64 * c;
-            if (k > j && k < na) g[c] -= w.L[tri(k) + j] * lj;
+        for (int q = 0; q < kPre; ++q)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int k = lane + 64 * c, j = j0 + q;
+                Lv[q][c] = w.L[(k > j && k < na) ? tri(k) + j : 0];   // clamped address, unconditional load: no branch per load
+            }
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const int j = j0 + q;
+            if (j < na - 1) {
+                const double lj = rlc<C>(g, j);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int k = lane + 64 * c;
+                    if (k > j && k < na) g[c] -= Lv[q][c] * lj;
+                }
+            }
         }
     }
     // l_k /= D_k ; d_new -= sum_k l_k^2 D_k, in k order (factorization.c:93-103)
@@ -424,20 +449,26 @@ __device__ __forceinline__ void forward_rows(Wave<C, NB, NP> &w, double (&acc)[C
 {
     // acc[c] holds the right-hand side of rows >= from; rows < from are final in xl
     const int lane = lane_id(), na = w.na;
-    for (int j = 0; j < from; ++j) {
-        const double xj = w.xl[j];
+    for (int j0 = 0; j0 < na - 1; j0 += kPre) {   // kPre columns of L per trip (loads first, then the ordered chain)
+        double Lv[kPre][C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int i = lane + 64 * c;
-            if (i >= from && i < na) acc[c] -= w.L[tri(i) + j] * xj;
-        }
-    }
-    for (int j = from; j < na - 1; ++j) {
-        const double xj = rlc<C>(acc, j);
+        for (int q = 0; q < kPre; ++q)
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int i = lane + 64 * c;
-            if (i > j && i < na) acc[c] -= w.L[tri(i) + j] * xj;
+            for (int c = 0; c < C; ++c) {
+                const int i = lane + 64 * c, j = j0 + q;
+                Lv[q][c] = w.L[(i >= from && i > j && i < na) ? tri(i) + j : 0];
+            }
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const int j = j0 + q;
+            if (j < na - 1) {
+                const double xj = (j < from) ? w.xl[j] : rlc<C>(acc, j);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int i = lane + 64 * c;
+                    if (i >= from && i > j && i < na) acc[c] -= Lv[q][c] * xj;
+                }
+            }
         }
     }
 }
@@ -446,13 +477,26 @@ template <int C, int NB, int NP>
 __device__ __forceinline__ void backward_rows(Wave<C, NB, NP> &w, double (&b)[C], int cnt)
 {
     const int lane = lane_id();
-    for (int j = cnt - 1; j >= 1; --j) {
-        const double bj = rlc<C>(b, j);
-        const double *Lj = w.L + tri(j);
+    for (int j0 = cnt - 1; j0 >= 1; j0 -= kPre) {
+        double Lv[kPre][C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int i = lane + 64 * c;
-            if (i < j) b[c] -= bj * Lj[i];
+        for (int q = 0; q < kPre; ++q)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = lane + 64 * c, j = j0 - q;
+                Lv[q][c] = w.L[(j >= 1 && i < j) ? tri(j) + i : 0];
+            }
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const int j = j0 - q;
+            if (j >= 1) {
+                const double bj = rlc<C>(b, j);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int i = lane + 64 * c;
+                    if (i < j) b[c] -= bj * Lv[q][c];
+                }
+            }
         }
     }
 }
@@ -567,14 +611,25 @@ __device__ __forceinline__ void primal_u(Wave<C, NB, NP> &w)
     double uu[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) uu[c] = 0;
-    for (int i = 0; i < na; ++i) {
-        const double li = w.lams[i];
-        const double *row = w.rowc + (size_t)i * w.ldr;
+    for (int i0 = 0; i0 < na; i0 += kPre) {   // kPre cached rows per trip
+        double rv[kPre][C], li[kPre];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int j = lane + 64 * c;
-            if (j < n) uu[c] -= row[j] * li;
+        for (int q = 0; q < kPre; ++q) {
+            const int i = i0 + q;
+            li[q] = (i < na) ? w.lams[i] : 0.0;
+            const double *row = w.rowc + (size_t)(i < na ? i : 0) * w.ldr;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int j = lane + 64 * c;
+                rv[q][c] = row[(j < n) ? j : 0];
+            }
         }
+#pragma unroll
+        for (int q = 0; q < kPre; ++q)
+            if (i0 + q < na) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) uu[c] -= rv[q][c] * li[q];
+            }
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {

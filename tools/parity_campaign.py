@@ -1,0 +1,46 @@
+"""One-off large parity campaign (exact mode: bit-identical to the oracle; default mode: north_star bar).
+usage: python tools/parity_campaign.py [nC2] [nC3] [nshapes]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import daqp_amd
+from oracle import oracle as O
+
+nC2 = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+nC3 = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+nsh = int(sys.argv[3]) if len(sys.argv) > 3 else 150
+ora = O.Oracle()
+
+
+def bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
+
+
+def run(tag, q, ms, exact):
+    os.environ["DAQP_AMD_EXACT"] = "1" if exact else "0"
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q.get("sense"), ms=ms)
+    r = ora.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q.get("sense"), ms=ms)
+    same_flag = (g["exitflag"] == r[3]); same_it = (g["iter"] == r[4]); same_as = (np.sign(g["lam"]) == np.sign(r[1])).all(axis=1)
+    ok = g["exitflag"] > 0
+    dx = np.abs(g["x"][ok] - r[0][ok]).max(initial=0)
+    bit = bits(g["x"][ok], r[0][ok]) and bits(g["lam"][ok], r[1][ok]) if exact else None
+    print(f"{tag:28s} exact={int(exact)} N={len(same_flag):6d} flags {same_flag.mean():.6f} iters {same_it.mean():.6f} active sets {same_as.mean():.6f} "
+          f"max|dx| {dx:.2e} bitwise {bit}", flush=True)
+    return same_flag.all() and same_it.all() and same_as.all() and dx < 1e-9 and (bit is not False)
+
+
+allok = True
+for cfg, N in (("C2", nC2), ("C3", nC3)):
+    n, m, ms, na, seed, _ = O.CONFIGS[cfg]
+    q = O.generate_batch(N, n, m, ms, na, seed, start=500000)
+    for exact in (True, False):
+        allok &= run(cfg, q, ms, exact)
+rng = np.random.default_rng(2024)
+for s in range(nsh):
+    n = int(rng.integers(2, 64)); m = int(rng.integers(n + 1, min(192, 4 * n + 8))); ms = int(rng.integers(0, min(n, m // 2) + 1))
+    na = int(rng.integers(1, max(2, min(n, m - ms))))
+    q = O.generate_batch(48, n, m, ms, na, 7000 + s)
+    for exact in (True, False):
+        ok = run(f"shape n={n} m={m} ms={ms} na={na}", q, ms, exact)
+        allok &= ok
+print("ALL OK" if allok else "MISMATCHES FOUND")

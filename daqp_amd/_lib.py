@@ -62,7 +62,7 @@ EXPORTS = [
     "daqp_quadprog", "daqp_solve", "setup_daqp", "setup_daqp_main", "daqp_update_ldp", "daqp_default_settings",
     "allocate_daqp_settings", "free_daqp_workspace", "free_daqp_ldp", "daqp_primal_init_active",
     "daqp_dual_init_active", "daqp_batch_create", "daqp_batch_free", "daqp_batch_set_stream",
-    "daqp_batch_set_settings", "daqp_batch_set_exact", "daqp_batch_setup", "daqp_batch_update", "daqp_batch_solve",
+    "daqp_batch_set_settings", "daqp_batch_set_exact", "daqp_batch_setup", "daqp_batch_setup_shared", "daqp_batch_update", "daqp_batch_solve",
     "daqp_batch_setup_flags", "daqp_batch_working_sets", "daqp_quadprog_batch", "daqp_batch_kernel_ms",
     "daqp_batch_device_bytes", "daqp_amd_last_error", "daqp_amd_device_count", "daqp_amd_version",
 ]
@@ -125,6 +125,7 @@ def lib():
     L.daqp_batch_set_exact.argtypes = [vp, ci]
     L.daqp_batch_set_exact.restype = None
     L.daqp_batch_setup.argtypes = [vp, C.POINTER(DAQPBatchProblem), ci]
+    L.daqp_batch_setup_shared.argtypes = [vp, C.POINTER(DAQPBatchProblem), ci]
     L.daqp_batch_update.argtypes = [vp, ci, C.POINTER(DAQPBatchProblem)]
     L.daqp_batch_solve.argtypes = [vp, C.POINTER(DAQPBatchResult)]
     L.daqp_batch_setup_flags.argtypes = [vp, c_int_p]

@@ -228,6 +228,18 @@ class BatchModel:
             raise RuntimeError(f"daqp_batch_setup failed ({rc}): {_lib.last_error()}")
         return self
 
+    def setup_shared(self, H, f, A, bupper, blower, sense=None):
+        """N problems with ONE H (n, n) and ONE A (m-ms, n) -- condensed MPC: same plant, per-problem f / bounds.
+        Same result as Model.setup once (open bounds) followed by Model.update(f_k, bu_k, bl_k) per problem -- the reference's
+        MPC usage; the factorisation runs once."""
+        assert H.ndim == 2 and (A is None or A.ndim == 2), "setup_shared takes a single H and a single A"
+        p, keep = self._problem(H, f, A, bupper, blower, sense)
+        self._keep = keep
+        rc = lib().daqp_batch_setup_shared(self._h, C.byref(p), 0)
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_setup_shared failed ({rc}): {_lib.last_error()}")
+        return self
+
     def setup_flags(self):
         fl = np.zeros(self.N, np.int32)
         lib().daqp_batch_setup_flags(self._h, _ip(fl))

@@ -68,6 +68,8 @@ struct DAQPBatch {
     bool spill = false;
     int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
     bool fast_setup = false, setup_spill = false;
+    double *wide_u = nullptr, *wide_l = nullptr;   // daqp_batch_setup_shared: +-1e30 bounds of the one factorisation
+    int *structural = nullptr, *shared_flag = nullptr;
     int pending_mask = 0;   // daqp_batch_update(UPDATE_v|UPDATE_d) not yet applied: the next solve launch does it (k_ldp_reg mode 2)
     size_t lds_setup = 0, lds_ldp = 0, lds_update = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -391,6 +393,7 @@ int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
     b->pending_mask = 0;   // a full setup supersedes any deferred update
     HIPCHK(hipSetDevice(b->device));
     BatchDev &d = b->d;
+    d.shared = 0;
     const size_t N = d.N;
     rc |= stage(b, p->H, p->memory, N * d.n * d.n, &b->sH, &d.H);
     rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &d.f);
@@ -416,6 +419,74 @@ int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
     HIPCHK(hipEventRecord(b->ev[1], b->stream));
     b->timed_setup = true;
     b->is_setup = true;
+    return 0;
+}
+
+// N problems that share H and A (condensed MPC: one plant, many states): p->H is ONE n x n matrix, p->A ONE (m-ms) x n
+// matrix; f, bupper, blower (and sense, if given) are per problem as usual.  Semantics: the reference's MPC usage -- one
+// setup_daqp (open bounds), then daqp_update_ldp(UPDATE_v|UPDATE_d) per problem -- for N problems at once.  The
+// factorisation (Cholesky, R^-1, M = A R^-1, scaling) runs ONCE; v and d of every problem are formed by the update path
+// (fused into the first solve launch for the register kernel), and every later solve reads the one shared image of M.
+int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
+{
+    int rc = check_problem(b, p);
+    if (rc) return rc;
+    if (!p->H || !p->f || !p->bupper || !p->blower || (b->d.mA > 0 && !p->A)) {
+        set_err("H, f, A, bupper, blower are required (LPs / missing linear term are outside this path)");
+        return DAQP_EXIT_UNSUPPORTED;
+    }
+    (void)init_mask;   // the unconstrained shortcut / elimination are per-problem decisions of daqp_quadprog: not taken here
+    b->pending_mask = 0;
+    HIPCHK(hipSetDevice(b->device));
+    BatchDev &d = b->d;
+    const size_t N = d.N;
+    rc |= stage(b, p->H, p->memory, (size_t)d.n * d.n, &b->sH, &d.H);
+    rc |= stage(b, p->A, p->memory, (size_t)d.mA * d.n, &b->sA, &d.A);
+    rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &d.f);
+    rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &d.bu);
+    rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &d.bl);
+    rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &d.sense_in);
+    if (rc) return DAQP_EXIT_UNSUPPORTED;
+    if (!b->wide_u) {
+        if (dev_alloc(b, &b->wide_u, d.m) || dev_alloc(b, &b->wide_l, d.m) || dev_alloc(b, &b->structural, d.m) || dev_alloc(b, &b->shared_flag, 1))
+            return DAQP_EXIT_UNSUPPORTED;
+        std::vector<double> hu(d.m, 1e30), hl(d.m, -1e30);
+        HIPCHK(hipMemcpy(b->wide_u, hu.data(), d.m * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->wide_l, hl.data(), d.m * sizeof(double), hipMemcpyHostToDevice));
+    }
+    // ---- the one factorisation: problem 0's slots, wide-open bounds, no sense => only structural bits in sense[0..m)
+    BatchDev t = d;
+    t.N = 1; t.shared = 0; t.bu = b->wide_u; t.bl = b->wide_l; t.sense_in = nullptr;
+    const int mask = DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
+    typedef void (*setup_kernel_t)(BatchDev, int);
+    setup_kernel_t ks = b->setup_spill ? k_setup<true> : k_setup<false>;
+    size_t lds_setup = b->lds_setup;
+    if (b->fast_setup) {
+        ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : (d.n <= 56 ? k_setup_fast<56> : k_setup_fast<64>));
+        lds_setup = (size_t)fast_lds(d.n, d.m, d.exact_setup).total_bytes;
+    }
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
+    HIPCHK(hipEventRecord(b->ev[0], b->stream));
+    hipLaunchKernelGGL(ks, dim3(1), dim3(64), lds_setup, b->stream, t, mask);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(b->structural, d.sense, d.m * sizeof(int), hipMemcpyDeviceToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->shared_flag, &d.qs[0].setup_flag, sizeof(int), hipMemcpyDeviceToDevice, b->stream));
+    // ---- per-problem state, then v and d of every problem through the update path
+    d.shared = 1;
+    hipLaunchKernelGGL(k_init_shared, dim3(d.N), dim3(64), 0, b->stream, d, (const int *)b->structural, (const int *)b->shared_flag);
+    HIPCHK(hipGetLastError());
+    b->is_setup = true;
+    const int upd = DAQP_UPDATE_v | DAQP_UPDATE_d;
+    const bool lazy = b->NB > 0 && !getenv("DAQP_AMD_EAGER_UPDATE") && p->sense == nullptr;
+    if (lazy) b->pending_mask = upd;
+    else {   // a given working set is activated now, and activation needs d
+        hipLaunchKernelGGL(k_update, dim3(d.N), dim3(64), b->lds_update, b->stream, d, upd);
+        HIPCHK(hipGetLastError());
+        rc = launch_ldp(b, 1);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(b->ev[1], b->stream));
+    b->timed_setup = true;
     return 0;
 }
 

@@ -38,10 +38,13 @@ struct BatchDev {
     long long *prof;   // [N][8] phase cycle sums, or NULL
     const DAQPSettings *st_dev;   // device copy of st (scalar-load friendly)
     int exact_setup;              // 1: M = A R^-1 in the reference's operation order (VALU); 0: MFMA f64
+    int shared;                   // 1: one H, A for the whole batch (daqp_batch_setup_shared): Mblk, Rinv, scaling hold ONE problem's factors
     DAQPSettings st;
 };
 
 __host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+// index of problem q's factors (M, R^-1, scaling): its own, or the single shared set
+__device__ __forceinline__ size_t qf(const BatchDev &b, int q) { return b.shared ? (size_t)0 : (size_t)q; }
 
 // ------------------------------------------------------------------------------------
 // LDS carve-ups (doubles first, ints last; every offset a multiple of 16 bytes)
@@ -356,6 +359,33 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
 // ------------------------------------------------------------------------------------
 // k_update: DAQP_UPDATE_v and/or DAQP_UPDATE_d on an existing LDP (utils.c:58-221 with those masks)
 // ------------------------------------------------------------------------------------
+// daqp_batch_setup_shared: per-problem state after the ONE factorisation (done with wide-open bounds, so the sense it
+// left holds only the structural bits: rows of A R^-1 that vanish, utils.c:586-613).  One wave per problem.
+__global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *structural, const int *shared_flag)
+{
+    const int q = blockIdx.x, lane = lane_id(), m = b.m;
+    const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
+    int flag = *shared_flag, bad = 0;
+    for (int i = lane; i < m; i += 64) {
+        int s = b.sense_in ? b.sense_in[(size_t)q * m + i] : 0;
+        if (s & DAQP_BINARY) bad |= 2;
+        if (structural[i] & DAQP_IMMUTABLE) {   // zero row: feasible only if 0 lies within its bounds (utils.c:598-606)
+            if (bu[i] < -b.st.zero_tol || bl[i] > b.st.zero_tol)
+                if (!(s & DAQP_IMMUTABLE) && !(s & DAQP_SOFT)) bad |= 1;
+            s = DAQP_IMMUTABLE;
+        }
+        b.sense[(size_t)q * m + i] = s;
+    }
+    if (flag > 0 && __any(bad & 2)) flag = DAQP_EXIT_UNSUPPORTED;
+    else if (flag > 0 && __any(bad & 1)) flag = DAQP_EXIT_INFEASIBLE;
+    if (lane == 0) {
+        QState *qs = b.qs + q;
+        qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = kEmpty; qs->iterations = 0;
+        qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0 && b.sense_in) ? 1 : 0;
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -365,8 +395,8 @@ __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
     QState *qs = b.qs + q;
     if (qs->setup_flag < 0) return;
     const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
-    const double *Rq = b.Rinv + (size_t)q * b.rtri;
-    const double *scq = b.scaling + (size_t)q * m;
+    const double *Rq = b.Rinv + qf(b, q) * b.rtri;
+    const double *scq = b.scaling + qf(b, q) * m;
     int *sens = b.sense + (size_t)q * m;
     const DAQPSettings &st = b.st;
     int bad = 0;
@@ -404,7 +434,7 @@ __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
     const double2 *v2 = reinterpret_cast<const double2 *>(vv);
     const bool odd = (n & 1) != 0;
     const int full = odd ? b.npair - 1 : b.npair;
-    const double *Mq = b.Mblk + (size_t)q * b.nblk * b.npair * 128;
+    const double *Mq = b.Mblk + qf(b, q) * b.nblk * b.npair * 128;
     for (int blk = 0; blk < b.nblk; ++blk) {
         const int r = blk * 64 + lane;
         if (r < m) {
@@ -471,8 +501,8 @@ void k_ldp(BatchDev b, int mode)
     double *lamA = smem + o.lamA, *lamB = smem + o.lamB;
     w.u = smem + o.u; w.pend_lam = smem + o.pend_lam;
     w.ws = ibase + o.ws; w.sense = ibase + o.sense; w.pend_id = ibase + o.pend_id;
-    w.Mblk = b.Mblk + (size_t)q * b.nblk * b.npair * 128;
-    w.dupper = b.dupper + (size_t)q * m; w.dlower = b.dlower + (size_t)q * m; w.scaling = b.scaling + (size_t)q * m;
+    w.Mblk = b.Mblk + qf(b, q) * b.nblk * b.npair * 128;
+    w.dupper = b.dupper + (size_t)q * m; w.dlower = b.dlower + (size_t)q * m; w.scaling = b.scaling + qf(b, q) * m;
     w.st = b.st;
     w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
     w.trace_cap = b.trace_cap; w.trace_len = 0;
@@ -532,7 +562,7 @@ void k_ldp(BatchDev b, int mode)
         }
         if (flag >= 0) flag = ldp_loop(w, iters);
         // ---- ldp2qp_solution (daqp.c:111-139) + daqp_extract_result (api.c:455-495)
-        const double *Rq = b.Rinv + (size_t)q * b.rtri, *vq = b.v + (size_t)q * n;
+        const double *Rq = b.Rinv + qf(b, q) * b.rtri, *vq = b.v + (size_t)q * n;
         if (flag > 0) {
             for (int i = lane; i < n; i += 64) w.u[i] = w.u[i] - vq[i];
             WSYNC();
@@ -661,7 +691,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     w.sing = __builtin_amdgcn_readfirstlane(qs->sing_ind);
     w.fval = rl(qs->fval, 0); w.soft = rl(qs->soft_slack, 0);
     const int swapped = __builtin_amdgcn_readfirstlane(qs->lam_swapped);
-    const double *gdu = b.dupper + (size_t)q * m, *gdl = b.dlower + (size_t)q * m, *gsc = b.scaling + (size_t)q * m;
+    const size_t qfac = qf(b, q);
+    const double *gdu = b.dupper + (size_t)q * m, *gdl = b.dlower + (size_t)q * m, *gsc = b.scaling + qfac * m;
     int *gsense = b.sense + (size_t)q * m;
     double *gv = b.vecs + (size_t)q * 5 * cap;
     int *gws = b.WS + (size_t)q * cap;
@@ -686,7 +717,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     double *Rl0 = w.rowc + rinv0;
     double f_in = 0;
     if (upd & DAQP_UPDATE_v) {
-        const double *Rq = b.Rinv + (size_t)q * b.rtri, *f = b.f + (size_t)q * n;
+        const double *Rq = b.Rinv + qfac * b.rtri, *f = b.f + (size_t)q * n;
         const int odd8 = (int)(((size_t)Rq >> 3) & 1);
         Rl0 += odd8;
         if (odd8) copy_async_dwords(Rl0, Rq, 1);
@@ -700,7 +731,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     double scr[NB];
     int softbits = 0;
     w.rs = 0;
-    const double2 *msrc = reinterpret_cast<const double2 *>(b.Mblk + (size_t)q * b.nblk * b.npair * 128);
+    const double2 *msrc = reinterpret_cast<const double2 *>(b.Mblk + qfac * b.nblk * b.npair * 128);
     const int npair_u = __builtin_amdgcn_readfirstlane(b.npair), nblk_u = __builtin_amdgcn_readfirstlane(b.nblk);
     // the small per-row loads go out first: in-order return means whoever waits for them would otherwise wait for
     // every row of M issued before them
@@ -870,7 +901,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     if (mode == 1) {
         if (lane == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
     } else {
-        const double *Rq = b.Rinv + (size_t)q * b.rtri;
+        const double *Rq = b.Rinv + qfac * b.rtri;
         // Everything that needs LDS hand-offs (x from the staged R^-1, lam assembled by working-set scatter) comes
         // first; the stores to HBM are issued together at the very end, so no fence ever waits for a store.
         // Packed R^-1 comes into the top of the (now dead) active-row cache in one HBM round trip; v and the scalings ride along.

@@ -188,6 +188,12 @@ void daqp_batch_set_exact(DAQPBatch *b, int exact);
  * set).  init_mask 0 = setup_daqp, DAQP_UPDATE_unconstrained = the daqp_quadprog variant.
  * Returns 0 when launched; per-problem flags (1 ok, <0 exit flag) via daqp_batch_setup_flags. */
 int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask);
+/* Shared-structure batches (condensed MPC; SURVEY.md 8f rank 3, docs/docs/linearmpc.md:18-21 of the reference): p->H is
+ * ONE n x n matrix and p->A ONE (m-ms) x n matrix for all N problems; f, bupper, blower (and sense) are per problem.
+ * This is the reference's MPC usage, batched: setup_daqp once (api.c:88-151, open bounds), then for every problem
+ * daqp_update_ldp(DAQP_UPDATE_v|DAQP_UPDATE_d) (utils.c:58-221) with its f and bounds -- bit for bit.  The factorisation
+ * runs once and every solve reads one shared image of M.  Follow with daqp_batch_solve / daqp_batch_update as usual. */
+int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask);
 /* daqp_update_ldp for every problem; supported masks: any combination of UPDATE_v, UPDATE_d
  * (new f and/or bounds; factors and working sets are kept: warm start), or a full re-setup
  * (UPDATE_Rinv|UPDATE_M|UPDATE_v|UPDATE_d|UPDATE_sense).  Pointers of `p` not covered by the

@@ -148,3 +148,47 @@ def test_concurrent_host_threads(oracle, gpu_lib):
         r = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
         assert np.array_equal(out[t]["exitflag"], r[3]) and np.array_equal(out[t]["iter"], r[4])
         assert same(out[t]["x"], r[0]) and same(out[t]["lam"], r[1])
+
+
+@pytest.mark.parametrize("shape", [(50, 150, 0, 20), (12, 48, 12, 6), (20, 40, 0, 8)])
+def test_shared_structure_batch(oracle, gpu_lib, shape):
+    """condensed-MPC batches: ONE H and A, per-problem f and bounds.  daqp_batch_setup_shared is the
+    reference's own MPC usage batched: factor once (setup_daqp with open bounds), then per problem
+    daqp_update_ldp(UPDATE_v|UPDATE_d) with its f / bounds and solve -- bit for bit, including later warm updates."""
+    import daqp_amd
+    n, m, ms, na = shape
+    N = 40
+    q0 = O.generate_qp(n, m, ms, na, rng=[811, n])
+    rng = np.random.default_rng([812, n])
+    f = q0["f"][None, :] + 0.3 * rng.standard_normal((N, n))
+    shift = 0.05 * rng.standard_normal((N, m))
+    bu, bl = q0["bupper"][None, :] + shift, q0["blower"][None, :] + shift
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    # the third shape passes an (all-zero) sense array: that takes the eager route (update kernel + activation pass at setup)
+    bm.setup_shared(q0["H"], f, q0["A"], bu, bl, np.zeros((N, m), np.int32) if n == 20 else None)
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q0["H"], f[k], q0["A"], np.full(m, 1e30), np.full(m, -1e30), None)
+        assert om.update(O.UPDATE_v | O.UPDATE_d, f=f[k], bupper=bu[k], blower=bl[k]) == 0
+        models.append(om)
+    for t in range(3):
+        if t > 0:
+            f = f + 0.05 * rng.standard_normal((N, n))
+            if t == 2:
+                sh = 0.02 * rng.standard_normal((N, m)); bu, bl = bu + sh, bl + sh
+                bm.update(f=f, bupper=bu, blower=bl)
+            else:
+                bm.update(f=f)
+            for k in range(N):
+                if t == 2:
+                    assert models[k].update(O.UPDATE_v | O.UPDATE_d, f=f[k], bupper=bu[k], blower=bl[k]) == 0
+                else:
+                    assert models[k].update(O.UPDATE_v, f=f[k]) == 0
+        g = bm.solve()
+        for k in range(N):
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (t, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            if r[3] > 0:
+                assert same(g["x"][k], r[0]) and same(g["lam"][k], r[1])
+    bm.close()

@@ -448,7 +448,7 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &d.sense_in);
     if (rc) return DAQP_EXIT_UNSUPPORTED;
     if (!b->wide_u) {
-        if (dev_alloc(b, &b->wide_u, d.m) || dev_alloc(b, &b->wide_l, d.m) || dev_alloc(b, &b->structural, d.m) || dev_alloc(b, &b->shared_flag, 1))
+        if (dev_alloc(b, &b->wide_u, d.m) || dev_alloc(b, &b->wide_l, d.m) || dev_alloc(b, &b->structural, d.m) || dev_alloc(b, &b->shared_flag, 2))
             return DAQP_EXIT_UNSUPPORTED;
         std::vector<double> hu(d.m, 1e30), hl(d.m, -1e30);
         HIPCHK(hipMemcpy(b->wide_u, hu.data(), d.m * sizeof(double), hipMemcpyHostToDevice));
@@ -471,6 +471,7 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(b->structural, d.sense, d.m * sizeof(int), hipMemcpyDeviceToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->shared_flag, &d.qs[0].setup_flag, sizeof(int), hipMemcpyDeviceToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->shared_flag + 1, &d.qs[0].diag_h, sizeof(int), hipMemcpyDeviceToDevice, b->stream));
     // ---- per-problem state, then v and d of every problem through the update path
     d.shared = 1;
     hipLaunchKernelGGL(k_init_shared, dim3(d.N), dim3(64), 0, b->stream, d, (const int *)b->structural, (const int *)b->shared_flag);

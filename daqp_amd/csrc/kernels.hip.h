@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     if (lane == 0) {
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
-        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0;
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = 0;   // dense arithmetic also for a diagonal H here
     }
 }
 
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
 // ------------------------------------------------------------------------------------
 // daqp_batch_setup_shared: per-problem state after the ONE factorisation (done with wide-open bounds, so the sense it
 // left holds only the structural bits: rows of A R^-1 that vanish, utils.c:586-613).  One wave per problem.
-__global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *structural, const int *shared_flag)
+__global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *structural, const int *shared_flag /* [setup_flag, diag_h] */)
 {
     const int q = blockIdx.x, lane = lane_id(), m = b.m;
     const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *struc
         QState *qs = b.qs + q;
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = kEmpty; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0 && b.sense_in) ? 1 : 0;
-        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0;
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = shared_flag[1];
     }
 }
 
@@ -415,7 +415,8 @@ __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
     }
     if (mask & DAQP_UPDATE_v) {   // utils.c:474-497 without UPDATE_Rinv: rows < ms of R^-1 are normalised
         const double *f = b.f + (size_t)q * n;
-        for (int i = lane; i < n; i += 64) fl[i] = (i < ms) ? f[i] / scq[i] : f[i];
+        const int diag = qs->diag_h;   // RinvD branch: v_i = f_i * RinvD_i, no scaling (utils.c:479-480)
+        for (int i = lane; i < n; i += 64) fl[i] = (i < ms && !diag) ? f[i] / scq[i] : f[i];
         WSYNC();
         for (int ic = 0; ic < n; ic += 64) {
             const int i = ic + lane;
@@ -572,7 +573,7 @@ void k_ldp(BatchDev b, int mode)
                     const double *row = Rq + roff(i, n);
                     double xi = w.u[i] * row[i];
                     for (int j = i + 1; j < n; ++j) xi += row[j] * w.u[j];
-                    if (i < b.ms) xi /= w.scaling[i];
+                    if (i < b.ms && !qs->diag_h) xi /= w.scaling[i];   // daqp.c:124-134: no division in the RinvD branch
                     if (b.x) b.x[(size_t)q * n + i] = xi;
                 }
             }
@@ -667,6 +668,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     // n_active becomes a divergent (exec-masked) loop with readfirstlane waterfalls around v_readlane
     const int sflag = __builtin_amdgcn_readfirstlane(qs->setup_flag);
     int q_need_act = __builtin_amdgcn_readfirstlane(qs->need_activate);
+    const int qdiag = __builtin_amdgcn_readfirstlane(qs->diag_h);
     if (mode == 1) { if (sflag < 0 || !q_need_act) return; }
     if (sflag < 0) {
         if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         const int body = (b.rtri - odd8) & ~1;
         copy_async(Rl0 + odd8, Rq + odd8, body);
         if (odd8 + body < b.rtri) copy_async_dwords(Rl0 + odd8 + body, Rq + odd8 + body, 1);
-        if (lane < n) f_in = (lane < b.ms) ? f[lane] / gsc[lane] : f[lane];
+        if (lane < n) f_in = (lane < b.ms && !qdiag) ? f[lane] / gsc[lane] : f[lane];
     }
     // ---- row view: bounds, tolerance, sense and the rows of M themselves -> registers
     const double ep = -w.stp->primal_tol;
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
 #pragma unroll
                 for (int k = 0; k < kChunk; ++k) if (j0 + k < n) xi += rr[k] * uu[k];
             }
-            if (lane < b.ms) xi /= sc_sb;
+            if (lane < b.ms && !qdiag) xi /= sc_sb;   // daqp.c:124-134: no division in the RinvD branch
         }
         WSYNC();
         const long long te3 = (long long)__builtin_readcyclecounter();

@@ -150,10 +150,13 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     if (lane < n) fl[lane] = f[lane];
     // --- 1/2 (H + H') (utils.c:318-324) into registers: lane j <-> column j, c[i] = row i
     double pmin = DAQP_INF, pmax = 0.0;
+    int diag = 0;        // H diagonal: the reference's RinvD branch (utils.c:245-312)
+    double hsq = 0;      // sqrt(H_ii) of this lane's coordinate in that branch
     if (flag > 0) {
         double c[NMAX], a[NMAX];
         if (direct) copy_wait(); else stage_rows(Rsq, H, n, n, n);
         WSYNC();
+        int offd = 0;    // an entry above the diagonal of this lane's column exceeds zero_tol (utils.c:245-252 looks at those only)
         {
             const int jj = lane < n ? lane : 0;
             static_for<NMAX / 8>([&](auto g) __attribute__((always_inline)) {
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                         const int ii = i < n ? i : 0;
                         const double hij = Rsq[ii * n + jj], hji = Rsq[jj * n + ii];
                         const double val = (jj == ii) ? hij : 0.5 * (hij + hji);
+                        offd |= (i < n && ii < jj && (hij > st.zero_tol || hij < -st.zero_tol)) ? 1 : 0;
                         c[i] = (lane < n && i < n) ? val : 0.0;
                         a[i] = 0.0;
                     });
@@ -170,6 +174,28 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                     static_for<8>([&](auto h) __attribute__((always_inline)) { c[8 * g + h] = 0.0; a[8 * g + h] = 0.0; });
                 }
             });
+        }
+        const bool isdiag = !__any(lane < n && offd);
+        if (isdiag) {
+            // RinvD_i = 1/sqrt(H_ii), scaling_i = sqrt(H_ii) for simple bounds; a diagonal entry at or below
+            // zero_tol * max|H_ii| would be shifted and handed to the proximal outer loop (outside this path)
+            const double hd = (lane < n) ? Rsq[lane * n + lane] : 1.0;
+            const double ha = hd < 0 ? -hd : hd;
+            const double hscale = -wave_min((lane < n) ? -ha : 0.0);
+            const double ftol = hscale > 0 ? st.zero_tol * hscale : st.zero_tol;
+            const bool fail = lane < n && hd <= ftol;
+            const int code = (st.eps_prox == 0.0 && hd <= st.zero_tol) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED;
+            const unsigned long long fm = __ballot(fail);
+            if (fm) flag = __builtin_amdgcn_readlane(code, __ffsll((long long)fm) - 1);   // the reference stops at the first such i
+            else {
+                hsq = sqrt(hd);
+                const double rinvd = 1 / hsq;
+                WSYNC();
+                for (int e = lane; e < n * nsq; e += 64) Rsq[e] = 0.0;
+                WSYNC();
+                if (lane < n) Rsq[lane * nsq + lane] = rinvd;
+                diag = 1;
+            }
         }
         WSYNC();
         if (lane < 8) Rsq[n * nsq + lane] = 0.0;   // padding behind the last row (read, never used, by the 8-column groups)
@@ -182,7 +208,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             constexpr int P = NMAX / 8 - pp;
             int k = n - 1 - 8 * P;
             if (k < 0) k = 0;
-            const int kend = (P == 0) ? n : n - 1 - 8 * (P - 1);
+            const int kend = isdiag ? 0 : ((P == 0) ? n : n - 1 - 8 * (P - 1));
             for (; k < kend && flag > 0; ++k) {
                 const double dg = rl(c[0], k);
                 if (dg <= st.zero_tol) { flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED; break; }
@@ -210,7 +236,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                 });
             }
         });
-        if (flag > 0 && pmin <= st.zero_tol * pmax)
+        if (flag > 0 && !isdiag && pmin <= st.zero_tol * pmax)
             flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED;
         WSYNC();
     }
@@ -262,8 +288,11 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             const int i = lane;
             const double *Ri = Rsq + i * nsq;
             double s = 0;
-            for (int j = i; j < n; ++j) s += Ri[j] * Ri[j];
-            s = 1 / sqrt(s);
+            if (diag) s = hsq;   // scaling_i = sqrt(H_ii) (utils.c:309); the row of R^-1 counts as the unit vector
+            else {
+                for (int j = i; j < n; ++j) s += Ri[j] * Ri[j];
+                s = 1 / sqrt(s);
+            }
             sc[i] = s;
             if (unc) {
                 const double u0 = bu[i] - xu[i], l0 = bl[i] - xu[i];
@@ -271,15 +300,19 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                 du[i] = u0 * s; dl[i] = l0 * s;
             } else {
                 double t = 0;
-                for (int j = i; j < n; ++j) t += (Ri[j] * s) * vv[j];
+                if (diag) t = vv[i];   // utils.c:527-531
+                else for (int j = i; j < n; ++j) t += (Ri[j] * s) * vv[j];
                 du[i] = bu[i] * s + t;
                 dl[i] = bl[i] * s + t;
             }
             double2 *dst = reinterpret_cast<double2 *>(Mq) + ((size_t)(i >> 6) * b.npair) * 64 + (i & 63);
             for (int t = 0; t < b.npair; ++t) {
                 double2 vpair;
-                vpair.x = (2 * t >= i) ? Ri[2 * t] * s : 0.0;
-                vpair.y = (2 * t + 1 >= i && 2 * t + 1 < n) ? Ri[2 * t + 1] * s : 0.0;
+                if (diag) { vpair.x = (2 * t == i) ? 1.0 : 0.0; vpair.y = (2 * t + 1 == i) ? 1.0 : 0.0; }
+                else {
+                    vpair.x = (2 * t >= i) ? Ri[2 * t] * s : 0.0;
+                    vpair.y = (2 * t + 1 >= i && 2 * t + 1 < n) ? Ri[2 * t + 1] * s : 0.0;
+                }
                 dst[(size_t)t * 64] = vpair;
             }
         }
@@ -290,7 +323,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             const int j = i + lane;
             if (j < n) {
                 double val = Rsq[i * nsq + j];
-                if (i < ms) val *= sc[i];
+                if (i < ms && !diag) val *= sc[i];
                 Rp[roff(i, n) + j] = val;
             }
         }
@@ -457,7 +490,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     if (lane == 0) {
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
-        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0;
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag;
         if (kProfile && b.prof) for (int i = 0; i < 10; ++i) b.prof[(size_t)q * 32 + i] = pt[i];
     }
 #undef SPROF

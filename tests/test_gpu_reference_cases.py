@@ -192,3 +192,45 @@ def test_shared_structure_batch(oracle, gpu_lib, shape):
             if r[3] > 0:
                 assert same(g["x"][k], r[0]) and same(g["lam"][k], r[1])
     bm.close()
+
+
+@pytest.mark.parametrize("shape", [(10, 30, 4, 4), (16, 40, 0, 6), (33, 80, 10, 10), (50, 150, 0, 20)])
+def test_diagonal_hessian_bitwise(oracle, gpu_lib, shape):
+    """a diagonal H takes the reference's RinvD branch (utils.c:245-312,455-468,479-480,527-531; daqp.c:130-134;
+    auxiliary.c:57-64,104-106): RinvD_i = 1/sqrt(H_ii), unit rows for the simple bounds, scaling_i = sqrt(H_ii).  Bit
+    for bit through daqp_quadprog semantics (batch), the persistent-workspace path and a warm update; identity H too."""
+    import daqp_amd
+    n, m, ms, na = shape
+    N = 32
+    q = O.generate_batch(N, n, m, ms, na, 5000 + n)
+    rng = np.random.default_rng([77, n])
+    H = np.zeros((N, n, n))
+    for k in range(N):
+        H[k] = np.diag(np.ones(n) if k % 4 == 0 else rng.uniform(0.3, 4.0, n))
+    r = oracle.quadprog_batch(H, q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    g = daqp_amd.solve_batch(H, q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert np.array_equal(g["exitflag"], r[3]) and np.array_equal(g["iter"], r[4])
+    ok = r[3] > 0
+    assert ok.any() and same(g["x"][ok], r[0][ok]) and same(g["lam"][ok], r[1][ok]) and same(g["fval"][ok], r[2][ok])
+    # persistent workspaces: setup (no unconstrained shortcut), solve, update f, solve
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup(H, q["f"], q["A"], q["bupper"], q["blower"])
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(H[k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        models.append(om)
+    f = q["f"].copy()
+    for t in range(2):
+        if t:
+            f = f + 0.05 * rng.standard_normal(f.shape)
+            bm.update(f=f)
+            for k in range(N):
+                assert models[k].update(O.UPDATE_v, f=f[k]) == 0
+        gg = bm.solve()
+        for k in range(N):
+            rr = models[k].solve()
+            assert gg["exitflag"][k] == rr[3] and gg["iter"][k] == rr[4], (t, k)
+            if rr[3] > 0:
+                assert same(gg["x"][k], rr[0]) and same(gg["lam"][k], rr[1])
+    bm.close()

@@ -747,6 +747,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         dlr[bb] = ok ? gdl[r] : 0.0;
         snr[bb] = ok ? (gsense[r] & 0xff) : 0;
     });
+    // a pending update also needs the new bounds: same early batch
+    double bur[NB], blr[NB];
+    if (upd) {
+        const double *nbu = b.bu + (size_t)q * m, *nbl = b.bl + (size_t)q * m;
+        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+            const int r = bb * 64 + lane;
+            bur[bb] = (r < m) ? nbu[r] : 0.0;
+            blr[bb] = (r < m) ? nbl[r] : 0.0;
+        });
+    }
+    // the warm-start state rides in the same early batch: working-set ids / vectors into registers, packed L and (as
+    // soon as the ids are there) the active rows straight into LDS -- all of it in flight together with the rows of M
+    const bool act = lane < w.na;
+    const int wsid_r = act ? gws[lane] : 0;
+    const double D_r = (lane < cap) ? gv[lane] : 0.0, xl_r = (lane < cap) ? gv[cap + lane] : 0.0, zl_r = (lane < cap) ? gv[2 * cap + lane] : 0.0;
+    const double la_r = (lane < cap) ? gv[3 * cap + lane] : 0.0, lb_r = (lane < cap) ? gv[4 * cap + lane] : 0.0;
+    copy_async(w.L, b.L + (size_t)q * b.ltri, round_up(tri(w.na), 2));
+    auto fetch_active_rows = [&]() __attribute__((always_inline)) {
+        for (int i = 0; i < w.na; ++i) {
+            const int id = rli(wsid_r, i);
+            const double2 *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63) + (size_t)lane * 64;
+            if (lane < b.npair)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(w.rowc + (size_t)i * w.ldr), 16, 0, 0);
+        }
+    };
+    const bool rows_early = !(upd & DAQP_UPDATE_v) || w.na * w.ldr <= rinv0;   // R^-1 is staged in the top of the row cache
+    if (rows_early) fetch_active_rows();
     __builtin_amdgcn_sched_barrier(0);
     if (nblk_u == NB && npair_u == NP) {
         // the shape fills the template exactly (the benchmark's case): NB*NP unconditional loads in ONE basic block, each
@@ -780,14 +808,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     const long long tp1 = kProfile ? (long long)__builtin_readcyclecounter() : 0;
     if (upd) {
         // ---- daqp_update_ldp(UPDATE_v|UPDATE_d) on the resident factors (utils.c:58-221 without Rinv/M), cf. k_update
-        const double *nbu = b.bu + (size_t)q * m, *nbl = b.bl + (size_t)q * m;
-        double bur[NB], blr[NB];
         int bad = 0;
         static_for<NB>([&](auto bb) __attribute__((always_inline)) {   // check_bounds (utils.c:546-567) on the stored sense
             const int r = bb * 64 + lane;
             const bool ok = r < m;
-            bur[bb] = ok ? nbu[r] : 0.0;
-            blr[bb] = ok ? nbl[r] : 0.0;
             const int sn = rsense_get(w, bb);
             if (ok && !(sn & DAQP_IMMUTABLE)) {
                 const double diff = bur[bb] - blr[bb];
@@ -852,18 +876,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         WSYNC();
     }
     // ---- working-set view
-    const bool act = lane < w.na;
-    w.wsid = act ? gws[lane] : 0;
+    w.wsid = wsid_r;
     w.slot = lane;
     w.slotmask = (w.na >= 64) ? ~0ull : ((1ull << w.na) - 1ull);
     w.hi_slot = w.na - 1;
     const int rinv_off = rowc_size - round_up(b.rtri, 2) - 2;
-    w.D = (lane < cap) ? gv[lane] : 0.0;
-    w.xl = (lane < cap) ? gv[cap + lane] : 0.0;
-    w.zl = (lane < cap) ? gv[2 * cap + lane] : 0.0;
-    const double la = (lane < cap) ? gv[3 * cap + lane] : 0.0, lb = (lane < cap) ? gv[4 * cap + lane] : 0.0;
-    w.lam = swapped ? lb : la;
-    w.lams = swapped ? la : lb;
+    w.D = D_r; w.xl = xl_r; w.zl = zl_r;
+    w.lam = swapped ? lb_r : la_r;
+    w.lams = swapped ? la_r : lb_r;
     {   // sense and bound of each working-set row are already in registers (row view): fetch them across lanes
         // (ds_bpermute) instead of a second, dependent trip to HBM
         const int src = w.wsid & 63, blk = w.wsid >> 6;
@@ -880,16 +900,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     {
         // warm start: packed L and the active-row cache come straight from HBM into LDS (global_load_lds, no VGPRs),
         // every instruction in flight at once -- one memory round trip instead of one per row
-        const double *gL = b.L + (size_t)q * b.ltri;
-        copy_async(w.L, gL, round_up(tri(w.na), 2));
         for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) w.u[e] = 0;
-        for (int i = 0; i < w.na; ++i) {
-            const int id = rli(w.wsid, i);
-            const double2 *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63) + (size_t)lane * 64;
-            if (lane < b.npair)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(w.rowc + (size_t)i * w.ldr), 16, 0, 0);
-        }
+        if (!rows_early) fetch_active_rows();
         if (kProfile && w.prof && lane == 0) { w.prof[26] = tp1 - t_start; w.prof[27] = (long long)__builtin_readcyclecounter() - tp1; }
         copy_wait();
         if (kProfile && w.prof && lane == 0) w.prof[31] = (long long)__builtin_readcyclecounter() - tp1;

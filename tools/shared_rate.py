@@ -30,3 +30,9 @@ for t in range(T):
     r = bm.solve(out="torch")
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"  warm: {N * T / dt / 1e6:.2f} M solves/s ({dt / T * 1e3:.2f} ms per step, mean iter {r['iter'].double().mean().item():.2f}), kernel_ms {bm.kernel_ms()}")
+if len(sys.argv) > 2:
+    bm.enable_profile(True)
+    f += 0.05 * torch.randn(f.shape, generator=g, **dd); bm.update(f=f); r = bm.solve(out="torch"); torch.cuda.synchronize()
+    p = bm.read_profile().astype(float)
+    print("  per QP cycles: prologue %d (rows %d, +copy issue %d, +copy done %d), epilogue %d, loop %d; iterations %.2f"
+          % (p[:, 28].mean(), p[:, 26].mean(), p[:, 27].mean(), p[:, 31].mean(), p[:, 29].mean(), p[:, 30].mean(), r["iter"].double().mean().item()))

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                         const int ii = i < n ? i : 0;
                         const double hij = Rsq[ii * n + jj], hji = Rsq[jj * n + ii];
                         const double val = (jj == ii) ? hij : 0.5 * (hij + hji);
-                        offd |= (i < n && ii < jj && (hij > st.zero_tol || hij < -st.zero_tol)) ? 1 : 0;
+                        if constexpr (i == 0) offd = (lane > 0 && lane < n && (hij > st.zero_tol || hij < -st.zero_tol)) ? 1 : 0;
                         c[i] = (lane < n && i < n) ? val : 0.0;
                         a[i] = 0.0;
                     });
@@ -175,7 +175,16 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                 }
             });
         }
-        const bool isdiag = !__any(lane < n && offd);
+        // offd so far: row 0 only (a dense H is dismissed here at the price of one compare); if row 0 passes, look at
+        // every entry above the diagonal of this lane's column
+        bool isdiag = !__any(offd);
+        if (isdiag) {
+            for (int i = 1; i < n; ++i) {
+                const double hij = Rsq[i * n + (lane < n ? lane : 0)];
+                offd |= (lane < n && i < lane && (hij > st.zero_tol || hij < -st.zero_tol)) ? 1 : 0;
+            }
+            isdiag = !__any(offd);
+        }
         if (isdiag) {
             // RinvD_i = 1/sqrt(H_ii), scaling_i = sqrt(H_ii) for simple bounds; a diagonal entry at or below
             // zero_tol * max|H_ii| would be shifted and handed to the proximal outer loop (outside this path)

@@ -129,3 +129,44 @@ def test_default_settings_match_reference_constants():
     o = O.default_settings()
     for name, _ in s._fields_:
         assert getattr(s, name) == getattr(o, name), name
+
+
+def test_warm_start_helpers_match_reference():
+    """daqp_dual_init_active / daqp_primal_init_active (api.c:579-633) are host-only: they must set exactly the sense bits
+    the reference's own functions set (compared against oracle/_ref when the reference library travelled here, and against
+    the documented rule otherwise: |lam| > 1e-12 -> ACTIVE, sign -> LOWER; |slack| < 1e-9 -> ACTIVE(+LOWER))."""
+    import daqp_amd
+    from daqp_amd._lib import DAQPProblem, c_double_p, c_int_p
+    L = daqp_amd.lib()
+    ref = None
+    if O.reference_available():
+        ref = O.Reference().lib
+        for fn in (ref.daqp_dual_init_active, ref.daqp_primal_init_active):
+            fn.argtypes = [C.c_void_p, c_double_p]
+            fn.restype = None
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        n, m, ms = 6, 14, 3
+        q = O.generate_qp(n, m, ms, 3, rng=[9, trial])
+        x, lam, *_ = O.Oracle().quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        lam = lam + (rng.random(m) < 0.2) * 1e-13        # values below the 1e-12 threshold must stay inactive
+        for which, vec in (("dual", lam), ("primal", x)):
+            out = []
+            for lib_ in (L, ref):
+                if lib_ is None:
+                    continue
+                sense = np.zeros(m, np.int32)
+                H, f, A, bu, bl = (np.ascontiguousarray(q[k], np.float64) for k in ("H", "f", "A", "bupper", "blower"))
+                v = np.ascontiguousarray(vec, np.float64)
+                qp = DAQPProblem(n, m, ms, H.ctypes.data_as(c_double_p), f.ctypes.data_as(c_double_p), A.ctypes.data_as(c_double_p),
+                                 bu.ctypes.data_as(c_double_p), bl.ctypes.data_as(c_double_p), sense.ctypes.data_as(c_int_p), None, 0, 0)
+                fn = getattr(lib_, f"daqp_{which}_init_active")
+                fn(C.byref(qp) if lib_ is L else C.cast(C.byref(qp), C.c_void_p), v.ctypes.data_as(c_double_p))
+                out.append(sense.copy())
+            if ref is not None:
+                assert np.array_equal(out[0], out[1]), (which, trial, out)
+            if which == "dual":
+                want = np.where(np.abs(lam) > 1e-12, O.ACTIVE + np.where(lam < 0, O.LOWER, 0), 0).astype(np.int32)
+                assert np.array_equal(out[0], want)
+            else:
+                assert (out[0][np.abs(lam) > 1e-6] & O.ACTIVE).all()     # rows active at the optimum have zero slack

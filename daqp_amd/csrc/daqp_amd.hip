@@ -838,5 +838,12 @@ void daqp_dual_init_active(DAQPProblem *qp, c_float *lam)
         else if (lam[i] < -tol) qp->sense[i] |= DAQP_ACTIVE + DAQP_LOWER;
     }
 }
+// api.c:636-641: the starting point of the proximal-point iterations.  This path (strictly convex QPs) never reads it --
+// daqp_solve overwrites x -- but the Cython binding declares and calls the symbol (daqp.pxd:74, daqp.pyx:53,438).
+void daqp_set_primal_start(DAQPWorkspace *work, c_float *x)
+{
+    if (!work || !x || !work->x || work->sing_ind == DAQP_UNCONSTRAINED_OPTIMAL) return;
+    for (int i = 0; i < work->n; ++i) work->x[i] = x[i];
+}
 
 } // extern "C"

@@ -144,6 +144,7 @@ void free_daqp_workspace(DAQPWorkspace *work);                                 /
 void free_daqp_ldp(DAQPWorkspace *work);                                       /* api.c:243-275 */
 void daqp_primal_init_active(DAQPProblem *qp, c_float *x);                     /* api.c:579-616 */
 void daqp_dual_init_active(DAQPProblem *qp, c_float *lam);                     /* api.c:620-633 */
+void daqp_set_primal_start(DAQPWorkspace *work, c_float *x);                   /* api.c:636-641 (a no-op for this path) */
 
 /* ------------------------------------------------------------------ */
 /* (2) batch entry points (additive; not in the reference)             */

@@ -846,4 +846,13 @@ void daqp_set_primal_start(DAQPWorkspace *work, c_float *x)
     for (int i = 0; i < work->n; ++i) work->x[i] = x[i];
 }
 
+// api.h: daqp_minrep (redundancy removal built on repeated LDP solves, src/api.c) is outside this path.  The symbol exists
+// so that the reference's Cython module (daqp.pxd:65) links against this library; it reports "unsupported".
+int daqp_minrep(int *is_redundant, c_float *A, c_float *b, int n, int m, int ms)
+{
+    (void)is_redundant; (void)A; (void)b; (void)n; (void)m; (void)ms;
+    set_err("daqp_minrep is outside the dense-QP path of this library");
+    return DAQP_EXIT_UNSUPPORTED;
+}
+
 } // extern "C"

@@ -145,6 +145,7 @@ void free_daqp_ldp(DAQPWorkspace *work);                                       /
 void daqp_primal_init_active(DAQPProblem *qp, c_float *x);                     /* api.c:579-616 */
 void daqp_dual_init_active(DAQPProblem *qp, c_float *lam);                     /* api.c:620-633 */
 void daqp_set_primal_start(DAQPWorkspace *work, c_float *x);                   /* api.c:636-641 (a no-op for this path) */
+int daqp_minrep(int *is_redundant, c_float *A, c_float *b, int n, int m, int ms);  /* api.h: outside the path -> DAQP_EXIT_UNSUPPORTED (link stub) */
 
 /* ------------------------------------------------------------------ */
 /* (2) batch entry points (additive; not in the reference)             */

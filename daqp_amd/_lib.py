@@ -61,7 +61,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 EXPORTS = [
     "daqp_quadprog", "daqp_solve", "setup_daqp", "setup_daqp_main", "daqp_update_ldp", "daqp_default_settings",
     "allocate_daqp_settings", "free_daqp_workspace", "free_daqp_ldp", "daqp_primal_init_active",
-    "daqp_dual_init_active", "daqp_set_primal_start", "daqp_minrep", "daqp_batch_create", "daqp_batch_free", "daqp_batch_set_stream",
+    "daqp_dual_init_active", "daqp_set_primal_start", "daqp_minrep", "allocate_daqp_workspace", "allocate_daqp_ldp", "daqp_first_violating", "daqp_batch_create", "daqp_batch_free", "daqp_batch_set_stream",
     "daqp_batch_set_settings", "daqp_batch_set_exact", "daqp_batch_setup", "daqp_batch_setup_shared", "daqp_batch_update", "daqp_batch_solve",
     "daqp_batch_setup_flags", "daqp_batch_working_sets", "daqp_quadprog_batch", "daqp_batch_kernel_ms",
     "daqp_batch_device_bytes", "daqp_amd_last_error", "daqp_amd_device_count", "daqp_amd_version",

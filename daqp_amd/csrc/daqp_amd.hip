@@ -846,6 +846,28 @@ void daqp_set_primal_start(DAQPWorkspace *work, c_float *x)
     for (int i = 0; i < work->n; ++i) work->x[i] = x[i];
 }
 
+// api.c:296-371: in the reference these malloc the workspace arrays.  Here the numerical state is created on the GPU by
+// setup_daqp / setup_daqp_main, so they only record the dimensions (callers that size a workspace by hand before setup --
+// api.h:41-42 -- keep working; nothing is allocated that would have to be freed).
+void allocate_daqp_workspace(DAQPWorkspace *work, int n, int ns) { if (work) { work->n = n; (void)ns; } }
+void allocate_daqp_ldp(DAQPWorkspace *work, int n, int m, int ms, int alloc_R, int alloc_v)
+{
+    (void)alloc_R; (void)alloc_v;
+    if (work) { work->n = n; work->m = m; work->ms = ms; }
+}
+// api.c:562-574 (host-only): index of the first constraint that x violates by more than tol, m if none
+int daqp_first_violating(c_float *x, c_float *A, c_float *bu, c_float *bl, int n, int m, int ms, c_float tol)
+{
+    int i = 0;
+    for (; i < ms; ++i)
+        if (x[i] > bu[i] + tol || x[i] < bl[i] - tol) return i;
+    for (size_t p = 0; i < m; ++i) {
+        c_float ax = 0;
+        for (int j = 0; j < n; ++j) ax += A[p++] * x[j];
+        if (ax > bu[i] + tol || ax < bl[i] - tol) return i;
+    }
+    return m;
+}
 // api.h: daqp_minrep (redundancy removal built on repeated LDP solves, src/api.c) is outside this path.  The symbol exists
 // so that the reference's Cython module (daqp.pxd:65) links against this library; it reports "unsupported".
 int daqp_minrep(int *is_redundant, c_float *A, c_float *b, int n, int m, int ms)

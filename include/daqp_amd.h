@@ -145,6 +145,9 @@ void free_daqp_ldp(DAQPWorkspace *work);                                       /
 void daqp_primal_init_active(DAQPProblem *qp, c_float *x);                     /* api.c:579-616 */
 void daqp_dual_init_active(DAQPProblem *qp, c_float *lam);                     /* api.c:620-633 */
 void daqp_set_primal_start(DAQPWorkspace *work, c_float *x);                   /* api.c:636-641 (a no-op for this path) */
+void allocate_daqp_workspace(DAQPWorkspace *work, int n, int ns);                /* api.h:41 (records n; state is created by setup_daqp) */
+void allocate_daqp_ldp(DAQPWorkspace *work, int n, int m, int ms, int alloc_R, int alloc_v);   /* api.h:42 (records n, m, ms) */
+int daqp_first_violating(c_float *x, c_float *A, c_float *bu, c_float *bl, int n, int m, int ms, c_float tol);   /* api.c:562-574, host-only */
 int daqp_minrep(int *is_redundant, c_float *A, c_float *b, int n, int m, int ms);  /* api.h: outside the path -> DAQP_EXIT_UNSUPPORTED (link stub) */
 
 /* ------------------------------------------------------------------ */

@@ -170,3 +170,18 @@ def test_warm_start_helpers_match_reference():
                 assert np.array_equal(out[0], want)
             else:
                 assert (out[0][np.abs(lam) > 1e-6] & O.ACTIVE).all()     # rows active at the optimum have zero slack
+
+
+def test_first_violating_host_helper():
+    """daqp_first_violating (api.c:562-574, host-only): first violated row, or m"""
+    import daqp_amd
+    L = daqp_amd.lib()
+    L.daqp_first_violating.argtypes = [C.POINTER(C.c_double)] * 4 + [C.c_int] * 3 + [C.c_double]
+    L.daqp_first_violating.restype = C.c_int
+    n, m, ms = 3, 5, 2
+    A = np.array([[1.0, 1, 0], [0, 1, 1], [1, 0, -1]])
+    bu, bl = np.array([1.0, 1, 2, 2, 0.5]), -np.array([1.0, 1, 2, 2, 0.5])
+    dp = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    for x, want in (([0, 0, 0], 5), ([2, 0, 0], 0), ([0.5, -1.5, 0], 1), ([1, 1, 1.5], 3), ([1, 0.2, 0.2], 4)):
+        xv = np.array(x, float)
+        assert L.daqp_first_violating(dp(xv), dp(A), dp(bu), dp(bl), n, m, ms, 1e-9) == want, (x, want)

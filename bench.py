@@ -42,11 +42,19 @@ def cpu_baseline(q_host, ms, gpu_res):
     from oracle import oracle as O
     S = q_host["f"].shape[0]
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    tried = ""
     if O.reference_available():
         kind = "reference"
-        dt, x, lam, fval, flag, it = O.timed_cpu_batch(os.path.join(O.HERE, "_ref", "libdaqp_ref.so"), cores,
-                                                       q_host["H"], q_host["f"], q_host["A"], q_host["bupper"],
-                                                       q_host["blower"], ms)
+        # the fastest of {all, 1/2, 1/4, 1/8 of} the host threads: with every hardware thread busy the per-thread rate
+        # collapses on these hosts (SMT + memory), and the baseline should be the CPU's best, not its most crowded
+        best = None
+        for th in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
+            r = O.timed_cpu_batch(os.path.join(O.HERE, "_ref", "libdaqp_ref.so"), th, q_host["H"], q_host["f"], q_host["A"],
+                                  q_host["bupper"], q_host["blower"], ms)
+            tried += f"{th} threads: {S / r[0]:.0f} QPs/s; "
+            if best is None or r[0] < best[1][0]:
+                best = (th, r)
+        cores, (dt, x, lam, fval, flag, it) = best[0], best[1]
     else:
         kind = "port"
         solver = O.Oracle(fast=True)
@@ -76,7 +84,7 @@ def cpu_baseline(q_host, ms, gpu_res):
     )
     return dict(value=S / dt, unit="QPs/s", cores=int(cores), kind=kind,
                 sample=f"first {S} QPs of the rank-0 batch, daqp_quadprog one QP at a time on {cores} host threads "
-                       f"({S * 1.0 / dt / cores:.0f} QPs/s per thread), wall {dt:.2f} s"), parity
+                       f"({S * 1.0 / dt / cores:.0f} QPs/s per thread), wall {dt:.2f} s" + (f" [best of: {tried.strip()}]" if tried else "")), parity
 
 
 def main():

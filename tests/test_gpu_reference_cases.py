@@ -234,3 +234,29 @@ def test_diagonal_hessian_bitwise(oracle, gpu_lib, shape):
             if rr[3] > 0:
                 assert same(gg["x"][k], rr[0]) and same(gg["lam"][k], rr[1])
     bm.close()
+
+
+def test_shared_structure_with_sense(oracle, gpu_lib):
+    """shared-structure batch whose problems carry equality (5) and soft (8) rows: the working set given by sense is
+    activated at setup (eager update + activation pass); results as the oracle's setup(open bounds, sense) + update + solve"""
+    import daqp_amd
+    N = 24
+    for trial in range(6):
+        rng = np.random.default_rng([91, trial])
+        q0 = O.generate_nasty(10, 26, 3, 4, 1e-2, rng, n_dup=0, n_eq=2, n_soft=2)
+        n, m, ms = 10, 26, 3
+        f = q0["f"][None, :] + 0.1 * rng.standard_normal((N, n))
+        bu = np.repeat(q0["bupper"][None, :], N, 0); bl = np.repeat(q0["blower"][None, :], N, 0)
+        sense = np.repeat(q0["sense"][None, :], N, 0).astype(np.int32)
+        bm = daqp_amd.BatchModel(N, n, m, ms, ns_max=2)
+        bm.setup_shared(q0["H"], f, q0["A"], bu, bl, sense)
+        g = bm.solve()
+        for k in range(N):
+            om = oracle.model(n, m, ms)
+            om.setup(q0["H"], f[k], q0["A"], np.full(m, 1e30), np.full(m, -1e30), q0["sense"])
+            assert om.update(O.UPDATE_v | O.UPDATE_d, f=f[k], bupper=bu[k], blower=bl[k]) == 0
+            r = om.solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (trial, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            if r[3] > 0:
+                assert same(g["x"][k], r[0]) and same(g["lam"][k], r[1])
+        bm.close()

@@ -146,7 +146,38 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     // --- Cholesky of 1/2(H+H') in packed-upper form, 1/r_ii on the diagonal (utils.c:318-352).
     // Row i: lane <-> column j, k-ordered subtraction chain kept in a register.
     double pmin = DAQP_INF, pmax = 0.0;
+    int diag = 0;   // H diagonal: the reference's RinvD branch (utils.c:245-312), as in k_setup_fast
     if (flag > 0) {
+        int offd = 0;
+        for (int e = lane; e < n * n; e += 64) {
+            const int i = e / n, j = e - i * n;
+            if (j > i && (H[e] > st.zero_tol || H[e] < -st.zero_tol)) offd = 1;   // entries above the diagonal only (utils.c:245-252)
+        }
+        if (!__any(offd)) {
+            double hmax = 0;
+            for (int i = lane; i < n; i += 64) { double a_ = H[(size_t)i * n + i]; if (a_ < 0) a_ = -a_; if (a_ > hmax) hmax = a_; }
+            const double hscale = -wave_min(-hmax);
+            const double ftol = hscale > 0 ? st.zero_tol * hscale : st.zero_tol;
+            for (int e = lane; e < b.rtri; e += 64) Ro[e] = 0.0;
+            WSYNC();
+            for (int ic = 0; ic < n && flag > 0; ic += 64) {   // ascending: the reference stops at the first bad entry
+                const int i = ic + lane;
+                const double hd = (i < n) ? H[(size_t)i * n + i] : 1.0;
+                const bool fail = i < n && hd <= ftol;
+                const int code = (st.eps_prox == 0.0 && hd <= st.zero_tol) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED;
+                const unsigned long long fm = __ballot(fail);
+                if (fm) { flag = __builtin_amdgcn_readlane(code, __ffsll((long long)fm) - 1); break; }
+                if (i < n) {
+                    const double hsq = sqrt(hd);
+                    Ro[roff(i, n) + i] = 1 / hsq;
+                    if (i < ms) sc[i] = hsq;
+                }
+            }
+            diag = 1;
+            WSYNC();
+        }
+    }
+    if (flag > 0 && !diag) {
         for (int e = lane; e < n * n; e += 64) {
             const int i = e / n, j = e - i * n;
             if (j >= i) R[roff(i, n) + j] = (i == j) ? H[e] : 0.5 * (H[e] + H[(size_t)j * n + i]);
@@ -182,6 +213,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     // --- R -> R^-1, row by row as utils.c:380-389: lane <-> row k works on its own copy,
     // reading the untouched Cholesky rows i > k
     if (flag > 0) {
+      if (!diag) {
         for (int e = lane; e < b.rtri; e += 64) Ro[e] = R[e];
         WSYNC();
         for (int kc = 0; kc < n; kc += 64) {
@@ -200,6 +232,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             }
         }
         WSYNC();
+      }
         // --- v = R^-T f (utils.c:474-497, mask has UPDATE_Rinv: no column scaling)
         for (int ic = 0; ic < n; ic += 64) {
             const int i = ic + lane;
@@ -310,25 +343,32 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             if (i < ms) {
                 const int pi = roff(i, n);
                 double s = 0;
-                for (int j = i; j < n; ++j) s += Ro[pi + j] * Ro[pi + j];
-                s = 1 / sqrt(s);
-                sc[i] = s;
-                for (int j = i; j < n; ++j) Ro[pi + j] *= s;
+                if (diag) s = sc[i];   // sqrt(H_ii); the row stays un-normalised and counts as the unit vector
+                else {
+                    for (int j = i; j < n; ++j) s += Ro[pi + j] * Ro[pi + j];
+                    s = 1 / sqrt(s);
+                    sc[i] = s;
+                    for (int j = i; j < n; ++j) Ro[pi + j] *= s;
+                }
                 if (unc) {
                     const double u0 = bu[i] - xu[i], l0 = bl[i] - xu[i];
                     if (u0 < -st.primal_tol || l0 > st.primal_tol) feasible = 0;
                     du[i] = u0 * s; dl[i] = l0 * s;
                 } else {
                     double t = 0;
-                    for (int j = i; j < n; ++j) t += Ro[pi + j] * vv[j];
+                    if (diag) t = vv[i];
+                    else for (int j = i; j < n; ++j) t += Ro[pi + j] * vv[j];
                     du[i] = bu[i] * s + t;
                     dl[i] = bl[i] * s + t;
                 }
                 double2 *dst = reinterpret_cast<double2 *>(Mq) + ((size_t)(i >> 6) * b.npair) * 64 + (i & 63);
                 for (int t = 0; t < b.npair; ++t) {
                     double2 vpair;
-                    vpair.x = (2 * t >= i) ? Ro[pi + 2 * t] : 0.0;
-                    vpair.y = (2 * t + 1 >= i && 2 * t + 1 < n) ? Ro[pi + 2 * t + 1] : 0.0;
+                    if (diag) { vpair.x = (2 * t == i) ? 1.0 : 0.0; vpair.y = (2 * t + 1 == i) ? 1.0 : 0.0; }
+                    else {
+                        vpair.x = (2 * t >= i) ? Ro[pi + 2 * t] : 0.0;
+                        vpair.y = (2 * t + 1 >= i && 2 * t + 1 < n) ? Ro[pi + 2 * t + 1] : 0.0;
+                    }
                     dst[(size_t)t * 64] = vpair;
                 }
             }
@@ -352,7 +392,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     if (lane == 0) {
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
-        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = 0;   // dense arithmetic also for a diagonal H here
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag;
     }
 }
 

@@ -194,7 +194,7 @@ def test_shared_structure_batch(oracle, gpu_lib, shape):
     bm.close()
 
 
-@pytest.mark.parametrize("shape", [(10, 30, 4, 4), (16, 40, 0, 6), (33, 80, 10, 10), (50, 150, 0, 20)])
+@pytest.mark.parametrize("shape", [(10, 30, 4, 4), (16, 40, 0, 6), (33, 80, 10, 10), (50, 150, 0, 20), (70, 150, 6, 14)])
 def test_diagonal_hessian_bitwise(oracle, gpu_lib, shape):
     """a diagonal H takes the reference's RinvD branch (utils.c:245-312,455-468,479-480,527-531; daqp.c:130-134;
     auxiliary.c:57-64,104-106): RinvD_i = 1/sqrt(H_ii), unit rows for the simple bounds, scaling_i = sqrt(H_ii).  Bit

@@ -178,9 +178,18 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
         }
     }
     if (flag > 0 && !diag) {
-        for (int e = lane; e < n * n; e += 64) {
-            const int i = e / n, j = e - i * n;
-            if (j >= i) R[roff(i, n) + j] = (i == j) ? H[e] : 0.5 * (H[e] + H[(size_t)j * n + i]);
+        for (int e0 = lane; e0 < n * n; e0 += 64 * 8) {   // 16 loads per lane per trip (H and its transpose), then the stores
+            double h1[8], h2[8];
+            int ii[8], jj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = (e0 + 64 * u < n * n) ? e0 + 64 * u : 0;
+                ii[u] = e / n; jj[u] = e - ii[u] * n;
+                h1[u] = H[e]; h2[u] = H[(size_t)jj[u] * n + ii[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + 64 * u < n * n && jj[u] >= ii[u]) R[roff(ii[u], n) + jj[u]] = (ii[u] == jj[u]) ? h1[u] : 0.5 * (h1[u] + h2[u]);
         }
         WSYNC();
         for (int i = 0; i < n && flag > 0; ++i) {
@@ -190,11 +199,21 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             for (int ch = 0; ch < nch; ++ch) {   // chunk 0 holds the diagonal (lane 0)
                 const int j = i + ch * 64 + lane;
                 double acc = (j < n) ? R[pi + j] : 0.0;
-                if (j < n)
-                    for (int k = 0; k < i; ++k) {
-                        const int pk = roff(k, n);
-                        acc -= R[pk + i] * R[pk + j];
+                {   // k-ordered chain, 8 steps per trip with their 16 loads issued first (R may live in HBM scratch: without
+                    // this every step is a memory round trip); lanes beyond the row read a valid element and discard
+                    const int jj = (j < n) ? j : i;
+                    for (int k0 = 0; k0 < i; k0 += 8) {
+                        double ra[8], rb[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const int k = (k0 + t < i) ? k0 + t : 0;
+                            const int pk = roff(k, n);
+                            ra[t] = R[pk + i]; rb[t] = R[pk + jj];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) if (k0 + t < i && j < n) acc -= ra[t] * rb[t];
                     }
+                }
                 if (ch == 0) {
                     const double dg = rl(acc, 0);
                     if (dg <= st.zero_tol) { flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED; break; }
@@ -227,7 +246,13 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                 if (own && i > k) {
                     const double t = Ro[pk + i] * R[pi + i];
                     Ro[pk + i] = t;
-                    for (int j = i + 1; j < n; ++j) Ro[pk + j] -= R[pi + j] * t;
+                    for (int j0 = i + 1; j0 < n; j0 += 8) {   // 8 entries per trip: 16 loads first, then the stores
+                        double ro[8], rr[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const int j = (j0 + u < n) ? j0 + u : n - 1; ro[u] = Ro[pk + j]; rr[u] = R[pi + j]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (j0 + u < n) Ro[pk + j0 + u] = ro[u] - rr[u] * t;
+                    }
                 }
             }
         }
@@ -283,10 +308,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
         for (int tb = 0; tb < mA && flag > 0; tb += 64) {
             const int rows = (mA - tb) < 64 ? (mA - tb) : 64;
             WSYNC();
-            for (int e = lane; e < rows * n; e += 64) {
-                const int rr = e / n, cc = e - rr * n;
-                tile[rr * ldr + cc] = A[(size_t)tb * n + e];
-            }
+            stage_rows(tile, A + (size_t)tb * n, rows, n, ldr);   // 16 loads per lane in flight, no division
             WSYNC();
             const int k = tb + lane;
             const bool own = lane < rows;
@@ -298,7 +320,13 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                 if (unc) { for (int j = 0; j < n; ++j) sunc += a[j] * xu[j]; }
                 for (int c = n - 1; c >= 0; --c) {
                     double acc = Ro[roff(c, n) + c] * a[c];
-                    for (int r = c - 1; r >= 0; --r) acc += Ro[roff(r, n) + c] * a[r];
+                    for (int r0 = c - 1; r0 >= 0; r0 -= 8) {   // decreasing r, 8 per trip with the loads first
+                        double rv[8], av[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const int r = (r0 - u >= 0) ? r0 - u : 0; rv[u] = Ro[roff(r, n) + c]; av[u] = a[r]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (r0 - u >= 0) acc += rv[u] * av[u];
+                    }
                     a[c] = acc;
                 }
                 double s = 0;

@@ -55,6 +55,31 @@ __device__ __forceinline__ void copy_async_dwords(double *dst, const double *src
 }
 __device__ __forceinline__ void copy_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */ }
 
+// dst[r*ld + c] = src[r*n + c] for r < rows, c < n: every lane walks the contiguous source with stride 64,
+// keeps (row, col) incrementally (no division) and has 16 loads in flight before the first LDS store --
+// at <= 3 waves per CU nothing else would hide the HBM latency of a load-store-load-store loop.
+__device__ __forceinline__ void stage_rows(double *dst, const double *src, int rows, int n, int ld)
+{
+    const int lane = lane_id(), total = rows * n;
+    int r = 0, c = lane;
+    while (c >= n) { c -= n; ++r; }
+    constexpr int DEPTH = 16;
+    for (int e0 = lane; e0 < total; e0 += 64 * DEPTH) {
+        double v[DEPTH];
+        int off[DEPTH];
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q) {
+            const int e = e0 + 64 * q;
+            v[q] = (e < total) ? src[e] : 0.0;
+            off[q] = r * ld + c;
+            c += 64;
+            while (c >= n) { c -= n; ++r; }
+        }
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q) if (e0 + 64 * q < total) dst[off[q]] = v[q];
+    }
+}
+
 // broadcast lane `src` (wave-uniform) of v to every lane: two v_readlane_b32
 __device__ __forceinline__ double rl(double v, int src)
 {

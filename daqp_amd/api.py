@@ -278,6 +278,22 @@ class BatchModel:
         self._out_keep = [o]
         return o
 
+    def set_primal_start(self, x):
+        """api.c:636-641 for every problem: where the proximal iterations (singular H) start from; x: (N, n)."""
+        keep = []
+        ptr, mem = _ptr(x, np.float64, keep)
+        rc = lib().daqp_batch_set_primal_start(self._h, ptr, mem)
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_set_primal_start failed ({rc}): {_lib.last_error()}")
+        return self
+
+    def prox_info(self):
+        """dict(n_prox, outer, eps): which problems go through the proximal outer loop (singular H), the outer
+        iterations of the last solve and the shift of each factor."""
+        npx, outer, eps = np.zeros(self.N, np.int32), np.zeros(self.N, np.int32), np.zeros(self.N)
+        lib().daqp_batch_prox_info(self._h, _ip(npx), _ip(outer), eps.ctypes.data)
+        return dict(n_prox=npx, outer=outer, eps=eps)
+
     def kernel_ms(self):
         a, b = C.c_float(0), C.c_float(0)
         lib().daqp_batch_kernel_ms(self._h, C.byref(a), C.byref(b))

@@ -13,6 +13,7 @@
 
 #include "kernels.hip.h"
 #include "setup_fast.hip.h"
+#include "prox.hip.h"
 
 using namespace daqp_amd;
 
@@ -75,6 +76,12 @@ struct DAQPBatch {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed_setup = false, timed_solve = false;
     bool is_setup = false;
+    // proximal outer loop (prox.hip.h): buffers appear with the first singular Hessian
+    ProxDev px{};
+    bool prox_ready = false;
+    int *counter_host = nullptr;   // pinned, 4 ints
+    int n_prox_qps = 0;            // problems of the current setup that go through the outer loop
+    int prox_outer = 0;            // outer iterations of the last solve (the longest loop of the batch)
 };
 
 namespace {
@@ -166,6 +173,114 @@ int stage(DAQPBatch *b, const T *src, int memory, size_t count, T **slot, const 
     if (*slot == nullptr) { if (dev_alloc(b, slot, count)) return DAQP_EXIT_UNSUPPORTED; }
     HIPCHK(hipMemcpyAsync(*slot, src, count * sizeof(T), hipMemcpyHostToDevice, b->stream));
     *out = *slot;
+    return 0;
+}
+
+// ---- singular Hessians: regularising setup passes and the proximal outer loop (prox.hip.h) -------------------------
+int read_counters(DAQPBatch *b)
+{
+    HIPCHK(hipMemcpyAsync(b->counter_host, b->px.counter, 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+int prox_buffers(DAQPBatch *b)
+{
+    if (b->prox_ready) return 0;
+    const size_t N = b->d.N, n = b->d.n;
+    ProxDev &p = b->px;
+    int rc = 0;
+    rc |= dev_alloc(b, &p.eps, N); rc |= dev_alloc(b, &p.hshift, N); rc |= dev_alloc(b, &p.tries, N);
+    rc |= dev_alloc(b, &p.center, N * n); rc |= dev_alloc(b, &p.xold, N * n); rc |= dev_alloc(b, &p.feff, N * n);
+    rc |= dev_alloc(b, &p.state, N * 4); rc |= dev_alloc(b, &p.saved_flag, N);
+    rc |= dev_alloc(b, &p.t_flag, N); rc |= dev_alloc(b, &p.t_iter, N); rc |= dev_alloc(b, &p.t_fval, N); rc |= dev_alloc(b, &p.t_soft, N);
+    rc |= dev_alloc(b, &b->d.prox_mask, N * n);
+    if (rc) return DAQP_EXIT_UNSUPPORTED;
+    HIPCHK(hipMemsetAsync(p.center, 0, N * n * sizeof(double), b->stream));   // api.c:318: the first centre is the origin
+    HIPCHK(hipMemsetAsync(p.state, 0, N * 4 * sizeof(int), b->stream));
+    b->d.hshift = p.hshift;
+    b->prox_ready = true;
+    return 0;
+}
+// After the first setup pass: problems whose Hessian Cholesky found singular (or all of them when eps_prox > 0) are set up
+// again from H + eps*I, eps doubling while the shifted factor is still ill-conditioned (utils.c:354-377).
+int regularise(DAQPBatch *b, int mask)
+{
+    BatchDev &d = b->d;
+    const int tpb = 128, nb = (d.N + tpb - 1) / tpb;
+    b->n_prox_qps = 0;
+    HIPCHK(hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream));
+    hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 2);
+    HIPCHK(hipGetLastError());
+    if (read_counters(b)) return DAQP_EXIT_UNSUPPORTED;
+    if (b->counter_host[0] == 0) return 0;
+    if (prox_buffers(b)) return DAQP_EXIT_UNSUPPORTED;
+    hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 0);
+    HIPCHK(hipGetLastError());
+    typedef void (*setup_kernel_t)(BatchDev, int);
+    // the shifted passes always take the generic kernel (M in the reference's operation order)
+    const bool gs = b->setup_spill;
+    const setup_kernel_t ks = gs ? k_setup<true> : k_setup<false>;
+    const size_t lds = (size_t)setup_lds(d.n, d.m, gs).total_bytes;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int pass = 0; pass < 18; ++pass) {
+        d.prox_pass = 1;
+        hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds, b->stream, d, mask & ~DAQP_UPDATE_unconstrained);   // utils.c:622
+        d.prox_pass = 0;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream));
+        hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 1);
+        HIPCHK(hipGetLastError());
+        if (read_counters(b)) return DAQP_EXIT_UNSUPPORTED;
+        if (b->counter_host[0] == 0) break;
+    }
+    HIPCHK(hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream));
+    hipLaunchKernelGGL(k_prox_final, dim3(nb), dim3(tpb), 0, b->stream, d, b->px);
+    HIPCHK(hipGetLastError());
+    if (read_counters(b)) return DAQP_EXIT_UNSUPPORTED;
+    b->n_prox_qps = b->counter_host[1];
+    return 0;
+}
+// daqp_update_ldp(mask within UPDATE_v|UPDATE_d) followed by daqp_solve, whichever kernels the shape uses
+int launch_update_solve(DAQPBatch *b, int mask)
+{
+    if (b->NB > 0) return launch_ldp(b, 2 | (mask << 4));
+    hipLaunchKernelGGL(k_update, dim3(b->d.N), dim3(64), b->lds_update, b->stream, b->d, mask);
+    HIPCHK(hipGetLastError());
+    if (launch_ldp(b, 1)) return DAQP_EXIT_UNSUPPORTED;
+    return launch_ldp(b, 0);
+}
+// daqp_solve for a batch that holds proximal problems: the ordinary ones are solved by one launch as usual, then the
+// outer iterations of daqp_prox.c:60-198 run for the others until each has stopped.
+int solve_with_prox(DAQPBatch *b, int mode)
+{
+    BatchDev &d = b->d;
+    const int tpb = 128, nb = (d.N + tpb - 1) / tpb;
+    hipLaunchKernelGGL(k_prox_mark, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 0);
+    HIPCHK(hipGetLastError());
+    if (b->n_prox_qps < d.N) { if (launch_ldp(b, mode)) return DAQP_EXIT_UNSUPPORTED; }
+    hipLaunchKernelGGL(k_prox_mark, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 1);
+    HIPCHK(hipGetLastError());
+    // the inner launches report into scratch; a problem's outputs are written when its loop ends
+    const double *f_user = d.f;
+    double *o_fval = d.fval, *o_soft = d.soft;
+    int *o_flag = d.exitflag, *o_iter = d.iter;
+    d.f = b->px.feff; d.fval = b->px.t_fval; d.soft = b->px.t_soft; d.exitflag = b->px.t_flag; d.iter = b->px.t_iter;
+    int rc = 0, outer = 0;
+    for (;; ++outer) {
+        hipLaunchKernelGGL(k_prox_pre, dim3(d.N), dim3(64), 0, b->stream, d, b->px, f_user);
+        if (hipGetLastError() != hipSuccess) { rc = 1; break; }
+        if (hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream) != hipSuccess) { rc = 1; break; }
+        if (launch_update_solve(b, DAQP_UPDATE_v | DAQP_UPDATE_d)) { rc = 1; break; }
+        hipLaunchKernelGGL(k_prox_post, dim3(d.N), dim3(64), 0, b->stream, d, b->px, (const double *)d.x, o_fval, o_soft, o_flag, o_iter);
+        if (hipGetLastError() != hipSuccess) { rc = 1; break; }
+        if (read_counters(b)) { rc = 1; break; }
+        if (b->counter_host[2] == 0) break;
+    }
+    b->prox_outer = outer + 1;
+    d.f = f_user; d.fval = o_fval; d.soft = o_soft; d.exitflag = o_flag; d.iter = o_iter;
+    hipLaunchKernelGGL(k_prox_mark, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 2);
+    HIPCHK(hipGetLastError());
+    if (rc) { set_err("proximal outer loop: a launch failed"); return DAQP_EXIT_UNSUPPORTED; }
     return 0;
 }
 
@@ -277,6 +392,8 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &b->oiter, Nn);
     rc |= dev_alloc(b, &b->st_dev, 1);
     rc |= dev_alloc(b, &b->d_dev, 1);
+    rc |= dev_alloc(b, &b->px.counter, 4);
+    if (!rc && hipHostMalloc(reinterpret_cast<void **>(&b->counter_host), 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = 1;
     if (!rc && hipMemcpy(b->st_dev, &d.st, sizeof(DAQPSettings), hipMemcpyHostToDevice) != hipSuccess) rc = 1;
     d.st_dev = b->st_dev;
     if (rc) { daqp_batch_free(b); return DAQP_EXIT_UNSUPPORTED; }
@@ -299,6 +416,7 @@ void daqp_batch_free(DAQPBatch *b)
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
     for (void *p : b->owned) (void)hipFree(p);
+    if (b->counter_host) (void)hipHostFree(b->counter_host);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }
@@ -414,6 +532,8 @@ int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
     hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask);
     HIPCHK(hipGetLastError());
+    // numerically singular Hessians: shifted re-runs for those problems (one tiny counting kernel when there are none)
+    if (!getenv("DAQP_AMD_NO_PROX")) { rc = regularise(b, mask); if (rc) return rc; }
     // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
     if (p->sense != nullptr || true) { rc = launch_ldp(b, 1); if (rc) return rc; }
     HIPCHK(hipEventRecord(b->ev[1], b->stream));
@@ -437,6 +557,7 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     }
     (void)init_mask;   // the unconstrained shortcut / elimination are per-problem decisions of daqp_quadprog: not taken here
     b->pending_mask = 0;
+    b->n_prox_qps = 0;   // (a shared singular Hessian is reported as unsupported: the outer loop is per problem)
     HIPCHK(hipSetDevice(b->device));
     BatchDev &d = b->d;
     const size_t N = d.N;
@@ -562,7 +683,7 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
     HIPCHK(hipEventRecord(b->ev[2], b->stream));
     const int mode = b->pending_mask ? (2 | (b->pending_mask << 4)) : 0;
     b->pending_mask = 0;
-    int rc = launch_ldp(b, mode);
+    int rc = b->n_prox_qps > 0 ? solve_with_prox(b, mode) : launch_ldp(b, mode);
     if (rc) return rc;
     HIPCHK(hipEventRecord(b->ev[3], b->stream));
     b->timed_solve = true;
@@ -578,6 +699,48 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
         r->solve_time = now_s() - t0;
     }
     return 0;
+}
+
+// api.c:636-641 for every problem: the point the proximal iterations start from (x: N*n).  Only problems whose Hessian
+// needed the shift ever read it; a later daqp_batch_solve continues from the previous solution, as the reference does.
+int daqp_batch_set_primal_start(DAQPBatch *b, const c_float *x, int memory)
+{
+    if (!b || !x) return DAQP_EXIT_UNSUPPORTED;
+    HIPCHK(hipSetDevice(b->device));
+    if (!b->prox_ready) return 0;   // no singular Hessian seen: nothing would read it
+    HIPCHK(hipMemcpyAsync(b->px.center, x, (size_t)b->d.N * b->d.n * sizeof(double),
+                          memory == DAQP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->stream));
+    if (memory != DAQP_MEM_DEVICE) HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+// Which problems of the last setup go through the proximal outer loop: n_prox (types.h:229; host int[N], 0 = ordinary),
+// outer iterations of the last solve (host int[N]) and the shift eps (host double[N]).  Any pointer may be NULL.
+// Returns the number of proximal problems (>= 0) or a negative flag.
+int daqp_batch_prox_info(DAQPBatch *b, int *n_prox_host, int *outer_host, c_float *eps_host)
+{
+    if (!b) return DAQP_EXIT_UNSUPPORTED;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    const int N = b->d.N;
+    if (n_prox_host) {
+        std::vector<QState> qs(N);
+        HIPCHK(hipMemcpy(qs.data(), b->d.qs, sizeof(QState) * N, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i) n_prox_host[i] = qs[i].setup_flag > 0 ? qs[i].n_prox : 0;
+    }
+    if (outer_host) {
+        for (int i = 0; i < N; ++i) outer_host[i] = 0;
+        if (b->prox_ready) {
+            std::vector<int> st(4 * (size_t)N);
+            HIPCHK(hipMemcpy(st.data(), b->px.state, sizeof(int) * 4 * N, hipMemcpyDeviceToHost));
+            for (int i = 0; i < N; ++i) outer_host[i] = st[4 * (size_t)i + 3];
+        }
+    }
+    if (eps_host) {
+        for (int i = 0; i < N; ++i) eps_host[i] = 0;
+        if (b->prox_ready && b->n_prox_qps > 0) HIPCHK(hipMemcpy(eps_host, b->px.eps, sizeof(double) * N, hipMemcpyDeviceToHost));
+    }
+    return b->n_prox_qps;
 }
 
 int daqp_batch_setup_flags(DAQPBatch *b, int *flags_host)
@@ -769,7 +932,8 @@ void daqp_solve(DAQPResult *res, DAQPWorkspace *work)
     r.memory = DAQP_MEM_HOST;
     const int rc = daqp_batch_solve(b, &r);
     if (rc < 0) { res->exitflag = rc; return; }
-    res->exitflag = flag; res->iter = iter; res->fval = fval; res->soft_slack = soft; res->nodes = 1;
+    res->exitflag = flag; res->iter = iter; res->fval = fval; res->soft_slack = soft;
+    res->nodes = b->n_prox_qps > 0 ? b->prox_outer : 1;   // api.c:488: work->nh, the outer iterations of daqp_prox (daqp_prox.c:34,129)
     if (flag > 0 || true)
         for (int i = 0; i < work->n; ++i) res->x[i] = work->x[i];
     refresh_mirrors(work);
@@ -844,6 +1008,8 @@ void daqp_set_primal_start(DAQPWorkspace *work, c_float *x)
 {
     if (!work || !x || !work->x || work->sing_ind == DAQP_UNCONSTRAINED_OPTIMAL) return;
     for (int i = 0; i < work->n; ++i) work->x[i] = x[i];
+    DAQPBatch *b = ws_batch(work);
+    if (b) (void)daqp_batch_set_primal_start(b, x, DAQP_MEM_HOST);   // the centre of the first proximal iteration
 }
 
 // api.c:296-371: in the reference these malloc the workspace arrays.  Here the numerical state is created on the GPU by

@@ -40,7 +40,16 @@ struct BatchDev {
     int exact_setup;              // 1: M = A R^-1 in the reference's operation order (VALU); 0: MFMA f64
     int shared;                   // 1: one H, A for the whole batch (daqp_batch_setup_shared): Mblk, Rinv, scaling hold ONE problem's factors
     DAQPSettings st;
+    // regularising re-runs of k_setup (utils.c:356-377): only the problems flagged DAQP_NEEDS_SHIFT, with H + hshift[q] on the diagonal
+    int prox_pass;
+    const double *hshift;         // [N]
+    int *prox_mask;               // [N][n] coordinates that carry the shift (all of them for a dense H)
 };
+// internal setup flag: the Hessian is numerically singular and eps_prox != 0 -- the host re-runs the setup with a shifted
+// diagonal (never leaves the library: it ends as 1 or DAQP_EXIT_NONCONVEX)
+#define DAQP_NEEDS_SHIFT (-100)
+// internal setup flag while the proximal driver runs: this problem sits out the launch (any negative flag does that)
+#define DAQP_PROX_SKIP (-101)
 
 __host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // index of problem q's factors (M, R^-1, scaling): its own, or the single shared set
@@ -118,6 +127,14 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     const DAQPSettings &st = b.st;
     QState *qs = b.qs + q;
     int flag = 1, activate = 0;
+    // a regularising re-run (utils.c:356-377): the flagged problems only, H + shift*I (or, for a diagonal H, the shift in
+    // its singular coordinates only: utils.c:284-312), the stricter pivot ratio for a Hessian that needed the shift
+    const int pp = b.prox_pass;
+    if (pp && __builtin_amdgcn_readfirstlane(qs->setup_flag) != DAQP_NEEDS_SHIFT) return;
+    const double shift = pp ? b.hshift[q] : 0.0;
+    const bool force = st.eps_prox > 0.0;
+    const int shift_code = (!pp && st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;   // eps == 0: utils.c:357,367
+    int nprox = 0;
 
     // --- sense (utils.c:84-91) and early bound check (utils.c:546-567)
     int bad = 0;
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     if (bad & 4) activate = 1;
     if (bad & 2) flag = DAQP_EXIT_UNSUPPORTED;
     else if (bad & 1) flag = DAQP_EXIT_INFEASIBLE;
-    if (st.eps_prox > 0.0) flag = DAQP_EXIT_UNSUPPORTED; // forced proximal mode is outside this path
+    if (force && !pp && flag > 0) flag = DAQP_NEEDS_SHIFT;   // forced proximal mode (utils.c:233-281): the host starts with the shifted pass
     for (int i = lane; i < n; i += 64) fl[i] = f[i];
     WSYNC();
 
@@ -162,9 +179,17 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             WSYNC();
             for (int ic = 0; ic < n && flag > 0; ic += 64) {   // ascending: the reference stops at the first bad entry
                 const int i = ic + lane;
-                const double hd = (i < n) ? H[(size_t)i * n + i] : 1.0;
-                const bool fail = i < n && hd <= ftol;
-                const int code = (st.eps_prox == 0.0 && hd <= st.zero_tol) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED;
+                double hd = (i < n) ? H[(size_t)i * n + i] : 1.0;
+                const bool low = i < n && (hd <= ftol || (pp && force));
+                bool fail = low;
+                int code = (st.eps_prox == 0.0 && hd <= st.zero_tol) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;
+                if (pp) {   // semi-proximal: shift the singular coordinates only, remember which (utils.c:294-303)
+                    if (low) hd += shift;
+                    if (i < n) b.prox_mask[(size_t)q * n + i] = low ? 1 : 0;
+                    nprox += __popcll(__ballot(low));
+                    fail = i < n && hd <= st.zero_tol;
+                    code = DAQP_EXIT_NONCONVEX;
+                }
                 const unsigned long long fm = __ballot(fail);
                 if (fm) { flag = __builtin_amdgcn_readlane(code, __ffsll((long long)fm) - 1); break; }
                 if (i < n) {
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (e0 + 64 * u < n * n && jj[u] >= ii[u]) R[roff(ii[u], n) + jj[u]] = (ii[u] == jj[u]) ? h1[u] : 0.5 * (h1[u] + h2[u]);
+                if (e0 + 64 * u < n * n && jj[u] >= ii[u]) R[roff(ii[u], n) + jj[u]] = (ii[u] == jj[u]) ? h1[u] + shift : 0.5 * (h1[u] + h2[u]);
         }
         WSYNC();
         for (int i = 0; i < n && flag > 0; ++i) {
@@ -216,7 +241,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                 }
                 if (ch == 0) {
                     const double dg = rl(acc, 0);
-                    if (dg <= st.zero_tol) { flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED; break; }
+                    if (dg <= st.zero_tol) { flag = shift_code; break; }
                     if (dg < pmin) pmin = dg;
                     if (dg > pmax) pmax = dg;
                     dgi = 1 / sqrt(dg);
@@ -226,8 +251,11 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             }
             WSYNC();
         }
-        if (flag > 0 && pmin <= st.zero_tol * pmax)
-            flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED;
+        if (flag > 0 && pmin <= ((pp && !force) ? sqrt(st.zero_tol) : st.zero_tol) * pmax) flag = shift_code;   // utils.c:354-356
+        if (pp && flag > 0) {
+            nprox = n;
+            for (int i = lane; i < n; i += 64) b.prox_mask[(size_t)q * n + i] = 1;
+        }
     }
     // --- R -> R^-1, row by row as utils.c:380-389: lane <-> row k works on its own copy,
     // reading the untouched Cholesky rows i > k
@@ -420,7 +448,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     if (lane == 0) {
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
-        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag;
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag; qs->n_prox = (flag > 0) ? nprox : 0;
     }
 }
 
@@ -434,6 +462,7 @@ __global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *struc
     const int q = blockIdx.x, lane = lane_id(), m = b.m;
     const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
     int flag = *shared_flag, bad = 0;
+    if (flag == DAQP_NEEDS_SHIFT) flag = DAQP_EXIT_UNSUPPORTED;   // a shared singular Hessian: the proximal driver is per-problem only
     for (int i = lane; i < m; i += 64) {
         int s = b.sense_in ? b.sense_in[(size_t)q * m + i] : 0;
         if (s & DAQP_BINARY) bad |= 2;
@@ -450,7 +479,7 @@ __global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *struc
         QState *qs = b.qs + q;
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = kEmpty; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0 && b.sense_in) ? 1 : 0;
-        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = shared_flag[1];
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = shared_flag[1]; qs->n_prox = 0;
     }
 }
 

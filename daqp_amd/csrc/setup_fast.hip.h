@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     if (bad & 4) activate = 1;
     if (bad & 2) flag = DAQP_EXIT_UNSUPPORTED;
     else if (bad & 1) flag = DAQP_EXIT_INFEASIBLE;
-    if (st.eps_prox > 0.0) flag = DAQP_EXIT_UNSUPPORTED;
+    if (st.eps_prox > 0.0 && flag > 0) flag = DAQP_NEEDS_SHIFT;   // forced proximal mode: the host runs the shifted pass of k_setup instead
     if (lane < n) fl[lane] = f[lane];
     // --- 1/2 (H + H') (utils.c:318-324) into registers: lane j <-> column j, c[i] = row i
     double pmin = DAQP_INF, pmax = 0.0;
@@ -162,13 +162,13 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
         }
         if (isdiag) {
             // RinvD_i = 1/sqrt(H_ii), scaling_i = sqrt(H_ii) for simple bounds; a diagonal entry at or below
-            // zero_tol * max|H_ii| would be shifted and handed to the proximal outer loop (outside this path)
+            // zero_tol * max|H_ii| is shifted by the regularising re-run of k_setup and solved by the proximal outer loop
             const double hd = (lane < n) ? Rsq[lane * n + lane] : 1.0;
             const double ha = hd < 0 ? -hd : hd;
             const double hscale = -wave_min((lane < n) ? -ha : 0.0);
             const double ftol = hscale > 0 ? st.zero_tol * hscale : st.zero_tol;
             const bool fail = lane < n && hd <= ftol;
-            const int code = (st.eps_prox == 0.0 && hd <= st.zero_tol) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED;
+            const int code = (st.eps_prox == 0.0 && hd <= st.zero_tol) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;
             const unsigned long long fm = __ballot(fail);
             if (fm) flag = __builtin_amdgcn_readlane(code, __ffsll((long long)fm) - 1);   // the reference stops at the first such i
             else {
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             const int kend = isdiag ? 0 : ((P == 0) ? n : n - 1 - 8 * (P - 1));
             for (; k < kend && flag > 0; ++k) {
                 const double dg = rl(c[0], k);
-                if (dg <= st.zero_tol) { flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED; break; }
+                if (dg <= st.zero_tol) { flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT; break; }
                 if (dg < pmin) pmin = dg;
                 if (dg > pmax) pmax = dg;
                 const double dgi = 1 / sqrt(dg);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             }
         });
         if (flag > 0 && !isdiag && pmin <= st.zero_tol * pmax)
-            flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_EXIT_UNSUPPORTED;
+            flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;
         WSYNC();
     }
     SPROF(0);
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     if (lane == 0) {
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
-        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag;
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag; qs->n_prox = 0;
         if (kProfile && b.prof) for (int i = 0; i < 10; ++i) b.prof[(size_t)q * 32 + i] = pt[i];
     }
 #undef SPROF

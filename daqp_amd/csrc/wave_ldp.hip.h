@@ -141,7 +141,8 @@ struct QState {   // per-problem scalars kept in HBM between launches
     int n_active, reuse_ind, sing_ind, iterations;
     int lam_swapped, setup_flag, need_activate, exitflag;
     double fval, soft_slack;
-    int diag_h, pad_;   // 1: H was diagonal -- the reference's RinvD branch (utils.c:245-312): rows < ms of R^-1 are kept
+    int diag_h, n_prox; // n_prox > 0: the factor is of a shifted Hessian, solves go through the proximal outer loop (prox.hip.h)
+                        // diag_h 1: H was diagonal -- the reference's RinvD branch (utils.c:245-312): rows < ms of R^-1 are kept
                         // un-normalised (their image in M is the exact unit vector) and x is not divided by the scaling
 };
 

@@ -19,10 +19,10 @@
  *      N independent problems of one shape (n, m, ms), stored back to back,
  *      solved by one wavefront each with the working set and LDL' factors in LDS.
  *
- * Only the hot path is implemented: dense, strictly convex H; sense bits
- * ACTIVE/LOWER/IMMUTABLE/SOFT.  Binary constraints, hierarchies, AVIs, LPs and
- * singular Hessians (the reference's bnb/hiqp/avi/prox outer loops) return
- * DAQP_EXIT_UNSUPPORTED.  There is NO CPU fallback: without a HIP device every
+ * Only the hot path is implemented: dense convex H (a singular one goes through
+ * the reference's proximal outer loop, daqp_prox.c); sense bits
+ * ACTIVE/LOWER/IMMUTABLE/SOFT.  Binary constraints, hierarchies, AVIs and LPs
+ * (the reference's bnb/hiqp/avi loops, H == NULL) return DAQP_EXIT_UNSUPPORTED.  There is NO CPU fallback: without a HIP device every
  * entry point fails with DAQP_EXIT_UNSUPPORTED and daqp_amd_last_error() says why.
  */
 #ifndef DAQP_AMD_H
@@ -85,7 +85,7 @@ typedef struct {
     c_float primal_tol, dual_tol, zero_tol, pivot_tol, progress_tol;
     int cycle_tol, iter_limit;
     c_float fval_bound;
-    c_float eps_prox, eta_prox; /* accepted, unused: proximal loop is out of scope */
+    c_float eps_prox, eta_prox; /* shift / stationarity tolerance of the proximal loop (singular H); < 0: automatic */
     c_float rho_soft;
     c_float rel_subopt, abs_subopt;
     c_float sing_tol, refactor_tol;
@@ -119,7 +119,7 @@ typedef struct DAQPWorkspace {
     int *WS;                                   /* host mirror of the working set */
     int n_active, iterations, sing_ind;
     int *prox_mask;                            /* NULL */
-    int n_prox;                                /* always 0 */
+    int n_prox;                                /* > 0: H was shifted, daqp_solve runs the proximal loop (host mirror) */
     c_float soft_slack;
     DAQPSettings *settings;
     void *bnb;                                 /* NULL */
@@ -144,7 +144,7 @@ void free_daqp_workspace(DAQPWorkspace *work);                                 /
 void free_daqp_ldp(DAQPWorkspace *work);                                       /* api.c:243-275 */
 void daqp_primal_init_active(DAQPProblem *qp, c_float *x);                     /* api.c:579-616 */
 void daqp_dual_init_active(DAQPProblem *qp, c_float *lam);                     /* api.c:620-633 */
-void daqp_set_primal_start(DAQPWorkspace *work, c_float *x);                   /* api.c:636-641 (a no-op for this path) */
+void daqp_set_primal_start(DAQPWorkspace *work, c_float *x);                   /* api.c:636-641 (first centre of the proximal loop) */
 void allocate_daqp_workspace(DAQPWorkspace *work, int n, int ns);                /* api.h:41 (records n; state is created by setup_daqp) */
 void allocate_daqp_ldp(DAQPWorkspace *work, int n, int m, int ms, int alloc_R, int alloc_v);   /* api.h:42 (records n, m, ms) */
 int daqp_first_violating(c_float *x, c_float *A, c_float *bu, c_float *bl, int n, int m, int ms, c_float tol);   /* api.c:562-574, host-only */
@@ -208,6 +208,16 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p);
  * x, lam, fval, exitflag, iter.  Blocks until results are in `r` unless r->memory is DEVICE
  * (then they are ordered on the batch's stream). */
 int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r);
+/* Singular Hessians (daqp_prox.c:21-221, utils.c:223-432): with eps_prox != 0 (default -1e-6:
+ * automatic) a problem whose Hessian Cholesky finds numerically singular is factorised from H + eps*I (eps doubling
+ * while still ill-conditioned; a diagonal H is shifted in its singular coordinates only), and daqp_batch_solve runs the
+ * reference's proximal-point outer loop for it: inner LDPs warm-started from each other until ||x - x_old||_inf <
+ * eta_prox/eps.  iter is the sum over the inner solves.  eps_prox > 0 forces the shift for every problem.
+ * daqp_batch_set_primal_start: api.c:636-641 for every problem (x: N*n), the centre of the first outer iteration.
+ * daqp_batch_prox_info: n_prox per problem (types.h:229), outer iterations of the last solve, eps; returns the number
+ * of proximal problems.  LPs (H == NULL) are not built. */
+int daqp_batch_set_primal_start(DAQPBatch *b, const c_float *x, int memory);
+int daqp_batch_prox_info(DAQPBatch *b, int *n_prox_host, int *outer_host, c_float *eps_host);
 /* copy out per-problem setup flags (host int[N]) */
 int daqp_batch_setup_flags(DAQPBatch *b, int *flags_host);
 /* copy out working sets: n_active (host int[N]) and WS (host int[N*(n+ns_max+1)], -1 padded); either may be NULL */

@@ -16,9 +16,11 @@
  * included -- it decides the last ulp) it restates.  Written from scratch:
  * one flat workspace, explicit loops for the reference's recursion.
  *
- * Scope (what the reference does when avi==NULL, bnb==NULL, nh<=1, n_prox==0,
- * no equality elimination, SOFT_WEIGHTS off): sense bits ACTIVE(1) LOWER(2)
- * IMMUTABLE(4) SOFT(8).  Anything else returns ORA_EXIT_UNSUPPORTED (-8).
+ * Scope (what the reference does when avi==NULL, bnb==NULL, nh<=1, no equality
+ * elimination, SOFT_WEIGHTS off): sense bits ACTIVE(1) LOWER(2) IMMUTABLE(4)
+ * SOFT(8); a singular or forcibly regularised Hessian (n_prox>0) goes through
+ * the proximal outer loop of daqp_prox.c.  LPs (H==NULL) and anything else
+ * return ORA_EXIT_UNSUPPORTED (-8).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -80,6 +82,9 @@ typedef struct {
     int *WS;
     int n_active, reuse_ind, sing_ind, iterations;
     double fval, soft_slack;
+    /* proximal outer loop (types.h:228-229; nh counts its outer iterations, daqp_prox.c:34) */
+    int n_prox, nh;
+    int *prox_mask;
     /* borrowed problem data (what work->qp points at) */
     const double *qH, *qf, *qA, *qbu, *qbl;
     const int *qsense;
@@ -133,6 +138,8 @@ ora_work *ora_create(int n, int m, int ms, int ns, const ora_settings *st)
     w->xldl = (double *)calloc(cap, sizeof(double));
     w->zldl = (double *)calloc(cap, sizeof(double));
     w->WS = (int *)calloc(cap, sizeof(int));
+    w->prox_mask = (int *)calloc(n + 1, sizeof(int)); /* api.c:322-323 */
+    w->nh = 1;
     for (int i = 0; i < ms; i++) w->scaling[i] = 1; /* api.c:346 */
     w->sing_ind = ORA_EMPTY;
     return w;
@@ -144,7 +151,7 @@ void ora_free(ora_work *w)
     free(w->M); free(w->R); free(w->v); free(w->scaling); free(w->dupper);
     free(w->dlower); free(w->sense); free(w->ubuf); free(w->xbuf);
     free(w->lamA); free(w->lamB); free(w->L); free(w->D); free(w->xldl);
-    free(w->zldl); free(w->WS); free(w);
+    free(w->zldl); free(w->WS); free(w->prox_mask); free(w);
 }
 
 void ora_set_trace(ora_work *w, int *buf, int cap) { w->trace = buf; w->trace_cap = cap; w->trace_len = 0; }
@@ -586,16 +593,29 @@ static int check_bounds(ora_work *w, const double *bu, const double *bl) /* util
     return act;
 }
 
-/* utils.c:223-391, unfactored H, eps_prox<=0 (automatic mode).  A Hessian that
- * the reference would shift (and then hand to the proximal outer loop) is
- * reported as unsupported: that outer loop is outside this path. */
+/* utils.c:13-20: the proximal shift for a Hessian whose largest |diagonal| is hscale */
+static double prox_eps_scaled(const ora_work *w, double hscale)
+{
+    double eps = w->st.eps_prox;
+    if (eps < 0.0) eps = -eps;                 /* negative: automatic mode */
+    const double lo = sqrt(w->st.zero_tol) * hscale;
+    if (eps > 0.0 && eps < lo) eps = lo;
+    return eps;
+}
+
+/* utils.c:223-391, unfactored H.  A Hessian that Cholesky finds numerically singular is shifted
+ * by eps*I (doubling eps up to 16 times while the shifted factor is still ill-conditioned); a
+ * diagonal one is shifted only in its singular coordinates (prox_mask).  n_prox>0 afterwards
+ * hands the solve to the proximal outer loop. */
 static int factor_hessian(ora_work *w, const double *H)
 {
     const int n = w->n;
     const double ztol = w->st.zero_tol;
-    double hscale = 0.0;
-    int diag = 1;
-    if (w->st.eps_prox > 0.0) return ORA_EXIT_UNSUPPORTED; /* forced proximal mode */
+    const int force = w->st.eps_prox > 0.0;
+    double hscale = 0.0, eps = w->st.eps_prox;
+    int diag = 1, all = force, tries = 0;
+    for (int i = 0; i < n; i++) w->prox_mask[i] = 0;
+    w->n_prox = 0;
     for (int i = 0, p = 1; i < n && diag; i++, p += i + 1) {
         double a = H[i * n + i];
         if (a < 0) a = -a;
@@ -603,13 +623,28 @@ static int factor_hessian(ora_work *w, const double *H)
         for (int j = 1; j < n - i; j++, p++)
             if (H[p] > ztol || H[p] < -ztol) { diag = 0; break; }
     }
+    if (force) {
+        if (!diag) {
+            hscale = 0.0;
+            for (int i = 0; i < n; i++) { double a = H[i * n + i]; if (a < 0.0) a = -a; if (a > hscale) hscale = a; }
+        }
+        eps = prox_eps_scaled(w, hscale);
+        if (eps <= 0.0) return ORA_EXIT_NONCONVEX;
+        w->n_prox = n;
+        for (int i = 0; i < n; i++) w->prox_mask[i] = 1;
+    }
     w->is_diag = diag;
     if (diag) {
         double ftol = ztol;
         if (hscale > 0) ftol = ztol * hscale;
+        eps = prox_eps_scaled(w, hscale);
         for (int i = 0; i < n; i++) {
             double h = H[i * n + i];
-            if (h <= ftol) return (w->st.eps_prox == 0.0 && h <= ztol) ? ORA_EXIT_NONCONVEX : ORA_EXIT_UNSUPPORTED;
+            if (force || h <= ftol) {
+                if (!force) { w->prox_mask[i] = 1; w->n_prox++; }
+                h += eps;
+            }
+            if (h <= ztol) return ORA_EXIT_NONCONVEX;
             h = sqrt(h);
             w->R[i] = 1 / h;
             if (i < w->ms) w->scaling[i] = h;
@@ -617,25 +652,41 @@ static int factor_hessian(ora_work *w, const double *H)
         return 1;
     }
     double *R = w->R;
-    for (int i = 0, p = 0; i < n; i++) {          /* pack 1/2 (H + H') */
-        R[p++] = H[i * n + i];
-        for (int j = i + 1; j < n; j++) R[p++] = 0.5 * (H[i * n + j] + H[j * n + i]);
-    }
-    double pmin = ORA_INF, pmax = 0.0;
-    for (int i = 0, p = 0; i < n; p += n - i, i++) { /* in-place Cholesky, 1/r_ii on the diagonal */
-        double dg = R[p];
-        for (int k = 0, q = i; k < i; k++, q += n - k) dg -= R[q] * R[q];
-        if (dg <= ztol) return (w->st.eps_prox == 0.0) ? ORA_EXIT_NONCONVEX : ORA_EXIT_UNSUPPORTED;
-        if (dg < pmin) pmin = dg;
-        if (dg > pmax) pmax = dg;
-        dg = 1 / sqrt(dg);
-        for (int j = 1; j < n - i; j++) {
-            for (int k = 0, q = i; k < i; k++, q += n - k) R[p + j] -= R[q] * R[q + j];
-            R[p + j] *= dg;
+    for (;;) {
+        for (int i = 0, p = 0; i < n; i++) {          /* pack 1/2 (H + H'), shifted diagonal */
+            R[p++] = H[i * n + i] + (all ? eps : 0.0);
+            for (int j = i + 1; j < n; j++) R[p++] = 0.5 * (H[i * n + j] + H[j * n + i]);
         }
-        R[p] = dg;
+        double pmin = ORA_INF, pmax = 0.0;
+        int ok = 1;
+        for (int i = 0, p = 0; i < n; p += n - i, i++) { /* in-place Cholesky, 1/r_ii on the diagonal */
+            double dg = R[p];
+            for (int k = 0, q = i; k < i; k++, q += n - k) dg -= R[q] * R[q];
+            if (dg <= ztol) { ok = 0; break; }
+            if (dg < pmin) pmin = dg;
+            if (dg > pmax) pmax = dg;
+            dg = 1 / sqrt(dg);
+            for (int j = 1; j < n - i; j++) {
+                for (int k = 0, q = i; k < i; k++, q += n - k) R[p + j] -= R[q] * R[q + j];
+                R[p + j] *= dg;
+            }
+            R[p] = dg;
+        }
+        /* an already shifted Hessian must clear the stricter sqrt(zero_tol) pivot ratio (utils.c:354-356) */
+        if (ok && !(pmin <= ((all && !force) ? sqrt(ztol) : ztol) * pmax)) break;
+        if (all) {
+            if (eps <= 0 || tries++ >= 16) return ORA_EXIT_NONCONVEX;
+            eps *= 2.0;
+        } else {
+            hscale = 0.0;
+            for (int k = 0; k < n; k++) { double a = H[k * n + k]; if (a < 0) a = -a; if (a > hscale) hscale = a; }
+            eps = prox_eps_scaled(w, hscale);
+            if (eps <= 0) return ORA_EXIT_NONCONVEX;
+            all = 1;
+            w->n_prox = n;
+            for (int k = 0; k < n; k++) w->prox_mask[k] = 1;
+        }
     }
-    if (pmin <= ztol * pmax) return (w->st.eps_prox == 0.0) ? ORA_EXIT_NONCONVEX : ORA_EXIT_UNSUPPORTED;
     for (int k = 0, p = 0; k < n; k++) {          /* R -> R^-1 in place, row by row */
         int q = p + 1;
         for (int j = k + 1; j < n; j++) R[q++] *= -R[p];
@@ -646,6 +697,22 @@ static int factor_hessian(ora_work *w, const double *H)
         }
     }
     return 1;
+}
+
+/* utils.c:393-432: the shift the factor in w->R was built with, reconstructed at solve time */
+static double prox_eps(const ora_work *w)
+{
+    double scale = 0.0;
+    if (w->n_prox == 0 || w->qH == NULL) return 0.0;
+    for (int i = 0; i < w->n; i++) { double a = w->qH[i * w->n + i]; if (a < 0.0) a = -a; if (a > scale) scale = a; }
+    if (w->is_diag) return prox_eps_scaled(w, scale);
+    double rinv = w->R[0];
+    if (w->ms > 0) rinv /= w->scaling[0];
+    const double recovered = 1.0 / (rinv * rinv) - w->qH[0];
+    double eps = prox_eps_scaled(w, scale);
+    if (eps <= 0.0) return 0.0;
+    while (1.5 * eps < recovered) eps *= 2.0;
+    return eps;
 }
 
 static void form_v(ora_work *w, const double *f, int mask) /* utils.c:474-497 */
@@ -754,6 +821,7 @@ static int try_unconstrained(ora_work *w, int mask)
     const int n = w->n;
     if (!(mask & ORA_UPD_UNCONSTRAINED)) return 0;
     if (!(mask & (ORA_UPD_RINV + ORA_UPD_M + ORA_UPD_V + ORA_UPD_D))) return 0;
+    if (w->n_prox > 0) return 0;                                  /* utils.c:622 */
     for (int i = 0; i < w->m; i++) if (w->sense[i] & (S_ACTIVE + S_IMMUTABLE)) return 0;
     /* the reference computes x_unc in its xold buffer and swaps pointers so
      * that u (and any warm start in it) survives a negative answer */
@@ -811,7 +879,7 @@ int ora_update(ora_work *w, int mask, const double *H, const double *f, const do
     if (bl) w->qbl = bl;
     if (mask & ORA_UPD_SENSE) w->qsense = sense;
     w->sing_ind = ORA_EMPTY;
-    w->x = w->ubuf;
+    if (w->n_prox == 0) w->x = w->ubuf;   /* (the proximal loop's centre lives in x across solves) */
     if (mask & ORA_UPD_SENSE) {
         if (w->qsense == NULL) for (int i = 0; i < w->m; i++) w->sense[i] = 0;
         else {
@@ -865,26 +933,85 @@ int ora_setup(ora_work *w, int init_mask, const double *H, const double *f, cons
     return flag < 0 ? flag : 1;
 }
 
-/* daqp_solve (api.c:8-59) + ldp2qp_solution (daqp.c:111-139) +
- * daqp_extract_result (api.c:455-495) */
+/* ldp2qp_solution (daqp.c:111-139): x = R^-1 (u - v) in place (u aliases x), duals back to the QP's scaling */
+static void ldp_to_qp(ora_work *w)
+{
+    const int n = w->n;
+    for (int i = 0; i < n; i++) w->x[i] = w->u[i] - w->v[i];
+    if (!w->is_diag) {
+        for (int i = 0, p = 0; i < n; i++) {
+            w->x[i] *= w->R[p++];
+            for (int j = i + 1; j < n; j++) w->x[i] += w->R[p++] * w->x[j];
+        }
+        for (int i = 0; i < w->ms; i++) w->x[i] /= w->scaling[i];
+    } else for (int i = 0; i < n; i++) w->x[i] *= w->R[i];
+    for (int i = 0; i < w->n_active; i++) w->lam_star[i] *= w->scaling[w->WS[i]];
+}
+
+/* daqp_prox (daqp_prox.c:21-221), QP branch: proximal-point iterations x+ = argmin 1/2 x'(H+eps*P)x + (f-eps*P*x)'x
+ * over the constraints, each an LDP warm-started from the previous one; P = I for a dense singular H, the
+ * singular coordinates of a diagonal one.  Returns the exit flag; iterations = the sum over the inner solves. */
+static int prox_loop(ora_work *w)
+{
+    const int n = w->n;
+    const double relax = 1.5, eps = prox_eps(w);
+    double eta = w->st.eta_prox;
+    int total = 0, relaxed = 0, flag = 0;
+    w->nh = 0;
+    if (eta < 0.0) {                                   /* automatic tolerance (daqp_prox.c:53-58) */
+        eta = 1e-6;
+        if (w->st.dual_tol != 1e-12 && 0.1 * w->st.dual_tol < eta) eta = 0.1 * w->st.dual_tol;
+    }
+    double *xold = (w->x == w->ubuf) ? w->xbuf : w->ubuf;
+    while (total < w->st.iter_limit) {
+        if (w->n_prox == n) for (int i = 0; i < n; i++) w->v[i] = w->qf[i] - eps * w->x[i];
+        else for (int i = 0; i < n; i++) w->v[i] = w->qf[i] - (w->prox_mask[i] ? eps : 0.0) * w->x[i];
+        form_v(w, w->v, 0);
+        form_d(w, w->qbu, w->qbl);
+        { double *t = xold; xold = w->x; w->x = t; }   /* xold <- x; the inner solve overwrites the other buffer */
+        w->u = w->x;
+        w->nh++;
+        flag = ldp_loop(w);
+        total += w->iterations;
+        if (flag < 0) break;
+        ldp_to_qp(w);
+        if (eps == 0) break;
+        const double tol = eta / eps;                  /* fixed point ||x - xold||_inf < tol */
+        int i;
+        for (i = 0; i < n; i++) {
+            const double df = w->x[i] - xold[i];
+            if (df > tol || df < -tol) break;
+        }
+        if (i == n) {
+            if (relaxed && total < w->st.iter_limit) { relaxed = 0; continue; }
+            flag = ORA_EXIT_OPTIMAL;
+            break;
+        }
+        if (w->iterations == 1 && total < w->st.iter_limit) {  /* unchanged working set: over-relax the affine map */
+            for (i = 0; i < n; i++) w->x[i] = xold[i] + relax * (w->x[i] - xold[i]);
+            relaxed = 1;
+        } else relaxed = 0;
+    }
+    if (total >= w->st.iter_limit) flag = ORA_EXIT_ITERLIMIT;
+    double pn = 0.0;
+    for (int i = 0; i < n; i++) if (w->prox_mask[i]) pn += w->x[i] * w->x[i];
+    w->fval += eps * pn;
+    w->iterations = total;
+    return flag;
+}
+
+/* daqp_solve (api.c:8-59) + daqp_extract_result (api.c:455-495) */
 int ora_solve(ora_work *w, double *x, double *lam, double *fval, int *iter, double *soft_slack)
 {
     const int n = w->n;
     int flag;
-    if (w->sing_ind != ORA_UNCONSTRAINED) {
+    w->nh = 1;
+    if (w->sing_ind != ORA_UNCONSTRAINED && w->n_prox > 0) {
+        flag = prox_loop(w);
+    } else if (w->sing_ind != ORA_UNCONSTRAINED) {
         w->x = w->u = w->ubuf;
         flag = ldp_loop(w);
-        if (flag > 0) {
-            for (int i = 0; i < n; i++) w->x[i] = w->u[i] - w->v[i];
-            if (!w->is_diag) {
-                for (int i = 0, p = 0; i < n; i++) {
-                    w->x[i] *= w->R[p++];
-                    for (int j = i + 1; j < n; j++) w->x[i] += w->R[p++] * w->x[j];
-                }
-                for (int i = 0; i < w->ms; i++) w->x[i] /= w->scaling[i];
-            } else for (int i = 0; i < n; i++) w->x[i] *= w->R[i];
-            for (int i = 0; i < w->n_active; i++) w->lam_star[i] *= w->scaling[w->WS[i]];
-        }
+        if (flag > 0) ldp_to_qp(w);
     } else {
         w->iterations = 1; w->fval = 0; w->soft_slack = 0;
         flag = ORA_EXIT_OPTIMAL;
@@ -935,6 +1062,12 @@ void ora_quadprog_batch(int N, int n, int m, int ms, const double *H, const doub
 }
 
 /* read-back helpers for tests */
+int ora_get_prox(const ora_work *w, int *nh, int *mask)
+{
+    if (nh) *nh = w->nh;
+    if (mask) for (int i = 0; i < w->n; i++) mask[i] = w->prox_mask[i];
+    return w->n_prox;
+}
 int ora_get_state(const ora_work *w, int *n_active, int *WS, int *sense, double *D)
 {
     *n_active = w->n_active;

@@ -432,3 +432,24 @@ def generate_nasty(n, m, ms, n_active, eps, rng, n_dup=3, n_eq=0, n_soft=0, dep_
         bl[ms + dst] = bu[ms + dst] - 1.0
     q.update(A=A, bupper=bu, blower=bl, sense=sense)
     return q
+
+
+def generate_singular_qp(n, m, ms, rank, rng, kind="dense"):
+    """A feasible QP whose Hessian is only positive SEMI-definite (the proximal outer loop's input, daqp_prox.c):
+    kind 'dense': H = T'T with T rank x n; 'diag': a diagonal H with zeros in ~40% of its coordinates.
+    Constraints are random rows around a random interior point, so the QP is bounded and strictly feasible."""
+    rng = np.random.default_rng(rng)
+    if kind == "diag":
+        d = rng.random(n) + 0.5
+        d[rng.random(n) < 0.4] = 0.0
+        H = np.diag(d)
+    else:
+        T = rng.standard_normal((rank, n))
+        H = T.T @ T
+    f = rng.standard_normal(n)
+    A = rng.standard_normal((m - ms, n))
+    x0 = rng.standard_normal(n)
+    s = np.concatenate([x0[:ms], A @ x0])
+    bu = s + 0.1 + rng.random(m)
+    bl = s - 0.1 - rng.random(m)
+    return dict(H=H, f=f, A=A, bupper=bu, blower=bl, sense=np.zeros(m, np.int32))

@@ -1,0 +1,144 @@
+"""Singular Hessians: the regularising setup passes (reference utils.c:223-432) and the proximal outer loop
+(daqp_prox.c:21-221) on the HIP path, against the oracle (itself pinned bit for bit on these cases against the
+reference: oracle/pin_oracle.py, tests/golden/prox_*.npz).  The inner solves are the ordinary kernels, so in exact
+mode everything is bitwise; in the default (MFMA) mode the shifted problems still are -- their setup always takes the
+reference-order kernel -- and the ordinary ones of a mixed batch keep their usual tolerance."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float64).view(np.uint64), np.ascontiguousarray(b, np.float64).view(np.uint64))
+
+
+def stack(qs):
+    return {k: np.stack([q[k] for q in qs]) for k in ("H", "f", "A", "bupper", "blower", "sense")}
+
+
+def oracle_each(oracle, qs, settings=None):
+    return [oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"], settings=settings) for q in qs]
+
+
+SHAPES = [(6, 14, 0), (12, 30, 4), (20, 60, 0), (33, 70, 5), (50, 150, 0), (70, 150, 6)]
+
+
+@pytest.mark.parametrize("exact", ["1", "0"])
+@pytest.mark.parametrize("n,m,ms", SHAPES)
+def test_singular_hessians_bitwise(oracle, gpu_lib, monkeypatch, n, m, ms, exact):
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", exact)
+    N = 24
+    qs = [O.generate_singular_qp(n, m, ms, rank=1 + (k * 7) % (n - 1), rng=[77, n, k], kind="diag" if k % 4 == 3 else "dense")
+          for k in range(N)]
+    ref = oracle_each(oracle, qs)
+    b = stack(qs)
+    r = daqp_amd.solve_batch(b["H"], b["f"], b["A"], b["bupper"], b["blower"], b["sense"], ms=ms)
+    assert all(rr[3] == 1 for rr in ref)
+    for k in range(N):
+        x, lam, fval, flag, it = ref[k]
+        assert r["exitflag"][k] == flag and r["iter"][k] == it, (k, r["exitflag"][k], flag, r["iter"][k], it)
+        assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), k
+
+
+def test_mixed_batch_and_info(oracle, gpu_lib, monkeypatch):
+    """definite and semidefinite Hessians in one batch: the former take one ordinary launch, the latter iterate."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, N = 16, 40, 3, 32
+    qs = []
+    for k in range(N):
+        if k % 3 == 0:
+            q = O.generate_qp(n, m, ms, 5, rng=[78, k])
+            qs.append({kk: q[kk] for kk in ("H", "f", "A", "bupper", "blower", "sense")})
+        else:
+            qs.append(O.generate_singular_qp(n, m, ms, rank=4 + k % 9, rng=[79, k]))
+    ref = oracle_each(oracle, qs)
+    b = stack(qs)
+    mdl = daqp_amd.BatchModel(N, n, m, ms)
+    mdl.setup(b["H"], b["f"], b["A"], b["bupper"], b["blower"], b["sense"], init_mask=64)
+    r = mdl.solve()
+    info = mdl.prox_info()
+    for k in range(N):
+        x, lam, fval, flag, it = ref[k]
+        assert (info["n_prox"][k] > 0) == (k % 3 != 0)
+        assert r["exitflag"][k] == flag and r["iter"][k] == it and same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), k
+    assert (info["outer"][np.arange(N) % 3 != 0] >= 1).all() and (info["eps"][np.arange(N) % 3 != 0] > 0).all()
+    mdl.close()
+
+
+def test_forced_shift_and_eta(oracle, gpu_lib, monkeypatch):
+    """eps_prox > 0 regularises every problem (utils.c:233-281), definite or not; eta_prox sets the stopping rule."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, N = 10, 24, 2, 16
+    qs = []
+    for k in range(N):
+        if k % 2:
+            q = O.generate_qp(n, m, ms, 4, rng=[80, k]); q = {kk: q[kk] for kk in ("H", "f", "A", "bupper", "blower", "sense")}
+            if k % 4 == 3:
+                q["H"] = np.diag(np.diag(q["H"]))
+        else:
+            q = O.generate_singular_qp(n, m, ms, rank=3 + k % 5, rng=[81, k])
+        qs.append(q)
+    for kw in (dict(eps_prox=1e-3), dict(eps_prox=1e-2, eta_prox=1e-8), dict(eps_prox=-1e-4, eta_prox=1e-5)):
+        st = O.default_settings(**kw)
+        ref = oracle_each(oracle, qs, settings=st)
+        b = stack(qs)
+        r = daqp_amd.solve_batch(b["H"], b["f"], b["A"], b["bupper"], b["blower"], b["sense"], ms=ms, **kw)
+        for k in range(N):
+            x, lam, fval, flag, it = ref[k]
+            assert r["exitflag"][k] == flag and r["iter"][k] == it, (kw, k, r["exitflag"][k], flag, r["iter"][k], it)
+            if flag > 0:
+                assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), (kw, k)
+
+
+def test_nonconvex_and_iteration_limit(oracle, gpu_lib, monkeypatch):
+    """an indefinite Hessian survives no shift (-5 after 16 doublings or at once with eps_prox = 0); a tiny iteration
+    budget ends the outer loop with -4 (daqp_prox.c:201)."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms = 8, 20, 0
+    q = O.generate_singular_qp(n, m, ms, rank=4, rng=[82, 0])
+    qn = dict(q); qn["H"] = q["H"] - 50.0 * np.eye(n)
+    for kw in ({}, dict(eps_prox=0.0), dict(iter_limit=7), dict(iter_limit=2)):
+        st = O.default_settings(**kw)
+        for prob in (q, qn):
+            x, lam, fval, flag, it = oracle.quadprog(prob["H"], prob["f"], prob["A"], prob["bupper"], prob["blower"], prob["sense"], settings=st)
+            xg, fg, flg, inf = daqp_amd.solve(prob["H"], prob["f"], prob["A"], prob["bupper"], prob["blower"], prob["sense"], **kw)
+            assert flg == flag, (kw, flg, flag)
+            if flag != -5:
+                assert inf["iterations"] == it, (kw, inf["iterations"], it)
+            if flag > 0:
+                assert same(xg, x) and fg == fval
+
+
+def test_model_warm_sequence_and_primal_start(oracle, gpu_lib, monkeypatch):
+    """setup once, then solve / update f / solve: the centre of the proximal iterations carries over between solves
+    (the reference keeps it in work->x), and daqp_set_primal_start (api.c:636-641) replaces it."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, N, T = 14, 36, 3, 12, 4
+    qs = [O.generate_singular_qp(n, m, ms, rank=3 + k % 8, rng=[83, k], kind="diag" if k % 5 == 4 else "dense") for k in range(N)]
+    b = stack(qs)
+    oms = [oracle.model(n, m, ms) for _ in range(N)]
+    for k, om in enumerate(oms):
+        assert om.setup(**qs[k]) == 1
+    mdl = daqp_amd.BatchModel(N, n, m, ms)
+    mdl.setup(b["H"], b["f"], b["A"], b["bupper"], b["blower"], b["sense"])
+    f = b["f"].copy()
+    rng = np.random.default_rng(84)
+    for t in range(T):
+        r = mdl.solve()
+        for k, om in enumerate(oms):
+            x, lam, fval, flag, it = om.solve()[:5]
+            assert r["exitflag"][k] == flag and r["iter"][k] == it, (t, k, r["iter"][k], it)
+            assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), (t, k)
+        f = f + 0.05 * rng.standard_normal(f.shape)
+        mdl.update(f=f)
+        for k, om in enumerate(oms):
+            om.update(4, f=f[k])
+    mdl.close()

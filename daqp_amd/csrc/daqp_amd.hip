@@ -500,7 +500,10 @@ int daqp_batch_read_ldp(DAQPBatch *b, int q, double *M, double *R, double *v, do
     return 0;
 }
 
-int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
+static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fresh);
+// setup_daqp_main on fresh workspaces (api.c:93-151): the iterate of the proximal loop starts at the origin again (api.c:318)
+int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask) { return batch_setup(b, p, init_mask, true); }
+static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fresh)
 {
     int rc = check_problem(b, p);
     if (rc) return rc;
@@ -510,6 +513,7 @@ int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask)
     }
     b->pending_mask = 0;   // a full setup supersedes any deferred update
     HIPCHK(hipSetDevice(b->device));
+    if (fresh && b->prox_ready) HIPCHK(hipMemsetAsync(b->px.center, 0, (size_t)b->d.N * b->d.n * sizeof(double), b->stream));
     BatchDev &d = b->d;
     d.shared = 0;
     const size_t N = d.N;
@@ -626,7 +630,7 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
         if (!p->H || !p->f || !p->A || !p->bupper || !p->blower) {
             if (p->memory != DAQP_MEM_DEVICE) { set_err("full re-setup from host memory needs every array"); return DAQP_EXIT_UNSUPPORTED; }
         }
-        return daqp_batch_setup(b, &pp, mask & (DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate));
+        return batch_setup(b, &pp, mask & (DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate), false);   // daqp_update_ldp keeps work->x
     }
     if (mask & ~(DAQP_UPDATE_v | DAQP_UPDATE_d)) {
         set_err("update mask %d: only DAQP_UPDATE_v|DAQP_UPDATE_d or a full re-setup are built", mask);

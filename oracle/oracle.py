@@ -92,6 +92,7 @@ class Oracle:
         L.ora_trace_len.argtypes = [C.c_void_p]
         L.ora_get_state.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p, c_double_p]
         L.ora_get_ldp.argtypes = [C.c_void_p] + [c_double_p] * 6
+        L.ora_get_prox.argtypes = [C.c_void_p, c_int_p, c_int_p]
 
     def quadprog(self, H, f, A, bupper, blower, sense=None, settings=None):
         H, f, A, bupper, blower, sense = _f64(H), _f64(f), _f64(A), _f64(bupper), _f64(blower), _i32(sense)
@@ -167,6 +168,12 @@ class OracleModel:
         WS, sense, D = np.zeros(self.n + self.m + 1, np.int32), np.zeros(self.m, np.int32), np.zeros(self.n + self.m + 1)
         sing = self.o.lib.ora_get_state(self.h, C.byref(na), _ip(WS), _ip(sense), _dp(D))
         return WS[: na.value].copy(), sense, D[: na.value].copy(), sing
+
+    def prox(self):
+        """(n_prox, outer iterations of the last solve, prox_mask)"""
+        nh, mask = C.c_int(0), np.zeros(self.n, np.int32)
+        npx = self.o.lib.ora_get_prox(self.h, C.byref(nh), _ip(mask))
+        return npx, nh.value, mask
 
     def ldp(self):
         n, m, ms = self.n, self.m, self.ms
@@ -434,10 +441,12 @@ def generate_nasty(n, m, ms, n_active, eps, rng, n_dup=3, n_eq=0, n_soft=0, dep_
     return q
 
 
-def generate_singular_qp(n, m, ms, rank, rng, kind="dense"):
+def generate_singular_qp(n, m, ms, rank, rng, kind="dense", in_range=False):
     """A feasible QP whose Hessian is only positive SEMI-definite (the proximal outer loop's input, daqp_prox.c):
     kind 'dense': H = T'T with T rank x n; 'diag': a diagonal H with zeros in ~40% of its coordinates.
-    Constraints are random rows around a random interior point, so the QP is bounded and strictly feasible."""
+    Constraints are random rows around a random interior point, so the QP is bounded and strictly feasible.
+    in_range: f = H g, so the minimiser is not a vertex and not unique -- the proximal iteration then creeps towards
+    the solution nearest to its start over many outer iterations (relaxation and confirmation steps included)."""
     rng = np.random.default_rng(rng)
     if kind == "diag":
         d = rng.random(n) + 0.5
@@ -447,6 +456,8 @@ def generate_singular_qp(n, m, ms, rank, rng, kind="dense"):
         T = rng.standard_normal((rank, n))
         H = T.T @ T
     f = rng.standard_normal(n)
+    if in_range:
+        f = H @ f
     A = rng.standard_normal((m - ms, n))
     x0 = rng.standard_normal(n)
     s = np.concatenate([x0[:ms], A @ x0])

@@ -162,6 +162,44 @@ def main():
         if k == 0:
             print("warm sequence iters:", [b[4] for _, b in seq], "setup flags", fa, fb)
         rm.close()
+    # proximal outer loop (daqp_prox.c; utils.c:223-432): semidefinite / diagonal-with-zeros / forcibly shifted Hessians
+    nprox = args.n_per_config
+    flags, outer_its = {}, []
+    for k in range(nprox):
+        rng = np.random.default_rng([201, k])
+        n = int(rng.integers(2, 30)); m = int(rng.integers(n, 3 * n + 2)); ms = int(rng.integers(0, min(n, m) + 1)) if k % 3 == 0 else 0
+        q = O.generate_singular_qp(n, m, ms, rank=int(rng.integers(1, n + 1)), rng=[202, k], kind="diag" if k % 4 == 1 else "dense",
+                                   in_range=(k % 2 == 0))
+        st = None
+        if k % 4 == 2:
+            st = O.default_settings(eps_prox=10.0 ** rng.uniform(-5, 0), eta_prox=(-1.0 if k % 8 == 2 else 10.0 ** rng.uniform(-10, -6)))
+        if k % 16 == 7:
+            q["H"] = q["H"] - 2.0 * np.eye(n)
+        if k % 16 == 11:
+            st = O.default_settings(iter_limit=int(rng.integers(2, 30)))
+        a, b = check(f"prox[{k}]", q, st)
+        flags[b[3]] = flags.get(b[3], 0) + 1
+        outer_its.append(b[4])
+    print(f"proximal: {nprox} QPs, exit flags {flags}, mean total iterations {np.mean(outer_its):.1f} max {max(outer_its)}")
+    for k in range(max(3, args.n_per_config // 10)):
+        rng = np.random.default_rng([203, k])
+        n = int(rng.integers(4, 30)); m = int(rng.integers(n, 3 * n + 2)); ms = 0 if k % 2 else min(3, n)
+        q = O.generate_singular_qp(n, m, ms, rank=int(rng.integers(1, n)), rng=[204, k], kind="diag" if k % 5 == 0 else "dense",
+                                   in_range=(k % 3 == 0))
+        st = O.default_settings(eps_prox=1e-2, eta_prox=1e-9) if k % 2 else None
+        om, rm = ora.model(n, m, ms, settings=st), strict.model(n, m, ms, settings=st)
+        fa, fb = om.setup(**q), rm.setup(**q)
+        assert fa == fb, (fa, fb)
+        f = q["f"].copy()
+        for t in range(4):
+            a, b = om.solve(), rm.solve()
+            total += 1
+            if not (a[3] == b[3] and a[4] == b[4] and same(a[0], b[0]) and same(a[1], b[1]) and same(a[2], b[2])):
+                bad += 1
+                print(f"MISMATCH prox warm[{k}][{t}] {a[3]}/{a[4]} vs {b[3]}/{b[4]}")
+            f = f + 0.3 * rng.standard_normal(n)
+            assert om.update(O.UPDATE_v, f=f) == rm.update(O.UPDATE_v, f=f) == 0
+        rm.close()
     print(f"pin result: {total - bad}/{total} bit-identical to the strict reference build")
     return 1 if bad else 0
 

@@ -85,6 +85,37 @@ def test_oracle_golden_warm_sequence(oracle):
         assert np.array_equal(x.view(np.uint64), g["x"][t].view(np.uint64))
 
 
+def test_oracle_golden_proximal(oracle):
+    """singular / forcibly shifted Hessians through the proximal outer loop: fixtures from the REFERENCE (strict build)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_prox.npz"), allow_pickle=False)
+    names = sorted({k.split("/")[0] for k in g.files} - {"warm"})
+    assert len(names) >= 40
+    flags = set()
+    for nm in names:
+        get = lambda f: g[f"{nm}/{f}"]
+        st = O.default_settings(eps_prox=float(get("eps_prox")), eta_prox=float(get("eta_prox")), iter_limit=int(get("iter_limit")))
+        x, lam, fval, flag, it = oracle.quadprog(get("H"), get("f"), get("A"), get("bupper"), get("blower"), get("sense"), settings=st)
+        assert flag == int(get("exitflag")), nm
+        flags.add(flag)
+        if flag != -5:
+            assert it == int(get("iter")), nm
+        if flag > 0:
+            assert np.array_equal(x.view(np.uint64), get("x").view(np.uint64)), nm
+            assert np.array_equal(lam.view(np.uint64), get("lam").view(np.uint64)), nm
+            assert fval == float(get("fval")), nm
+    assert flags == {1, -4, -5}
+    n, m, ms = int(g["warm/n"]), int(g["warm/m"]), int(g["warm/ms"])
+    om = oracle.model(n, m, ms)
+    assert om.setup(g["warm/H"], g["warm/fs"][0], g["warm/A"], g["warm/bupper"], g["warm/blower"], None) == 1
+    for t in range(g["warm/fs"].shape[0]):
+        if t > 0:
+            assert om.update(O.UPDATE_v, f=g["warm/fs"][t]) == 0
+        x, lam, fval, flag, it = om.solve()
+        assert flag == int(g["warm/exitflag"][t]) and it == int(g["warm/iter"][t]), t
+        assert np.array_equal(x.view(np.uint64), g["warm/x"][t].view(np.uint64)) and fval == float(g["warm/fval"][t])
+        assert np.array_equal(lam.view(np.uint64), g["warm/lam"][t].view(np.uint64))
+
+
 def test_c_abi_exports_every_declared_symbol():
     import daqp_amd
     from daqp_amd._lib import EXPORTS

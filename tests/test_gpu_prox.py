@@ -44,6 +44,32 @@ def test_singular_hessians_bitwise(oracle, gpu_lib, monkeypatch, n, m, ms, exact
         assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), k
 
 
+def test_many_outer_iterations(oracle, gpu_lib, monkeypatch):
+    """f in the range of H: the minimiser is not a vertex, the proximal map creeps -- tens of outer iterations with
+    over-relaxed centres and confirmation steps (daqp_prox.c:159-191), problems of one batch stopping at different times."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    for (n, m, ms), kw in (((12, 30, 2), dict(eps_prox=1e-2, eta_prox=1e-9)), ((24, 50, 0), dict(eps_prox=1e-1, eta_prox=1e-10)),
+                           ((50, 150, 0), dict(eps_prox=-1e-2, eta_prox=1e-8))):
+        N = 40
+        qs = [O.generate_singular_qp(n, m, ms, rank=2 + (k * 5) % (n - 3), rng=[85, n, k], kind="diag" if k % 5 == 4 else "dense",
+                                     in_range=True) for k in range(N)]
+        st = O.default_settings(**kw)
+        ref = oracle_each(oracle, qs, settings=st)
+        b = stack(qs)
+        mdl = daqp_amd.BatchModel(N, n, m, ms, **kw)
+        mdl.setup(b["H"], b["f"], b["A"], b["bupper"], b["blower"], b["sense"], init_mask=64)
+        r = mdl.solve()
+        outer = mdl.prox_info()["outer"]
+        assert outer.max() >= 10 and len(set(outer.tolist())) >= 5, outer
+        for k in range(N):
+            x, lam, fval, flag, it = ref[k]
+            assert r["exitflag"][k] == flag and r["iter"][k] == it, (k, r["exitflag"][k], flag, r["iter"][k], it)
+            if flag > 0:
+                assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), k
+        mdl.close()
+
+
 def test_mixed_batch_and_info(oracle, gpu_lib, monkeypatch):
     """definite and semidefinite Hessians in one batch: the former take one ordinary launch, the latter iterate."""
     import daqp_amd
@@ -142,3 +168,29 @@ def test_model_warm_sequence_and_primal_start(oracle, gpu_lib, monkeypatch):
         for k, om in enumerate(oms):
             om.update(4, f=f[k])
     mdl.close()
+
+
+def test_golden_proximal_fixtures(gpu_lib, monkeypatch):
+    """the reference's own outputs (tests/golden/golden_prox.npz, written by make_golden.py from the strict build)"""
+    import os
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_prox.npz"), allow_pickle=False)
+    for nm in sorted({k.split("/")[0] for k in g.files} - {"warm"}):
+        get = lambda f: g[f"{nm}/{f}"]
+        x, fval, flag, info = daqp_amd.solve(get("H"), get("f"), get("A"), get("bupper"), get("blower"), get("sense"),
+                                             eps_prox=float(get("eps_prox")), eta_prox=float(get("eta_prox")), iter_limit=int(get("iter_limit")))
+        assert flag == int(get("exitflag")), nm
+        if flag != -5:
+            assert info["iterations"] == int(get("iter")), nm
+        if flag > 0:
+            assert same(x, get("x")) and same(info["lam"], get("lam")) and fval == float(get("fval")), nm
+    n, m, ms = int(g["warm/n"]), int(g["warm/m"]), int(g["warm/ms"])
+    mdl = daqp_amd.Model()
+    mdl.setup(g["warm/H"], g["warm/fs"][0], g["warm/A"], g["warm/bupper"], g["warm/blower"], np.zeros(m, np.int32))
+    for t in range(g["warm/fs"].shape[0]):
+        if t > 0:
+            mdl.update(f=g["warm/fs"][t])
+        x, fval, flag, info = mdl.solve()
+        assert flag == int(g["warm/exitflag"][t]) and info["iterations"] == int(g["warm/iter"][t]), t
+        assert same(x, g["warm/x"][t]) and same(info["lam"], g["warm/lam"][t]) and fval == float(g["warm/fval"][t]), t

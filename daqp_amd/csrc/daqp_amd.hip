@@ -82,6 +82,7 @@ struct DAQPBatch {
     int *counter_host = nullptr;   // pinned, 4 ints
     int n_prox_qps = 0;            // problems of the current setup that go through the outer loop
     int prox_outer = 0;            // outer iterations of the last solve (the longest loop of the batch)
+    double *ident = nullptr;       // LP batches (H == NULL): the one n x n identity the setup pass reads as H
 };
 
 namespace {
@@ -203,18 +204,21 @@ int prox_buffers(DAQPBatch *b)
 }
 // After the first setup pass: problems whose Hessian Cholesky found singular (or all of them when eps_prox > 0) are set up
 // again from H + eps*I, eps doubling while the shifted factor is still ill-conditioned (utils.c:354-377).
-int regularise(DAQPBatch *b, int mask)
+int regularise(DAQPBatch *b, int mask, bool lp)
 {
     BatchDev &d = b->d;
     const int tpb = 128, nb = (d.N + tpb - 1) / tpb;
     b->n_prox_qps = 0;
-    HIPCHK(hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream));
-    hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 2);
-    HIPCHK(hipGetLastError());
-    if (read_counters(b)) return DAQP_EXIT_UNSUPPORTED;
-    if (b->counter_host[0] == 0) return 0;
+    b->px.lp = lp ? 1 : 0;
+    if (!lp) {
+        HIPCHK(hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream));
+        hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 2);
+        HIPCHK(hipGetLastError());
+        if (read_counters(b)) return DAQP_EXIT_UNSUPPORTED;
+        if (b->counter_host[0] == 0) return 0;
+    }
     if (prox_buffers(b)) return DAQP_EXIT_UNSUPPORTED;
-    hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 0);
+    hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, lp ? 3 : 0);
     HIPCHK(hipGetLastError());
     typedef void (*setup_kernel_t)(BatchDev, int);
     // the shifted passes always take the generic kernel (M in the reference's operation order)
@@ -223,7 +227,7 @@ int regularise(DAQPBatch *b, int mask)
     const size_t lds = (size_t)setup_lds(d.n, d.m, gs).total_bytes;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int pass = 0; pass < 18; ++pass) {
-        d.prox_pass = 1;
+        d.prox_pass = lp ? 2 : 1;
         hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds, b->stream, d, mask & ~DAQP_UPDATE_unconstrained);   // utils.c:622
         d.prox_pass = 0;
         HIPCHK(hipGetLastError());
@@ -265,14 +269,25 @@ int solve_with_prox(DAQPBatch *b, int mode)
     double *o_fval = d.fval, *o_soft = d.soft;
     int *o_flag = d.exitflag, *o_iter = d.iter;
     d.f = b->px.feff; d.fval = b->px.t_fval; d.soft = b->px.t_soft; d.exitflag = b->px.t_flag; d.iter = b->px.t_iter;
+    const ProxOut po = {f_user, d.lam, o_fval, o_soft, o_flag, o_iter};
+    const size_t lds_grad = (size_t)ldp_lds(d.n, d.m, d.cap, b->spill).total_bytes;
+    if (b->px.lp) {
+        if (b->spill) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_gradient<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grad));
+        else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_gradient<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grad));
+    }
     int rc = 0, outer = 0;
     for (;; ++outer) {
         hipLaunchKernelGGL(k_prox_pre, dim3(d.N), dim3(64), 0, b->stream, d, b->px, f_user);
         if (hipGetLastError() != hipSuccess) { rc = 1; break; }
         if (hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream) != hipSuccess) { rc = 1; break; }
         if (launch_update_solve(b, DAQP_UPDATE_v | DAQP_UPDATE_d)) { rc = 1; break; }
-        hipLaunchKernelGGL(k_prox_post, dim3(d.N), dim3(64), 0, b->stream, d, b->px, (const double *)d.x, o_fval, o_soft, o_flag, o_iter);
+        hipLaunchKernelGGL(k_prox_post, dim3(d.N), dim3(64), 0, b->stream, d, b->px, (const double *)d.x, po);
         if (hipGetLastError() != hipSuccess) { rc = 1; break; }
+        if (b->px.lp) {   // LP iterates off a vertex walk to the next constraint (a no-op launch for everybody else)
+            if (b->spill) hipLaunchKernelGGL((k_lp_gradient<4, true>), dim3(d.N), dim3(64), lds_grad, b->stream, d, b->px, d.x, po);
+            else hipLaunchKernelGGL((k_lp_gradient<4, false>), dim3(d.N), dim3(64), lds_grad, b->stream, d, b->px, d.x, po);
+            if (hipGetLastError() != hipSuccess) { rc = 1; break; }
+        }
         if (read_counters(b)) { rc = 1; break; }
         if (b->counter_host[2] == 0) break;
     }
@@ -507,17 +522,26 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
 {
     int rc = check_problem(b, p);
     if (rc) return rc;
-    if (!p->H || !p->f || !p->bupper || !p->blower || (b->d.mA > 0 && !p->A)) {
-        set_err("H, f, A, bupper, blower are required (LPs / missing linear term are outside this path)");
+    if (!p->f || !p->bupper || !p->blower || (b->d.mA > 0 && !p->A)) {
+        set_err("f, A, bupper, blower are required (H may be NULL: an LP)");
         return DAQP_EXIT_UNSUPPORTED;
     }
+    const bool lp = p->H == nullptr || (b->ident && p->H == b->ident);   // api.c:183-185
     b->pending_mask = 0;   // a full setup supersedes any deferred update
     HIPCHK(hipSetDevice(b->device));
     if (fresh && b->prox_ready) HIPCHK(hipMemsetAsync(b->px.center, 0, (size_t)b->d.N * b->d.n * sizeof(double), b->stream));
     BatchDev &d = b->d;
     d.shared = 0;
     const size_t N = d.N;
-    rc |= stage(b, p->H, p->memory, N * d.n * d.n, &b->sH, &d.H);
+    if (lp) {
+        if (!b->ident) {
+            if (dev_alloc(b, &b->ident, (size_t)d.n * d.n)) return DAQP_EXIT_UNSUPPORTED;
+            std::vector<double> eye((size_t)d.n * d.n, 0.0);
+            for (int i = 0; i < d.n; ++i) eye[(size_t)i * d.n + i] = 1.0;
+            HIPCHK(hipMemcpy(b->ident, eye.data(), eye.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        d.H = b->ident;
+    } else rc |= stage(b, p->H, p->memory, N * d.n * d.n, &b->sH, &d.H);
     rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &d.f);
     rc |= stage(b, p->A, p->memory, N * d.mA * d.n, &b->sA, &d.A);
     rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &d.bu);
@@ -534,10 +558,13 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
-    hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask);
-    HIPCHK(hipGetLastError());
-    // numerically singular Hessians: shifted re-runs for those problems (one tiny counting kernel when there are none)
-    if (!getenv("DAQP_AMD_NO_PROX")) { rc = regularise(b, mask); if (rc) return rc; }
+    if (!lp) {
+        hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask);
+        HIPCHK(hipGetLastError());
+    } else HIPCHK(hipMemsetAsync(d.qs, 0, (size_t)d.N * sizeof(QState), b->stream));   // fresh records: the LP pass below fills them
+    // numerically singular Hessians: shifted re-runs for those problems (one tiny counting kernel when there are none);
+    // an LP batch: its one setup pass
+    if (lp || !getenv("DAQP_AMD_NO_PROX")) { rc = regularise(b, mask, lp); if (rc) return rc; }
     // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
     if (p->sense != nullptr || true) { rc = launch_ldp(b, 1); if (rc) return rc; }
     HIPCHK(hipEventRecord(b->ev[1], b->stream));
@@ -627,7 +654,8 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
         BatchDev &d = b->d;
         if (!pp.H) { pp.H = d.H; } if (!pp.f) pp.f = d.f; if (!pp.A) pp.A = d.A;
         if (!pp.bupper) pp.bupper = d.bu; if (!pp.blower) pp.blower = d.bl;
-        if (!p->H || !p->f || !p->A || !p->bupper || !p->blower) {
+        const bool lp = b->ident && d.H == b->ident;   // an LP batch has no H to resend
+        if ((!p->H && !lp) || !p->f || !p->A || !p->bupper || !p->blower) {
             if (p->memory != DAQP_MEM_DEVICE) { set_err("full re-setup from host memory needs every array"); return DAQP_EXIT_UNSUPPORTED; }
         }
         return batch_setup(b, &pp, mask & (DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate), false);   // daqp_update_ldp keeps work->x
@@ -861,8 +889,8 @@ int setup_daqp_main(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time, i
     const double t0 = now_s();
     if (setup_time) *setup_time = 0;
     int own_settings = 1;
-    if (qp->problem_type != 0 || qp->nh > 1 || qp->break_points != nullptr || qp->H == nullptr || qp->f == nullptr) {
-        set_err("AVI / hierarchical / LP problems are outside this path");
+    if (qp->problem_type != 0 || qp->nh > 1 || qp->break_points != nullptr || qp->f == nullptr) {
+        set_err("AVI / hierarchical problems and problems without a linear term are outside this path");
         return DAQP_EXIT_UNSUPPORTED;
     }
     int ns = 0;
@@ -900,6 +928,7 @@ int setup_daqp_main(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time, i
     work->WS = static_cast<int *>(calloc(b->d.cap, sizeof(int)));
     work->timer = b;
     refresh_mirrors(work);
+    (void)daqp_batch_prox_info(b, &work->n_prox, nullptr, nullptr);   // types.h:229: > 0 sends daqp_solve through daqp_prox
     if (setup_time) *setup_time = now_s() - t0;
     return 1;
 }

@@ -41,6 +41,8 @@ struct BatchDev {
     int shared;                   // 1: one H, A for the whole batch (daqp_batch_setup_shared): Mblk, Rinv, scaling hold ONE problem's factors
     DAQPSettings st;
     // regularising re-runs of k_setup (utils.c:356-377): only the problems flagged DAQP_NEEDS_SHIFT, with H + hshift[q] on the diagonal
+    // (1), or the one setup pass of an LP batch (2): b.H is ONE identity matrix -- the reference's Rinv == RinvD == NULL
+    // branches are its RinvD branches with RinvD = 1 (utils.c:455-468,478-481, daqp.c:119-134), every direction proximal
     int prox_pass;
     const double *hshift;         // [N]
     int *prox_mask;               // [N][n] coordinates that carry the shift (all of them for a dense H)
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     double *fl = smem + o.fv, *vv = smem + o.vv, *xu = smem + o.xu;
     double *sc = smem + o.sc, *du = smem + o.du, *dl = smem + o.dl;
     int *sens = reinterpret_cast<int *>(smem + o.sens);
-    const double *H = b.H + (size_t)q * n * n, *f = b.f + (size_t)q * n, *A = b.A + (size_t)q * mA * n;
+    const double *H = b.H + (b.prox_pass == 2 ? (size_t)0 : (size_t)q * n * n), *f = b.f + (size_t)q * n, *A = b.A + (size_t)q * mA * n;
     const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
     const DAQPSettings &st = b.st;
     QState *qs = b.qs + q;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     const int pp = b.prox_pass;
     if (pp && __builtin_amdgcn_readfirstlane(qs->setup_flag) != DAQP_NEEDS_SHIFT) return;
     const double shift = pp ? b.hshift[q] : 0.0;
-    const bool force = st.eps_prox > 0.0;
+    const bool force = st.eps_prox > 0.0 && pp != 2;
     const int shift_code = (!pp && st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;   // eps == 0: utils.c:357,367
     int nprox = 0;
 
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                     nprox += __popcll(__ballot(low));
                     fail = i < n && hd <= st.zero_tol;
                     code = DAQP_EXIT_NONCONVEX;
+                    if (pp == 2 && i < n) b.prox_mask[(size_t)q * n + i] = 1;   // LP (api.c:183-185): n_prox = n
                 }
                 const unsigned long long fm = __ballot(fail);
                 if (fm) { flag = __builtin_amdgcn_readlane(code, __ffsll((long long)fm) - 1); break; }
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                 }
             }
             diag = 1;
+            if (pp == 2) nprox = n;
             WSYNC();
         }
     }

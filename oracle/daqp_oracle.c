@@ -19,8 +19,9 @@
  * Scope (what the reference does when avi==NULL, bnb==NULL, nh<=1, no equality
  * elimination, SOFT_WEIGHTS off): sense bits ACTIVE(1) LOWER(2) IMMUTABLE(4)
  * SOFT(8); a singular or forcibly regularised Hessian (n_prox>0) goes through
- * the proximal outer loop of daqp_prox.c.  LPs (H==NULL) and anything else
- * return ORA_EXIT_UNSUPPORTED (-8).
+ * the proximal outer loop of daqp_prox.c, and so does an LP (H==NULL: R = I,
+ * adaptive smoothing, gradient steps).  Anything else returns
+ * ORA_EXIT_UNSUPPORTED (-8).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -35,6 +36,7 @@
 #define ORA_EXIT_OPTIMAL 1
 #define ORA_EXIT_INFEASIBLE (-1)
 #define ORA_EXIT_CYCLE (-2)
+#define ORA_EXIT_UNBOUNDED (-3)
 #define ORA_EXIT_ITERLIMIT (-4)
 #define ORA_EXIT_NONCONVEX (-5)
 #define ORA_EXIT_OVERDETERMINED (-6)
@@ -72,6 +74,7 @@ typedef struct {
     double *M;                    /* (m-ms) x n, row-major, rows normalised */
     double *R;                    /* packed upper R^-1, or the diagonal if is_diag */
     int is_diag;
+    int is_lp;                    /* H == NULL: Rinv == RinvD == NULL in the reference (R = I); is_diag is set too */
     double *v, *scaling, *dupper, *dlower;
     int *sense;
     /* iterate + factor */
@@ -718,6 +721,7 @@ static double prox_eps(const ora_work *w)
 static void form_v(ora_work *w, const double *f, int mask) /* utils.c:474-497 */
 {
     const int n = w->n;
+    if (w->is_lp) { for (int i = 0; i < n; i++) w->v[i] = f[i]; return; }
     if (w->is_diag) { for (int i = 0; i < n; i++) w->v[i] = f[i] * w->R[i]; return; }
     int stop = (mask & ORA_UPD_RINV) ? 0 : w->ms;
     int p = tri(n), j;
@@ -770,6 +774,9 @@ static int form_M(ora_work *w, const double *A, int mask) /* utils.c:434-472 */
                 w->M[e - j] = w->R[--p] * as;
             }
         }
+    } else if (w->is_lp) {
+        for (int k = 0, p = 0; k < mA; k++)
+            for (int i = 0; i < n; i++, p++) w->M[p] = A[p];
     } else {
         for (int k = 0, p = 0; k < mA; k++)
             for (int i = 0; i < n; i++, p++) w->M[p] = A[p] * w->R[i];
@@ -927,8 +934,13 @@ int ora_update(ora_work *w, int mask, const double *H, const double *f, const do
 int ora_setup(ora_work *w, int init_mask, const double *H, const double *f, const double *A,
               const double *bu, const double *bl, const int *sense)
 {
-    if (H == NULL || f == NULL) return ORA_EXIT_UNSUPPORTED;
-    int mask = init_mask | ORA_UPD_M | ORA_UPD_D | ORA_UPD_SENSE | ORA_UPD_RINV | ORA_UPD_V;
+    if (f == NULL) return ORA_EXIT_UNSUPPORTED;
+    int mask = init_mask | ORA_UPD_M | ORA_UPD_D | ORA_UPD_SENSE | ORA_UPD_V;
+    if (H != NULL) mask |= ORA_UPD_RINV;
+    else {   /* LP (api.c:183-185): no factor at all, every direction is proximal */
+        w->is_lp = 1; w->is_diag = 1; w->n_prox = w->n;
+        for (int i = 0; i < w->n; i++) w->R[i] = 1.0;
+    }
     int flag = ora_update(w, mask, H, f, A, bu, bl, sense);
     return flag < 0 ? flag : 1;
 }
@@ -944,8 +956,44 @@ static void ldp_to_qp(ora_work *w)
             for (int j = i + 1; j < n; j++) w->x[i] += w->R[p++] * w->x[j];
         }
         for (int i = 0; i < w->ms; i++) w->x[i] /= w->scaling[i];
-    } else for (int i = 0; i < n; i++) w->x[i] *= w->R[i];
+    } else if (!w->is_lp) for (int i = 0; i < n; i++) w->x[i] *= w->R[i];
     for (int i = 0; i < w->n_active; i++) w->lam_star[i] *= w->scaling[w->WS[i]];
+}
+
+/* gradient_step (daqp_prox.c:232-303): an LP iterate that is not at a vertex moves along x - xold until the first
+ * constraint blocks, and that constraint joins the working set.  Returns its index or ORA_EMPTY (unbounded). */
+static int lp_gradient_step(ora_work *w, const double *xold)
+{
+    const int n = w->n, m = w->m, ms = w->ms;
+    int pick = ORA_EMPTY, lower = 0;
+    double amin = ORA_INF;
+    for (int j = 0; j < ms; j++) {
+        if (w->sense[j] & (S_ACTIVE + S_IMMUTABLE)) continue;
+        const double ds = w->x[j] - xold[j];
+        if (ds > 0 && w->qbu[j] < ORA_INF && w->qbu[j] - w->x[j] < amin * ds) {
+            pick = j; lower = 0; amin = (w->qbu[j] - w->x[j]) / ds;
+        } else if (ds < 0 && w->qbl[j] > -ORA_INF && w->qbl[j] - w->x[j] > amin * ds) {
+            pick = j; lower = 1; amin = (w->qbl[j] - w->x[j]) / ds;
+        }
+    }
+    for (int j = ms, p = 0; j < m; j++) {
+        if (w->sense[j] & (S_ACTIVE + S_IMMUTABLE)) { p += n; continue; }
+        double ax = 0, ds = 0;
+        for (int k = 0; k < n; k++) { ax += w->M[p] * w->x[k]; ds -= w->M[p++] * xold[k]; }
+        ds += ax;
+        ax /= w->scaling[j]; ds /= w->scaling[j];
+        if (ds > 0 && w->qbu[j] < ORA_INF && w->qbu[j] - ax < ds * amin) {
+            pick = j; lower = 0; amin = (w->qbu[j] - ax) / ds;
+        } else if (ds < 0 && w->qbl[j] > -ORA_INF && w->qbl[j] - ax > ds * amin) {
+            pick = j; lower = 1; amin = (w->qbl[j] - ax) / ds;
+        }
+    }
+    if (pick != ORA_EMPTY) {
+        for (int k = 0; k < n; k++) w->x[k] += amin * (w->x[k] - xold[k]);
+        if (lower) w->sense[pick] |= S_LOWER; else w->sense[pick] &= ~S_LOWER;
+        add_constraint(w, pick, lower ? -1.0 : 1.0);
+    }
+    return pick;
 }
 
 /* daqp_prox (daqp_prox.c:21-221), QP branch: proximal-point iterations x+ = argmin 1/2 x'(H+eps*P)x + (f-eps*P*x)'x
@@ -954,7 +1002,9 @@ static void ldp_to_qp(ora_work *w)
 static int prox_loop(ora_work *w)
 {
     const int n = w->n;
-    const double relax = 1.5, eps = prox_eps(w);
+    const double relax = 1.5;
+    const int lp = w->is_lp;
+    double eps = lp ? 1.0 : prox_eps(w);
     double eta = w->st.eta_prox;
     int total = 0, relaxed = 0, flag = 0;
     w->nh = 0;
@@ -964,9 +1014,15 @@ static int prox_loop(ora_work *w)
     }
     double *xold = (w->x == w->ubuf) ? w->xbuf : w->ubuf;
     while (total < w->st.iter_limit) {
-        if (w->n_prox == n) for (int i = 0; i < n; i++) w->v[i] = w->qf[i] - eps * w->x[i];
-        else for (int i = 0; i < n; i++) w->v[i] = w->qf[i] - (w->prox_mask[i] ? eps : 0.0) * w->x[i];
-        form_v(w, w->v, 0);
+        if (lp) {   /* smoothing weight: grow while the inner LP stalls, shrink otherwise (daqp_prox.c:69-78) */
+            if (total > 0) eps *= (w->iterations == 1) ? 10.0 : 0.9;
+            if (eps > 1e3) eps = 1e3;
+            for (int i = 0; i < n; i++) w->v[i] = w->qf[i] * eps - w->x[i];
+        } else {
+            if (w->n_prox == n) for (int i = 0; i < n; i++) w->v[i] = w->qf[i] - eps * w->x[i];
+            else for (int i = 0; i < n; i++) w->v[i] = w->qf[i] - (w->prox_mask[i] ? eps : 0.0) * w->x[i];
+            form_v(w, w->v, 0);
+        }
         form_d(w, w->qbu, w->qbl);
         { double *t = xold; xold = w->x; w->x = t; }   /* xold <- x; the inner solve overwrites the other buffer */
         w->u = w->x;
@@ -976,7 +1032,7 @@ static int prox_loop(ora_work *w)
         if (flag < 0) break;
         ldp_to_qp(w);
         if (eps == 0) break;
-        const double tol = eta / eps;                  /* fixed point ||x - xold||_inf < tol */
+        const double tol = lp ? eta * eps : eta / eps; /* fixed point ||x - xold||_inf < tol */
         int i;
         for (i = 0; i < n; i++) {
             const double df = w->x[i] - xold[i];
@@ -987,15 +1043,21 @@ static int prox_loop(ora_work *w)
             flag = ORA_EXIT_OPTIMAL;
             break;
         }
-        if (w->iterations == 1 && total < w->st.iter_limit) {  /* unchanged working set: over-relax the affine map */
+        if (!lp && w->iterations == 1 && total < w->st.iter_limit) {  /* unchanged working set: over-relax the affine map */
             for (i = 0; i < n; i++) w->x[i] = xold[i] + relax * (w->x[i] - xold[i]);
             relaxed = 1;
         } else relaxed = 0;
+        if (lp && w->iterations == 1 && w->n_active != n) {           /* not at a vertex: walk to the next constraint */
+            if (lp_gradient_step(w, xold) == ORA_EMPTY) { flag = ORA_EXIT_UNBOUNDED; break; }
+        }
     }
     if (total >= w->st.iter_limit) flag = ORA_EXIT_ITERLIMIT;
-    double pn = 0.0;
-    for (int i = 0; i < n; i++) if (w->prox_mask[i]) pn += w->x[i] * w->x[i];
-    w->fval += eps * pn;
+    if (lp) for (int i = 0; i < w->n_active; i++) w->lam_star[i] /= eps;
+    else {
+        double pn = 0.0;
+        for (int i = 0; i < n; i++) if (w->prox_mask[i]) pn += w->x[i] * w->x[i];
+        w->fval += eps * pn;
+    }
     w->iterations = total;
     return flag;
 }
@@ -1022,8 +1084,11 @@ int ora_solve(ora_work *w, double *x, double *lam, double *fval, int *iter, doub
         for (int i = 0; i < w->n_active; i++) lam[w->WS[i]] = w->lam_star[i];
     }
     double fv = w->fval;
-    for (int i = 0; i < n; i++) fv -= w->v[i] * w->v[i];
-    fv *= 0.5;
+    if (w->is_lp) { fv = 0; for (int i = 0; i < n; i++) fv += w->qf[i] * w->x[i]; }   /* api.c:479-482 */
+    else {
+        for (int i = 0; i < n; i++) fv -= w->v[i] * w->v[i];
+        fv *= 0.5;
+    }
     if (fval) *fval = fv;
     if (iter) *iter = w->iterations;
     if (soft_slack) *soft_slack = w->soft_slack;

@@ -464,3 +464,20 @@ def generate_singular_qp(n, m, ms, rank, rng, kind="dense", in_range=False):
     bu = s + 0.1 + rng.random(m)
     bl = s - 0.1 - rng.random(m)
     return dict(H=H, f=f, A=A, bupper=bu, blower=bl, sense=np.zeros(m, np.int32))
+
+
+def generate_lp(n, m, ms, rng, unbounded=False):
+    """min f'x over a random polytope around a random point (H is None: the reference's LP branch of daqp_prox.c).
+    The first ms rows are simple bounds.  unbounded: most rows are dropped to one-sided so that -f is a recession direction."""
+    rng = np.random.default_rng(rng)
+    f = rng.standard_normal(n)
+    A = rng.standard_normal((m - ms, n))
+    x0 = rng.standard_normal(n)
+    s = np.concatenate([x0[:ms], A @ x0])
+    bu = s + 0.1 + rng.random(m)
+    bl = s - 0.1 - rng.random(m)
+    if unbounded:
+        d = np.concatenate([-f[:ms], A @ (-f)])
+        bu[d > 0] = 1e30
+        bl[d < 0] = -1e30
+    return dict(H=None, f=f, A=A, bupper=bu, blower=bl, sense=np.zeros(m, np.int32))

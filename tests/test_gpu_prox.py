@@ -194,3 +194,70 @@ def test_golden_proximal_fixtures(gpu_lib, monkeypatch):
         x, fval, flag, info = mdl.solve()
         assert flag == int(g["warm/exitflag"][t]) and info["iterations"] == int(g["warm/iter"][t]), t
         assert same(x, g["warm/x"][t]) and same(info["lam"], g["warm/lam"][t]) and fval == float(g["warm/fval"][t]), t
+
+
+def lp_cases(count, seed, nmax=25):
+    out = []
+    for k in range(count):
+        rng = np.random.default_rng([seed, k])
+        n = int(rng.integers(2, nmax)); m = int(rng.integers(n + 1, 3 * n + 3)); ms = int(rng.integers(0, min(n, m) + 1)) if k % 2 else 0
+        kw = {}
+        if k % 5 == 4:
+            kw = dict(eta_prox=1e-9)
+        if k % 11 == 5:
+            kw = dict(iter_limit=int(rng.integers(2, 15)))
+        out.append((O.generate_lp(n, m, ms, [seed + 1, k], unbounded=(k % 7 == 3)), kw))
+    return out
+
+
+def test_linear_programs_single(oracle, gpu_lib, monkeypatch):
+    """H = None: the LP branch of daqp_prox.c (R = I, adaptive smoothing, gradient steps, unbounded detection) through
+    the drop-in daqp_quadprog, against the oracle (pinned bit for bit on LPs against the reference)."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    flags = set()
+    for q, kw in lp_cases(60, 410):
+        x, lam, fval, flag, it = oracle.quadprog(None, q["f"], q["A"], q["bupper"], q["blower"], q["sense"], settings=O.default_settings(**kw))
+        xg, fg, flg, inf = daqp_amd.solve(None, q["f"], q["A"], q["bupper"], q["blower"], q["sense"], **kw)
+        assert flg == flag and inf["iterations"] == it, (kw, flg, flag, inf["iterations"], it)
+        flags.add(flag)
+        if flag > 0:
+            assert same(xg, x) and same(inf["lam"], lam) and fg == fval
+    assert flags == {1, -3, -4}
+
+
+@pytest.mark.parametrize("n,m,ms", [(5, 12, 0), (12, 30, 4), (24, 60, 0), (50, 150, 0), (70, 160, 10)])
+def test_linear_program_batches(oracle, gpu_lib, monkeypatch, n, m, ms):
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    N = 32
+    qs = [O.generate_lp(n, m, ms, [420, n, k], unbounded=(k % 9 == 4)) for k in range(N)]
+    ref = [oracle.quadprog(None, q["f"], q["A"], q["bupper"], q["blower"], q["sense"]) for q in qs]
+    b = {k: np.stack([q[k] for q in qs]) for k in ("f", "A", "bupper", "blower", "sense")}
+    mdl = daqp_amd.BatchModel(N, n, m, ms)
+    mdl.setup(None, b["f"], b["A"], b["bupper"], b["blower"], b["sense"], init_mask=64)
+    r = mdl.solve()
+    info = mdl.prox_info()
+    assert (info["n_prox"] == n).all()
+    for k in range(N):
+        x, lam, fval, flag, it = ref[k]
+        assert r["exitflag"][k] == flag and r["iter"][k] == it, (k, r["exitflag"][k], flag, r["iter"][k], it)
+        if flag > 0:
+            assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), k
+    # a second solve after new costs: warm working sets, the iterate carries over
+    f2 = b["f"] + 0.3 * np.random.default_rng(421).standard_normal(b["f"].shape)
+    oms = []
+    for k, q in enumerate(qs):
+        om = oracle.model(n, m, ms)
+        assert om.setup(None, q["f"], q["A"], q["bupper"], q["blower"], q["sense"]) == 1
+        om.solve()
+        om.update(4, f=f2[k])
+        oms.append(om)
+    mdl.update(f=f2)
+    r2 = mdl.solve()
+    for k, om in enumerate(oms):
+        x, lam, fval, flag, it = om.solve()[:5]
+        assert r2["exitflag"][k] == flag and r2["iter"][k] == it, (k, r2["exitflag"][k], flag, r2["iter"][k], it)
+        if flag > 0:
+            assert same(r2["x"][k], x) and same(r2["lam"][k], lam) and same(r2["fval"][k], fval), k
+    mdl.close()

@@ -564,7 +564,8 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
     } else HIPCHK(hipMemsetAsync(d.qs, 0, (size_t)d.N * sizeof(QState), b->stream));   // fresh records: the LP pass below fills them
     // numerically singular Hessians: shifted re-runs for those problems (one tiny counting kernel when there are none);
     // an LP batch: its one setup pass
-    if (lp || !getenv("DAQP_AMD_NO_PROX")) { rc = regularise(b, mask, lp); if (rc) return rc; }
+    rc = regularise(b, mask, lp);
+    if (rc) return rc;
     // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
     if (p->sense != nullptr || true) { rc = launch_ldp(b, 1); if (rc) return rc; }
     HIPCHK(hipEventRecord(b->ev[1], b->stream));

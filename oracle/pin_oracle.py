@@ -200,6 +200,37 @@ def main():
             f = f + 0.3 * rng.standard_normal(n)
             assert om.update(O.UPDATE_v, f=f) == rm.update(O.UPDATE_v, f=f) == 0
         rm.close()
+    # linear programs (H == NULL): the LP branch of daqp_prox.c -- R = I, adaptive smoothing, gradient steps, unbounded rays
+    flags, its = {}, []
+    for k in range(args.n_per_config):
+        rng = np.random.default_rng([401, k])
+        n = int(rng.integers(2, 25)); m = int(rng.integers(n + 1, 3 * n + 3)); ms = int(rng.integers(0, min(n, m) + 1)) if k % 2 else 0
+        q = O.generate_lp(n, m, ms, [402, k], unbounded=(k % 7 == 3))
+        st = None
+        if k % 5 == 4:
+            st = O.default_settings(eta_prox=1e-9)
+        if k % 11 == 5:
+            st = O.default_settings(iter_limit=int(rng.integers(2, 15)))
+        a, b = check(f"lp[{k}]", q, st)
+        flags[b[3]] = flags.get(b[3], 0) + 1
+        its.append(b[4])
+    print(f"linear programs: {args.n_per_config} LPs, exit flags {flags}, mean total iterations {np.mean(its):.1f} max {max(its)}")
+    for k in range(max(3, args.n_per_config // 10)):
+        rng = np.random.default_rng([403, k])
+        n = int(rng.integers(3, 25)); m = int(rng.integers(n + 1, 3 * n + 3)); ms = 0 if k % 2 else min(3, n)
+        q = O.generate_lp(n, m, ms, [404, k])
+        om, rm = ora.model(n, m, ms), strict.model(n, m, ms)
+        assert om.setup(**q) == rm.setup(**q) == 1
+        f = q["f"].copy()
+        for t in range(4):
+            a, b = om.solve(), rm.solve()
+            total += 1
+            if not (a[3] == b[3] and a[4] == b[4] and (a[3] < 0 or (same(a[0], b[0]) and same(a[1], b[1]) and same(a[2], b[2])))):
+                bad += 1
+                print(f"MISMATCH lp warm[{k}][{t}] {a[3]}/{a[4]} vs {b[3]}/{b[4]}")
+            f = f + 0.3 * rng.standard_normal(n)
+            assert om.update(O.UPDATE_v, f=f) == rm.update(O.UPDATE_v, f=f) == 0
+        rm.close()
     print(f"pin result: {total - bad}/{total} bit-identical to the strict reference build")
     return 1 if bad else 0
 

@@ -86,11 +86,16 @@ def main():
         cases.append((f"prox_{k:02d}", q, kw))
     qd = O.generate_qp(9, 20, 2, 4, rng=[103, 0])
     cases.append(("prox_forced_definite", {kk: qd[kk] for kk in ("H", "f", "A", "bupper", "blower", "sense")}, dict(eps_prox=1e-3)))
+    for k in range(24):   # linear programs: H is None (stored as an empty array)
+        rng = np.random.default_rng([111, k])
+        n = int(rng.integers(2, 22)); m = int(rng.integers(n + 1, 3 * n + 3)); ms = int(rng.integers(0, min(n, m) + 1)) if k % 2 else 0
+        kw = dict(iter_limit=11) if k == 7 else (dict(eta_prox=1e-9) if k % 5 == 4 else {})
+        cases.append((f"lp_{k:02d}", O.generate_lp(n, m, ms, [112, k], unbounded=(k % 6 == 3)), kw))
     for name, q, kw in cases:
         st = O.default_settings(**kw)
         x, lam, fval, flag, it = ref.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"], settings=st)
-        for kk, v in dict(H=q["H"], f=q["f"], A=np.ascontiguousarray(q["A"]).reshape(-1, q["f"].size), bupper=q["bupper"], blower=q["blower"],
-                          sense=q["sense"], x=x, lam=lam, fval=np.float64(fval), exitflag=np.int32(flag), iter=np.int32(it),
+        for kk, v in dict(H=(q["H"] if q["H"] is not None else np.zeros((0, 0))), f=q["f"], A=np.ascontiguousarray(q["A"]).reshape(-1, q["f"].size),
+                          bupper=q["bupper"], blower=q["blower"], sense=q["sense"], x=x, lam=lam, fval=np.float64(fval), exitflag=np.int32(flag), iter=np.int32(it),
                           eps_prox=np.float64(kw.get("eps_prox", -1e-6)), eta_prox=np.float64(kw.get("eta_prox", -1.0)),
                           iter_limit=np.int32(kw.get("iter_limit", 10000))).items():
             px[f"{name}/{kk}"] = np.asarray(v)

@@ -86,7 +86,7 @@ def test_oracle_golden_warm_sequence(oracle):
 
 
 def test_oracle_golden_proximal(oracle):
-    """singular / forcibly shifted Hessians through the proximal outer loop: fixtures from the REFERENCE (strict build)"""
+    """singular / forcibly shifted Hessians and LPs through the proximal outer loop: fixtures from the REFERENCE (strict build)"""
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_prox.npz"), allow_pickle=False)
     names = sorted({k.split("/")[0] for k in g.files} - {"warm"})
     assert len(names) >= 40
@@ -94,7 +94,8 @@ def test_oracle_golden_proximal(oracle):
     for nm in names:
         get = lambda f: g[f"{nm}/{f}"]
         st = O.default_settings(eps_prox=float(get("eps_prox")), eta_prox=float(get("eta_prox")), iter_limit=int(get("iter_limit")))
-        x, lam, fval, flag, it = oracle.quadprog(get("H"), get("f"), get("A"), get("bupper"), get("blower"), get("sense"), settings=st)
+        H = get("H") if get("H").size else None    # an LP
+        x, lam, fval, flag, it = oracle.quadprog(H, get("f"), get("A"), get("bupper"), get("blower"), get("sense"), settings=st)
         assert flag == int(get("exitflag")), nm
         flags.add(flag)
         if flag != -5:
@@ -103,7 +104,7 @@ def test_oracle_golden_proximal(oracle):
             assert np.array_equal(x.view(np.uint64), get("x").view(np.uint64)), nm
             assert np.array_equal(lam.view(np.uint64), get("lam").view(np.uint64)), nm
             assert fval == float(get("fval")), nm
-    assert flags == {1, -4, -5}
+    assert flags == {1, -3, -4, -5}
     n, m, ms = int(g["warm/n"]), int(g["warm/m"]), int(g["warm/ms"])
     om = oracle.model(n, m, ms)
     assert om.setup(g["warm/H"], g["warm/fs"][0], g["warm/A"], g["warm/bupper"], g["warm/blower"], None) == 1

@@ -548,7 +548,10 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
     rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &d.bl);
     rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &d.sense_in);
     if (rc) return DAQP_EXIT_UNSUPPORTED;
-    const int mask = init_mask | DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
+    // DAQP_UPDATE_eliminate (daqp_quadprog, eq_elim.c): the reference projects many equalities out of the LDP first.  That
+    // reduction is not built; such problems are solved on the full LDP instead (what setup_daqp + daqp_solve do): same exit
+    // flag and active set, x and lam equal to ~1e-13, only the iteration count may differ (tests/test_gpu_reference_cases.py).
+    const int mask = (init_mask & ~DAQP_UPDATE_eliminate) | DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
     typedef void (*setup_kernel_t)(BatchDev, int);
     setup_kernel_t ks = b->setup_spill ? k_setup<true> : k_setup<false>;
     size_t lds_setup = b->lds_setup;

@@ -481,3 +481,22 @@ def generate_lp(n, m, ms, rng, unbounded=False):
         bu[d > 0] = 1e30
         bl[d < 0] = -1e30
     return dict(H=None, f=f, A=A, bupper=bu, blower=bl, sense=np.zeros(m, np.int32))
+
+
+def generate_equality_qp(n, m, ms, neq, rng):
+    """A generator QP with neq of its general rows turned into equalities (sense 5) through a common point: with
+    neq > 5 and 10 neq > n the reference's daqp_quadprog eliminates them first (eq_elim.c:127-164)."""
+    q = generate_qp(n, m, ms, max(1, min(n // 3, m - ms - neq - 1)), rng=rng)
+    q = {k: q[k] for k in ("H", "f", "A", "bupper", "blower", "sense")}
+    r = np.random.default_rng(rng)
+    x0 = 0.1 * r.standard_normal(n)
+    idx = ms + r.choice(m - ms, neq, replace=False)
+    full = np.concatenate([x0[:ms], q["A"] @ x0])
+    bu = np.maximum(q["bupper"], full + 0.05)
+    bl = np.minimum(q["blower"], full - 0.05)
+    s = q["sense"].copy()
+    for j in idx:
+        bu[j] = bl[j] = full[j]
+        s[j] = 5
+    q.update(bupper=bu, blower=bl, sense=s)
+    return q

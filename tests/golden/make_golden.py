@@ -4,6 +4,7 @@ Runs only in the build container (needs /root/reference -> oracle/_ref via oracl
 The fixtures hold inputs and the reference's outputs (strict-IEEE build, so they are compiler-flag
 independent): golden_quadprog.npz  (daqp_quadprog on hand cases, degenerate cases, config samples)
               golden_warm.npz      (setup_daqp -> solve -> {update_ldp(UPDATE_v) -> solve}*)
+              golden_eliminated.npz (daqp_quadprog on equality-heavy QPs, which the reference pre-reduces: eq_elim.c)
               golden_prox.npz      (singular / forcibly shifted Hessians: daqp_quadprog through daqp_prox, and a
                                     setup_daqp -> solve -> {update_ldp(UPDATE_v) -> solve}* sequence on one)
 """
@@ -114,6 +115,22 @@ def main():
     for kk, v in dict(n=n, m=m, ms=ms, H=q["H"], A=q["A"], bupper=q["bupper"], blower=q["blower"], fs=np.array(fs), x=np.array(xs),
                       lam=np.array(lams), fval=np.array(fvs), iter=np.array(its, np.int32), exitflag=np.array(flags, np.int32)).items():
         px[f"warm/{kk}"] = np.asarray(v)
+    # ---- daqp_quadprog on equality-heavy QPs: the reference eliminates the equalities first (eq_elim.c); this library
+    # solves the full LDP instead, so these fixtures are compared with a tolerance (and not by the oracle, which reports
+    # the unbuilt reduction as -8)
+    el = {}
+    for k in range(16):
+        rng = np.random.default_rng([121, k])
+        n = int(rng.integers(8, 40)); ms = int(rng.integers(0, 5)) if k % 2 else 0
+        neq = int(rng.integers(max(6, n // 10 + 1), max(7, n // 2)))
+        m = ms + neq + int(rng.integers(n, 2 * n))
+        q = O.generate_equality_qp(n, m, ms, neq, [122, k])
+        x, lam, fval, flag, it = ref.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        for kk, v in dict(H=q["H"], f=q["f"], A=q["A"], bupper=q["bupper"], blower=q["blower"], sense=q["sense"], x=x, lam=lam,
+                          fval=np.float64(fval), exitflag=np.int32(flag), iter=np.int32(it)).items():
+            el[f"elim_{k:02d}/{kk}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, "golden_eliminated.npz"), **el)
+    print("wrote 16 equality-eliminated cases: flags", sorted({int(el[f'elim_{k:02d}/exitflag']) for k in range(16)}))
     np.savez_compressed(os.path.join(HERE, "golden_prox.npz"), **px)
     print("wrote", len(cases), "proximal cases: flags", sorted({int(px[f'{c[0]}/exitflag']) for c in cases}), "warm iters", its)
 

@@ -260,3 +260,30 @@ def test_shared_structure_with_sense(oracle, gpu_lib):
             if r[3] > 0:
                 assert same(g["x"][k], r[0]) and same(g["lam"][k], r[1])
         bm.close()
+
+
+def test_equality_heavy_quadprog_against_reference_fixtures(gpu_lib):
+    """daqp_quadprog on QPs with many equalities: the reference eliminates them before solving (eq_elim.c:127-164, more than
+    5 equalities and 10 neq > n); this library solves the full LDP.  Same exit flag and active set, x and lam to the
+    north-star tolerance; the iteration count is the one documented difference.  Fixtures: outputs of the reference
+    (tests/golden/golden_eliminated.npz, make_golden.py)."""
+    import os
+    import daqp_amd
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_eliminated.npz"), allow_pickle=False)
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) == 16
+    for nm in names:
+        get = lambda f: g[f"{nm}/{f}"]
+        x, fval, flag, info = daqp_amd.solve(get("H"), get("f"), get("A"), get("bupper"), get("blower"), get("sense"))
+        assert flag == int(get("exitflag")) == 1, nm
+        assert np.abs(x - get("x")).max() < 1e-9, nm
+        assert np.abs(info["lam"] - get("lam")).max() < 1e-7 * max(1.0, np.abs(get("lam")).max()), nm
+        ineq = get("sense") != 5
+        assert np.array_equal(np.sign(info["lam"][ineq]), np.sign(get("lam")[ineq])), nm
+        assert abs(fval - float(get("fval"))) < 1e-9 * max(1.0, abs(float(get("fval")))), nm
+    # batched, default arithmetic
+    sel = [nm for nm in names if g[f"{nm}/H"].shape[0] == g[f"{names[0]}/H"].shape[0] and g[f"{nm}/bupper"].size == g[f"{names[0]}/bupper"].size]
+    nm = sel[0]
+    q = {k: np.stack([g[f"{nm}/{k}"]] * 3) for k in ("H", "f", "A", "bupper", "blower", "sense")}
+    r = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+    assert (r["exitflag"] == 1).all() and np.abs(r["x"] - g[f"{nm}/x"]).max() < 1e-9

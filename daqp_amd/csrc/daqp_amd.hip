@@ -221,15 +221,23 @@ int regularise(DAQPBatch *b, int mask, bool lp)
     hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, lp ? 3 : 0);
     HIPCHK(hipGetLastError());
     typedef void (*setup_kernel_t)(BatchDev, int);
-    // the shifted passes always take the generic kernel (M in the reference's operation order)
+    // the shifted passes keep M in the reference's operation order whatever the arithmetic mode of the batch (their
+    // problems are then bit-identical to the reference in both modes); an LP's one pass is the generic kernel's diagonal path
     const bool gs = b->setup_spill;
-    const setup_kernel_t ks = gs ? k_setup<true> : k_setup<false>;
-    const size_t lds = (size_t)setup_lds(d.n, d.m, gs).total_bytes;
+    setup_kernel_t ks = gs ? k_setup<true> : k_setup<false>;
+    size_t lds = (size_t)setup_lds(d.n, d.m, gs).total_bytes;
+    if (b->fast_setup && !lp) {
+        ks = (d.n <= 16) ? k_setup_fast<16, true> : (d.n <= 32 ? k_setup_fast<32, true> : (d.n <= 56 ? k_setup_fast<56, true> : k_setup_fast<64, true>));
+        lds = (size_t)fast_lds(d.n, d.m, 1).total_bytes;
+    }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int exact_saved = d.exact_setup;
     for (int pass = 0; pass < 18; ++pass) {
         d.prox_pass = lp ? 2 : 1;
+        d.exact_setup = 1;
         hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds, b->stream, d, mask & ~DAQP_UPDATE_unconstrained);   // utils.c:622
         d.prox_pass = 0;
+        d.exact_setup = exact_saved;
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream));
         hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 1);

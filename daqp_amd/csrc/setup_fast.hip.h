@@ -79,7 +79,10 @@ __host__ __device__ inline FastLds fast_lds(int n, int m, int exact)
     return s;
 }
 
-template <int NMAX>
+// PROX = true: the regularising re-run of the problems flagged DAQP_NEEDS_SHIFT (utils.c:354-377, see k_setup): the same
+// code with H + hshift[q] on the diagonal (a diagonal H: in its singular coordinates only), the stricter pivot ratio and
+// the list of shifted coordinates written out.  A separate instantiation, so that the ordinary pass keeps its code.
+template <int NMAX, bool PROX = false>
 __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -94,6 +97,13 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
     const DAQPSettings &st = b.st;
     QState *qs = b.qs + q;
+    double shift = 0.0;
+    int nprox = 0;
+    const bool force = st.eps_prox > 0.0;
+    if constexpr (PROX) {
+        if (__builtin_amdgcn_readfirstlane(qs->setup_flag) != DAQP_NEEDS_SHIFT) return;
+        shift = b.hshift[q];
+    }
     // rows of even length (and not a multiple of 32 doubles, which would put every row of the tile on the same
     // LDS banks) are copied HBM -> LDS directly, unpadded; everything else is staged through registers with an odd stride
     const bool direct = !(n & 1) && (n & 31) && !(((size_t)H | (size_t)A) & 15);
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     if (bad & 4) activate = 1;
     if (bad & 2) flag = DAQP_EXIT_UNSUPPORTED;
     else if (bad & 1) flag = DAQP_EXIT_INFEASIBLE;
-    if (st.eps_prox > 0.0 && flag > 0) flag = DAQP_NEEDS_SHIFT;   // forced proximal mode: the host runs the shifted pass of k_setup instead
+    if (!PROX && force && flag > 0) flag = DAQP_NEEDS_SHIFT;   // forced proximal mode: the host starts with the shifted pass
     if (lane < n) fl[lane] = f[lane];
     // --- 1/2 (H + H') (utils.c:318-324) into registers: lane j <-> column j, c[i] = row i
     double pmin = DAQP_INF, pmax = 0.0;
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                         constexpr int i = 8 * g + h;
                         const int ii = i < n ? i : 0;
                         const double hij = Rsq[ii * n + jj], hji = Rsq[jj * n + ii];
-                        const double val = (jj == ii) ? hij : 0.5 * (hij + hji);
+                        const double val = (jj == ii) ? (PROX ? hij + shift : hij) : 0.5 * (hij + hji);
                         if constexpr (i == 0) offd = (lane > 0 && lane < n && (hij > st.zero_tol || hij < -st.zero_tol)) ? 1 : 0;
                         c[i] = (lane < n && i < n) ? val : 0.0;
                         a[i] = 0.0;
@@ -163,12 +173,20 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
         if (isdiag) {
             // RinvD_i = 1/sqrt(H_ii), scaling_i = sqrt(H_ii) for simple bounds; a diagonal entry at or below
             // zero_tol * max|H_ii| is shifted by the regularising re-run of k_setup and solved by the proximal outer loop
-            const double hd = (lane < n) ? Rsq[lane * n + lane] : 1.0;
+            double hd = (lane < n) ? Rsq[lane * n + lane] : 1.0;
             const double ha = hd < 0 ? -hd : hd;
             const double hscale = -wave_min((lane < n) ? -ha : 0.0);
             const double ftol = hscale > 0 ? st.zero_tol * hscale : st.zero_tol;
-            const bool fail = lane < n && hd <= ftol;
-            const int code = (st.eps_prox == 0.0 && hd <= st.zero_tol) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;
+            bool fail = lane < n && hd <= ftol;
+            int code = (st.eps_prox == 0.0 && hd <= st.zero_tol) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;
+            if constexpr (PROX) {   // semi-proximal: the singular coordinates only, remembered in prox_mask (utils.c:294-303)
+                const bool low = lane < n && (fail || force);
+                if (low) hd += shift;
+                if (lane < n) b.prox_mask[(size_t)q * n + lane] = low ? 1 : 0;
+                nprox = __popcll(__ballot(low));
+                fail = lane < n && hd <= st.zero_tol;
+                code = DAQP_EXIT_NONCONVEX;
+            }
             const unsigned long long fm = __ballot(fail);
             if (fm) flag = __builtin_amdgcn_readlane(code, __ffsll((long long)fm) - 1);   // the reference stops at the first such i
             else {
@@ -195,7 +213,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
             const int kend = isdiag ? 0 : ((P == 0) ? n : n - 1 - 8 * (P - 1));
             for (; k < kend && flag > 0; ++k) {
                 const double dg = rl(c[0], k);
-                if (dg <= st.zero_tol) { flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT; break; }
+                if (dg <= st.zero_tol) { flag = (!PROX && st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT; break; }
                 if (dg < pmin) pmin = dg;
                 if (dg > pmax) pmax = dg;
                 const double dgi = 1 / sqrt(dg);
@@ -220,8 +238,14 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
                 });
             }
         });
-        if (flag > 0 && !isdiag && pmin <= st.zero_tol * pmax)
-            flag = (st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;
+        if (flag > 0 && !isdiag && pmin <= ((PROX && !force) ? sqrt(st.zero_tol) : st.zero_tol) * pmax)   // utils.c:354-356
+            flag = (!PROX && st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;
+        if constexpr (PROX) {
+            if (flag > 0 && !isdiag) {
+                nprox = n;
+                if (lane < n) b.prox_mask[(size_t)q * n + lane] = 1;
+            }
+        }
         WSYNC();
     }
     SPROF(0);
@@ -474,7 +498,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
     if (lane == 0) {
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
-        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag; qs->n_prox = 0;
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag; qs->n_prox = (flag > 0) ? nprox : 0;
         if (kProfile && b.prof) for (int i = 0; i < 10; ++i) b.prof[(size_t)q * 32 + i] = pt[i];
     }
 #undef SPROF

@@ -500,3 +500,22 @@ def generate_equality_qp(n, m, ms, neq, rng):
         s[j] = 5
     q.update(bupper=bu, blower=bl, sense=s)
     return q
+
+
+def add_sense_variety(q, ms, n_eq, n_soft, rng):
+    """Turn n_eq general rows of a generated problem into equalities through the midpoint of their bounds (sense 5) and
+    flag n_soft others as soft (sense 8): the equality / soft-constraint branches inside the proximal loop."""
+    r = np.random.default_rng(rng)
+    m = q["bupper"].size
+    rows = ms + r.permutation(m - ms)
+    s = q["sense"].copy()
+    bu, bl = q["bupper"].copy(), q["blower"].copy()
+    for j in rows[:n_eq]:
+        mid = 0.5 * (min(bu[j], 1e3) + max(bl[j], -1e3))
+        bu[j] = bl[j] = mid
+        s[j] = 5
+    for j in rows[n_eq:n_eq + n_soft]:
+        s[j] = 8
+    out = dict(q)
+    out.update(bupper=bu, blower=bl, sense=s)
+    return out

@@ -231,6 +231,16 @@ def main():
             f = f + 0.3 * rng.standard_normal(n)
             assert om.update(O.UPDATE_v, f=f) == rm.update(O.UPDATE_v, f=f) == 0
         rm.close()
+    # equalities and soft rows inside the proximal loop (QPs and LPs)
+    for k in range(args.n_per_config):
+        rng = np.random.default_rng([601, k])
+        n = int(rng.integers(3, 25)); m = int(rng.integers(n + 3, 3 * n + 4)); ms = int(rng.integers(0, min(n, 4) + 1)) if k % 2 else 0
+        if k % 3 == 0:
+            q = O.generate_lp(n, m, ms, [602, k])
+        else:
+            q = O.generate_singular_qp(n, m, ms, rank=int(rng.integers(1, n)), rng=[603, k], kind="diag" if k % 4 == 1 else "dense", in_range=(k % 5 == 0))
+        q = O.add_sense_variety(q, ms, int(rng.integers(0, min(4, n - 1) + 1)), int(rng.integers(0, 3)), [604, k])
+        check(f"prox_sense[{k}]", q, O.default_settings(eps_prox=1e-2, eta_prox=1e-8) if k % 5 == 0 else None)
     print(f"pin result: {total - bad}/{total} bit-identical to the strict reference build")
     return 1 if bad else 0
 

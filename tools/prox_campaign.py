@@ -44,6 +44,10 @@ for s, (n, m, ms) in enumerate(shapes):
         else:
             qs.append(O.generate_singular_qp(n, m, ms, rank=1 + (k * 5) % max(1, n - 1), rng=[503, s, k],
                                              kind="diag" if kind == "diag" else "dense", in_range=(kind == "range")))
+    if s % 3 == 1:   # equalities (at most 4: below the reference's elimination threshold) and soft rows inside the proximal loop
+        vr = np.random.default_rng([504, s])
+        qs = [O.add_sense_variety(q, ms, int(vr.integers(0, min(4, n - 1, m - ms) + 1)), int(vr.integers(0, 3)) if m - ms > 6 else 0, [505, s, k])
+              for k, q in enumerate(qs)]
     st = O.default_settings(**kw)
     ref = [ora.quadprog(q.get("H"), q["f"], q["A"], q["bupper"], q["blower"], q["sense"], settings=st) for q in qs]
     b = {k: np.stack([q[k] for q in qs]) for k in ("f", "A", "bupper", "blower", "sense")}

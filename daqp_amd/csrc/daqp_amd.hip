@@ -136,12 +136,12 @@ ldp_kernel_t pick_ldp(const DAQPBatch *b)
 #endif
 }
 
-int launch_ldp(DAQPBatch *b, int mode)
+int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
 {
     if (b->NB > 0) {
         ldp_reg_kernel_t kr = pick_ldp_reg(b);
         // the descriptor travels through device memory: stream-ordered copy, then the launch
-        HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
+        if (descriptor_changed) HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
         hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode);
         HIPCHK(hipGetLastError());
@@ -253,9 +253,9 @@ int regularise(DAQPBatch *b, int mask, bool lp)
     return 0;
 }
 // daqp_update_ldp(mask within UPDATE_v|UPDATE_d) followed by daqp_solve, whichever kernels the shape uses
-int launch_update_solve(DAQPBatch *b, int mask)
+int launch_update_solve(DAQPBatch *b, int mask, bool descriptor_changed)
 {
-    if (b->NB > 0) return launch_ldp(b, 2 | (mask << 4));
+    if (b->NB > 0) return launch_ldp(b, 2 | (mask << 4), descriptor_changed);
     hipLaunchKernelGGL(k_update, dim3(b->d.N), dim3(64), b->lds_update, b->stream, b->d, mask);
     HIPCHK(hipGetLastError());
     if (launch_ldp(b, 1)) return DAQP_EXIT_UNSUPPORTED;
@@ -284,20 +284,21 @@ int solve_with_prox(DAQPBatch *b, int mode)
         else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_gradient<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grad));
     }
     int rc = 0, outer = 0;
-    for (;; ++outer) {
-        hipLaunchKernelGGL(k_prox_pre, dim3(d.N), dim3(64), 0, b->stream, d, b->px, f_user);
-        if (hipGetLastError() != hipSuccess) { rc = 1; break; }
+    hipLaunchKernelGGL(k_prox_pre, dim3(d.N), dim3(64), 0, b->stream, d, b->px, f_user);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+    for (; !rc; ++outer) {
         if (hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream) != hipSuccess) { rc = 1; break; }
-        if (launch_update_solve(b, DAQP_UPDATE_v | DAQP_UPDATE_d)) { rc = 1; break; }
+        if (launch_update_solve(b, DAQP_UPDATE_v | DAQP_UPDATE_d, outer == 0)) { rc = 1; break; }
+        // the fixed-point test; problems that go on get their next input here (or from the gradient step below)
         hipLaunchKernelGGL(k_prox_post, dim3(d.N), dim3(64), 0, b->stream, d, b->px, (const double *)d.x, po);
         if (hipGetLastError() != hipSuccess) { rc = 1; break; }
-        if (b->px.lp) {   // LP iterates off a vertex walk to the next constraint (a no-op launch for everybody else)
+        if (read_counters(b)) { rc = 1; break; }
+        if (b->counter_host[2] == 0) break;
+        if (b->counter_host[3] > 0) {   // LP iterates off a vertex walk to the next constraint
             if (b->spill) hipLaunchKernelGGL((k_lp_gradient<4, true>), dim3(d.N), dim3(64), lds_grad, b->stream, d, b->px, d.x, po);
             else hipLaunchKernelGGL((k_lp_gradient<4, false>), dim3(d.N), dim3(64), lds_grad, b->stream, d, b->px, d.x, po);
             if (hipGetLastError() != hipSuccess) { rc = 1; break; }
         }
-        if (read_counters(b)) { rc = 1; break; }
-        if (b->counter_host[2] == 0) break;
     }
     b->prox_outer = outer + 1;
     d.f = f_user; d.fval = o_fval; d.soft = o_soft; d.exitflag = o_flag; d.iter = o_iter;

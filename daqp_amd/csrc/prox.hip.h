@@ -115,14 +115,15 @@ __global__ void k_prox_mark(BatchDev b, ProxDev p, int which)
     } else if (qs->setup_flag == DAQP_PROX_SKIP) qs->setup_flag = p.saved_flag[q];
 }
 
-// One wave per problem: v's input f - eps*P*x and xold <- x (daqp_prox.c:66-104,125-126)
-__global__ __launch_bounds__(64) void k_prox_pre(BatchDev b, ProxDev p, const double *f)
+// The input of the next inner problem (daqp_prox.c:66-104,125-126): f - eps*P*x (an LP: eps*f - x with the adapted eps)
+// and xold <- x, from the centre.  Whole wave; every lane reads only centre entries it wrote itself (index = lane + 64 j).
+// total: inner iterations so far in this solve, last_it: those of the last inner solve.
+__device__ inline void prox_next_input(const BatchDev &b, const ProxDev &p, const double *f, int q, int total, int last_it)
 {
-    const int q = blockIdx.x, lane = threadIdx.x, n = b.n;
-    if (!p.state[4 * (size_t)q]) return;
+    const int lane = threadIdx.x, n = b.n;
     if (p.lp) {   // smoothing weight: x10 while the inner LP stalls, x0.9 otherwise, at most 1e3 (daqp_prox.c:69-78)
         double eps = p.eps[q];
-        if (p.state[4 * (size_t)q + 1] > 0) eps *= (p.t_iter[q] == 1) ? 10.0 : 0.9;
+        if (total > 0) eps *= (last_it == 1) ? 10.0 : 0.9;
         if (eps > 1e3) eps = 1e3;
         for (int i = lane; i < n; i += 64) {
             const double x = p.center[(size_t)q * n + i];
@@ -139,6 +140,13 @@ __global__ __launch_bounds__(64) void k_prox_pre(BatchDev b, ProxDev p, const do
         p.feff[(size_t)q * n + i] = f[(size_t)q * n + i] - (mask[i] ? eps : 0.0) * x;
         p.xold[(size_t)q * n + i] = x;
     }
+}
+// the first outer iteration's input (the later ones are formed by k_prox_post / k_lp_gradient as they decide to go on)
+__global__ __launch_bounds__(64) void k_prox_pre(BatchDev b, ProxDev p, const double *f)
+{
+    const int q = blockIdx.x;
+    if (!p.state[4 * (size_t)q]) return;
+    prox_next_input(b, p, f, q, 0, 0);
 }
 
 // The end of a problem's loop (daqp_prox.c:200-221, api.c:455-495): exit flag (the iteration budget overrides), fval,
@@ -178,7 +186,7 @@ __device__ inline void prox_finish(const BatchDev &b, const ProxDev &p, const Pr
 
 // One wave per problem, after an inner solve: daqp_prox.c:137-198.  x is the inner solution (already R^-1 (u - v), in the
 // output array); the per-problem outputs are written when its loop ends.  state[0] after this: 0 finished, 1 goes on,
-// 2 goes on after a gradient step (LP, k_lp_gradient).  counter[2] += problems that go on.
+// 2 goes on after a gradient step (LP, k_lp_gradient).  counter[2] += problems that go on, counter[3] += those of state 2.
 __global__ __launch_bounds__(64) void k_prox_post(BatchDev b, ProxDev p, const double *x_all, ProxOut o)
 {
     const int q = blockIdx.x, lane = threadIdx.x, n = b.n;
@@ -224,7 +232,10 @@ __global__ __launch_bounds__(64) void k_prox_post(BatchDev b, ProxDev p, const d
     if (done) {
         if (flag >= 0 || total >= limit) for (int i = lane; i < n; i += 64) center[i] = x[i];
         prox_finish(b, p, o, q, flag, total, x);
-    } else if (lane == 0) { st[0] = grad ? 2 : 1; atomicAdd(p.counter + 2, 1); }
+    } else {
+        if (lane == 0) { st[0] = grad ? 2 : 1; atomicAdd(p.counter + 2, 1); if (grad) atomicAdd(p.counter + 3, 1); }
+        if (!grad) prox_next_input(b, p, o.f, q, total, it);
+    }
 }
 
 // gradient_step (daqp_prox.c:232-303) for the LP problems that asked for it (state 2): move x along x - xold to the first
@@ -347,6 +358,7 @@ __global__ __launch_bounds__(64) void k_lp_gradient(BatchDev b, ProxDev p, doubl
     }
     __threadfence();
     if (total >= b.st.iter_limit) prox_finish(b, p, o, q, DAQP_EXIT_ITERLIMIT, total, xo);   // the budget ran out on this very step
+    else prox_next_input(b, p, o.f, q, total, 1);   // (a gradient step follows an inner solve of one iteration)
 }
 
 } // namespace daqp_amd

@@ -1127,6 +1127,11 @@ void ora_quadprog_batch(int N, int n, int m, int ms, const double *H, const doub
 }
 
 /* read-back helpers for tests */
+/* daqp_set_primal_start (api.c:636-641): the iterate the proximal loop starts from */
+void ora_set_primal_start(ora_work *w, const double *x)
+{
+    if (w->sing_ind != ORA_UNCONSTRAINED) for (int i = 0; i < w->n; i++) w->x[i] = x[i];
+}
 int ora_get_prox(const ora_work *w, int *nh, int *mask)
 {
     if (nh) *nh = w->nh;

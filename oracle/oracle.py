@@ -93,6 +93,8 @@ class Oracle:
         L.ora_get_state.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p, c_double_p]
         L.ora_get_ldp.argtypes = [C.c_void_p] + [c_double_p] * 6
         L.ora_get_prox.argtypes = [C.c_void_p, c_int_p, c_int_p]
+        L.ora_set_primal_start.argtypes = [C.c_void_p, c_double_p]
+        L.ora_set_primal_start.restype = None
 
     def quadprog(self, H, f, A, bupper, blower, sense=None, settings=None):
         H, f, A, bupper, blower, sense = _f64(H), _f64(f), _f64(A), _f64(bupper), _f64(blower), _i32(sense)
@@ -169,6 +171,9 @@ class OracleModel:
         sing = self.o.lib.ora_get_state(self.h, C.byref(na), _ip(WS), _ip(sense), _dp(D))
         return WS[: na.value].copy(), sense, D[: na.value].copy(), sing
 
+    def set_primal_start(self, x):
+        self.o.lib.ora_set_primal_start(self.h, _dp(_f64(x)))
+
     def prox(self):
         """(n_prox, outer iterations of the last solve, prox_mask)"""
         nh, mask = C.c_int(0), np.zeros(self.n, np.int32)
@@ -226,6 +231,8 @@ class Reference:
         L.free_daqp_workspace.argtypes = [C.c_void_p]
         L.free_daqp_ldp.argtypes = [C.c_void_p]
         L.daqp_default_settings.argtypes = [C.POINTER(Settings)]
+        L.daqp_set_primal_start.argtypes = [C.c_void_p, c_double_p]
+        L.daqp_set_primal_start.restype = None
 
     @staticmethod
     def _problem(H, f, A, bupper, blower, sense, ms):
@@ -296,6 +303,10 @@ class ReferenceModel:
         res = _Result(_dp(x), _dp(lam), 0, 0, 0, 0, 0, 0, 0)
         self.r.lib.daqp_solve(C.byref(res), self.ws)
         return x, lam, res.fval, res.exitflag, res.iter
+
+    def set_primal_start(self, x):
+        x = _f64(x)
+        self.r.lib.daqp_set_primal_start(C.byref(self.ws), _dp(x))
 
     def working_set(self):
         na = C.c_int.from_buffer(self.ws, _WS_NACTIVE_OFF).value

@@ -241,6 +241,22 @@ def main():
             q = O.generate_singular_qp(n, m, ms, rank=int(rng.integers(1, n)), rng=[603, k], kind="diag" if k % 4 == 1 else "dense", in_range=(k % 5 == 0))
         q = O.add_sense_variety(q, ms, int(rng.integers(0, min(4, n - 1) + 1)), int(rng.integers(0, 3)), [604, k])
         check(f"prox_sense[{k}]", q, O.default_settings(eps_prox=1e-2, eta_prox=1e-8) if k % 5 == 0 else None)
+    # daqp_set_primal_start (api.c:636-641): the proximal loop from a given iterate
+    for k in range(max(10, args.n_per_config // 3)):
+        rng = np.random.default_rng([701, k])
+        n = int(rng.integers(3, 25)); m = int(rng.integers(n + 2, 3 * n + 3)); ms = 0 if k % 2 else min(2, n)
+        q = O.generate_lp(n, m, ms, [702, k]) if k % 3 == 0 else O.generate_singular_qp(n, m, ms, rank=int(rng.integers(1, n)), rng=[703, k], in_range=(k % 2 == 0))
+        st = O.default_settings(eps_prox=1e-2, eta_prox=1e-8) if k % 4 == 0 else None
+        om, rm = ora.model(n, m, ms, settings=st), strict.model(n, m, ms, settings=st)
+        assert om.setup(**q) == rm.setup(**q) == 1
+        x0 = rng.standard_normal(n)
+        om.set_primal_start(x0); rm.set_primal_start(x0)
+        a, b = om.solve(), rm.solve()
+        total += 1
+        if not (a[3] == b[3] and a[4] == b[4] and (a[3] < 0 or (same(a[0], b[0]) and same(a[1], b[1]) and same(a[2], b[2])))):
+            bad += 1
+            print(f"MISMATCH primal_start[{k}] {a[3]}/{a[4]} vs {b[3]}/{b[4]}")
+        rm.close()
     print(f"pin result: {total - bad}/{total} bit-identical to the strict reference build")
     return 1 if bad else 0
 

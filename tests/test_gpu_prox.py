@@ -262,3 +262,44 @@ def test_linear_program_batches(oracle, gpu_lib, monkeypatch, n, m, ms):
         if flag > 0:
             assert same(r2["x"][k], x) and same(r2["lam"][k], lam) and same(r2["fval"][k], fval), k
     mdl.close()
+
+
+def test_primal_start(oracle, gpu_lib, monkeypatch):
+    """daqp_set_primal_start (api.c:636-641) / daqp_batch_set_primal_start: the proximal iterations from a given point --
+    batch API and drop-in workspace, singular QPs and LPs."""
+    import ctypes as C
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, N = 10, 26, 2, 12
+    for lp in (False, True):
+        qs = [O.generate_lp(n, m, ms, [86, k]) if lp else O.generate_singular_qp(n, m, ms, rank=3 + k % 5, rng=[87, k], in_range=(k % 2 == 0))
+              for k in range(N)]
+        kw = {} if lp else dict(eps_prox=1e-2, eta_prox=1e-8)
+        x0 = np.random.default_rng(88).standard_normal((N, n))
+        refs = []
+        for k, q in enumerate(qs):
+            om = oracle.model(n, m, ms, settings=O.default_settings(**kw))
+            assert om.setup(**q) == 1
+            om.set_primal_start(x0[k])
+            refs.append(om.solve())
+        b = {kk: np.stack([q[kk] for q in qs]) for kk in ("f", "A", "bupper", "blower", "sense")}
+        H = None if lp else np.stack([q["H"] for q in qs])
+        mdl = daqp_amd.BatchModel(N, n, m, ms, **kw)
+        mdl.setup(H, b["f"], b["A"], b["bupper"], b["blower"], b["sense"])
+        mdl.set_primal_start(x0)
+        r = mdl.solve()
+        for k in range(N):
+            x, lam, fval, flag, it = refs[k][:5]
+            assert r["exitflag"][k] == flag and r["iter"][k] == it, (lp, k, r["iter"][k], it)
+            if flag > 0:
+                assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), (lp, k)
+        mdl.close()
+        # the drop-in workspace
+        one = daqp_amd.Model()
+        q = qs[0]
+        flag, _ = one.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"], **kw)
+        assert flag == 1
+        xs = np.ascontiguousarray(x0[0])
+        daqp_amd.lib().daqp_set_primal_start(one._ws, xs.ctypes.data_as(C.POINTER(C.c_double)))
+        x, fval, fl, info = one.solve()
+        assert fl == refs[0][3] and info["iterations"] == refs[0][4] and same(x, refs[0][0]) and fval == refs[0][2]

@@ -303,3 +303,34 @@ def test_primal_start(oracle, gpu_lib, monkeypatch):
         daqp_amd.lib().daqp_set_primal_start(one._ws, xs.ctypes.data_as(C.POINTER(C.c_double)))
         x, fval, fl, info = one.solve()
         assert fl == refs[0][3] and info["iterations"] == refs[0][4] and same(x, refs[0][0]) and fval == refs[0][2]
+
+
+def test_shift_doubling(oracle, gpu_lib, monkeypatch):
+    """slightly indefinite Hessians: the first shift is not enough, eps doubles pass after pass (utils.c:357-360) -- a
+    different number of passes for different problems of one batch, some never definite (-5)."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, N = 9, 22, 2, 14
+    qs = []
+    for k in range(N):
+        q = O.generate_singular_qp(n, m, ms, rank=4 + k % 4, rng=[89, k])
+        q["H"] = q["H"] - [1e-5, 1e-3, 0.05, 0.7, 3.0, 40.0, 1e5][k % 7] * np.eye(n)
+        qs.append(q)
+    ref = oracle_each(oracle, qs)
+    assert {r[3] for r in ref} >= {1, -5}
+    b = stack(qs)
+    mdl = daqp_amd.BatchModel(N, n, m, ms)
+    mdl.setup(b["H"], b["f"], b["A"], b["bupper"], b["blower"], b["sense"], init_mask=64)
+    flags = mdl.setup_flags()
+    r = mdl.solve()
+    eps = mdl.prox_info()["eps"]
+    assert len({float(e) for e in eps if e > 0}) >= 4      # several different numbers of doublings in one batch
+    for k in range(N):
+        x, lam, fval, flag, it = ref[k]
+        assert r["exitflag"][k] == flag, (k, r["exitflag"][k], flag)
+        assert (flags[k] == 1) == (flag != -5)
+        if flag != -5:
+            assert r["iter"][k] == it
+        if flag > 0:
+            assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), k
+    mdl.close()

@@ -1,7 +1,7 @@
-// daqp_amd/csrc/prox.hip.h -- the proximal outer loop for singular (or forcibly regularised) Hessians.
+// daqp_amd/csrc/prox.hip.h -- the proximal outer loop for singular (or forcibly regularised) Hessians and for LPs.
 //
-// Reference: daqp_prox (src/daqp_prox.c:21-221, QP branch), the regularisation logic of daqp_update_Rinv
-// (src/utils.c:223-391) and daqp_get_proximal_regularization (src/utils.c:393-432).
+// Reference: daqp_prox and its gradient_step (src/daqp_prox.c:21-303, QP and LP branches), the regularisation logic of
+// daqp_update_Rinv (src/utils.c:223-391) and daqp_get_proximal_regularization (src/utils.c:393-432).
 //
 // The inner least-distance problems are solved by the very same kernels as every other problem (k_ldp_reg / k_ldp with
 // a fused or eager UPDATE_v|UPDATE_d): the outer loop is a handful of O(n) kernels around those launches, driven from the
@@ -14,7 +14,7 @@
 namespace daqp_amd {
 
 struct ProxDev {
-    double *eps;        // [N] shift the factor in use was built with (as reconstructed by utils.c:393-432)
+    double *eps;        // [N] shift the factor in use was built with (as reconstructed by utils.c:393-432); an LP: its current smoothing weight
     double *hshift;     // [N] shift tried by the current setup pass
     int *tries;         // [N] doublings so far (utils.c:358)
     double *center;     // [N][n] the reference's work->x between inner solves: survives daqp_batch_solve calls

@@ -79,7 +79,7 @@ struct DAQPBatch {
     // proximal outer loop (prox.hip.h): buffers appear with the first singular Hessian
     ProxDev px{};
     bool prox_ready = false;
-    int *counter_host = nullptr;   // pinned, 4 ints
+    int counter_host[4] = {0, 0, 0, 0};   // read-back of px.counter
     int n_prox_qps = 0;            // problems of the current setup that go through the outer loop
     int prox_outer = 0;            // outer iterations of the last solve (the longest loop of the batch)
     double *ident = nullptr;       // LP batches (H == NULL): the one n x n identity the setup pass reads as H
@@ -417,7 +417,6 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &b->st_dev, 1);
     rc |= dev_alloc(b, &b->d_dev, 1);
     rc |= dev_alloc(b, &b->px.counter, 4);
-    if (!rc && hipHostMalloc(reinterpret_cast<void **>(&b->counter_host), 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = 1;
     if (!rc && hipMemcpy(b->st_dev, &d.st, sizeof(DAQPSettings), hipMemcpyHostToDevice) != hipSuccess) rc = 1;
     d.st_dev = b->st_dev;
     if (rc) { daqp_batch_free(b); return DAQP_EXIT_UNSUPPORTED; }
@@ -440,7 +439,6 @@ void daqp_batch_free(DAQPBatch *b)
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
     for (void *p : b->owned) (void)hipFree(p);
-    if (b->counter_host) (void)hipHostFree(b->counter_host);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }

@@ -69,7 +69,8 @@ __host__ __device__ inline SetupLds setup_lds(int n, int m, bool gs = false)
     s.R = o; if (!gs) o += rt; s.Rout = o; if (!gs) o += rt;
     s.fv = o; o += np; s.vv = o; o += np; s.xu = o; o += np;
     s.sc = o; o += mp; s.du = o; o += mp; s.dl = o; o += mp;
-    s.tile = o; if (!gs) o += round_up(64 * ldr, 2);
+    s.tile = o;   // !gs: the 64-row Cholesky/inverse tile; both: the 16-row block of A and the 16 x 64 result block of the M phase
+    { const int mblk = 16 * np + 16 * 64, til = gs ? 0 : round_up(64 * ldr, 2); o += til > mblk ? til : mblk; }
     s.sens = o;
     s.total_bytes = o * 8 + round_up(m, 4) * 4;
     return s;
@@ -137,6 +138,10 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     const bool force = st.eps_prox > 0.0 && pp != 2;
     const int shift_code = (!pp && st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;   // eps == 0: utils.c:357,367
     int nprox = 0;
+    // optional phase cycle counters -> b.prof[q][16..21]: checks, Cholesky, inverse, v/x_unc, M rows, simple bounds + write-back
+    long long gpt[6] = {0, 0, 0, 0, 0, 0};
+    long long gt0 = b.prof ? (long long)__builtin_readcyclecounter() : 0;
+#define GPROF(slot) do { if (b.prof) { const long long t1 = (long long)__builtin_readcyclecounter(); gpt[slot] += t1 - gt0; gt0 = t1; } } while (0)
 
     // --- sense (utils.c:84-91) and early bound check (utils.c:546-567)
     int bad = 0;
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             WSYNC();
         }
     }
+    GPROF(0);
     if (flag > 0 && !diag) {
         for (int e0 = lane; e0 < n * n; e0 += 64 * 8) {   // 16 loads per lane per trip (H and its transpose), then the stores
             double h1[8], h2[8];
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             for (int i = lane; i < n; i += 64) b.prox_mask[(size_t)q * n + i] = 1;
         }
     }
+    GPROF(1);
     // --- R -> R^-1, row by row as utils.c:380-389: lane <-> row k works on its own copy,
     // reading the untouched Cholesky rows i > k
     if (flag > 0) {
@@ -290,6 +297,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
         }
         WSYNC();
       }
+        GPROF(2);
         // --- v = R^-T f (utils.c:474-497, mask has UPDATE_Rinv: no column scaling)
         for (int ic = 0; ic < n; ic += 64) {
             const int i = ic + lane;
@@ -332,69 +340,148 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     }
 
     // --- general rows: M = A R^-1 (utils.c:434-472), normalise (utils.c:586-613), d (utils.c:499-544
-    // or, after the shortcut, utils.c:664-676 + 151-159).  64 rows at a time through an LDS tile;
-    // lane <-> row; the row is overwritten in place from the last column down.
+    // or, after the shortcut, utils.c:664-676 + 151-159).
+    // Phase A forms the unnormalised rows, KB at a time, with lane <-> COLUMN: entry (k, c) is the reference's chain
+    // R^-1[c][c] a[c] + R^-1[c-1][c] a[c-1] + ... + R^-1[0][c] a[0] in that order, so step r of all 64 chains of a column
+    // block reads one contiguous stretch of row r of the packed R^-1 (a coalesced load, shared by the KB rows) and the KB
+    // values a_k[r] as LDS broadcasts -- wherever the factors live (LDS or HBM scratch) nothing is fetched per lane and
+    // per term any more.  Phase B (lane <-> row, the blocked image read back coalesced) normalises and forms d.
     int feasible = 1;
     double *Mq = b.Mblk + (size_t)q * b.nblk * b.npair * 128;
     if (flag > 0) {
-        for (int tb = 0; tb < mA && flag > 0; tb += 64) {
-            const int rows = (mA - tb) < 64 ? (mA - tb) : 64;
+        constexpr int KB = 16;
+        const int np2 = round_up(n, 2);
+        double *at = smem + o.tile;               // [KB][np2] rows of A
+        double *ob = at + KB * np2;               // [KB][64] one column block of results on its way to the blocked image
+        double2 *Mq2 = reinterpret_cast<double2 *>(Mq);
+        for (int kb = 0; kb < mA; kb += KB) {
+            const int rows = (mA - kb) < KB ? (mA - kb) : KB;
             WSYNC();
-            stage_rows(tile, A + (size_t)tb * n, rows, n, ldr);   // 16 loads per lane in flight, no division
+            stage_rows(at, A + (size_t)kb * n, rows, n, np2);
+            for (int e = lane; e < (KB - rows) * np2; e += 64) at[rows * np2 + e] = 0.0;
             WSYNC();
-            const int k = tb + lane;
-            const bool own = lane < rows;
-            double *a = tile + lane * ldr;
-            double sunc = 0, scal = 1.0, dsum = 0;
-            int zero_row = 0, rowbad = 0;
-            if (own) {
-                const int gi = ms + k;
-                if (unc) { for (int j = 0; j < n; ++j) sunc += a[j] * xu[j]; }
-                for (int c = n - 1; c >= 0; --c) {
-                    double acc = Ro[roff(c, n) + c] * a[c];
-                    for (int r0 = c - 1; r0 >= 0; r0 -= 8) {   // decreasing r, 8 per trip with the loads first
-                        double rv[8], av[8];
+            if (unc && lane < rows) {             // A_k . x_unc, parked in dupper until phase B (utils.c:664-668)
+                double sunc = 0;
+                for (int j = 0; j < n; ++j) sunc += at[lane * np2 + j] * xu[j];
+                du[ms + kb + lane] = sunc;
+            }
+            for (int cb = 0; cb < n; cb += 64) {
+                const int c = cb + lane;
+                const bool has = c < n;
+                double acc[KB];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { const int r = (r0 - u >= 0) ? r0 - u : 0; rv[u] = Ro[roff(r, n) + c]; av[u] = a[r]; }
+                for (int k = 0; k < KB; ++k) acc[k] = 0.0;
+                const int rtop = (n - 1 < cb + 63) ? n - 1 : cb + 63;
+                // the diagonal block: a lane joins at r == c with an assignment (utils.c:444), lanes right of it accumulate
+                for (int r0 = rtop; r0 >= cb; r0 -= 8) {
+                    double rv[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) if (r0 - u >= 0) acc += rv[u] * av[u];
+                    for (int u = 0; u < 8; ++u) { const int r = r0 - u; rv[u] = (has && r >= cb && r <= c) ? Ro[roff(r, n) + c] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int r = r0 - u;
+                        if (r >= cb) {
+                            const bool on = has && r <= c;
+#pragma unroll
+                            for (int k = 0; k < KB; ++k) {
+                                const double pr = rv[u] * at[k * np2 + r];
+                                acc[k] = (r == c) ? pr : (on ? acc[k] + pr : acc[k]);
+                            }
+                        }
                     }
-                    a[c] = acc;
                 }
+                // above it every lane of the block takes part: 8 rows of R^-1 in flight, then KB x 8 multiply-adds
+                for (int rb = (cb >> 3) - 1; rb >= 0; --rb) {   // rows 8 rb + 7 ... 8 rb (cb is a multiple of 64)
+                    double rv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rv[u] = has ? Ro[roff(8 * rb + 7 - u, n) + c] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) {
+                        const double2 *ap = reinterpret_cast<const double2 *>(at + k * np2 + 8 * rb);   // 64-byte aligned: four 16-byte broadcasts
+                        const double2 a67 = ap[3], a45 = ap[2], a23 = ap[1], a01 = ap[0];
+                        acc[k] += rv[0] * a67.y; acc[k] += rv[1] * a67.x;
+                        acc[k] += rv[2] * a45.y; acc[k] += rv[3] * a45.x;
+                        acc[k] += rv[4] * a23.y; acc[k] += rv[5] * a23.x;
+                        acc[k] += rv[6] * a01.y; acc[k] += rv[7] * a01.x;
+                    }
+                }
+                // through LDS into the blocked image [row/64][col/2][row%64][col%2]: 16 rows x 16 bytes contiguous per column pair
+                WSYNC();
+#pragma unroll
+                for (int k = 0; k < KB; ++k) ob[k * 64 + lane] = has ? acc[k] : 0.0;
+                WSYNC();
+                const int pairs = ((rtop - cb) >> 1) + 1;
+                for (int idx = lane; idx < pairs * KB; idx += 64) {
+                    const int k = idx & (KB - 1), t = idx >> 4;
+                    if (k < rows) {
+                        const int gi = ms + kb + k;
+                        double2 vpair;
+                        vpair.x = ob[k * 64 + 2 * t];
+                        vpair.y = (cb + 2 * t + 1 < n) ? ob[k * 64 + 2 * t + 1] : 0.0;
+                        Mq2[((size_t)(gi >> 6) * b.npair + (cb >> 1) + t) * 64 + (gi & 63)] = vpair;
+                    }
+                }
+            }
+        }
+        __threadfence();   // phase B reads the image back through other lanes
+        WSYNC();
+        for (int tb = 0; tb < mA && flag > 0; tb += 64) {
+            const int k = tb + lane;
+            const bool own = k < mA;
+            const int gi = ms + (own ? k : 0);
+            double2 *rowp = Mq2 + ((size_t)(gi >> 6) * b.npair) * 64 + (gi & 63);
+            int rowbad = 0;
+            if (own) {
                 double s = 0;
-                for (int c = 0; c < n; ++c) s += a[c] * a[c];
+                for (int t0 = 0; t0 < b.npair; t0 += 8) {   // ||M_k||^2 in column order, 8 loads in flight
+                    double2 v8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v8[u] = rowp[(size_t)((t0 + u < b.npair) ? t0 + u : 0) * 64];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = t0 + u;
+                        if (t < b.npair) { s += v8[u].x * v8[u].x; if (2 * t + 1 < n) s += v8[u].y * v8[u].y; }
+                    }
+                }
+                double scal = 1.0;
+                bool scale_it = true;
                 if (s < st.zero_tol) {
-                    zero_row = 1;
+                    scale_it = false;
                     if (bu[gi] < -st.zero_tol || bl[gi] > st.zero_tol)
                         if (!(sens[gi] & DAQP_IMMUTABLE) && !(sens[gi] & DAQP_SOFT)) rowbad = 1;
                     sens[gi] = DAQP_IMMUTABLE;
-                } else {
-                    scal = 1 / sqrt(s);
-                    for (int c = 0; c < n; ++c) a[c] *= scal;
+                } else scal = 1 / sqrt(s);
+                double dsum = 0;
+                for (int t0 = 0; t0 < b.npair; t0 += 8) {
+                    double2 v8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v8[u] = rowp[(size_t)((t0 + u < b.npair) ? t0 + u : 0) * 64];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = t0 + u;
+                        if (t < b.npair) {
+                            double2 w = v8[u];
+                            if (scale_it) { w.x *= scal; if (2 * t + 1 < n) w.y *= scal; }
+                            if (!unc) { dsum += w.x * vv[2 * t]; if (2 * t + 1 < n) dsum += w.y * vv[2 * t + 1]; }
+                            if (scale_it) rowp[(size_t)t * 64] = w;
+                        }
+                    }
                 }
                 sc[gi] = scal;
                 if (unc) {
+                    const double sunc = du[gi];
                     const double u0 = bu[gi] - sunc, l0 = bl[gi] - sunc;
                     if (u0 < -st.primal_tol || l0 > st.primal_tol) feasible = 0;
                     du[gi] = u0 * scal; dl[gi] = l0 * scal;
                 } else {
-                    for (int j = 0; j < n; ++j) dsum += a[j] * vv[j];
                     du[gi] = bu[gi] * scal + dsum;
                     dl[gi] = bl[gi] * scal + dsum;
                 }
-                // blocked store: [row/64][k/2][row%64][k%2]
-                double2 *dst = reinterpret_cast<double2 *>(Mq) + ((size_t)(gi >> 6) * b.npair) * 64 + (gi & 63);
-                for (int t = 0; t < b.npair; ++t) {
-                    double2 vpair;
-                    vpair.x = a[2 * t];
-                    vpair.y = (2 * t + 1 < n) ? a[2 * t + 1] : 0.0;
-                    dst[(size_t)t * 64] = vpair;
-                }
             }
-            (void)zero_row;
             if (__any(rowbad)) flag = DAQP_EXIT_INFEASIBLE; // reference returns at the first such row
         }
     }
+    GPROF(4);
     // --- simple bounds: normalise rows < ms of R^-1 (utils.c:569-585), their d, and their dense image in M
     if (flag > 0) {
         WSYNC();
@@ -454,6 +541,9 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag; qs->n_prox = (flag > 0) ? nprox : 0;
     }
+    GPROF(5);
+    if (b.prof && lane == 0) for (int i = 0; i < 6; ++i) b.prof[(size_t)q * 32 + 16 + i] = gpt[i];
+#undef GPROF
 }
 
 // ------------------------------------------------------------------------------------

@@ -21,5 +21,7 @@ if len(sys.argv) > 2:
     pr = bm.read_profile().astype(float)
     it = r["iter"].double().sum().item()
     names = ["csp", "ratio test(no block)", "primal", "scan", "add (incl. guard)", "ratio test + drop", "-", "-"]
+    sp = pr[:, 16:22].mean(axis=0)
+    print("  setup cycles per QP: checks %.0f, Cholesky %.0f, inverse %.0f, v/x_unc %.0f, M rows %.0f, bounds+write-back %.0f | total %.0f" % (*sp, sp.sum()))
     print("  cycles/iteration:", ", ".join(f"{names[k]} {pr[:, k].sum() / it:.0f}" for k in range(6)), f"| total {pr[:, :6].sum() / it:.0f}")
 print(f"C4 N={N}: {N / dt:.0f} QPs/s, kernels setup/solve ms {bm.kernel_ms()}, mean iter {r['iter'].double().mean().item():.1f}, optimal {(r['exitflag'] == 1).all().item()}, parity(16) {ok}, max|dx| {np.abs(r['x'][:16].cpu().numpy() - ref[0]).max():.1e}")

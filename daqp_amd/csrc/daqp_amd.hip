@@ -407,7 +407,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &d.WS, Nn * cap);
     rc |= dev_alloc(b, &d.qs, Nn);
     if (b->spill) rc |= dev_alloc(b, &d.rowc_g, Nn * cap * d.ldr);
-    if (b->setup_spill) rc |= dev_alloc(b, &d.setup_g, Nn * (2 * (size_t)round_up(d.rtri, 2) + round_up(64 * d.ldr, 2)));
+    if (b->setup_spill) rc |= dev_alloc(b, &d.setup_g, Nn * 2 * (size_t)round_up(d.rtri, 2));
     rc |= dev_alloc(b, &b->ox, Nn * n);
     rc |= dev_alloc(b, &b->olam, Nn * m);
     rc |= dev_alloc(b, &b->ofval, Nn);

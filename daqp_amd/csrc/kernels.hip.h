@@ -29,7 +29,7 @@ struct BatchDev {
     int *WS;           // [N][cap]
     QState *qs;        // [N]
     double *rowc_g;    // [N][cap*ldr] only when the active-row cache / L spill out of LDS
-    double *setup_g;   // [N][2*rtri + 64*ldr] only when the setup factors spill out of LDS
+    double *setup_g;   // [N][2*rtri] only when the setup factors spill out of LDS
     // outputs
     double *x, *lam, *fval, *soft;
     int *exitflag, *iter;
@@ -64,13 +64,12 @@ struct SetupLds { int R, Rout, fv, vv, xu, sc, du, dl, tile, sens, total_bytes; 
 __host__ __device__ inline SetupLds setup_lds(int n, int m, bool gs = false)
 {
     SetupLds s;
-    const int rt = round_up(n * (n + 1) / 2, 2), np = round_up(n, 2), mp = round_up(m, 2), ldr = n | 1;
+    const int rt = round_up(n * (n + 1) / 2, 2), np = round_up(n, 2), mp = round_up(m, 2);
     int o = 0;
     s.R = o; if (!gs) o += rt; s.Rout = o; if (!gs) o += rt;
     s.fv = o; o += np; s.vv = o; o += np; s.xu = o; o += np;
     s.sc = o; o += mp; s.du = o; o += mp; s.dl = o; o += mp;
-    s.tile = o;   // !gs: the 64-row Cholesky/inverse tile; both: the 16-row block of A and the 16 x 64 result block of the M phase
-    { const int mblk = 16 * np + 16 * 64, til = gs ? 0 : round_up(64 * ldr, 2); o += til > mblk ? til : mblk; }
+    s.tile = o; o += 16 * np + 16 * 64;   // the 16-row block of A and the 16 x 64 result block of the M phase
     s.sens = o;
     s.total_bytes = o * 8 + round_up(m, 4) * 4;
     return s;
@@ -107,7 +106,7 @@ __host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill, int
 // ------------------------------------------------------------------------------------
 // k_setup: one wave per QP
 // ------------------------------------------------------------------------------------
-// GS = true: the packed Cholesky factor, R^-1 and the A tile live in per-QP HBM scratch (b.setup_g)
+// GS = true: the packed Cholesky factor and R^-1 live in per-QP HBM scratch (b.setup_g)
 // instead of LDS -- the n = 200 class of problems, where 2 x 160 KB of factors cannot be staged.
 template <bool GS>
 __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
@@ -116,12 +115,12 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     const int q = blockIdx.x, lane = lane_id();
     const int n = b.n, m = b.m, ms = b.ms, mA = b.mA, ldr = b.ldr;
     const SetupLds o = setup_lds(n, m, GS);
-    double *R, *Ro, *tile;
+    double *R, *Ro;
     if constexpr (GS) {
-        const size_t per = 2 * (size_t)round_up(b.rtri, 2) + round_up(64 * ldr, 2);
+        const size_t per = 2 * (size_t)round_up(b.rtri, 2);
         double *g = b.setup_g + (size_t)q * per;
-        R = g; Ro = g + round_up(b.rtri, 2); tile = g + 2 * (size_t)round_up(b.rtri, 2);
-    } else { R = smem + o.R; Ro = smem + o.Rout; tile = smem + o.tile; }
+        R = g; Ro = g + round_up(b.rtri, 2);
+    } else { R = smem + o.R; Ro = smem + o.Rout; }
     double *fl = smem + o.fv, *vv = smem + o.vv, *xu = smem + o.xu;
     double *sc = smem + o.sc, *du = smem + o.du, *dl = smem + o.dl;
     int *sens = reinterpret_cast<int *>(smem + o.sens);

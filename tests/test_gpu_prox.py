@@ -334,3 +334,25 @@ def test_shift_doubling(oracle, gpu_lib, monkeypatch):
         if flag > 0:
             assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), k
     mdl.close()
+
+
+@pytest.mark.parametrize("n,m,ms,kind", [(120, 260, 5, "sing"), (150, 300, 0, "lp"), (200, 420, 10, "diag")])
+def test_large_shapes(oracle, gpu_lib, monkeypatch, n, m, ms, kind):
+    """n > 64: the generic setup kernel (factors in LDS or HBM scratch) and the streamed / spilled solve kernels, with the
+    spilled instantiation of the LP gradient step."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    N = 4
+    if kind == "lp":
+        qs = [O.generate_lp(n, m, ms, [90, n, k], unbounded=(k == 3)) for k in range(N)]
+    else:
+        qs = [O.generate_singular_qp(n, m, ms, rank=n // 2 + 7 * k, rng=[90, n, k], kind="diag" if kind == "diag" else "dense") for k in range(N)]
+    ref = [oracle.quadprog(q.get("H"), q["f"], q["A"], q["bupper"], q["blower"], q["sense"]) for q in qs]
+    b = {k: np.stack([q[k] for q in qs]) for k in ("f", "A", "bupper", "blower", "sense")}
+    H = None if kind == "lp" else np.stack([q["H"] for q in qs])
+    r = daqp_amd.solve_batch(H, b["f"], b["A"], b["bupper"], b["blower"], b["sense"], ms=ms)
+    for k in range(N):
+        x, lam, fval, flag, it = ref[k]
+        assert r["exitflag"][k] == flag and r["iter"][k] == it, (k, r["exitflag"][k], flag, r["iter"][k], it)
+        if flag > 0:
+            assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), k

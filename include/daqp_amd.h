@@ -19,10 +19,10 @@
  *      N independent problems of one shape (n, m, ms), stored back to back,
  *      solved by one wavefront each with the working set and LDL' factors in LDS.
  *
- * Only the hot path is implemented: dense convex H (a singular one goes through
- * the reference's proximal outer loop, daqp_prox.c); sense bits
- * ACTIVE/LOWER/IMMUTABLE/SOFT.  Binary constraints, hierarchies, AVIs and LPs
- * (the reference's bnb/hiqp/avi loops, H == NULL) return DAQP_EXIT_UNSUPPORTED.  There is NO CPU fallback: without a HIP device every
+ * Only the hot path is implemented: dense convex H (a singular one, and an LP
+ * with H == NULL, go through the reference's proximal outer loop, daqp_prox.c);
+ * sense bits ACTIVE/LOWER/IMMUTABLE/SOFT.  Binary constraints, hierarchies and AVIs
+ * (the reference's bnb/hiqp/avi loops) return DAQP_EXIT_UNSUPPORTED.  There is NO CPU fallback: without a HIP device every
  * entry point fails with DAQP_EXIT_UNSUPPORTED and daqp_amd_last_error() says why.
  */
 #ifndef DAQP_AMD_H
@@ -215,7 +215,8 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r);
  * eta_prox/eps.  iter is the sum over the inner solves.  eps_prox > 0 forces the shift for every problem.
  * daqp_batch_set_primal_start: api.c:636-641 for every problem (x: N*n), the centre of the first outer iteration.
  * daqp_batch_prox_info: n_prox per problem (types.h:229), outer iterations of the last solve, eps; returns the number
- * of proximal problems.  LPs (H == NULL) are not built. */
+ * of proximal problems.  An LP batch: p->H == NULL in daqp_batch_setup (every problem of the batch; R = I, adaptive
+ * smoothing weight, gradient steps, exit flag -3 for an unbounded one: daqp_prox.c LP branch). */
 int daqp_batch_set_primal_start(DAQPBatch *b, const c_float *x, int memory);
 int daqp_batch_prox_info(DAQPBatch *b, int *n_prox_host, int *outer_host, c_float *eps_host);
 /* copy out per-problem setup flags (host int[N]) */

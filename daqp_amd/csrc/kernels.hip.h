@@ -60,16 +60,21 @@ __device__ __forceinline__ size_t qf(const BatchDev &b, int q) { return b.shared
 // ------------------------------------------------------------------------------------
 // LDS carve-ups (doubles first, ints last; every offset a multiple of 16 bytes)
 // ------------------------------------------------------------------------------------
+// rows of A per pass of k_setup's M phase (LDS: this many rows of A plus as many rows of one 64-column result block)
+#ifndef DAQP_AMD_SETUP_ROWS
+#define DAQP_AMD_SETUP_ROWS 8
+#endif
+constexpr int kSetupRows = DAQP_AMD_SETUP_ROWS;
 struct SetupLds { int R, Rout, fv, vv, xu, sc, du, dl, tile, sens, total_bytes; };
 __host__ __device__ inline SetupLds setup_lds(int n, int m, bool gs = false)
 {
     SetupLds s;
-    const int rt = round_up(n * (n + 1) / 2, 2), np = round_up(n, 2), mp = round_up(m, 2);
+    const int rt = round_up(n * (n + 1) / 2, 2), np = round_up(n, 2);
     int o = 0;
     s.R = o; if (!gs) o += rt; s.Rout = o; if (!gs) o += rt;
     s.fv = o; o += np; s.vv = o; o += np; s.xu = o; o += np;
-    s.sc = o; o += mp; s.du = o; o += mp; s.dl = o; o += mp;
-    s.tile = o; o += 16 * np + 16 * 64;   // the 16-row block of A and the 16 x 64 result block of the M phase
+    s.sc = s.du = s.dl = o;   // (not in LDS any more)
+    s.tile = o; o += kSetupRows * np + kSetupRows * 64;   // the block of rows of A and the result block of the M phase
     s.sens = o;
     s.total_bytes = o * 8 + round_up(m, 4) * 4;
     return s;
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
         R = g; Ro = g + round_up(b.rtri, 2);
     } else { R = smem + o.R; Ro = smem + o.Rout; }
     double *fl = smem + o.fv, *vv = smem + o.vv, *xu = smem + o.xu;
-    double *sc = smem + o.sc, *du = smem + o.du, *dl = smem + o.dl;
+    // scaling and d go straight to their HBM arrays (LDS per workgroup decides how many problems share a CU here)
+    double *sc = b.scaling + (size_t)q * m, *du = b.dupper + (size_t)q * m, *dl = b.dlower + (size_t)q * m;
     int *sens = reinterpret_cast<int *>(smem + o.sens);
     const double *H = b.H + (b.prox_pass == 2 ? (size_t)0 : (size_t)q * n * n), *f = b.f + (size_t)q * n, *A = b.A + (size_t)q * mA * n;
     const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     int feasible = 1;
     double *Mq = b.Mblk + (size_t)q * b.nblk * b.npair * 128;
     if (flag > 0) {
-        constexpr int KB = 16;
+        constexpr int KB = kSetupRows;
         const int np2 = round_up(n, 2);
         double *at = smem + o.tile;               // [KB][np2] rows of A
         double *ob = at + KB * np2;               // [KB][64] one column block of results on its way to the blocked image
@@ -389,19 +395,20 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                         }
                     }
                 }
-                // above it every lane of the block takes part: 8 rows of R^-1 in flight, then KB x 8 multiply-adds
-                for (int rb = (cb >> 3) - 1; rb >= 0; --rb) {   // rows 8 rb + 7 ... 8 rb (cb is a multiple of 64)
-                    double rv[8];
+                // above it every lane of the block takes part: 16 rows of R^-1 in flight, then KB x 16 multiply-adds
+                for (int rb = (cb >> 4) - 1; rb >= 0; --rb) {   // rows 16 rb + 15 ... 16 rb (cb is a multiple of 64)
+                    double rv[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) rv[u] = has ? Ro[roff(8 * rb + 7 - u, n) + c] : 0.0;
+                    for (int u = 0; u < 16; ++u) rv[u] = has ? Ro[roff(16 * rb + 15 - u, n) + c] : 0.0;
 #pragma unroll
                     for (int k = 0; k < KB; ++k) {
-                        const double2 *ap = reinterpret_cast<const double2 *>(at + k * np2 + 8 * rb);   // 64-byte aligned: four 16-byte broadcasts
-                        const double2 a67 = ap[3], a45 = ap[2], a23 = ap[1], a01 = ap[0];
-                        acc[k] += rv[0] * a67.y; acc[k] += rv[1] * a67.x;
-                        acc[k] += rv[2] * a45.y; acc[k] += rv[3] * a45.x;
-                        acc[k] += rv[4] * a23.y; acc[k] += rv[5] * a23.x;
-                        acc[k] += rv[6] * a01.y; acc[k] += rv[7] * a01.x;
+                        const double2 *ap = reinterpret_cast<const double2 *>(at + k * np2 + 16 * rb);   // 128-byte aligned: eight 16-byte broadcasts
+#pragma unroll
+                        for (int h = 7; h >= 0; --h) {
+                            const double2 a2 = ap[h];
+                            acc[k] += rv[15 - (2 * h + 1)] * a2.y;
+                            acc[k] += rv[15 - 2 * h] * a2.x;
+                        }
                     }
                 }
                 // through LDS into the blocked image [row/64][col/2][row%64][col%2]: 16 rows x 16 bytes contiguous per column pair
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                 WSYNC();
                 const int pairs = ((rtop - cb) >> 1) + 1;
                 for (int idx = lane; idx < pairs * KB; idx += 64) {
-                    const int k = idx & (KB - 1), t = idx >> 4;
+                    const int k = idx & (KB - 1), t = idx / KB;
                     if (k < rows) {
                         const int gi = ms + kb + k;
                         double2 vpair;
@@ -528,11 +535,6 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     if (flag > 0) {
         for (int e = lane; e < b.rtri; e += 64) b.Rinv[(size_t)q * b.rtri + e] = Ro[e];
         for (int i = lane; i < n; i += 64) { b.v[(size_t)q * n + i] = vv[i]; if (unc) b.xunc[(size_t)q * n + i] = xu[i]; }
-        for (int i = lane; i < m; i += 64) {
-            b.scaling[(size_t)q * m + i] = sc[i];
-            b.dupper[(size_t)q * m + i] = du[i];
-            b.dlower[(size_t)q * m + i] = dl[i];
-        }
     }
     for (int i = lane; i < m; i += 64) b.sense[(size_t)q * m + i] = sens[i];
     if (lane == 0) {

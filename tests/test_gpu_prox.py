@@ -356,3 +356,29 @@ def test_large_shapes(oracle, gpu_lib, monkeypatch, n, m, ms, kind):
         assert r["exitflag"][k] == flag and r["iter"][k] == it, (k, r["exitflag"][k], flag, r["iter"][k], it)
         if flag > 0:
             assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), k
+
+
+def test_only_simple_bounds(oracle, gpu_lib, monkeypatch):
+    """m == ms: no general rows at all (A is empty) -- a box LP ends at the vertex picked by the signs of f, a singular QP
+    moves only inside its box."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n = 7
+    rng = np.random.default_rng(91)
+    for lp in (True, False):
+        N = 6
+        f = rng.standard_normal((N, n))
+        bu, bl = 0.5 + rng.random((N, n)), -0.5 - rng.random((N, n))
+        A = np.zeros((N, 0, n))
+        H = None
+        if not lp:
+            T = rng.standard_normal((N, 3, n))
+            H = np.einsum("qri,qrj->qij", T, T)
+        ref = [oracle.quadprog(None if lp else H[k], f[k], np.zeros((0, n)), bu[k], bl[k], np.zeros(n, np.int32)) for k in range(N)]
+        r = daqp_amd.solve_batch(H, f, A, bu, bl, None, ms=n)
+        for k in range(N):
+            x, lam, fval, flag, it = ref[k]
+            assert r["exitflag"][k] == flag == 1 and r["iter"][k] == it, (lp, k, r["exitflag"][k], flag, r["iter"][k], it)
+            assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), (lp, k)
+            if lp:
+                assert np.abs(x - np.where(f[k] > 0, bl[k], bu[k])).max() < 1e-9

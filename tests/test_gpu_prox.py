@@ -382,3 +382,39 @@ def test_only_simple_bounds(oracle, gpu_lib, monkeypatch):
             assert same(r["x"][k], x) and same(r["lam"][k], lam) and same(r["fval"][k], fval), (lp, k)
             if lp:
                 assert np.abs(x - np.where(f[k] > 0, bl[k], bu[k])).max() < 1e-9
+
+
+def test_concurrent_host_threads_proximal(oracle, gpu_lib, monkeypatch):
+    """the outer loop is host-driven (launches and read-backs per outer iteration): four host threads, each with its own
+    batch of singular QPs / LPs, must get the answers of a serial run"""
+    import threading
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, N = 11, 28, 2, 24
+    probs = []
+    for t in range(4):
+        if t % 2:
+            qs = [O.generate_lp(n, m, ms, [92, t, k]) for k in range(N)]
+        else:
+            qs = [O.generate_singular_qp(n, m, ms, rank=3 + k % 6, rng=[93, t, k], in_range=(k % 2 == 0)) for k in range(N)]
+        probs.append(qs)
+    out = [None] * 4
+
+    def work(t):
+        qs = probs[t]
+        b = {k: np.stack([q[k] for q in qs]) for k in ("f", "A", "bupper", "blower", "sense")}
+        H = None if t % 2 else np.stack([q["H"] for q in qs])
+        for _ in range(3):
+            out[t] = daqp_amd.solve_batch(H, b["f"], b["A"], b["bupper"], b["blower"], b["sense"], ms=ms)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for t in range(4):
+        for k, q in enumerate(probs[t]):
+            x, lam, fval, flag, it = oracle.quadprog(q.get("H"), q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+            assert out[t]["exitflag"][k] == flag and out[t]["iter"][k] == it, (t, k)
+            if flag > 0:
+                assert same(out[t]["x"][k], x) and same(out[t]["lam"][k], lam), (t, k)

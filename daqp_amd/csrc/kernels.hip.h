@@ -273,29 +273,74 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
         }
     }
     GPROF(1);
-    // --- R -> R^-1, row by row as utils.c:380-389: lane <-> row k works on its own copy,
-    // reading the untouched Cholesky rows i > k
+    // --- R -> R^-1, row by row as utils.c:380-389.  Lane <-> COLUMN: row k of the inverse lives in registers (one entry
+    // per 64-column block and lane); step i takes t = x_i / r_ii from the lane that holds it and subtracts t times row i
+    // of the Cholesky factor -- one coalesced load per block, shared by the KR rows of R^-1 that sweep together (their
+    // chains are independent: each hides the other's broadcast latency).  Every entry still receives its terms in
+    // ascending i, as in the reference.
     if (flag > 0) {
       if (!diag) {
-        for (int e = lane; e < b.rtri; e += 64) Ro[e] = R[e];
-        WSYNC();
-        for (int kc = 0; kc < n; kc += 64) {
-            const int k = kc + lane;
-            const bool own = k < n;
-            const int pk = own ? roff(k, n) : 0;
-            const double rkk = own ? Ro[pk + k] : 0.0;
-            if (own) for (int j = k + 1; j < n; ++j) Ro[pk + j] *= -rkk;
-            for (int i = kc + 1; i < n; ++i) {
-                const int pi = roff(i, n);
-                if (own && i > k) {
-                    const double t = Ro[pk + i] * R[pi + i];
-                    Ro[pk + i] = t;
-                    for (int j0 = i + 1; j0 < n; j0 += 8) {   // 8 entries per trip: 16 loads first, then the stores
-                        double ro[8], rr[8];
+        constexpr int KR = 8, NBK = 4;
+        for (int k0 = 0; k0 < n; k0 += KR) {
+            double x[KR][NBK];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { const int j = (j0 + u < n) ? j0 + u : n - 1; ro[u] = Ro[pk + j]; rr[u] = R[pi + j]; }
+            for (int r = 0; r < KR; ++r) {      // utils.c:382-384: the diagonal 1/r_kk stays, the rest of row k times -(1/r_kk)
+                const int k = k0 + r;
+                const int pk = roff(k < n ? k : 0, n);
+                const double rkk = (k < n) ? R[pk + k] : 0.0;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) if (j0 + u < n) Ro[pk + j0 + u] = ro[u] - rr[u] * t;
+                for (int jb = 0; jb < NBK; ++jb) {
+                    const int j = jb * 64 + lane;
+                    const double v = (k < n && j < n && j >= k) ? R[pk + j] : 0.0;
+                    x[r][jb] = (j > k) ? v * -rkk : v;
+                }
+            }
+            for (int i0 = k0 + 1; i0 < n; i0 += 4) {   // four rows of the factor in flight
+                double ri[4][NBK], rii[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = (i0 + u < n) ? i0 + u : n - 1;
+                    const int pi = roff(i, n), bi = i >> 6;
+                    rii[u] = R[pi + i];
+#pragma unroll
+                    for (int jb = 0; jb < NBK; ++jb) {
+                        const int j = jb * 64 + lane;
+                        ri[u][jb] = (jb >= bi && j > i && j < n) ? R[pi + j] : 0.0;
+                    }
+                }
+                static_for<4>([&](auto uu) __attribute__((always_inline)) {
+                    constexpr int u = uu;
+                    const int i = i0 + u;
+                    if (i < n) {
+                        const int bi = i >> 6, li = i & 63;
+                        static_for<KR>([&](auto rr) __attribute__((always_inline)) {
+                            constexpr int r = rr;
+                            const int k = k0 + r;
+                            if (k < i && k < n) {       // (rows of the group that have not started yet sit this step out)
+                                double xi = x[r][0];
+                                if (bi == 1) xi = x[r][1];
+                                if (bi == 2) xi = x[r][2];
+                                if (bi == 3) xi = x[r][3];
+                                const double t = rl(xi, li) * rii[u];          // utils.c:386
+                                static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
+                                    constexpr int jb = jj;
+                                    const int j = jb * 64 + lane;
+                                    if (jb >= bi) x[r][jb] = (j == i) ? t : ((j > i) ? x[r][jb] - ri[u][jb] * t : x[r][jb]);   // utils.c:387-388
+                                });
+                            }
+                        });
+                    }
+                });
+            }
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int k = k0 + r;
+                if (k < n) {
+                    const int pk = roff(k, n);
+#pragma unroll
+                    for (int jb = 0; jb < NBK; ++jb) {
+                        const int j = jb * 64 + lane;
+                        if (j >= k && j < n) Ro[pk + j] = x[r][jb];
                     }
                 }
             }

@@ -418,11 +418,13 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             for (int cb = 0; cb < n; cb += 64) {
                 const int c = cb + lane;
                 const bool has = c < n;
+                // A chain starts with an assignment (utils.c:444).  -0.0 + p == p bit for bit for every p (signed zeros
+                // included), so the accumulators start at -0.0 and the first term is added like the others.
                 double acc[KB];
 #pragma unroll
-                for (int k = 0; k < KB; ++k) acc[k] = 0.0;
+                for (int k = 0; k < KB; ++k) acc[k] = -0.0;
                 const int rtop = (n - 1 < cb + 63) ? n - 1 : cb + 63;
-                // the diagonal block: a lane joins at r == c with an assignment (utils.c:444), lanes right of it accumulate
+                // the diagonal block: a lane joins its chain at r == c, lanes right of it accumulate, lanes left of it sit out
                 for (int r0 = rtop; r0 >= cb; r0 -= 8) {
                     double rv[8];
 #pragma unroll
@@ -431,11 +433,9 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                     for (int u = 0; u < 8; ++u) {
                         const int r = r0 - u;
                         if (r >= cb) {
-                            const bool on = has && r <= c;
+                            if (has && r <= c) {
 #pragma unroll
-                            for (int k = 0; k < KB; ++k) {
-                                const double pr = rv[u] * at[k * np2 + r];
-                                acc[k] = (r == c) ? pr : (on ? acc[k] + pr : acc[k]);
+                                for (int k = 0; k < KB; ++k) acc[k] += rv[u] * at[k * np2 + r];
                             }
                         }
                     }

@@ -232,39 +232,101 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                 if (e0 + 64 * u < n * n && jj[u] >= ii[u]) R[roff(ii[u], n) + jj[u]] = (ii[u] == jj[u]) ? h1[u] + shift : 0.5 * (h1[u] + h2[u]);
         }
         WSYNC();
-        for (int i = 0; i < n && flag > 0; ++i) {
-            const int pi = roff(i, n);
-            const int nch = (n - i + 63) >> 6;
-            double dgi = 0;
-            for (int ch = 0; ch < nch; ++ch) {   // chunk 0 holds the diagonal (lane 0)
-                const int j = i + ch * 64 + lane;
-                double acc = (j < n) ? R[pi + j] : 0.0;
-                {   // k-ordered chain, 8 steps per trip with their 16 loads issued first (R may live in HBM scratch: without
-                    // this every step is a memory round trip); lanes beyond the row read a valid element and discard
-                    const int jj = (j < n) ? j : i;
-                    for (int k0 = 0; k0 < i; k0 += 8) {
-                        double ra[8], rb[8];
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            const int k = (k0 + t < i) ? k0 + t : 0;
-                            const int pk = roff(k, n);
-                            ra[t] = R[pk + i]; rb[t] = R[pk + jj];
-                        }
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) if (k0 + t < i && j < n) acc -= ra[t] * rb[t];
-                    }
+        // Left-looking, KR rows at a time, lane <-> column (one entry per 64-column block and lane): the finished rows k < i0
+        // are streamed once for the whole group (a coalesced stretch per block plus the KR entries R[k][i0..] as broadcasts),
+        // then the rows of the group finish one after the other, each updating the later ones from registers.  Every entry
+        // receives its subtractions in ascending k (utils.c:335-352).
+        {
+            constexpr int KR = 8, NBK = 4;
+            for (int i0 = 0; i0 < n && flag > 0; i0 += KR) {
+                const int b0 = i0 >> 6;
+                double acc[KR][NBK];
+                static_for<KR>([&](auto rr) __attribute__((always_inline)) {
+                    constexpr int r = rr;
+                    const int i = i0 + r;
+                    const int pi = roff(i < n ? i : 0, n);
+                    static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
+                        constexpr int jb = jj;
+                        const int j = jb * 64 + lane;
+                        acc[r][jb] = (i < n && j >= i && j < n) ? R[pi + j] : 0.0;
+                    });
+                });
+                for (int k0 = 0; k0 < i0; k0 += 2) {      // two finished rows in flight (i0 is a multiple of KR)
+                    double rk[2][NBK], ru[2][KR];
+                    static_for<2>([&](auto tt) __attribute__((always_inline)) {
+                        constexpr int t = tt;
+                        const int pk = roff(k0 + t, n);
+                        static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
+                            constexpr int jb = jj;
+                            const int j = jb * 64 + lane;
+                            rk[t][jb] = (jb >= b0 && j >= i0 && j < n) ? R[pk + j] : 0.0;
+                        });
+                        static_for<KR>([&](auto rr) __attribute__((always_inline)) {
+                            constexpr int r = rr;
+                            ru[t][r] = R[pk + ((i0 + r < n) ? i0 + r : i0)];
+                        });
+                    });
+                    static_for<2>([&](auto tt) __attribute__((always_inline)) {
+                        constexpr int t = tt;
+                        static_for<KR>([&](auto rr) __attribute__((always_inline)) {
+                            constexpr int r = rr;
+                            static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
+                                constexpr int jb = jj;
+                                if (jb >= b0) acc[r][jb] -= ru[t][r] * rk[t][jb];
+                            });
+                        });
+                    });
                 }
-                if (ch == 0) {
-                    const double dg = rl(acc, 0);
-                    if (dg <= st.zero_tol) { flag = shift_code; break; }
-                    if (dg < pmin) pmin = dg;
-                    if (dg > pmax) pmax = dg;
-                    dgi = 1 / sqrt(dg);
-                    if (lane == 0) acc = dgi; else acc *= dgi;
-                } else acc *= dgi;
-                if (j < n) R[pi + j] = acc;
+                static_for<KR>([&](auto rr) __attribute__((always_inline)) {
+                    constexpr int r = rr;
+                    const int i = i0 + r;
+                    if (i < n && flag > 0) {
+                        const int bi = i >> 6, li = i & 63;
+                        double dsel = acc[r][0];
+                        if (bi == 1) dsel = acc[r][1];
+                        if (bi == 2) dsel = acc[r][2];
+                        if (bi == 3) dsel = acc[r][3];
+                        const double dg = rl(dsel, li);
+                        if (dg <= st.zero_tol) flag = shift_code;
+                        else {
+                            if (dg < pmin) pmin = dg;
+                            if (dg > pmax) pmax = dg;
+                            const double dgi = 1 / sqrt(dg);
+                            static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
+                                constexpr int jb = jj;
+                                const int j = jb * 64 + lane;
+                                acc[r][jb] = (j == i) ? dgi : acc[r][jb] * dgi;
+                            });
+                            const int pi = roff(i, n);
+                            static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
+                                constexpr int jb = jj;
+                                const int j = jb * 64 + lane;
+                                if (j >= i && j < n) R[pi + j] = acc[r][jb];
+                            });
+                            // this row is the next k for the later rows of the group
+                            static_for<KR>([&](auto qq) __attribute__((always_inline)) {
+                                constexpr int r2 = qq;
+                                if constexpr (r2 > r) {
+                                    const int i2 = i0 + r2;
+                                    if (i2 < n) {
+                                        const int b2 = i2 >> 6, l2 = i2 & 63;
+                                        double ssel = acc[r][0];
+                                        if (b2 == 1) ssel = acc[r][1];
+                                        if (b2 == 2) ssel = acc[r][2];
+                                        if (b2 == 3) ssel = acc[r][3];
+                                        const double sv = rl(ssel, l2);
+                                        static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
+                                            constexpr int jb = jj;
+                                            if (jb >= b0) acc[r2][jb] -= sv * acc[r][jb];
+                                        });
+                                    }
+                                }
+                            });
+                        }
+                    }
+                });
+                WSYNC();
             }
-            WSYNC();
         }
         if (flag > 0 && pmin <= ((pp && !force) ? sqrt(st.zero_tol) : st.zero_tol) * pmax) flag = shift_code;   // utils.c:354-356
         if (pp && flag > 0) {

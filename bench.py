@@ -1,21 +1,24 @@
 #!/usr/bin/env python
-"""bench.py -- QPs/sec (fp64) for batched random dense QPs n=50 m=150 on 1/2/4/8 MI355X.
+"""bench.py -- QPs/sec (fp64) for batched random dense QPs on 1/2/4/8 MI355X.
 
-One "step" = the whole hot path (QP->LDP setup, dual active-set iteration, back-transform) over
-one batch of 100 000 synthetic QPs per GPU (config C2 of BASELINE.json / SURVEY.md section 8d),
-inputs already resident in HBM, results left in HBM.  One process per GPU; independent batches are
-sharded across ranks with no data-path collective (weak scaling); the only communication is the
-barrier + MAX of the elapsed time the contract asks for.
+One "step" = the whole hot path (QP->LDP setup, dual active-set iteration, back-transform) over one batch of synthetic
+QPs per GPU, inputs already resident in HBM, results left in HBM.  The headline (`value`) is BASELINE.json's metric:
+config C2, 100 000 QPs per GPU, n=50 m=150.  The same JSON line carries the other BASELINE configs under "configs"
+(C3: MPC-size QPs n=12 m=48 ms=12; C4: n=200 m=600; C5: warm-started sequence on the C2 batch), each with its own
+throughput, solve-kernel roofline, CPU baseline sample and parity against that CPU run.
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-           --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 2
+One process per GPU; independent QPs are sharded across ranks with no data-path collective; the only communication is
+the barrier + MAX of the elapsed time the contract asks for.
+
+    python bench.py --gpus 1 --steps 20 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+           bench.py --gpus 8 --steps 20 --warmup 2                      # weak scaling: 100k C2 QPs per GPU
+    ... bench.py --gpus 8 --config C3 --strong                          # ONE 1M-QP C3 batch, QP k on rank k mod 8
 """
 import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -25,42 +28,54 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
+# name -> (n, m, ms, active at the optimum, QPs per GPU (weak) / in total (strong), description)
+CONFIGS = {
+    "C2": dict(n=50, m=150, ms=0, na=20, per_gpu=100_000, total=100_000, what="random dense QPs"),
+    "C3": dict(n=12, m=48, ms=12, na=6, per_gpu=125_000, total=1_000_000, what="MPC-size QPs with simple bounds (1M over 8 GPUs)"),
+    "C4": dict(n=200, m=600, ms=0, na=80, per_gpu=10_000, total=10_000, what="large QPs (working set beyond LDS)"),
+    "C5": dict(n=50, m=150, ms=0, na=20, per_gpu=100_000, total=100_000, what="warm-started sequence: T=10 steps f <- f + 0.05 N(0,I) on device-resident factors"),
+}
+METRIC = {
+    "C2": "QPs/sec (fp64) for batched random dense QPs n=50 m=150",
+    "C3": "QPs/sec (fp64) for batched MPC-size dense QPs n=12 m=48 ms=12",
+    "C4": "QPs/sec (fp64) for batched random dense QPs n=200 m=600",
+    "C5": "warm solves/sec (fp64) for a warm-started sequence of dense QPs n=50 m=150",
+}
 
-def algorithmic_bytes(n, m, ms, iters):
-    """per-QP  B = B_io + it * 8 (m-ms) n."""
+
+def algorithmic_bytes(n, m, ms, iters, warm=False):
+    """per-QP  B = B_io + it * 8 (m-ms) n; a warm step (C5) reads only the new f."""
     mA = m - ms
-    b_in = 8 * (n * n + n + mA * n + 2 * m) + 4 * m
+    b_in = 8 * n if warm else 8 * (n * n + n + mA * n + 2 * m) + 4 * m
     b_out = 8 * (n + m) + 8
     stream = iters.astype(np.float64) * 8.0 * mA * n
     return b_in, b_out, stream
 
 
-def cpu_baseline(q_host, ms, gpu_res):
-    """The same QPs solved one at a time by daqp_quadprog on ALL host cores: the reference library
-    itself (oracle/_ref, driven by oracle/ref_batch.c: one pthread per contiguous slice) when it
-    travelled with the repo, else this repo's C restatement built with the reference's flags."""
+def cpu_baseline(q_host, ms, gpu_res, threads_options):
+    """The same QPs solved one at a time by daqp_quadprog on host threads: the reference library itself (oracle/_ref, driven
+    by oracle/ref_batch.c: one pthread per contiguous slice) when it travelled with the repo, else this repo's C restatement
+    built with the reference's flags.  Reported: the best of the thread counts tried."""
     from oracle import oracle as O
     S = q_host["f"].shape[0]
-    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     tried = ""
-    if O.reference_available():
-        kind = "reference"
-        # the fastest of {all, 1/2, 1/4, 1/8 of} the host threads: with every hardware thread busy the per-thread rate
-        # collapses on these hosts (SMT + memory), and the baseline should be the CPU's best, not its most crowded
-        best = None
-        for th in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
-            r = O.timed_cpu_batch(os.path.join(O.HERE, "_ref", "libdaqp_ref.so"), th, q_host["H"], q_host["f"], q_host["A"],
-                                  q_host["bupper"], q_host["blower"], ms)
+    kind = "reference" if O.reference_available() else "port"
+    libpath = os.path.join(O.HERE, "_ref", "libdaqp_ref.so") if kind == "reference" else os.path.join(O.HERE, "liboracle_fast.so")
+    best = None
+    if kind == "reference":
+        for th in threads_options:
+            r = O.timed_cpu_batch(libpath, th, q_host["H"], q_host["f"], q_host["A"], q_host["bupper"], q_host["blower"], ms)
             tried += f"{th} threads: {S / r[0]:.0f} QPs/s; "
             if best is None or r[0] < best[1][0]:
                 best = (th, r)
         cores, (dt, x, lam, fval, flag, it) = best[0], best[1]
     else:
-        kind = "port"
+        import threading
         solver = O.Oracle(fast=True)
         n, m = q_host["f"].shape[1], q_host["bupper"].shape[1]
         x, lam = np.zeros((S, n)), np.zeros((S, m))
         flag, it = np.zeros(S, np.int32), np.zeros(S, np.int32)
+        cores = threads_options[0]
 
         def work(lo, hi):   # one C call per slice; ctypes drops the GIL for its duration
             r = solver.quadprog_batch(q_host["H"][lo:hi], q_host["f"][lo:hi], q_host["A"][lo:hi],
@@ -84,128 +99,279 @@ def cpu_baseline(q_host, ms, gpu_res):
     )
     return dict(value=S / dt, unit="QPs/s", cores=int(cores), kind=kind,
                 sample=f"first {S} QPs of the rank-0 batch, daqp_quadprog one QP at a time on {cores} host threads "
-                       f"({S * 1.0 / dt / cores:.0f} QPs/s per thread), wall {dt:.2f} s" + (f" [best of: {tried.strip()}]" if tried else "")), parity
+                       f"({S * 1.0 / dt / cores:.0f} QPs/s per thread), wall {dt:.2f} s" + (f" [best of: {tried.strip()}]" if tried else "")), parity, cores
+
+
+def cpu_baseline_warm(q_host, fs_host, ms, gpu_x, gpu_iter):
+    """C5 on one host core: the reference's setup_daqp -> solve -> {update_ldp(UPDATE_v) -> solve}* per QP (oracle/_ref through
+    ctypes, else the C restatement) over the same walk of f; only the warm steps are timed."""
+    from oracle import oracle as O
+    S, P = q_host["f"].shape[0], fs_host.shape[0]
+    n, m = q_host["f"].shape[1], q_host["bupper"].shape[1]
+    kind = "reference" if O.reference_available() else "port"
+    drv = O.Reference() if kind == "reference" else O.Oracle(fast=True)
+    dt = 0.0
+    same_iter, max_dx = 0, 0.0
+    for k in range(S):
+        md = drv.model(n, m, ms)
+        md.setup(q_host["H"][k], q_host["f"][k], q_host["A"][k], q_host["bupper"][k], q_host["blower"][k], None)
+        md.solve()
+        t0 = time.perf_counter()
+        for t in range(P):
+            md.update(O.UPDATE_v, f=fs_host[t, k])
+            r = md.solve()
+        dt += time.perf_counter() - t0
+        same_iter += int(r[4] == gpu_iter[k])
+        max_dx = max(max_dx, float(np.abs(r[0] - gpu_x[k]).max()))
+        if hasattr(md, "close"):
+            md.close()
+    return dict(value=S * P / dt, unit="warm solves/s", cores=1, kind=kind,
+                sample=f"first {S} QPs x {P} warm steps (the whole walk of f), daqp_update_ldp(UPDATE_v) + daqp_solve per step on one "
+                       f"host thread (python/ctypes call overhead included), wall {dt:.2f} s"), \
+        dict(sample=int(S), identical_iter_last_step=same_iter / S, max_abs_dx_last_step=max_dx)
+
+
+class Runner:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(args.backend)
+        self.red_device = "cuda" if (self.world > 1 and args.backend == "nccl") else "cpu"
+        cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        # the fastest of {all, 1/2, 1/4, 1/8 of} the host threads: with every hardware thread busy the per-thread rate
+        # collapses on these hosts (SMT + memory), and the baseline should be the CPU's best, not its most crowded
+        self.thread_options = sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def generate(self, cfg, N_local, strong, N_total):
+        """this rank's QPs: an independent shard (weak), or QP k of ONE batch of N_total on rank k mod world (strong: every
+        rank draws the same global stream chunk by chunk and keeps its interleaved share, daqp_amd.parallel.shard_indices)"""
+        from daqp_amd.synthetic import generate_batch_torch
+        from daqp_amd.parallel import shard_indices
+        torch = self.torch
+        dev = f"cuda:{self.local_rank}"
+        c = CONFIGS[cfg]
+        if not strong:
+            return generate_batch_torch(N_local, c["n"], c["m"], c["ms"], c["na"], seed=42 + 1000 * self.rank, device=dev)
+        idx = shard_indices(N_total, self.rank, self.world)
+        parts, chunk = [], 65536
+        for s in range(0, N_total, chunk):
+            B = min(chunk, N_total - s)
+            g = generate_batch_torch(B, c["n"], c["m"], c["ms"], c["na"], seed=4242 + s, device=dev)
+            mine = torch.from_numpy(idx[(idx >= s) & (idx < s + B)] - s).to(dev)
+            parts.append({k: v[mine] for k, v in g.items()})
+        return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+
+    def run(self, cfg, steps, warmup, batch=None, strong=False, cpu_sample=-1, thread_options=None):
+        import daqp_amd
+        from daqp_amd.parallel import max_over_ranks
+        torch = self.torch
+        c = CONFIGS[cfg]
+        n, m, ms = c["n"], c["m"], c["ms"]
+        N_total = (batch if batch else c["total"]) if strong else None
+        N = len(range(self.rank, N_total, self.world)) if strong else (batch if batch else c["per_gpu"])
+        q = self.generate(cfg, N, strong, N_total)
+        bm = daqp_amd.BatchModel(N, n, m, ms, device=self.local_rank)
+        mask = daqp_amd.UPDATE_unconstrained | daqp_amd.UPDATE_eliminate   # daqp_quadprog semantics
+        warm = cfg == "C5"
+        T = 10
+
+        def cold_step():
+            bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=mask)
+            return bm.solve(out="torch")
+
+        if warm:
+            # the random walk of f over every pass (warm-up included), drawn up front; a pass = T consecutive warm steps
+            gen = torch.Generator(device=q["f"].device)
+            gen.manual_seed(45 + self.rank)
+            P = (warmup + steps) * T
+            fs = torch.empty((P,) + tuple(q["f"].shape), dtype=torch.float64, device=q["f"].device)
+            cur = q["f"]
+            for t in range(P):
+                cur = cur + 0.05 * torch.randn(tuple(q["f"].shape), generator=gen, dtype=torch.float64, device=q["f"].device)
+                fs[t] = cur
+            cursor = [0]
+
+            def step():
+                res = None
+                for _ in range(T):
+                    bm.update(f=fs[cursor[0]])
+                    cursor[0] += 1
+                    res = bm.solve(out="torch")
+                return res
+
+            bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=0)   # setup_daqp + the cold solve: untimed
+            bm.solve(out="torch")
+        else:
+            step, fs = cold_step, None
+
+        for _ in range(warmup):
+            res = step()
+        setup_ms, solve_ms = [], []
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+            if self.rank == 0:
+                a, b = bm.kernel_ms()      # HIP events recorded on the launch stream around the kernels of the last launches
+                setup_ms.append(0.0 if warm else a); solve_ms.append(b)
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        elapsed = max_over_ranks(elapsed, device=self.red_device)
+        return q, res, bm, dict(N=N, N_total=N_total, elapsed=elapsed, setup_ms=setup_ms, solve_ms=solve_ms, T=T if warm else 1, fs=fs)
+
+    def report(self, cfg, q, res, info, steps, cpu_sample, headline):
+        """rank 0: the JSON fields of one configuration"""
+        c = CONFIGS[cfg]
+        n, m, ms = c["n"], c["m"], c["ms"]
+        warm = cfg == "C5"
+        N, T = info["N"], info["T"]
+        units = (info["N_total"] if info["N_total"] else self.world * N) * steps * T
+        iters = res["iter"].cpu().numpy()
+        b_in, b_out, stream = algorithmic_bytes(n, m, ms, iters, warm)
+        ldp_bytes = float(stream.sum() + b_out * N)           # what one solve launch must move (SURVEY 8d without the inputs)
+        all_bytes = float(stream.sum() + (b_in + b_out) * N)  # SURVEY 8(d) B summed over the batch
+        io_bytes = float((b_in + b_out) * N)                  # B_io only: the floor if M never leaves the chip
+        t_ldp = float(np.mean(info["solve_ms"])) * 1e-3
+        t_setup = float(np.mean(info["setup_ms"])) * 1e-3
+        ach = ldp_bytes / t_ldp / 1e9
+        flags_ok = bool((res["exitflag"] == 1).all().item())
+        out = {
+            "metric": METRIC[cfg], "value": units / info["elapsed"], "unit": "warm solves/s" if warm else "QPs/s",
+            "ms_per_step": info["elapsed"] / steps * 1e3, "steps": steps,
+            "workload": f"{cfg}: {N} {c['what']} per GPU" + (f" (ONE batch of {info['N_total']}, QP k on rank k mod {self.world})" if info["N_total"] else "")
+                        + f", n={n} m={m} ms={ms}, {c['na']} active at the optimum, kappa=100 (reference generate_test_QP), "
+                        + ("setup_daqp + cold solve untimed, then per step T=10 x {daqp_update_ldp(UPDATE_v) + daqp_solve}" if warm else
+                           "daqp_quadprog semantics: setup + solve per step") + ", inputs and outputs resident in HBM",
+            "batch_per_gpu": N, "mean_iterations": float(iters.mean()),
+            "roofline": {"bound": "hbm", "kernel": "solve launch (dual active-set iteration + back-transform" + (", fused UPDATE_v" if warm else "") + ")",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "avg_launch_ms": t_ldp * 1e3, "algorithmic_bytes_per_launch": ldp_bytes,
+                         # the same time against B_io alone (inputs + outputs of the step): what is left if M stays on chip
+                         "floor_frac": io_bytes / max(t_ldp + t_setup, 1e-12) / 1e9 / HBM_PEAK_GBS},
+            "checks": {"all_optimal": flags_ok},
+        }
+        if not warm:
+            out["roofline"]["pipeline"] = {"achieved": all_bytes / (t_ldp + t_setup) / 1e9, "frac": all_bytes / (t_ldp + t_setup) / 1e9 / HBM_PEAK_GBS,
+                                           "setup_ms": t_setup * 1e3, "solve_ms": t_ldp * 1e3, "algorithmic_bytes_per_step": all_bytes}
+            out["checks"]["max_abs_x_minus_analytic_optimum"] = float((res["x"] - q["xref"]).abs().max().item())
+        prof = committed_counters(cfg, N, n, m)
+        if prof:
+            out["roofline"].update(prof)
+        elif headline:
+            out["roofline"]["traffic"] = None
+        if cpu_sample > 0 and self.world == 1:
+            S = min(N, cpu_sample)
+            if warm:
+                qh = {k: q[k][:S].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}
+                base, parity = cpu_baseline_warm(qh, info["fs"][:, :S].cpu().numpy(), ms, res["x"][:S].cpu().numpy(), iters[:S])
+            else:
+                qh = {k: q[k][:S].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}
+                gh = {k: res[k][:S].cpu().numpy() for k in ("x", "lam", "iter", "exitflag")}
+                base, parity, best = cpu_baseline(qh, ms, gh, self.thread_options if headline else self.side_threads)
+                if headline:
+                    self.side_threads = [best]
+            out["cpu_baseline"] = base
+            out["parity_vs_cpu"] = parity
+        return out
+
+
+def committed_counters(cfg, N, n, m):
+    """HBM bytes per solve launch and the issue-side counters from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
+    and the SQ groups each in its own run, corrected as MI355X_MICROARCH.md prescribes; profiles/README.md).  Counters cannot be
+    collected from inside this process, so the figures are those measured with this same workload, and only quoted for it."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1])).get(cfg)
+    if not d or d.get("batch") != N:
+        return None
+    out = {"traffic": d.get("traffic_bytes_per_launch"), "traffic_source": "profiles/" + os.path.basename(files[-1])}
+    if "binding" in d:
+        out["binding"] = d["binding"]
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=100_000, help="QPs per GPU per step (config C2: 100k)")
-    ap.add_argument("--n", type=int, default=50)
-    ap.add_argument("--m", type=int, default=150)
-    ap.add_argument("--ms", type=int, default=0)
-    ap.add_argument("--n-active", type=int, default=20)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="the configuration `value` is quoted on (BASELINE headline: C2)")
+    ap.add_argument("--batch", type=int, default=0, help="QPs per GPU per step (0: the config's own; with --strong: in total)")
+    ap.add_argument("--strong", action="store_true", help="ONE batch split over the ranks (QP k -> rank k mod G) instead of one batch per rank")
+    ap.add_argument("--side-configs", default="auto", help="comma list of further configs reported under \"configs\" (auto: C3,C4,C5 at N=1 for the C2 headline; none)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="QPs for the CPU baseline (-1: auto, 0: skip)")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (multi-rank smoke test on a 1-GPU box; use --backend gloo)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import daqp_amd
-    from daqp_amd.synthetic import generate_batch_torch
+    R = Runner(args)
+    R.side_threads = R.thread_options[-2:-1] or R.thread_options
+    auto_sample = {"C2": 65536, "C3": 262144, "C4": 1024, "C5": 256}   # ~10-25 CPU-seconds each on one core-group
+    sample = lambda cfg: 0 if (args.cpu_sample == 0 or R.world > 1) else (auto_sample[cfg] if args.cpu_sample < 0 else args.cpu_sample)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n, m, ms, N = args.n, args.m, args.ms, args.batch
-
-    # synthetic data of the reference's generator family; each rank owns an independent shard
-    q = generate_batch_torch(N, n, m, ms, args.n_active, seed=42 + 1000 * rank, device=f"cuda:{local_rank}")
-    bm = daqp_amd.BatchModel(N, n, m, ms, device=local_rank)
-    mask = daqp_amd.UPDATE_unconstrained | daqp_amd.UPDATE_eliminate   # daqp_quadprog semantics
-
-    def step():
-        bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=mask)
-        return bm.solve(out="torch")
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        res = step()
-    sync()
-    setup_ms, solve_ms = [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-        if rank == 0:
-            a, b = bm.kernel_ms()      # HIP events recorded on the launch stream around the kernels
-            setup_ms.append(a); solve_ms.append(b)
-    sync()
-    elapsed = time.perf_counter() - t0
-    from daqp_amd.parallel import max_over_ranks
-    elapsed = max_over_ranks(elapsed, device="cuda")
-
-    # whole-batch properties on every rank: optimal everywhere, analytic optimum reproduced
-    flags_ok = bool((res["exitflag"] == 1).all().item())
-    max_dx_analytic = float((res["x"] - q["xref"]).abs().max().item())
-    if rank == 0:
-        iters = res["iter"].cpu().numpy()
-        b_in, b_out, stream = algorithmic_bytes(n, m, ms, iters)
-        ldp_bytes = float(stream.sum() + b_out * N)          # what one k_ldp launch must move
-        all_bytes = float(stream.sum() + (b_in + b_out) * N)  # SURVEY 8(d) B summed over the batch
-        t_ldp = float(np.mean(solve_ms)) * 1e-3
-        t_setup = float(np.mean(setup_ms)) * 1e-3
-        ach = ldp_bytes / t_ldp / 1e9
-        traffic, traffic_src = pmc_traffic(N, n, m)
-        out = {
-            "metric": "QPs/sec (fp64) for batched random dense QPs n=50 m=150",
-            "value": world * N * args.steps / elapsed, "unit": "QPs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2: {N} random dense QPs per GPU, n={n} m={m} ms={ms}, {args.n_active} active at the "
-                                   "optimum, kappa=100 (reference generate_test_QP), daqp_quadprog semantics: setup + solve "
-                                   "per step, inputs and outputs resident in HBM", "batch_per_gpu": N,
-                       "mean_iterations": float(iters.mean()), "parallelism": f"independent shards x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_ldp (dual active-set iteration + back-transform)",
-                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": t_ldp * 1e3,
-                         "algorithmic_bytes_per_launch": ldp_bytes,
-                         "pipeline": {"achieved": all_bytes / (t_ldp + t_setup) / 1e9, "frac": all_bytes / (t_ldp + t_setup) / 1e9 / HBM_PEAK_GBS,
-                                      "k_setup_ms": t_setup * 1e3, "k_ldp_ms": t_ldp * 1e3, "algorithmic_bytes_per_step": all_bytes}},
-            "checks": {"all_optimal": flags_ok, "max_abs_x_minus_analytic_optimum": max_dx_analytic},
+    q, res, bm, info = R.run(args.config, args.steps, args.warmup, batch=args.batch or None, strong=args.strong)
+    line = None
+    if R.rank == 0:
+        h = R.report(args.config, q, res, info, args.steps, sample(args.config), headline=True)
+        line = {
+            "metric": h["metric"], "value": h["value"], "unit": h["unit"], "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": h["workload"], "batch_per_gpu": h["batch_per_gpu"], "mean_iterations": h["mean_iterations"],
+                       "parallelism": f"independent shards x{R.world}, no collective"},
+            "roofline": h["roofline"], "checks": h["checks"],
         }
-        sample = args.cpu_sample
-        if sample < 0:
-            sample = 0 if world > 1 else min(N, 65536)   # ~17 CPU-seconds of reference work at ~3.8k QPs/s/core
-        if sample > 0 and world == 1:
-            qh = {k: q[k][:sample].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}
-            gh = {k: res[k][:sample].cpu().numpy() for k in ("x", "lam", "iter", "exitflag")}
-            base, parity = cpu_baseline(qh, ms, gh)
-            out["cpu_baseline"] = base
-            out["parity_vs_cpu"] = parity
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        for k in ("cpu_baseline", "parity_vs_cpu"):
+            if k in h:
+                line[k] = h[k]
     bm.close()
+    del q, res, bm
+    R.torch.cuda.empty_cache()
 
-
-def pmc_traffic(N, n, m):
-    """HBM bytes per solve launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE each in its
-    own run, corrected as MI355X_MICROARCH.md prescribes; see profiles/README.md).  Counters cannot be collected
-    from inside this process, so the figure is the one measured with this same command line, and only quoted
-    for the workload it was measured on."""
-    import glob
-    here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_hbm.json")))
-    if not files or (N, n, m) != (100000, 50, 150):
-        return None, None
-    d = json.load(open(files[-1]))
-    for k, v in d.items():
-        if k.startswith("k_ldp_reg") and isinstance(v, dict) and "traffic_bytes_per_launch" in v:
-            return v["traffic_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
-    return None, None
+    side = args.side_configs
+    if side == "auto":
+        side = "C3,C4,C5" if (R.world == 1 and args.config == "C2" and not args.batch and not args.strong) else "none"
+    side_steps = {"C3": (10, 2), "C4": (3, 1), "C5": (3, 1), "C2": (5, 1)}
+    if side != "none":
+        cfgs = {}
+        for cfg in [s for s in side.split(",") if s and s != args.config]:
+            st, wu = side_steps[cfg]
+            q, res, bm, info = R.run(cfg, st, wu)
+            if R.rank == 0:
+                r = R.report(cfg, q, res, info, st, sample(cfg), headline=False)
+                cfgs[cfg] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "workload", "batch_per_gpu", "mean_iterations",
+                                               "roofline", "checks", "cpu_baseline", "parity_vs_cpu") if k in r}
+            bm.close()
+            del q, res, bm
+            R.torch.cuda.empty_cache()
+        if R.rank == 0:
+            line["configs"] = cfgs
+    if R.rank == 0:
+        print(json.dumps(line))
+    if R.world > 1:
+        R.dist.barrier()
+        R.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -65,6 +65,8 @@ EXPORTS = [
     "daqp_batch_set_settings", "daqp_batch_set_exact", "daqp_batch_setup", "daqp_batch_setup_shared", "daqp_batch_update", "daqp_batch_solve",
     "daqp_batch_setup_flags", "daqp_batch_working_sets", "daqp_batch_set_primal_start", "daqp_batch_prox_info", "daqp_quadprog_batch", "daqp_batch_kernel_ms",
     "daqp_batch_device_bytes", "daqp_amd_last_error", "daqp_amd_device_count", "daqp_amd_version",
+    "setup_daqp_ldp", "daqp_ldp", "ldp2qp_solution", "daqp_extract_result",
+    "daqp_batch_enable_trace", "daqp_batch_read_trace", "daqp_batch_enable_profile", "daqp_batch_read_profile", "daqp_batch_read_ldp",
 ]
 
 
@@ -158,6 +160,13 @@ def lib():
     L.daqp_primal_init_active.restype = None
     L.daqp_dual_init_active.argtypes = [C.POINTER(DAQPProblem), c_double_p]
     L.daqp_dual_init_active.restype = None
+    L.setup_daqp_ldp.argtypes = [vp, C.POINTER(DAQPProblem), ci]
+    L.daqp_ldp.argtypes = [vp]
+    L.ldp2qp_solution.argtypes = [vp]
+    L.ldp2qp_solution.restype = None
+    L.daqp_extract_result.argtypes = [C.POINTER(DAQPResult), vp]
+    L.daqp_extract_result.restype = None
+    L.daqp_minrep.restype = None
     _lib = L
     return L
 

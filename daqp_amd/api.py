@@ -19,6 +19,8 @@ from ._lib import (DAQPBatchProblem, DAQPBatchResult, DAQPProblem, DAQPResult, M
 UPDATE_Rinv, UPDATE_M, UPDATE_v, UPDATE_d, UPDATE_sense = 1, 2, 4, 8, 16
 UPDATE_unconstrained, UPDATE_eliminate = 64, 128
 INF = 1e30
+TRACE_MARK = 0x40000000
+TRACE_PIVOT, TRACE_SINGULAR, TRACE_REFINE, TRACE_REFACTOR, TRACE_CYCLE_RESET = (TRACE_MARK + k for k in range(1, 6))
 
 try:  # torch is plumbing only (device memory, streams); the package works on numpy without it
     import torch
@@ -188,11 +190,14 @@ class BatchModel:
         if rc != 0:
             raise RuntimeError(f"daqp_batch_create failed ({rc}): {_lib.last_error()}")
         self._h = h
-        self._keep = []
+        self._keep = {}          # name -> array/tensor the device currently reads (one entry per input, replaced one by one)
         self._out_keep = []
-        self.device = device
         if torch is not None and torch.cuda.is_available():
-            lib().daqp_batch_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            # the batch lives on ONE device: its launches go to that device's current stream and its outputs are allocated there
+            self.device = torch.cuda.current_device() if device is None else int(device)
+            lib().daqp_batch_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        else:
+            self.device = device
 
     def close(self):
         if getattr(self, "_h", None):
@@ -206,19 +211,25 @@ class BatchModel:
             pass
 
     def _problem(self, H=None, f=None, A=None, bupper=None, blower=None, sense=None):
-        keep = []
+        """DAQPBatchProblem of the given arrays.  Device arrays are used in place by the library (and bounds / f are read
+        again by every later update and solve), so each one stays referenced under its own name until a later call
+        replaces THAT array -- an update(f=...) must not drop the bounds adopted at setup."""
+        keep = {}
         mems = set()
         ptrs = []
-        for a, dt in ((H, np.float64), (f, np.float64), (A, np.float64), (bupper, np.float64), (blower, np.float64),
-                      (sense, np.int32)):
-            p, mem = _ptr(a, dt, keep)
+        for name, a, dt in (("H", H, np.float64), ("f", f, np.float64), ("A", A, np.float64), ("bupper", bupper, np.float64),
+                            ("blower", blower, np.float64), ("sense", sense, np.int32)):
+            tmp = []
+            p, mem = _ptr(a, dt, tmp)
             ptrs.append(p)
             if mem is not None:
                 mems.add(mem)
+                keep[name] = tmp[0]
         if len(mems) > 1:
             raise ValueError("mix of host and device arrays in one call")
         mem = mems.pop() if mems else MEM_HOST
-        self._keep = keep if mem == MEM_DEVICE else self._keep
+        if mem == MEM_DEVICE:
+            self._keep.update(keep)
         return DAQPBatchProblem(self.N, self.n, self.m, self.ms, *ptrs, mem), keep
 
     def setup(self, H, f, A, bupper, blower, sense=None, init_mask=0):
@@ -234,7 +245,6 @@ class BatchModel:
         MPC usage; the factorisation runs once."""
         assert H.ndim == 2 and (A is None or A.ndim == 2), "setup_shared takes a single H and a single A"
         p, keep = self._problem(H, f, A, bupper, blower, sense)
-        self._keep = keep
         rc = lib().daqp_batch_setup_shared(self._h, C.byref(p), 0)
         if rc != 0:
             raise RuntimeError(f"daqp_batch_setup_shared failed ({rc}): {_lib.last_error()}")
@@ -248,7 +258,6 @@ class BatchModel:
     def update(self, f=None, bupper=None, blower=None):
         mask = (UPDATE_v if f is not None else 0) | (UPDATE_d if (bupper is not None or blower is not None) else 0)
         p, keep = self._problem(None, f, None, bupper, blower, None)
-        self._upd_keep = keep
         rc = lib().daqp_batch_update(self._h, mask, C.byref(p))
         if rc != 0:
             raise RuntimeError(f"daqp_batch_update failed ({rc}): {_lib.last_error()}")
@@ -258,7 +267,7 @@ class BatchModel:
         """Returns dict(x, lam, fval, exitflag, iter, soft_slack); out='numpy' or 'torch' (device tensors)."""
         N, n, m = self.N, self.n, self.m
         if out == "torch":
-            dev = torch.device("cuda", torch.cuda.current_device())
+            dev = torch.device("cuda", self.device)
             o = dict(x=torch.empty((N, n), dtype=torch.float64, device=dev),
                      lam=torch.empty((N, m), dtype=torch.float64, device=dev),
                      fval=torch.empty(N, dtype=torch.float64, device=dev),
@@ -313,10 +322,13 @@ class BatchModel:
         lib().daqp_batch_enable_trace(self._h, cap)
         self._trace_cap = cap
 
-    def read_trace(self):
+    def read_trace(self, marks=False):
+        """Per problem: +(id+1) for an added constraint, -(id+1) for a removed one, in order.  marks=True keeps the branch
+        markers as well (TRACE_PIVOT, TRACE_SINGULAR, TRACE_REFINE, TRACE_REFACTOR, TRACE_CYCLE_RESET)."""
         t = np.zeros((self.N, self._trace_cap), np.int32)
         lib().daqp_batch_read_trace(self._h, _ip(t))
-        return [t[q, : min(t[q, -1], self._trace_cap - 1)].copy() for q in range(self.N)]
+        out = [t[q, : min(t[q, -1], self._trace_cap - 1)].copy() for q in range(self.N)]
+        return out if marks else [e[e < TRACE_MARK] for e in out]
 
     def enable_profile(self, on=True):
         lib().daqp_batch_enable_profile(self._h, 1 if on else 0)

@@ -60,6 +60,8 @@ struct DAQPBatch {
     // staging copies of host inputs (allocated on first use)
     double *sH = nullptr, *sf = nullptr, *sA = nullptr, *sbu = nullptr, *sbl = nullptr;
     int *ssense = nullptr;
+    size_t nH = 0, nf = 0, nA = 0, nbu = 0, nbl = 0, nsense = 0;   // elements each staging slot can hold
+    bool was_shared = false;   // last set up by daqp_batch_setup_shared: d.H / d.A are ONE matrix, not N
     // library-owned result buffers
     double *ox = nullptr, *olam = nullptr, *ofval = nullptr, *osoft = nullptr;
     int *oflag = nullptr, *oiter = nullptr;
@@ -83,6 +85,10 @@ struct DAQPBatch {
     int n_prox_qps = 0;            // problems of the current setup that go through the outer loop
     int prox_outer = 0;            // outer iterations of the last solve (the longest loop of the batch)
     double *ident = nullptr;       // LP batches (H == NULL): the one n x n identity the setup pass reads as H
+    // single-problem workspaces: results of the last daqp_ldp, waiting for daqp_extract_result
+    std::vector<double> one_lam;
+    double one_fval = 0, one_soft = 0;
+    int one_flag = 0, one_iter = 0;
 };
 
 namespace {
@@ -166,12 +172,29 @@ int flush_update(DAQPBatch *b)
 }
 
 // copy (host) or adopt (device) one input array
+// a staging slot that can hold `count` elements (grown when a later call needs more: setup_shared stages ONE H / A,
+// a later per-problem setup N of them)
 template <typename T>
-int stage(DAQPBatch *b, const T *src, int memory, size_t count, T **slot, const T **out)
+int slot_reserve(DAQPBatch *b, T **slot, size_t *cap, size_t count)
+{
+    if (*slot != nullptr && *cap >= count) return 0;
+    if (*slot != nullptr) {
+        HIPCHK(hipStreamSynchronize(b->stream));   // nothing in flight may still read the old buffer
+        for (auto &o : b->owned) if (o == *slot) { o = b->owned.back(); b->owned.pop_back(); break; }
+        (void)hipFree(*slot);
+        b->bytes -= *cap * sizeof(T);
+        *slot = nullptr; *cap = 0;
+    }
+    if (dev_alloc(b, slot, count)) return DAQP_EXIT_UNSUPPORTED;
+    *cap = count ? count : 1;
+    return 0;
+}
+template <typename T>
+int stage(DAQPBatch *b, const T *src, int memory, size_t count, T **slot, size_t *cap, const T **out)
 {
     if (src == nullptr) { *out = nullptr; return 0; }
     if (memory == DAQP_MEM_DEVICE) { *out = src; return 0; }
-    if (*slot == nullptr) { if (dev_alloc(b, slot, count)) return DAQP_EXIT_UNSUPPORTED; }
+    if (slot_reserve(b, slot, cap, count)) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipMemcpyAsync(*slot, src, count * sizeof(T), hipMemcpyHostToDevice, b->stream));
     *out = *slot;
     return 0;
@@ -548,13 +571,14 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
             HIPCHK(hipMemcpy(b->ident, eye.data(), eye.size() * sizeof(double), hipMemcpyHostToDevice));
         }
         d.H = b->ident;
-    } else rc |= stage(b, p->H, p->memory, N * d.n * d.n, &b->sH, &d.H);
-    rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &d.f);
-    rc |= stage(b, p->A, p->memory, N * d.mA * d.n, &b->sA, &d.A);
-    rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &d.bu);
-    rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &d.bl);
-    rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &d.sense_in);
+    } else rc |= stage(b, p->H, p->memory, N * d.n * d.n, &b->sH, &b->nH, &d.H);
+    rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &b->nf, &d.f);
+    rc |= stage(b, p->A, p->memory, N * d.mA * d.n, &b->sA, &b->nA, &d.A);
+    rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &b->nbu, &d.bu);
+    rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &b->nbl, &d.bl);
+    rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &b->nsense, &d.sense_in);
     if (rc) return DAQP_EXIT_UNSUPPORTED;
+    b->was_shared = false;
     // DAQP_UPDATE_eliminate (daqp_quadprog, eq_elim.c): the reference projects many equalities out of the LDP first.  That
     // reduction is not built; such problems are solved on the full LDP instead (what setup_daqp + daqp_solve do): same exit
     // flag and active set, x and lam equal to ~1e-13, only the iteration count may differ (tests/test_gpu_reference_cases.py).
@@ -603,13 +627,14 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     HIPCHK(hipSetDevice(b->device));
     BatchDev &d = b->d;
     const size_t N = d.N;
-    rc |= stage(b, p->H, p->memory, (size_t)d.n * d.n, &b->sH, &d.H);
-    rc |= stage(b, p->A, p->memory, (size_t)d.mA * d.n, &b->sA, &d.A);
-    rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &d.f);
-    rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &d.bu);
-    rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &d.bl);
-    rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &d.sense_in);
+    rc |= stage(b, p->H, p->memory, (size_t)d.n * d.n, &b->sH, &b->nH, &d.H);
+    rc |= stage(b, p->A, p->memory, (size_t)d.mA * d.n, &b->sA, &b->nA, &d.A);
+    rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &b->nf, &d.f);
+    rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &b->nbu, &d.bu);
+    rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &b->nbl, &d.bl);
+    rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &b->nsense, &d.sense_in);
     if (rc) return DAQP_EXIT_UNSUPPORTED;
+    b->was_shared = true;
     if (!b->wide_u) {
         if (dev_alloc(b, &b->wide_u, d.m) || dev_alloc(b, &b->wide_l, d.m) || dev_alloc(b, &b->structural, d.m) || dev_alloc(b, &b->shared_flag, 2))
             return DAQP_EXIT_UNSUPPORTED;
@@ -666,8 +691,13 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
         if (!pp.H) { pp.H = d.H; } if (!pp.f) pp.f = d.f; if (!pp.A) pp.A = d.A;
         if (!pp.bupper) pp.bupper = d.bu; if (!pp.blower) pp.blower = d.bl;
         const bool lp = b->ident && d.H == b->ident;   // an LP batch has no H to resend
-        if ((!p->H && !lp) || !p->f || !p->A || !p->bupper || !p->blower) {
+        const bool need_A = d.mA > 0;                   // only simple bounds: A is legitimately NULL
+        if ((!p->H && !lp) || !p->f || (need_A && !p->A) || !p->bupper || !p->blower) {
             if (p->memory != DAQP_MEM_DEVICE) { set_err("full re-setup from host memory needs every array"); return DAQP_EXIT_UNSUPPORTED; }
+        }
+        if (b->was_shared && ((!p->H && !lp) || (need_A && !p->A))) {   // the batch holds ONE H / A: nothing per problem to reuse
+            set_err("full re-setup after daqp_batch_setup_shared needs per-problem H and A (or call daqp_batch_setup_shared again)");
+            return DAQP_EXIT_UNSUPPORTED;
         }
         return batch_setup(b, &pp, mask & (DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate), false);   // daqp_update_ldp keeps work->x
     }
@@ -684,19 +714,19 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
     // arrays are copied into the batch's own buffers (stream-ordered, a few tens of microseconds) instead of adopted.
     const bool lazy = b->NB > 0 && !getenv("DAQP_AMD_EAGER_UPDATE");
     const int mem = p->memory;
-    auto take = [&](const double *src, size_t count, double **slot, const double **out) -> int {
-        if (!lazy || mem != DAQP_MEM_DEVICE) return stage(b, src, mem, count, slot, out);
-        if (*slot == nullptr) { if (dev_alloc(b, slot, count)) return DAQP_EXIT_UNSUPPORTED; }
+    auto take = [&](const double *src, size_t count, double **slot, size_t *cap, const double **out) -> int {
+        if (!lazy || mem != DAQP_MEM_DEVICE) return stage(b, src, mem, count, slot, cap, out);
+        if (src != *slot && slot_reserve(b, slot, cap, count)) return DAQP_EXIT_UNSUPPORTED;
         if (src != *slot) HIPCHK(hipMemcpyAsync(*slot, src, count * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
         *out = *slot;
         return 0;
     };
     if (mask & DAQP_UPDATE_v) {
         if (!p->f) { set_err("DAQP_UPDATE_v needs f"); return DAQP_EXIT_UNSUPPORTED; }
-        rc |= take(p->f, N * d.n, &b->sf, &tmp); d.f = tmp;
+        rc |= take(p->f, N * d.n, &b->sf, &b->nf, &tmp); d.f = tmp;
     }
-    if (p->bupper) { rc |= take(p->bupper, N * d.m, &b->sbu, &tmp); d.bu = tmp; }
-    if (p->blower) { rc |= take(p->blower, N * d.m, &b->sbl, &tmp); d.bl = tmp; }
+    if (p->bupper) { rc |= take(p->bupper, N * d.m, &b->sbu, &b->nbu, &tmp); d.bu = tmp; }
+    if (p->blower) { rc |= take(p->blower, N * d.m, &b->sbl, &b->nbl, &tmp); d.bl = tmp; }
     if (rc) return DAQP_EXIT_UNSUPPORTED;
     if (lazy) { b->pending_mask |= mask; b->timed_setup = false; return 0; }
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
@@ -794,7 +824,8 @@ int daqp_batch_setup_flags(DAQPBatch *b, int *flags_host)
     HIPCHK(hipStreamSynchronize(b->stream));
     std::vector<QState> qs(b->d.N);
     HIPCHK(hipMemcpy(qs.data(), b->d.qs, sizeof(QState) * b->d.N, hipMemcpyDeviceToHost));
-    for (int i = 0; i < b->d.N; ++i) flags_host[i] = qs[i].setup_flag;
+    // (a daqp_update_ldp whose bound check failed reports its flag here until the next update, as the call itself does in the reference)
+    for (int i = 0; i < b->d.N; ++i) flags_host[i] = (qs[i].setup_flag > 0 && qs[i].upd_flag < 0) ? qs[i].upd_flag : qs[i].setup_flag;
     return 0;
 }
 
@@ -859,6 +890,7 @@ int daqp_quadprog_batch(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQ
 // single-problem drop-in entry points: a batch of one behind the reference's workspace struct
 // ------------------------------------------------------------------------------------
 static DAQPBatch *ws_batch(DAQPWorkspace *w) { return reinterpret_cast<DAQPBatch *>(w->timer); }
+static void free_daqp_workspace_keep_settings(DAQPWorkspace *work);
 
 static DAQPBatchProblem one_problem(const DAQPProblem *qp)
 {
@@ -869,7 +901,10 @@ static DAQPBatchProblem one_problem(const DAQPProblem *qp)
     return p;
 }
 
-static void refresh_mirrors(DAQPWorkspace *w)
+// Host mirrors of the device state behind a single-problem workspace.  `ldp`: also the LDP itself (M, R^-1, v, d, scaling:
+// after a setup or an update; read-only copies for bindings that inspect them -- interfaces/daqp-eigen/daqp.cpp:250-271
+// reads Rinv / RinvD / v / sense -- writing to them does not reach the device).
+static void refresh_mirrors(DAQPWorkspace *w, bool ldp = false)
 {
     DAQPBatch *b = ws_batch(w);
     if (!b) return;
@@ -884,6 +919,27 @@ static void refresh_mirrors(DAQPWorkspace *w)
     if (w->lam_star) {
         const double *src = b->d.vecs + (qs.lam_swapped ? 3 : 4) * (size_t)b->d.cap;
         (void)hipMemcpy(w->lam_star, src, sizeof(double) * b->d.cap, hipMemcpyDeviceToHost);
+    }
+    if (!ldp || qs.setup_flag < 0) return;
+    const BatchDev &d = b->d;
+    const bool lp = b->ident && d.H == b->ident;
+    if (w->v) (void)hipMemcpy(w->v, d.v, sizeof(double) * d.n, hipMemcpyDeviceToHost);
+    if (w->dupper) (void)hipMemcpy(w->dupper, d.dupper, sizeof(double) * d.m, hipMemcpyDeviceToHost);
+    if (w->dlower) (void)hipMemcpy(w->dlower, d.dlower, sizeof(double) * d.m, hipMemcpyDeviceToHost);
+    if (w->scaling) (void)hipMemcpy(w->scaling, d.scaling, sizeof(double) * d.m, hipMemcpyDeviceToHost);
+    std::vector<double> R(d.rtri);
+    if (!lp && hipMemcpy(R.data(), d.Rinv, sizeof(double) * d.rtri, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (qs.diag_h) {   // the reference's RinvD branch (utils.c:245-312): Rinv == NULL, RinvD = 1/sqrt(H_ii)
+            if (w->RinvD) for (int i = 0; i < d.n; ++i) w->RinvD[i] = R[((2 * d.n - i - 1) * i) / 2 + i];
+        } else if (w->Rinv) memcpy(w->Rinv, R.data(), sizeof(double) * d.rtri);
+    }
+    if (w->M && d.mA > 0) {   // the reference's layout: (m - ms) x n row-major, rows normalised
+        const size_t per = (size_t)d.nblk * d.npair * 128;
+        std::vector<double> blk(per);
+        if (hipMemcpy(blk.data(), d.Mblk, per * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int r = d.ms; r < d.m; ++r)
+                for (int k = 0; k < d.n; ++k)
+                    w->M[(size_t)(r - d.ms) * d.n + k] = blk[(((size_t)(r >> 6) * d.npair + (k >> 1)) * 64 + (r & 63)) * 2 + (k & 1)];
     }
 }
 
@@ -928,9 +984,21 @@ int setup_daqp_main(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time, i
     }
     // host-visible part of the workspace (everything numerical stays on the device)
     work->qp = qp; work->n = qp->n; work->m = qp->m; work->ms = qp->ms;
-    work->M = work->dupper = work->dlower = work->Rinv = work->v = nullptr;
-    work->scaling = work->RinvD = work->xold = work->lam = work->u = nullptr;
+    work->xold = work->lam = work->u = nullptr;
     work->L = work->D = work->xldl = work->zldl = work->Mu = nullptr;
+    {   // read-only host mirrors of the LDP (api.c:343-371 allocates the originals)
+        const size_t n = qp->n, m = qp->m, mA = qp->m - qp->ms;
+        work->M = mA ? static_cast<c_float *>(calloc(mA * n, sizeof(c_float))) : nullptr;
+        work->dupper = static_cast<c_float *>(calloc(m ? m : 1, sizeof(c_float)));
+        work->dlower = static_cast<c_float *>(calloc(m ? m : 1, sizeof(c_float)));
+        work->scaling = static_cast<c_float *>(calloc(m ? m : 1, sizeof(c_float)));
+        work->v = static_cast<c_float *>(calloc(n, sizeof(c_float)));
+        QState q0;
+        const bool diag = hipMemcpy(&q0, b->d.qs, sizeof(QState), hipMemcpyDeviceToHost) == hipSuccess && q0.diag_h;
+        const bool lp = qp->H == nullptr;
+        work->Rinv = (!lp && !diag) ? static_cast<c_float *>(calloc(n * (n + 1) / 2, sizeof(c_float))) : nullptr;
+        work->RinvD = (!lp && diag) ? static_cast<c_float *>(calloc(n, sizeof(c_float))) : nullptr;
+    }
     work->prox_mask = nullptr; work->n_prox = 0; work->bnb = nullptr; work->avi = nullptr; work->eq = nullptr;
     work->nh = 1; work->break_points = nullptr;
     work->sense = static_cast<int *>(calloc(qp->m > 0 ? qp->m : 1, sizeof(int)));
@@ -938,7 +1006,7 @@ int setup_daqp_main(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time, i
     work->lam_star = static_cast<c_float *>(calloc(b->d.cap, sizeof(c_float)));
     work->WS = static_cast<int *>(calloc(b->d.cap, sizeof(int)));
     work->timer = b;
-    refresh_mirrors(work);
+    refresh_mirrors(work, true);
     (void)daqp_batch_prox_info(b, &work->n_prox, nullptr, nullptr);   // types.h:229: > 0 sends daqp_solve through daqp_prox
     if (setup_time) *setup_time = now_s() - t0;
     return 1;
@@ -958,46 +1026,78 @@ int daqp_update_ldp(const int mask, DAQPWorkspace *work, DAQPProblem *qp)
     int flag = 1;
     rc = daqp_batch_setup_flags(b, &flag);
     if (rc < 0) return rc;
-    refresh_mirrors(work);
+    refresh_mirrors(work, true);
     return flag < 0 ? flag : 0;
 }
 
-void daqp_solve(DAQPResult *res, DAQPWorkspace *work)
+// daqp.h:12.  Here the device launch that iterates also back-transforms (ldp2qp_solution, daqp.c:111-139) and assembles the
+// per-constraint multipliers; what daqp_extract_result needs is parked behind the workspace.  Returns the exit flag.
+int daqp_ldp(DAQPWorkspace *work)
 {
     DAQPBatch *b = ws_batch(work);
-    if (!b) { res->exitflag = DAQP_EXIT_UNSUPPORTED; set_err("workspace has not been set up"); return; }
-    const double t0 = now_s();
+    if (!b) { set_err("workspace has not been set up"); return DAQP_EXIT_UNSUPPORTED; }
     if (work->settings) daqp_batch_set_settings(b, work->settings);
     DAQPBatchResult r;
     memset(&r, 0, sizeof(r));
-    double fval = 0, soft = 0;
-    int flag = 0, iter = 0;
-    r.x = work->x; r.lam = res->lam; r.fval = &fval; r.soft_slack = &soft; r.exitflag = &flag; r.iter = &iter;
+    b->one_lam.resize(work->m > 0 ? work->m : 1);
+    r.x = work->x; r.lam = b->one_lam.data(); r.fval = &b->one_fval; r.soft_slack = &b->one_soft; r.exitflag = &b->one_flag; r.iter = &b->one_iter;
     r.memory = DAQP_MEM_HOST;
     const int rc = daqp_batch_solve(b, &r);
-    if (rc < 0) { res->exitflag = rc; return; }
-    res->exitflag = flag; res->iter = iter; res->fval = fval; res->soft_slack = soft;
-    res->nodes = b->n_prox_qps > 0 ? b->prox_outer : 1;   // api.c:488: work->nh, the outer iterations of daqp_prox (daqp_prox.c:34,129)
-    if (flag > 0 || true)
-        for (int i = 0; i < work->n; ++i) res->x[i] = work->x[i];
+    if (rc < 0) { b->one_flag = rc; return rc; }
     refresh_mirrors(work);
+    work->iterations = b->one_iter;
+    return b->one_flag;
+}
+void ldp2qp_solution(DAQPWorkspace *work) { (void)work; }   // daqp.h:13: done on the device by daqp_ldp (work->x already holds x)
+
+// api.c:455-495: package the last daqp_ldp / daqp_solve of this workspace
+void daqp_extract_result(DAQPResult *res, DAQPWorkspace *work)
+{
+    DAQPBatch *b = ws_batch(work);
+    if (!b || !res) return;
+    if (res->x && work->x) for (int i = 0; i < work->n; ++i) res->x[i] = work->x[i];
+    if (res->lam) for (int i = 0; i < work->m; ++i) res->lam[i] = i < (int)b->one_lam.size() ? b->one_lam[i] : 0.0;
+    res->fval = b->one_fval; res->soft_slack = b->one_soft; res->iter = b->one_iter;
+    res->nodes = b->n_prox_qps > 0 ? b->prox_outer : 1;   // api.c:488: work->nh, the outer iterations of daqp_prox (daqp_prox.c:34,129)
+}
+
+void daqp_solve(DAQPResult *res, DAQPWorkspace *work)   // api.c:8-59
+{
+    if (!ws_batch(work)) { res->exitflag = DAQP_EXIT_UNSUPPORTED; set_err("workspace has not been set up"); return; }
+    const double t0 = now_s();
+    res->exitflag = daqp_ldp(work);
+    daqp_extract_result(res, work);
     res->solve_time = now_s() - t0;
 }
 
-void free_daqp_workspace(DAQPWorkspace *work)
+// api.c:161-209: QP -> LDP on a workspace (what setup_daqp_main does after its checks).  The device workspace is created
+// here; returns 1 or a negative exit flag.
+int setup_daqp_ldp(DAQPWorkspace *work, DAQPProblem *qp, const int init_mask)
+{
+    if (!work || !qp) return DAQP_EXIT_UNSUPPORTED;
+    if (ws_batch(work)) { free_daqp_workspace_keep_settings(work); free_daqp_ldp(work); }
+    return setup_daqp_main(qp, work, nullptr, init_mask);
+}
+
+static void free_daqp_workspace_keep_settings(DAQPWorkspace *work)
 {
     if (work->timer) { daqp_batch_free(ws_batch(work)); work->timer = nullptr; }
     free(work->x); work->x = nullptr;
     free(work->lam_star); work->lam_star = nullptr;
     free(work->WS); work->WS = nullptr;
+}
+void free_daqp_workspace(DAQPWorkspace *work)
+{
+    free_daqp_workspace_keep_settings(work);
     if (work->settings != nullptr) { free(work->settings); work->settings = nullptr; }
 }
 
-void free_daqp_ldp(DAQPWorkspace *work)
+void free_daqp_ldp(DAQPWorkspace *work)   // api.c:243-275
 {
     if (work->sense == nullptr) return;
-    free(work->sense);
-    work->sense = nullptr;
+    free(work->sense); work->sense = nullptr;
+    free(work->M); free(work->dupper); free(work->dlower); free(work->scaling); free(work->v); free(work->Rinv); free(work->RinvD);
+    work->M = work->dupper = work->dlower = work->scaling = work->v = work->Rinv = work->RinvD = nullptr;
 }
 
 void daqp_quadprog(DAQPResult *res, DAQPProblem *qp, DAQPSettings *settings)
@@ -1079,12 +1179,12 @@ int daqp_first_violating(c_float *x, c_float *A, c_float *bu, c_float *bl, int n
     return m;
 }
 // api.h: daqp_minrep (redundancy removal built on repeated LDP solves, src/api.c) is outside this path.  The symbol exists
-// so that the reference's Cython module (daqp.pxd:65) links against this library; it reports "unsupported".
-int daqp_minrep(int *is_redundant, c_float *A, c_float *b, int n, int m, int ms)
+// so that the reference's Cython module (daqp.pxd:65) links against this library; it leaves is_redundant untouched and
+// records the reason in daqp_amd_last_error().
+void daqp_minrep(int *is_redundant, c_float *A, c_float *b, int n, int m, int ms)
 {
     (void)is_redundant; (void)A; (void)b; (void)n; (void)m; (void)ms;
     set_err("daqp_minrep is outside the dense-QP path of this library");
-    return DAQP_EXIT_UNSUPPORTED;
 }
 
 } // extern "C"

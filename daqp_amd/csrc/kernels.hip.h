@@ -648,6 +648,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag; qs->n_prox = (flag > 0) ? nprox : 0;
+        qs->upd_flag = 0;
     }
     GPROF(5);
     if (b.prof && lane == 0) for (int i = 0; i < 6; ++i) b.prof[(size_t)q * 32 + 16 + i] = gpt[i];
@@ -682,6 +683,7 @@ __global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *struc
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = kEmpty; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0 && b.sense_in) ? 1 : 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = shared_flag[1]; qs->n_prox = 0;
+        qs->upd_flag = 0;
     }
 }
 
@@ -698,20 +700,21 @@ __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
     const double *scq = b.scaling + qf(b, q) * m;
     int *sens = b.sense + (size_t)q * m;
     const DAQPSettings &st = b.st;
+    // check_bounds (utils.c:546-567) on the stored sense.  The reference walks the rows in order and returns at the first
+    // crossed pair: unmarked equalities BEFORE it have been marked by then, nothing else of the workspace has changed
+    // (utils.c:98-103 comes before v, d and the activation) -- the workspace stays usable and the next update starts afresh.
+    int first_bad = kBig;
+    for (int i = lane; i < m; i += 64)
+        if (!(sens[i] & DAQP_IMMUTABLE) && bu[i] - bl[i] < -st.primal_tol && first_bad == kBig) first_bad = i;
+    first_bad = -(int)wave_min(-(double)first_bad);   // lowest index over the wave (exact: |i| < 2^31)
     int bad = 0;
-    for (int i = lane; i < m; i += 64) {   // check_bounds (utils.c:546-567) on the stored sense
-        int s = sens[i];
-        if (!(s & DAQP_IMMUTABLE)) {
-            const double diff = bu[i] - bl[i];
-            if (diff < -st.primal_tol) bad |= 1;
-            else if (diff < st.zero_tol && !(s & DAQP_SOFT)) { sens[i] = s | DAQP_ACTIVE | DAQP_IMMUTABLE; bad |= 4; }
-        }
+    for (int i = lane; i < m && i < first_bad; i += 64) {
+        const int s = sens[i];
+        if (!(s & DAQP_IMMUTABLE) && !(s & DAQP_SOFT) && bu[i] - bl[i] < st.zero_tol) { sens[i] = s | DAQP_ACTIVE | DAQP_IMMUTABLE; bad |= 4; }
     }
-    const int inf = __any(bad & 1), eq = __any(bad & 4);
-    if (inf) {
-        if (lane == 0) { qs->exitflag = DAQP_EXIT_INFEASIBLE; qs->setup_flag = DAQP_EXIT_INFEASIBLE; }
-        return;
-    }
+    const int inf = first_bad != kBig, eq = __any(bad & 4);
+    if (lane == 0) { qs->upd_flag = inf ? DAQP_EXIT_INFEASIBLE : 0; qs->sing_ind = kEmpty; }   // utils.c:80-81 precedes the check
+    if (inf) return;
     if (mask & DAQP_UPDATE_v) {   // utils.c:474-497 without UPDATE_Rinv: rows < ms of R^-1 are normalised
         const double *f = b.f + (size_t)q * n;
         const int diag = qs->diag_h;   // RinvD branch: v_i = f_i * RinvD_i, no scaling (utils.c:479-480)
@@ -783,9 +786,14 @@ void k_ldp(BatchDev b, int mode)
         if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
         return;
     }
+    if (mode == 0 && qs->upd_flag < 0) {   // the last update failed its bound check: report that, keep the state (see k_update)
+        if (lane == 0) { b.exitflag[q] = qs->upd_flag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
+        return;
+    }
     const LdpLds o = ldp_lds(n, m, cap, SPILL);
     int *ibase = reinterpret_cast<int *>(smem + o.dbl);
     Wave<C, NB, NP> w;
+    w.t_start = __builtin_amdgcn_s_memrealtime();
     w.profiling = (b.prof != nullptr) && mode == 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) w.prof[i] = 0;
@@ -973,7 +981,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
         return;
     }
+    if (mode == 0 && !upd) {   // the last update failed its bound check: report that, keep the state (see k_update)
+        const int uflag = __builtin_amdgcn_readfirstlane(qs->upd_flag);
+        if (uflag < 0) {
+            if (lane == 0) { b.exitflag[q] = uflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
+            return;
+        }
+    }
     typedef RegLds<NB> o;
+    if (lane == 0) reinterpret_cast<unsigned long long *>(smem + o::u)[66] = __builtin_amdgcn_s_memrealtime();   // time_limit stamp (rrun)
     const int rowc_size = reg_lds_rowc_size(n, m, cap, b.ldrc);
     RWave<NB, NP> w;
     // phase counters live in the (otherwise unused) D/xl slots of the LDS carve-up
@@ -1107,24 +1123,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     const long long tp1 = kProfile ? (long long)__builtin_readcyclecounter() : 0;
     if (upd) {
         // ---- daqp_update_ldp(UPDATE_v|UPDATE_d) on the resident factors (utils.c:58-221 without Rinv/M), cf. k_update
-        int bad = 0;
-        static_for<NB>([&](auto bb) __attribute__((always_inline)) {   // check_bounds (utils.c:546-567) on the stored sense
+        // check_bounds (utils.c:546-567) on the stored sense: the first crossed pair (in index order) ends the update with
+        // -1; unmarked equalities before it have been marked by then, nothing else changes (see k_update)
+        int first_bad = kBig;
+        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
             const int r = bb * 64 + lane;
-            const bool ok = r < m;
+            if (r < m && !(rsense_get(w, bb) & DAQP_IMMUTABLE) && bur[bb] - blr[bb] < -w.stp->primal_tol && first_bad == kBig) first_bad = r;
+        });
+        first_bad = -(int)wave_min(-(double)first_bad);
+        int bad = 0;
+        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+            const int r = bb * 64 + lane;
             const int sn = rsense_get(w, bb);
-            if (ok && !(sn & DAQP_IMMUTABLE)) {
-                const double diff = bur[bb] - blr[bb];
-                if (diff < -w.stp->primal_tol) bad |= 1;
-                else if (diff < w.stp->zero_tol && !(sn & DAQP_SOFT)) { w.rs |= (unsigned)(DAQP_ACTIVE | DAQP_IMMUTABLE) << (8 * bb); bad |= 4; }
+            if (r < m && r < first_bad && !(sn & DAQP_IMMUTABLE) && !(sn & DAQP_SOFT) && bur[bb] - blr[bb] < w.stp->zero_tol) {
+                w.rs |= (unsigned)(DAQP_ACTIVE | DAQP_IMMUTABLE) << (8 * bb); bad |= 4;
             }
         });
-        if (__any(bad & 1)) {
+        if (first_bad != kBig) {
+            static_for<NB>([&](auto bb) __attribute__((always_inline)) { const int r = bb * 64 + lane; if (r < m) gsense[r] = rsense_get(w, bb); });
             if (lane == 0) {
-                qs->exitflag = DAQP_EXIT_INFEASIBLE; qs->setup_flag = DAQP_EXIT_INFEASIBLE;
+                qs->upd_flag = DAQP_EXIT_INFEASIBLE; qs->sing_ind = kEmpty;
                 b.exitflag[q] = DAQP_EXIT_INFEASIBLE; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0;
             }
+            copy_wait();   // nothing may still be landing in LDS when the workgroup ends
             return;
         }
+        if (lane == 0) qs->upd_flag = 0;
         if (__any(bad & 4)) q_need_act = 1;
         double *vv = w.u, *fl = w.pend_lam;       // both regions are free until the loop starts (u is zeroed below)
         for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) vv[e] = 0;

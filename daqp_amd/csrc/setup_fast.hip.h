@@ -499,6 +499,7 @@ __global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag; qs->n_prox = (flag > 0) ? nprox : 0;
+        qs->upd_flag = 0;
         if (kProfile && b.prof) for (int i = 0; i < 10; ++i) b.prof[(size_t)q * 32 + i] = pt[i];
     }
 #undef SPROF

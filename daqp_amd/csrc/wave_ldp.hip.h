@@ -141,6 +141,8 @@ struct QState {   // per-problem scalars kept in HBM between launches
     int n_active, reuse_ind, sing_ind, iterations;
     int lam_swapped, setup_flag, need_activate, exitflag;
     double fval, soft_slack;
+    int upd_flag, pad_;  // upd_flag < 0: the last daqp_update_ldp(UPDATE_v|UPDATE_d) failed its bound check (utils.c:98-103): solves report it
+                         // until the next update; factors and working set are kept (the reference's workspace stays usable too)
     int diag_h, n_prox; // n_prox > 0: the factor is of a shifted Hessian, solves go through the proximal outer loop (prox.hip.h)
                         // diag_h 1: H was diagonal -- the reference's RinvD branch (utils.c:245-312): rows < ms of R^-1 are kept
                         // un-normalised (their image in M is the exact unit vector) and x is not divided by the scaling
@@ -170,10 +172,26 @@ struct Wave {
     // optional phase cycle counters (s_memtime): csp, blocking, primal, scan, add, remove, other
     long long prof[8];
     bool profiling;
+    // settings->time_limit > 0 (daqp.c:95-103): ticks of the 100 MHz constant clock at the start of this problem's solve
+    unsigned long long t_start;
 };
+
+// seconds -> ticks of s_memrealtime (constant 100 MHz on gfx950)
+__device__ __forceinline__ bool time_is_up(unsigned long long t_start, double limit_s)
+{
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    return (double)(now - t_start) * 1e-8 > limit_s;
+}
 
 #define PROF_T0(w) long long prof_t0_ = (w).profiling ? (long long)__builtin_readcyclecounter() : 0
 #define PROF_ACC(w, slot) do { if ((w).profiling) { const long long t1_ = (long long)__builtin_readcyclecounter(); (w).prof[slot] += t1_ - prof_t0_; prof_t0_ = t1_; } } while (0)
+
+// branch markers in the event trace (tests count them; daqp_batch_read_trace hands them out with the adds / removes):
+// pivot_last swapped a constraint out (auxiliary.c:379-396), a singular direction was followed (auxiliary.c:357-376),
+// the active rows were refined (auxiliary.c:498-593), the factor was rebuilt at a KKT point (daqp.c:33-46) or by the
+// cycle guard (daqp.c:66-85)
+enum : int { kTraceMark = 0x40000000, kTracePivot = kTraceMark + 1, kTraceSingular = kTraceMark + 2, kTraceRefine = kTraceMark + 3,
+             kTraceRefactor = kTraceMark + 4, kTraceCycleReset = kTraceMark + 5 };
 
 template <int C, int NB, int NP>
 __device__ __forceinline__ void trace_ev(Wave<C, NB, NP> &w, int ev)
@@ -442,6 +460,7 @@ __device__ __forceinline__ void pivot_tail(Wave<C, NB, NP> &w)
             piv = dr < w.st.pivot_tol && dr < dl;
         }
         if (piv) {
+            trace_ev(w, kTracePivot);
             if (lane == 0) { w.pend_id[depth] = w.ws[r]; w.pend_lam[depth] = w.lam[r]; }
             depth++;
             WSYNC();
@@ -884,7 +903,10 @@ __device__ __forceinline__ int ldp_loop(Wave<C, NB, NP> &w, int &iterations)
             PROF_ACC(w, 0);
             const int blocked = remove_blocking(w);
             if (blocked) PROF_ACC(w, 5); else PROF_ACC(w, 1);
-            if (blocked) continue;
+            if (blocked) {   // falls through to the end of the reference's loop body: the clock check applies
+                if (w.st.time_limit > 0 && (it & 31) == 0 && time_is_up(w.t_start, w.st.time_limit)) { flag = DAQP_EXIT_TIMELIMIT; break; }
+                continue;
+            }
             primal_u(w);
             PROF_ACC(w, 2);
             int upper = 0;
@@ -896,6 +918,7 @@ __device__ __forceinline__ int ldp_loop(Wave<C, NB, NP> &w, int &iterations)
                 for (int i = 1; i < w.na; ++i) { const double di = w.D[i]; if (di < dmin) dmin = di; }
                 if (w.na > 2 && repaired != 1 && dmin < w.st.refactor_tol) {
                     repaired = 1;
+                    trace_ev(w, kTraceRefactor);
                     for (int i = lane; i < w.na; i += 64) {
                         const int id = w.ws[i];
                         if (w.lam[i] >= 0) w.sense[id] &= ~DAQP_LOWER; else w.sense[id] |= DAQP_LOWER;
@@ -906,6 +929,7 @@ __device__ __forceinline__ int ldp_loop(Wave<C, NB, NP> &w, int &iterations)
                     continue;
                 }
                 if (w.na > 0 && dmin < w.st.pivot_tol) {
+                    trace_ev(w, kTraceRefine);
                     refine_active(w);
                     pick = scan_rows(w, upper, false);
                     if (pick != kBig) { commit_add(w, pick, upper); continue; }
@@ -919,6 +943,7 @@ __device__ __forceinline__ int ldp_loop(Wave<C, NB, NP> &w, int &iterations)
                 if (stall++ > w.st.cycle_tol) {
                     if (repaired == 1) { flag = DAQP_EXIT_CYCLE; break; }
                     repaired = 1;
+                    trace_ev(w, kTraceCycleReset);
                     reset_ws(w);
                     activate_marked(w);
                     stall = 0;
@@ -926,9 +951,12 @@ __device__ __forceinline__ int ldp_loop(Wave<C, NB, NP> &w, int &iterations)
                 }
             } else { best = w.fval; stall = 0; }
         } else {
+            trace_ev(w, kTraceSingular);
             singular_direction(w);
             if (!remove_blocking(w)) { flag = DAQP_EXIT_INFEASIBLE; break; }
         }
+        // daqp.c:95-103: every 32nd iteration that reaches the end of the loop body looks at the clock
+        if (w.st.time_limit > 0 && (it & 31) == 0 && time_is_up(w.t_start, w.st.time_limit)) { flag = DAQP_EXIT_TIMELIMIT; break; }
     }
     iterations = it;
     return flag;

@@ -685,6 +685,11 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
     // the compiler from hoisting them itself)
     const double progress_tol = rl(w.stp->progress_tol, 0);
     const int cycle_tol = __builtin_amdgcn_readfirstlane(w.stp->cycle_tol);
+    // settings->time_limit > 0 (daqp.c:95-103): every 32nd iteration that reaches the end of the reference's loop body looks
+    // at the clock; the start stamp sits in LDS (u[66], see k_ldp_reg) so that it costs no register across the loop
+    const bool tl_armed = rl(w.stp->time_limit, 0) > 0.0;
+    int tl_skip = 0;   // this iteration ends with one of the reference's `continue`s: no clock check
+#define RTL_CHECK() (tl_armed && !tl_skip && (it & 31) == 0 && time_is_up(reinterpret_cast<const unsigned long long *>(w.u)[66], rl(w.stp->time_limit, 0)))
     // edit request (add / drop, then the pivot_last cascade) and its continuation
     int depth = 0, req_add = 1, req_id = 0, req_r = 0, after_edit = AFTER_NEXT_ITER;
     double req_lam = 0;
@@ -705,9 +710,10 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
             break;
         // ---- one iteration of daqp_ldp up to its working-set edit (daqp.c:12-64, 86-93)
         case PC_ITER: {
+            tl_skip = 0;
             const bool was_singular = (w.sing != kEmpty);
             RPROF_T0(w);
-            if (!was_singular) rsolve_csp(w); else rsingular_direction(w);
+            if (!was_singular) rsolve_csp(w); else { rtrace(w, kTraceSingular); rsingular_direction(w); }
             RPROF_ACC(w, 7);
             const int blk = rblocking_test(w);
             RPROF_ACC(w, 8);
@@ -724,6 +730,8 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
                 const double dmin = (w.na > 0) ? wave_min(lane < w.na ? w.D : (double)DAQP_INF) : (double)DAQP_INF;
                 if (w.na > 2 && repaired != 1 && dmin < w.stp->refactor_tol) {
                     repaired = 1;
+                    tl_skip = 1;
+                    rtrace(w, kTraceRefactor);
                     for (int i = 0; i < w.na; ++i) {
                         const int id = rli(w.wsid, i);
                         if (rl(w.lam, i) >= 0) sense_set(w, id, 0, DAQP_LOWER); else sense_set(w, id, DAQP_LOWER, 0);
@@ -733,9 +741,11 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
                     break;
                 }
                 if (w.na > 0 && dmin < w.pivot_tol) {
+                    rtrace(w, kTraceRefine);
                     rrefine_active(w);
                     pick = rscan_rows(w, upper, false);
                     after_edit = AFTER_NEXT_ITER;
+                    tl_skip = 1;
                 }
                 if (pick == kBig) {
                     flag = (w.soft > w.stp->primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
@@ -765,6 +775,7 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
                         piv = dr < w.pivot_tol && dr < dlast;
                     }
                     if (piv) {
+                        rtrace(w, kTracePivot);
                         const int idp = rli(w.wsid, r);
                         const double lp = rl(w.lam, r);
                         if (lane == 0) { w.pend_id[depth] = idp; w.pend_lam[depth] = lp; }
@@ -788,12 +799,14 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
                     if (stall++ > cycle_tol) {
                         if (repaired == 1) { flag = DAQP_EXIT_CYCLE; pc = PC_DONE; break; }
                         repaired = 1;
+                        rtrace(w, kTraceCycleReset);
                         rreset_ws(w);
                         act_then = ACT_THEN_CYCLE_RESET; pc = PC_ACT_BEGIN;
                         break;
                     }
                 } else { best = w.fval; stall = 0; }
             }
+            if (RTL_CHECK()) { flag = DAQP_EXIT_TIMELIMIT; pc = PC_DONE; break; }
             ++it;
             pc = (it < iter_limit) ? PC_ITER : PC_DONE;   // falling out of the loop: flag stays ITERLIMIT
             break;
@@ -811,6 +824,7 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
                 else if (act_then == ACT_THEN_LOOP) pc = PC_START_LOOP;
                 else {
                     if (act_then == ACT_THEN_CYCLE_RESET) { stall = 0; best = -1; }
+                    if (RTL_CHECK()) { flag = DAQP_EXIT_TIMELIMIT; pc = PC_DONE; break; }
                     ++it;
                     pc = (it < iter_limit) ? PC_ITER : PC_DONE;
                 }
@@ -872,6 +886,7 @@ __device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activa
             if (lane == 0) { w.prof[pc_now] += t_out - t_in; w.prof[16 + pc_now] += 1; }
         }
     }
+#undef RTL_CHECK
     iterations = it;
     return (mode == 1) ? act_flag : flag;
 }

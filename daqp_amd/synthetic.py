@@ -8,8 +8,19 @@ stream differs from the numpy generator (only the distribution is the same).
 import torch
 
 
-def generate_batch_torch(N, n, m, ms, n_active, seed, kappa=100.0, device="cuda", chunk=8192):
+def _right_solve_upper(Rc, Q):
+    """Q Rc^-1 for upper-triangular Rc, batched.  hipBLAS' batched trsm runs out of workspace for large n x batch: fall back to
+    the general (LU) solve of the transposed system."""
+    try:
+        return torch.linalg.solve_triangular(Rc, Q, upper=True, left=False)
+    except RuntimeError:
+        return torch.linalg.solve(Rc.transpose(1, 2), Q.transpose(1, 2)).transpose(1, 2).contiguous()
+
+
+def generate_batch_torch(N, n, m, ms, n_active, seed, kappa=100.0, device="cuda", chunk=None):
     """Returns dict of device tensors H (N,n,n), f (N,n), A (N,m-ms,n), bupper/blower (N,m), xref (N,n)."""
+    if chunk is None:   # bounded scratch per chunk (the batched factorisations need O(chunk n^2) workspace)
+        chunk = max(128, min(8192, (1 << 24) // (n * n)))
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
     dd = dict(dtype=torch.float64, device=device)
@@ -28,7 +39,7 @@ def generate_batch_torch(N, n, m, ms, n_active, seed, kappa=100.0, device="cuda"
         Q = rndn(B, n, n)
         for _ in range(2):
             Rc = torch.linalg.cholesky(Q.transpose(1, 2) @ Q, upper=True)
-            Q = torch.linalg.solve_triangular(Rc, Q, upper=True, left=False)
+            Q = _right_solve_upper(Rc, Q)
         sq = eig.sqrt()
         T = sq[:, :, None] * Q.transpose(1, 2)
         Tinv = Q / sq[:, None, :]

@@ -14,6 +14,7 @@
  *        reference include/utils.h:11    daqp_update_ldp
  *        reference include/api.h:40-52   allocate_/free_ helpers, daqp_default_settings
  *        reference include/api.h:56-58   daqp_primal_init_active, daqp_dual_init_active
+ *        reference include/api.h:35,54, include/daqp.h:12-13   setup_daqp_ldp, daqp_extract_result, daqp_ldp, ldp2qp_solution
  *
  *  (2) The additive batch entry points (daqp_batch_* / daqp_quadprog_batch):
  *      N independent problems of one shape (n, m, ms), stored back to back,
@@ -89,7 +90,8 @@ typedef struct {
     c_float rho_soft;
     c_float rel_subopt, abs_subopt;
     c_float sing_tol, refactor_tol;
-    c_float time_limit;         /* accepted, unused: bound work with iter_limit */
+    c_float time_limit;         /* seconds, 0 = none: checked every 32nd iteration on the device clock, per problem
+                                   from the start of its solve (daqp.c:95-103) -> DAQP_EXIT_TIMELIMIT */
 } DAQPSettings;
 
 /* Result: layout of reference include/api.h:15-27 (64 bytes). x and lam are caller-owned. */
@@ -108,9 +110,11 @@ typedef struct {
 typedef struct DAQPWorkspace {
     DAQPProblem *qp;
     int n, m, ms;
-    c_float *M, *dupper, *dlower, *Rinv, *v;   /* device-resident: NULL on the host */
+    c_float *M, *dupper, *dlower, *Rinv, *v;   /* READ-ONLY host mirrors of the device-resident LDP (refreshed by setup / update_ldp;
+                                                  layouts of the reference: M (m-ms) x n row-major, Rinv packed upper; Rinv is NULL
+                                                  for a diagonal H (then RinvD) and for an LP) */
     int *sense;                                /* host mirror, m */
-    c_float *scaling, *RinvD;                  /* NULL */
+    c_float *scaling, *RinvD;                  /* host mirrors (see above) */
     c_float *x, *xold;                         /* x: host mirror of the last primal solution */
     c_float *lam, *lam_star, *u;               /* lam_star: host mirror (n_active multipliers) */
     c_float fval;
@@ -148,7 +152,11 @@ void daqp_set_primal_start(DAQPWorkspace *work, c_float *x);                   /
 void allocate_daqp_workspace(DAQPWorkspace *work, int n, int ns);                /* api.h:41 (records n; state is created by setup_daqp) */
 void allocate_daqp_ldp(DAQPWorkspace *work, int n, int m, int ms, int alloc_R, int alloc_v);   /* api.h:42 (records n, m, ms) */
 int daqp_first_violating(c_float *x, c_float *A, c_float *bu, c_float *bl, int n, int m, int ms, c_float tol);   /* api.c:562-574, host-only */
-int daqp_minrep(int *is_redundant, c_float *A, c_float *b, int n, int m, int ms);  /* api.h: outside the path -> DAQP_EXIT_UNSUPPORTED (link stub) */
+void daqp_minrep(int *is_redundant, c_float *A, c_float *b, int n, int m, int ms); /* api.h:55: outside the path (link stub: is_redundant untouched, daqp_amd_last_error() says so) */
+int setup_daqp_ldp(DAQPWorkspace *work, DAQPProblem *qp, const int init_mask);      /* api.c:161-209 (api.h:35) */
+int daqp_ldp(DAQPWorkspace *work);                                                  /* daqp.c:6-108 (daqp.h:12): iterate from the workspace's state; returns the exit flag */
+void ldp2qp_solution(DAQPWorkspace *work);                                          /* daqp.c:111-139 (daqp.h:13): done on the device by daqp_ldp -- a no-op kept for callers of the pair */
+void daqp_extract_result(DAQPResult *res, DAQPWorkspace *work);                     /* api.c:455-495 (api.h:54): x, lam, fval, iter of the workspace's last daqp_ldp / daqp_solve */
 
 /* ------------------------------------------------------------------ */
 /* (2) batch entry points (additive; not in the reference)             */
@@ -230,6 +238,16 @@ int daqp_quadprog_batch(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQ
 int daqp_batch_kernel_ms(DAQPBatch *b, float *setup_ms, float *solve_ms);
 /* bytes of device memory held by the batch */
 unsigned long long daqp_batch_device_bytes(const DAQPBatch *b);
+
+/* ---- test / tuning hooks (used by tests/ and tools/; not needed by a caller of the solver) ---- */
+/* per-problem add/remove event trace: `cap` ints per problem (+(id+1) add, -(id+1) remove; the last slot = event count); 0 = off */
+int daqp_batch_enable_trace(DAQPBatch *b, int cap);
+int daqp_batch_read_trace(DAQPBatch *b, int *host /* N*cap */);
+/* cycle counters of the kernels' phases (32 x int64 per problem); on = 0 switches them off */
+int daqp_batch_enable_profile(DAQPBatch *b, int on);
+int daqp_batch_read_profile(DAQPBatch *b, long long *host /* N*32 */);
+/* LDP of problem q as the reference stores it: M (m-ms) x n row-major, R^-1 packed upper, v, dupper, dlower, scaling; any may be NULL */
+int daqp_batch_read_ldp(DAQPBatch *b, int q, c_float *M, c_float *R, c_float *v, c_float *dupper, c_float *dlower, c_float *scaling);
 
 /* diagnostics */
 const char *daqp_amd_last_error(void);

@@ -1,0 +1,397 @@
+"""The reference's OWN outputs (tests/golden/*.npz, written by make_golden.py from the reference library) replayed through
+the HIP path and the C ABI, plus the reference's warm-start known-answer test and the edge cases of daqp_update_ldp.
+
+exact mode (DAQP_AMD_EXACT=1): bit-identical x, lam, fval, iteration count and exit flag.
+default mode (M = A R^-1 on the matrix cores): identical exit flag, iteration count and active set, |x - x_ref| < 1e-9.
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+XTOL = 1e-9
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float64).view(np.uint64),
+                          np.ascontiguousarray(b, np.float64).view(np.uint64))
+
+
+def golden_cases(fname):
+    g = np.load(os.path.join(ROOT, "tests", "golden", fname), allow_pickle=False)
+    for nm in sorted({k.split("/")[0] for k in g.files}):
+        get = lambda f, nm=nm: g[f"{nm}/{f}"]
+        yield nm, get, (get("sense") if f"{nm}/sense" in g.files else None)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_golden_quadprog(gpu_lib, monkeypatch, exact):
+    """76 daqp_quadprog outputs of the reference: hand examples, zero rows of A (normalize_M's IMMUTABLE / INFEASIBLE
+    branch, utils.c:598-606), unmarked equalities (check_bounds, utils.c:560-563), pre-activated sense, soft rows,
+    near-dependent rows, config samples"""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
+    seen = set()
+    cnt = 0
+    for nm, get, sense in golden_cases("golden_quadprog.npz"):
+        x, fval, flag, info = daqp_amd.solve(get("H"), get("f"), get("A"), get("bupper"), get("blower"), sense)
+        assert flag == int(get("exitflag")), (nm, flag, int(get("exitflag")), info["error"])
+        assert info["iterations"] == int(get("iter")), (nm, info["iterations"], int(get("iter")))
+        seen.add(flag)
+        cnt += 1
+        if flag > 0:
+            if exact:
+                assert bits_equal(x, get("x")) and bits_equal(info["lam"], get("lam")) and fval == float(get("fval")), nm
+            else:
+                assert np.array_equal(np.sign(info["lam"]), np.sign(get("lam"))), nm
+                assert np.abs(x - get("x")).max() < XTOL and abs(fval - float(get("fval"))) < 1e-9 * max(1.0, abs(float(get("fval")))), nm
+    assert cnt >= 70 and {1, -1} <= seen
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_golden_warm_sequence(gpu_lib, monkeypatch, exact):
+    """setup_daqp -> daqp_solve -> {daqp_update_ldp(UPDATE_v) -> daqp_solve}* against the reference's own sequence"""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_warm.npz"), allow_pickle=False)
+    d = daqp_amd.Model()
+    flag, _ = d.setup(g["H"], g["f0"], g["A"], g["bupper"], g["blower"], None)
+    assert flag == 1
+    for t in range(g["fs"].shape[0]):
+        if t > 0:
+            assert d.update(f=g["fs"][t]) == 0
+        x, fval, ef, info = d.solve()
+        assert ef == int(g["exitflag"][t]) and info["iterations"] == int(g["iter"][t]), t
+        if exact:
+            assert bits_equal(x, g["x"][t]), t
+        else:
+            assert np.abs(x - g["x"][t]).max() < XTOL, t
+
+
+def _problem_struct(q, sense):
+    import ctypes as C
+    from daqp_amd._lib import DAQPProblem, c_double_p, c_int_p
+    keep = [np.ascontiguousarray(q[k], np.float64) for k in ("H", "f", "A", "bupper", "blower")] + [np.ascontiguousarray(sense, np.int32)]
+    dp = lambda a: a.ctypes.data_as(c_double_p)
+    n, m = keep[1].size, keep[3].size
+    ms = m - keep[2].reshape(-1, n).shape[0]
+    return DAQPProblem(n, m, ms, dp(keep[0]), dp(keep[1]), dp(keep[2]), dp(keep[3]), dp(keep[4]),
+                       keep[5].ctypes.data_as(c_int_p), None, 0, 0), keep
+
+
+@pytest.mark.parametrize("helper", ["dual", "primal"])
+def test_init_active_then_one_iteration(gpu_lib, helper):
+    """core_tests.jl:523-545: the optimal active set handed over by daqp_dual_init_active / daqp_primal_init_active
+    (api.c:579-633) makes daqp_quadprog stop in its first iteration -- helpers and solve both through the C ABI"""
+    import ctypes as C
+    from daqp_amd._lib import DAQPResult, c_double_p, default_settings
+    L = gpu_lib
+    n, m, ms, na, seed, _ = O.CONFIGS["C1"]
+    for k in range(6):
+        q = O.generate_qp(n, m, ms, na, rng=[seed, 10 + k])
+        sense0 = np.zeros(m, np.int32)
+        qp, keep = _problem_struct(q, sense0)
+        x, lam = np.zeros(n), np.zeros(m)
+        res = DAQPResult(x.ctypes.data_as(c_double_p), lam.ctypes.data_as(c_double_p), 0, 0, 0, 0, 0, 0, 0)
+        st = default_settings()
+        L.daqp_quadprog(C.byref(res), C.byref(qp), C.byref(st))
+        assert res.exitflag == 1 and res.iter > 1
+        x0, lam0 = x.copy(), lam.copy()
+        if helper == "dual":
+            L.daqp_dual_init_active(C.byref(qp), lam0.ctypes.data_as(c_double_p))
+        else:
+            L.daqp_primal_init_active(C.byref(qp), x0.ctypes.data_as(c_double_p))
+        sense = keep[5]
+        assert ((sense & 1) != 0).sum() == (lam0 != 0).sum()                  # exactly the optimal active set ...
+        assert np.array_equal((sense & 2) != 0, lam0 < 0)                     # ... on the right side
+        L.daqp_quadprog(C.byref(res), C.byref(qp), C.byref(st))
+        assert res.exitflag == 1 and res.iter == 1, (k, res.iter)
+        assert np.abs(x - x0).max() < 1e-10 and np.array_equal(np.sign(lam), np.sign(lam0))
+
+
+def _nasty(trial):
+    rng = np.random.default_rng([99, trial])
+    eps = 10.0 ** rng.uniform(-13, -2)
+    n = int(rng.integers(4, 16)); m = int(rng.integers(n + 4, 4 * n)); ms = int(rng.integers(0, min(n, m // 3) + 1))
+    na = int(rng.integers(1, min(n, m - ms)))
+    return O.generate_nasty(n, m, ms, na, eps, rng, n_dup=int(rng.integers(0, 5)), n_eq=int(rng.integers(0, 3)),
+                            n_soft=int(rng.integers(0, 3)), dep_eq=bool(rng.integers(0, 2)))
+
+
+def test_degenerate_cases_fast_mode(oracle, gpu_lib, monkeypatch):
+    """the 400 near-degenerate problems of test_gpu_parity (duplicate rows at 1e-13..1e-2, dependent equalities, soft rows)
+    in the DEFAULT arithmetic mode.  M differs from the reference's in the last bit there, and these problems sit on the
+    solver's thresholds on purpose, so a decision may legitimately fall the other way: the bar is the exit flag class
+    for every problem, and identical iterations / active set / x within 1e-9 relative for (nearly) all of them."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "0")
+    same = 0
+    total = 0
+    for trial in range(400):
+        q = _nasty(trial)
+        x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        r = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        assert (flag > 0) == (r[3] > 0), (trial, flag, r[3])
+        total += 1
+        if flag == r[3] and info["iterations"] == r[4] and (flag < 0 or (
+                np.array_equal(np.sign(info["lam"]), np.sign(r[1])) and np.abs(x - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max()))):
+            same += 1
+        elif flag > 0:   # a different path must still end at the same optimum
+            assert abs(fval - r[2]) < 1e-6 * max(1.0, abs(r[2])), (trial, fval, r[2])
+    assert same >= 0.97 * total, (same, total)
+
+
+def test_degenerate_branches_are_taken_on_the_gpu(oracle, gpu_lib, monkeypatch):
+    """the degenerate set drives the GPU state machines through pivot_last, the singular direction, refine_active and the
+    refactor repair (event-trace markers), with the add/remove sequence of the oracle step for step"""
+    import daqp_amd
+    from daqp_amd import api
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    counts = {api.TRACE_PIVOT: 0, api.TRACE_SINGULAR: 0, api.TRACE_REFINE: 0, api.TRACE_REFACTOR: 0, api.TRACE_CYCLE_RESET: 0}
+    for variant in ("", "stream"):
+        if variant:
+            monkeypatch.setenv("DAQP_AMD_STREAM_M", "1")   # the generic solve kernel (wave_ldp.hip.h)
+        for trial in range(0, 400, 2 if variant else 1):
+            q = _nasty(trial)
+            n, m = q["f"].size, q["bupper"].size
+            ms = m - q["A"].reshape(-1, n).shape[0]
+            ns = int(((q["sense"] & O.SOFT) != 0).sum())
+            bm = daqp_amd.BatchModel(1, n, m, ms, ns)
+            bm.enable_trace(1024)
+            bm.setup(q["H"][None], q["f"][None], q["A"].reshape(1, m - ms, n), q["bupper"][None], q["blower"][None], q["sense"][None])
+            if bm.setup_flags()[0] < 0:
+                bm.close()
+                continue
+            g = bm.solve()
+            tr = bm.read_trace(marks=True)[0]
+            bm.close()
+            om = oracle.model(n, m, ms, ns)
+            om.enable_trace()
+            if om.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"]) < 0:
+                continue
+            r = om.solve()
+            assert g["exitflag"][0] == r[3] and g["iter"][0] == r[4], (variant, trial)
+            assert np.array_equal(tr[tr < api.TRACE_MARK], om.get_trace()), (variant, trial)
+            for k in counts:
+                counts[k] += int((tr == k).sum())
+    assert counts[api.TRACE_PIVOT] > 0 and counts[api.TRACE_SINGULAR] > 0, counts
+    assert counts[api.TRACE_REFINE] > 0 and counts[api.TRACE_REFACTOR] > 0, counts
+
+
+@pytest.mark.parametrize("variant", ["lazy", "eager", "generic"])
+def test_update_with_crossed_bounds_does_not_poison_the_problem(oracle, gpu_lib, monkeypatch, variant):
+    """daqp_update_ldp returns -1 at crossed bounds and leaves the workspace usable (utils.c:98-103): in a batched MPC run
+    one bad step gives -1 for that problem and that solve only; the next update with valid bounds is solved warm and
+    bit-identical to the reference sequence {update(bad) = -1, update(good) = 0, solve}"""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    if variant == "eager":
+        monkeypatch.setenv("DAQP_AMD_EAGER_UPDATE", "1")
+    if variant == "generic":
+        monkeypatch.setenv("DAQP_AMD_STREAM_M", "1")
+    n, m, ms, na = 13, 40, 5, 5
+    N = 16
+    q = O.generate_batch(N, n, m, ms, na, 3100)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        assert om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None) == 1
+        models.append(om)
+    g = bm.solve()
+    for k in range(N):
+        r = models[k].solve()
+        assert g["iter"][k] == r[4] and bits_equal(g["x"][k], r[0])
+    bad = np.arange(N) % 3 == 0
+    f, bu, bl = q["f"].copy(), q["bupper"].copy(), q["blower"].copy()
+    for t in range(1, 4):
+        rng = np.random.default_rng([47, t])
+        f = f + 0.05 * rng.standard_normal((N, n))
+        shift = 0.02 * rng.standard_normal((N, m))
+        bu_t, bl_t = bu + shift, bl + shift
+        if t == 2:   # step 2: every third problem gets a crossed pair (row 7 + k, general or simple)
+            for k in np.nonzero(bad)[0]:
+                bu_t[k, (7 + k) % m] = bl_t[k, (7 + k) % m] - 1.0
+        bm.update(f=f, bupper=bu_t, blower=bl_t)
+        g = bm.solve()
+        for k in range(N):
+            rc = models[k].update(O.UPDATE_v | O.UPDATE_d, f=f[k], bupper=bu_t[k], blower=bl_t[k])
+            if t == 2 and bad[k]:
+                assert rc == -1 and g["exitflag"][k] == -1 and g["iter"][k] == 0, (t, k, rc, g["exitflag"][k])
+                continue
+            assert rc == 0
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (t, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            assert bits_equal(g["x"][k], r[0]) and bits_equal(g["lam"][k], r[1]), (t, k)
+        if t == 2:
+            fl = bm.setup_flags()
+            assert (fl[bad] == -1).all() and (fl[~bad] == 1).all()
+        bu, bl = bu_t if t != 2 else bu, bl_t if t != 2 else bl
+    bm.close()
+
+
+def test_shared_setup_then_per_problem_setup_on_one_batch(oracle, gpu_lib, monkeypatch):
+    """staging slots sized for ONE H / A by daqp_batch_setup_shared must grow for a later per-problem setup"""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, na = 10, 30, 2, 4
+    N = 40
+    q = O.generate_batch(N, n, m, ms, na, 3200)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup_shared(q["H"][0], q["f"], q["A"][0], q["bupper"], q["blower"])
+    g = bm.solve()
+    assert (np.abs(g["exitflag"]) >= 1).all()
+    with pytest.raises(RuntimeError):    # full re-setup that would reuse the ONE shared H as if it were N of them
+        p = bm._problem(None, q["f"], None, q["bupper"], q["blower"], None)[0]
+        rc = daqp_amd.lib().daqp_batch_update(bm._h, 31, p)
+        if rc != 0:
+            raise RuntimeError(daqp_amd.last_error())
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+    g = bm.solve()
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)   # (no shortcut taken: all constrained)
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        r = om.solve()
+        assert g["iter"][k] == r[4] and bits_equal(g["x"][k], r[0]), k
+    bm.close()
+
+
+def test_adopted_device_arrays_outlive_an_update(oracle, gpu_lib, monkeypatch):
+    """bounds handed over as NON-contiguous device tensors are converted by the front-end; the converted copies are read
+    by every later update / solve and must stay referenced when update(f=...) replaces only f"""
+    import torch
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    N = 48
+    q = O.generate_batch(N, n, m, ms, na, seed, start=7000)
+    dev = {k: torch.from_numpy(q[k]).cuda() for k in ("H", "f", "A")}
+    both = torch.from_numpy(np.stack([q["bupper"], q["blower"]], axis=2)).cuda()   # (N, m, 2): the two views are strided
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup(dev["H"], dev["f"], dev["A"], both[:, :, 0], both[:, :, 1])
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        models.append(om)
+    bm.solve()
+    for k in range(N):
+        models[k].solve()
+    f = q["f"].copy()
+    for t in range(1, 4):
+        f = f + 0.05 * np.random.default_rng([48, t]).standard_normal((N, n))
+        bm.update(f=torch.from_numpy(f).cuda())
+        junk = [torch.full((N, m), float("nan"), dtype=torch.float64, device="cuda") for _ in range(8)]   # recycles freed blocks
+        g = bm.solve(out="torch")
+        torch.cuda.synchronize()
+        del junk
+        for k in range(N):
+            assert models[k].update(O.UPDATE_v, f=f[k]) == 0
+            r = models[k].solve()
+            assert int(g["exitflag"][k]) == r[3] and int(g["iter"][k]) == r[4], (t, k)
+            assert bits_equal(g["x"][k].cpu().numpy(), r[0]), (t, k)
+    bm.close()
+
+
+def test_box_constrained_model_full_update(gpu_lib):
+    """only simple bounds (A is NULL): Model.update(H=...) is a full re-setup and must be accepted (the reference does)"""
+    import daqp_amd
+    d = daqp_amd.Model()
+    flag, _ = d.setup(np.eye(2), np.array([2.0, 2.0]), np.zeros((0, 2)), np.ones(2), -np.ones(2), np.zeros(2, np.int32))
+    assert flag >= 0
+    x, _, ef, _ = d.solve()
+    assert ef == 1 and np.allclose(x, [-1, -1], atol=1e-6)
+    assert d.update(H=np.diag([4.0, 1.0])) == 0, daqp_amd.last_error()
+    x, _, ef, _ = d.solve()
+    assert ef == 1 and np.allclose(x, [-0.5, -1.0], atol=1e-6)
+
+
+@pytest.mark.parametrize("cfg,N", [("C2", 64), ("C4", 4)])
+def test_time_limit_gives_minus_seven(oracle, gpu_lib, cfg, N):
+    """settings.time_limit (daqp.c:95-103): the device clock is read every 32nd iteration; with a budget of 100 ns every
+    problem that needs more than 32 iterations stops there with DAQP_EXIT_TIMELIMIT, the others are untouched"""
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS[cfg]
+    q = O.generate_batch(N, n, m, ms, na, seed, start=300)
+    q["ms"] = ms
+    free = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    lim = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms, time_limit=1e-7)
+    long_ = free["iter"] > 32
+    assert long_.any()
+    assert (lim["exitflag"][long_] == -7).all() and (lim["iter"][long_] == 32).all()
+    assert np.array_equal(lim["exitflag"][~long_], free["exitflag"][~long_]) and np.array_equal(lim["iter"][~long_], free["iter"][~long_])
+    gen = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms, time_limit=3600.0)
+    assert np.array_equal(gen["iter"], free["iter"]) and np.array_equal(gen["exitflag"], free["exitflag"])
+
+
+def test_workspace_mirrors_and_ldp_entry_points(oracle, gpu_lib, monkeypatch):
+    """setup_daqp_ldp / daqp_ldp / ldp2qp_solution / daqp_extract_result (api.h:35,54, daqp.h:12-13) and the read-only host
+    mirrors a binding may inspect (Rinv, v, M, d, scaling, sense; interfaces/daqp-eigen/daqp.cpp:250-271)"""
+    import ctypes as C
+    from daqp_amd import _lib
+    from daqp_amd._lib import DAQPResult, c_double_p
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    L = gpu_lib
+    n, m, ms, na = 9, 24, 3, 4
+    q = O.generate_qp(n, m, ms, na, rng=[3300, 0])
+    qp, keep = _problem_struct(q, np.zeros(m, np.int32))
+    ws = C.create_string_buffer(_lib.WORKSPACE_BYTES)
+    assert L.setup_daqp_ldp(ws, C.byref(qp), 0) == 1
+    om = oracle.model(n, m, ms)
+    assert om.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None) == 1
+    Mo, Ro, vo, duo, dlo, sco = om.ldp()
+    ptr = lambda off: C.cast(C.c_void_p.from_buffer(ws, off).value, c_double_p)
+    # offsets of types.h:187-264 on x86-64: M 24, dupper 32, dlower 40, Rinv 48, v 56, scaling 72
+    assert bits_equal(np.ctypeslib.as_array(ptr(24), ((m - ms) * n,)), Mo.ravel())
+    assert bits_equal(np.ctypeslib.as_array(ptr(32), (m,)), duo) and bits_equal(np.ctypeslib.as_array(ptr(40), (m,)), dlo)
+    assert bits_equal(np.ctypeslib.as_array(ptr(48), (n * (n + 1) // 2,)), Ro) and bits_equal(np.ctypeslib.as_array(ptr(56), (n,)), vo)
+    assert bits_equal(np.ctypeslib.as_array(ptr(72), (m,)), sco)
+    flag = L.daqp_ldp(ws)
+    L.ldp2qp_solution(ws)
+    x, lam = np.zeros(n), np.zeros(m)
+    res = DAQPResult(x.ctypes.data_as(c_double_p), lam.ctypes.data_as(c_double_p), 0, 0, 0, 0, 0, 0, 0)
+    L.daqp_extract_result(C.byref(res), ws)
+    r = om.solve()
+    assert flag == r[3] == 1 and res.iter == r[4] and res.nodes == 1
+    assert bits_equal(x, r[0]) and bits_equal(lam, r[1]) and res.fval == r[2]
+    L.free_daqp_workspace(ws)
+    L.free_daqp_ldp(ws)
+
+
+def test_two_batches_on_one_device_from_two_host_threads(oracle, gpu_lib, monkeypatch):
+    """the single-process multi-GPU shape (one host thread + one stream per batch) exercised on ONE device:
+    two batches on device 0, each on its own stream, driven concurrently from two threads through the C ABI"""
+    import torch
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    N = 96
+    out = [None, None]
+    qs = [O.generate_batch(N, n, m, ms, na, seed, start=9000 + 500 * t) for t in range(2)]
+
+    def work(t):
+        s = torch.cuda.Stream(device=0)
+        with torch.cuda.stream(s):
+            bm = daqp_amd.BatchModel(N, n, m, ms, device=0)
+            q = qs[t]
+            for _ in range(3):
+                bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=daqp_amd.UPDATE_unconstrained)
+                out[t] = bm.solve()
+            bm.close()
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for t in range(2):
+        q = qs[t]
+        ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+        assert out[t] is not None and np.array_equal(out[t]["iter"], ref[4]) and bits_equal(out[t]["x"], ref[0])

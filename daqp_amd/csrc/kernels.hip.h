@@ -46,6 +46,11 @@ struct BatchDev {
     int prox_pass;
     const double *hshift;         // [N]
     int *prox_mask;               // [N][n] coordinates that carry the shift (all of them for a dense H)
+    // workgroup-per-problem solve kernel (wg_kernel.hip.h): persistent workgroups, scratch per WORKGROUP
+    int *wg_counter;              // next problem to take
+    double *wg_rowc, *wg_rowcT;   // [grid][cap][ldr] active rows, [grid][n][wg_capT] the same transposed
+    int *fallback;                // [N] 1: the working set outgrew the LDS-resident L -- the one-wave kernel solves this problem
+    int wg_capL, wg_capT;
 };
 // internal setup flag: the Hessian is numerically singular and eps_prox != 0 -- the host re-runs the setup with a shifted
 // diagonal (never leaves the library: it ends as 1 or DAQP_EXIT_NONCONVEX)
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
     int first_bad = kBig;
     for (int i = lane; i < m; i += 64)
         if (!(sens[i] & DAQP_IMMUTABLE) && bu[i] - bl[i] < -st.primal_tol && first_bad == kBig) first_bad = i;
-    first_bad = -(int)wave_min(-(double)first_bad);   // lowest index over the wave (exact: |i| < 2^31)
+    first_bad = (int)wave_min((double)first_bad);   // lowest index over the wave (exact in fp64)
     int bad = 0;
     for (int i = lane; i < m && i < first_bad; i += 64) {
         const int s = sens[i];
@@ -1130,7 +1135,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
             const int r = bb * 64 + lane;
             if (r < m && !(rsense_get(w, bb) & DAQP_IMMUTABLE) && bur[bb] - blr[bb] < -w.stp->primal_tol && first_bad == kBig) first_bad = r;
         });
-        first_bad = -(int)wave_min(-(double)first_bad);
+        first_bad = (int)wave_min((double)first_bad);
         int bad = 0;
         static_for<NB>([&](auto bb) __attribute__((always_inline)) {
             const int r = bb * 64 + lane;

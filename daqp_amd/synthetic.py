@@ -9,12 +9,18 @@ import torch
 
 
 def _right_solve_upper(Rc, Q):
-    """Q Rc^-1 for upper-triangular Rc, batched.  hipBLAS' batched trsm runs out of workspace for large n x batch: fall back to
-    the general (LU) solve of the transposed system."""
-    try:
+    """Q Rc^-1 for upper-triangular Rc, batched.  hipBLAS' batched trsm / getrf fail to allocate their workspace for n in the
+    hundreds (ROCm 7.2), so large n takes a column-by-column forward substitution made of batched mat-vecs."""
+    n = Q.shape[-1]
+    if n <= 128:
         return torch.linalg.solve_triangular(Rc, Q, upper=True, left=False)
-    except RuntimeError:
-        return torch.linalg.solve(Rc.transpose(1, 2), Q.transpose(1, 2)).transpose(1, 2).contiguous()
+    X = torch.empty_like(Q)
+    for j in range(n):
+        col = Q[:, :, j]
+        if j:
+            col = col - (X[:, :, :j] @ Rc[:, :j, j:j + 1])[:, :, 0]
+        X[:, :, j] = col / Rc[:, j, j:j + 1]
+    return X
 
 
 def generate_batch_torch(N, n, m, ms, n_active, seed, kappa=100.0, device="cuda", chunk=None):

@@ -98,6 +98,10 @@ typedef struct {
 static int tri(int k) { return k * (k + 1) / 2; }                 /* DAQP_ARSUM */
 static int roff(int i, int n) { return ((2 * n - i - 1) * i) / 2; } /* DAQP_R_OFFSET */
 
+/* branch markers (same codes as the GPU kernels' traces): pivot_last swapped, singular direction, refine_active, refactor
+ * repair at a KKT point, cycle-guard rebuild */
+enum { ORA_TRACE_MARK = 0x40000000, ORA_TRACE_PIVOT = ORA_TRACE_MARK + 1, ORA_TRACE_SINGULAR = ORA_TRACE_MARK + 2, ORA_TRACE_REFINE = ORA_TRACE_MARK + 3,
+       ORA_TRACE_REFACTOR = ORA_TRACE_MARK + 4, ORA_TRACE_CYCLE_RESET = ORA_TRACE_MARK + 5 };
 static void trace_ev(ora_work *w, int ev)
 {
     if (w->trace && w->trace_len < w->trace_cap) w->trace[w->trace_len] = ev;
@@ -305,6 +309,7 @@ static void pivot_tail(ora_work *w)
     for (;;) {
         int r = w->n_active - 2;
         if (w->n_active > 1 && w->D[r] < w->st.pivot_tol && w->D[r] < w->D[w->n_active - 1]) {
+            trace_ev(w, ORA_TRACE_PIVOT);
             pend_id[depth] = w->WS[r]; pend_lam[depth] = w->lam[r]; depth++;
             if (drop_core(w, r)) break;
             continue;                             /* the removal's own tail pivot */
@@ -544,6 +549,7 @@ static int ldp_loop(ora_work *w)
                 for (int i = 1; i < w->n_active; i++) if (w->D[i] < dmin) dmin = w->D[i];
                 if (w->n_active > 2 && repaired != 1 && dmin < w->st.refactor_tol) {
                     repaired = 1;
+                    trace_ev(w, ORA_TRACE_REFACTOR);
                     for (int i = 0; i < w->n_active; i++) {
                         if (w->lam[i] >= 0) w->sense[w->WS[i]] &= ~S_LOWER;
                         else w->sense[w->WS[i]] |= S_LOWER;
@@ -553,6 +559,7 @@ static int ldp_loop(ora_work *w)
                     continue;
                 }
                 if (w->n_active > 0 && dmin < w->st.pivot_tol) {
+                    trace_ev(w, ORA_TRACE_REFINE);
                     refine_active(w);
                     if (add_infeasible(w)) continue;
                 }
@@ -563,6 +570,7 @@ static int ldp_loop(ora_work *w)
                 if (stall++ > w->st.cycle_tol) {
                     if (repaired == 1) { flag = ORA_EXIT_CYCLE; break; }
                     repaired = 1;
+                    trace_ev(w, ORA_TRACE_CYCLE_RESET);
                     reset_ws(w);
                     activate_marked(w);
                     stall = 0;
@@ -570,6 +578,7 @@ static int ldp_loop(ora_work *w)
                 }
             } else { best = w->fval; stall = 0; }
         } else {
+            trace_ev(w, ORA_TRACE_SINGULAR);
             singular_direction(w);
             if (!remove_blocking(w)) { flag = ORA_EXIT_INFEASIBLE; break; }
         }

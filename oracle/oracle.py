@@ -23,6 +23,7 @@ c_int_p = C.POINTER(C.c_int)
 UPDATE_Rinv, UPDATE_M, UPDATE_v, UPDATE_d, UPDATE_sense = 1, 2, 4, 8, 16
 UPDATE_unconstrained, UPDATE_eliminate = 64, 128
 ACTIVE, LOWER, IMMUTABLE, SOFT = 1, 2, 4, 8
+TRACE_MARK = 0x40000000
 
 
 class Settings(C.Structure):
@@ -141,8 +142,11 @@ class OracleModel:
         self.trace = np.zeros(cap, np.int32)
         self.o.lib.ora_set_trace(self.h, _ip(self.trace), cap)
 
-    def get_trace(self):
-        return self.trace[: self.o.lib.ora_trace_len(self.h)].copy()
+    def get_trace(self, marks=False):
+        """+(id+1) add / -(id+1) remove in order; marks=True keeps the branch markers (TRACE_MARK + 1..5: pivot, singular
+        direction, refine, refactor repair, cycle-guard rebuild -- the GPU kernels' traces carry the same codes)"""
+        t = self.trace[: self.o.lib.ora_trace_len(self.h)].copy()
+        return t if marks else t[t < TRACE_MARK]
 
     def _hold(self, **kw):
         for k, v in kw.items():

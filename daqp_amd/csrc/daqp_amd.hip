@@ -14,6 +14,7 @@
 #include "kernels.hip.h"
 #include "setup_fast.hip.h"
 #include "prox.hip.h"
+#include "wg_kernel.hip.h"
 
 using namespace daqp_amd;
 
@@ -71,6 +72,10 @@ struct DAQPBatch {
     bool spill = false;
     int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
     bool fast_setup = false, setup_spill = false;
+    // workgroup-per-problem solve kernel (wg_kernel.hip.h): shapes without a register variant and more than 64 working-set rows
+    bool use_wg = false;
+    int wg_W = 0, wg_C = 0, wg_grid = 0;
+    size_t lds_wg = 0;
     double *wide_u = nullptr, *wide_l = nullptr;   // daqp_batch_setup_shared: +-1e30 bounds of the one factorisation
     int *structural = nullptr, *shared_flag = nullptr;
     int pending_mask = 0;   // daqp_batch_update(UPDATE_v|UPDATE_d) not yet applied: the next solve launch does it (k_ldp_reg mode 2)
@@ -144,6 +149,21 @@ ldp_kernel_t pick_ldp(const DAQPBatch *b)
 
 int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
 {
+    if (b->use_wg) {
+        // persistent workgroups pull problems from a counter; whatever outgrows the LDS-resident L is flagged and solved by
+        // the one-wave kernel right behind (mode | 4: flagged problems only -- an empty pass costs a few microseconds)
+        typedef void (*wg_kernel_t)(BatchDev, int);
+        wg_kernel_t kw = b->wg_C == 2 ? k_ldp_wg<2> : k_ldp_wg<4>;
+        HIPCHK(hipMemsetAsync(b->d.wg_counter, 0, sizeof(int), b->stream));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg));
+        hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, b->d, mode);
+        HIPCHK(hipGetLastError());
+        ldp_kernel_t kf = pick_ldp(b);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
+        hipLaunchKernelGGL(kf, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, b->d, mode | 4);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (b->NB > 0) {
         ldp_reg_kernel_t kr = pick_ldp_reg(b);
         // the descriptor travels through device memory: stream-ordered copy, then the launch
@@ -402,6 +422,19 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.ldrc = l;
     }
     b->lds_ldp = b->NB > 0 ? (size_t)reg_lds_bytes(b->NB, n, m, cap, d.ldrc) : (size_t)ldp_lds(n, m, cap, b->spill, d.ldrc).total_bytes;
+    if (b->NB == 0 && cap > 64 && !getenv("DAQP_AMD_NO_WG")) {
+        int W = d.nblk < 4 ? 4 : (d.nblk > kWgMaxWaves ? kWgMaxWaves : d.nblk);
+        if (const char *we = getenv("DAQP_AMD_WG_WAVES")) { const int v = atoi(we); if (v >= 4 && v <= kWgMaxWaves) W = v; }
+        const int lds_max = 160 * 1024 - 256;          // (the kernel's few static words come on top of the dynamic allocation)
+        int capL = cap;
+        while (capL > 16 && wg_lds(n, m, cap, capL, W).total_bytes > lds_max) --capL;
+        if (const char *ce = getenv("DAQP_AMD_WG_CAPL")) { const int v = atoi(ce); if (v >= 2 && v < capL) capL = v; }   // (tests: force the hand-over)
+        if (wg_lds(n, m, cap, capL, W).total_bytes <= lds_max && capL >= (cap < 48 ? cap : 48)) {
+            b->use_wg = true; b->wg_W = W; b->wg_C = cap <= 128 ? 2 : 4;
+            d.wg_capL = capL; d.wg_capT = round_up(cap, 8);
+            b->lds_wg = (size_t)wg_lds(n, m, cap, capL, W).total_bytes;
+        }
+    }
     b->fast_setup = (n <= 64) && !getenv("DAQP_AMD_SLOW_SETUP");
     {   // DAQP_AMD_EXACT=1: keep the reference's summation order in M = A R^-1 (bit-exact LDP); default: MFMA
         const char *ex = getenv("DAQP_AMD_EXACT");
@@ -440,6 +473,23 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &b->st_dev, 1);
     rc |= dev_alloc(b, &b->d_dev, 1);
     rc |= dev_alloc(b, &b->px.counter, 4);
+    if (b->use_wg && !rc) {
+        typedef void (*wg_kernel_t)(BatchDev, int);
+        wg_kernel_t kw = b->wg_C == 2 ? k_ldp_wg<2> : k_ldp_wg<4>;
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kw), 64 * b->wg_W, b->lds_wg) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        long long g = (long long)cus * per_cu;
+        if (const char *ge = getenv("DAQP_AMD_WG_GRID")) { const long long v = atoll(ge); if (v >= 1) g = v; }   // tuning: problems in flight
+        b->wg_grid = (int)(g < N ? g : N);
+        rc |= dev_alloc(b, &d.wg_counter, 1);
+        rc |= dev_alloc(b, &d.wg_rowc, (size_t)b->wg_grid * cap * d.ldr);
+        rc |= dev_alloc(b, &d.wg_rowcT, (size_t)b->wg_grid * n * d.wg_capT);
+        rc |= dev_alloc(b, &d.fallback, Nn);
+        if (!rc && hipMemset(d.fallback, 0, Nn * sizeof(int)) != hipSuccess) rc = 1;
+    }
     if (!rc && hipMemcpy(b->st_dev, &d.st, sizeof(DAQPSettings), hipMemcpyHostToDevice) != hipSuccess) rc = 1;
     d.st_dev = b->st_dev;
     if (rc) { daqp_batch_free(b); return DAQP_EXIT_UNSUPPORTED; }

@@ -779,11 +779,14 @@ __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
 // cost more in scratch spills than they hide in latency: 604 / 613 / 635 ms per 8 192 QPs of config C4).
 template <int C, bool SPILL, int NB, int NP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPILL ? DAQP_AMD_SPILL_WAVES : 1, SPILL ? DAQP_AMD_SPILL_WAVES : 8)))
-void k_ldp(BatchDev b, int mode)
+void k_ldp(BatchDev b, int mode_in)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = lane_id();
     const int n = b.n, m = b.m, cap = b.cap;
+    // mode | 4: behind the workgroup kernel (wg_kernel.hip.h) -- only the problems it flagged as too large for its LDS
+    if ((mode_in & 4) && !b.fallback[q]) return;
+    const int mode = mode_in & 3;
     QState *qs = b.qs + q;
     const int sflag = qs->setup_flag;
     if (mode == 1) { if (sflag < 0 || !qs->need_activate) return; }

@@ -15,7 +15,7 @@ def fast_mode(monkeypatch):
     monkeypatch.delenv("DAQP_AMD_EXACT", raising=False)
 
 
-@pytest.mark.parametrize("cfg,N", [("C1", 256), ("C2", 2048), ("C3", 4096)])
+@pytest.mark.parametrize("cfg,N", [("C1", 256), ("C2", 2048), ("C3", 4096), ("C4", 48)])
 def test_fast_mode_parity(oracle, gpu_lib, cfg, N):
     import daqp_amd
     n, m, ms, na, seed, _ = O.CONFIGS[cfg]
@@ -37,6 +37,19 @@ def test_fast_mode_shapes(oracle, gpu_lib, shape):
     import daqp_amd
     n, m, ms, na = shape
     q = O.generate_batch(64, n, m, ms, na, 900 + n)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4])
+    assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1]))
+    assert np.abs(g["x"] - ref[0]).max() < XTOL
+
+
+@pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (129, 200, 10, 30), (229, 400, 20, 60)])
+def test_fast_mode_workgroup_kernel_shapes(oracle, gpu_lib, shape):
+    """the workgroup solve kernel in the default arithmetic: primal step and Gram column summed in per-wave segments"""
+    import daqp_amd
+    n, m, ms, na = shape
+    q = O.generate_batch(12, n, m, ms, na, 1900 + n)
     ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
     g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
     assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4])

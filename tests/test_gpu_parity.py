@@ -75,9 +75,69 @@ def test_setup_shapes(oracle, gpu_lib, shape):
     check_batch(oracle, (n, m, ms, na, 900 + n, 0), 48)
 
 
-def test_c4_spill(oracle, gpu_lib):
-    """n=200: L and the active-row cache spill from LDS to HBM scratch"""
+def test_c4_workgroup_kernel(oracle, gpu_lib):
+    """config C4 (n=200, m=600): the workgroup-per-problem solve kernel (wg_kernel.hip.h: packed L in LDS, scan / primal
+    step / Gram column spread over the waves) -- 64 QPs, bit for bit in exact mode"""
+    check_batch(oracle, "C4", 64)
+
+
+def test_c4_one_wave_kernel(oracle, gpu_lib, monkeypatch):
+    """the one-wave generic kernel with L and the active-row cache in HBM scratch (what a problem falls back to when its
+    working set outgrows the workgroup kernel's LDS)"""
+    monkeypatch.setenv("DAQP_AMD_NO_WG", "1")
     check_batch(oracle, "C4", 6)
+
+
+@pytest.mark.parametrize("capl", [60, 110])
+def test_workgroup_kernel_hands_over_large_working_sets(oracle, gpu_lib, monkeypatch, capl):
+    """packed L capped at `capl` rows in LDS: C4 working sets peak at 130-160 rows, so most (60) or some (110) problems are
+    flagged during the solve and redone by the one-wave kernel from their untouched state -- results unchanged, bit for bit"""
+    monkeypatch.setenv("DAQP_AMD_WG_CAPL", str(capl))
+    check_batch(oracle, "C4", 12)
+
+
+@pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (128, 300, 0, 50), (129, 200, 10, 30), (229, 400, 20, 60)])
+def test_workgroup_kernel_shapes(oracle, gpu_lib, shape):
+    """working sets of 66 ... 230 rows (two- and four-chunk masters), simple bounds, odd n, fewer row blocks than waves"""
+    n, m, ms, na = shape
+    check_batch(oracle, (n, m, ms, na, 1900 + n, 0), 10)
+
+
+def test_workgroup_kernel_event_trace_and_warm_sequence(oracle, gpu_lib):
+    """n=100: the add/remove sequence of the reference step for step, then warm updates of f and of the bounds
+    (k_update + the workgroup kernel from the stored factors and working set)"""
+    import daqp_amd
+    n, m, ms, na = 100, 260, 7, 40
+    N, T = 6, 3
+    q = O.generate_batch(N, n, m, ms, na, 2100)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.enable_trace(4096)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        om.enable_trace()
+        models.append(om)
+    f, bu, bl = q["f"].copy(), q["bupper"].copy(), q["blower"].copy()
+    for t in range(T + 1):
+        if t > 0:
+            for k in range(N):
+                rng = np.random.default_rng([49, k, t])
+                f[k] = f[k] + 0.05 * rng.standard_normal(n)
+                shift = 0.02 * rng.standard_normal(m)
+                bu[k] = bu[k] + shift; bl[k] = bl[k] + shift
+                assert models[k].update(O.UPDATE_v | O.UPDATE_d, f=f[k], bupper=bu[k], blower=bl[k]) == 0
+                models[k].enable_trace()
+            bm.update(f=f, bupper=bu, blower=bl)
+        g = bm.solve()
+        tr = bm.read_trace(marks=True)
+        for k in range(N):
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (t, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            assert np.array_equal(tr[k], models[k].get_trace(marks=True)), (t, k)
+            assert bits_equal(g["x"][k], r[0]) and bits_equal(g["lam"][k], r[1]) and g["fval"][k] == r[2]
+    bm.close()
 
 
 def test_iteration_limit(oracle, gpu_lib):
@@ -258,7 +318,7 @@ def test_full_size_properties(gpu_lib):
     import torch
     import daqp_amd
     from daqp_amd.synthetic import generate_batch_torch
-    for (N, n, m, ms, na) in ((100_000, 50, 150, 0, 20), (250_000, 12, 48, 12, 6)):
+    for (N, n, m, ms, na) in ((100_000, 50, 150, 0, 20), (250_000, 12, 48, 12, 6), (10_000, 200, 600, 0, 80)):
         q = generate_batch_torch(N, n, m, ms, na, seed=7)
         g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms, out="torch")
         assert bool((g["exitflag"] == 1).all())

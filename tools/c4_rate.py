@@ -6,8 +6,9 @@ import torch, daqp_amd
 from oracle import oracle as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 n, m, ms, na, seed, _ = O.CONFIGS["C4"]
-qn = O.generate_batch(N, n, m, ms, na, seed)
-q = {k: torch.from_numpy(np.ascontiguousarray(qn[k])).cuda() for k in ("H", "f", "A", "bupper", "blower", "xref")}
+from daqp_amd.synthetic import generate_batch_torch
+q = generate_batch_torch(N, n, m, ms, na, seed=seed)
+qn = {k: q[k][:16].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}
 bm = daqp_amd.BatchModel(N, n, m, ms)
 if len(sys.argv) > 2: bm.enable_profile(True)
 def step():

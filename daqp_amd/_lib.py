@@ -14,7 +14,6 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIBPATH = os.path.join(LIBDIR, "libdaqp_amd.so")
-SOURCES = ["daqp_amd.hip", "kernels.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h", "setup_fast.hip.h", "prox.hip.h", "wg_ldp.hip.h", "wg_kernel.hip.h"]
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -70,12 +69,29 @@ EXPORTS = [
 ]
 
 
+# translation units -> what each one includes (a unit is recompiled when any of these is newer than its object)
+UNITS = {
+    "daqp_amd.hip": ["daqp_amd.hip", "kernels.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h", "setup_fast.hip.h", "prox.hip.h",
+                     "wg_layout.hip.h", "batch_dev.hip.h"],
+    "wg_kernel.hip": ["wg_kernel.hip", "wg_kernel.hip.h", "wg_ldp.hip.h", "wg_layout.hip.h", "batch_dev.hip.h", "wave_ldp.hip.h"],
+}
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+OBJDIR = os.path.join(LIBDIR, "obj")
+
+
+def _unit_stale(unit, extra_flags=()):
+    obj = os.path.join(OBJDIR, unit + ".o")
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, d) for d in UNITS[unit]] + [os.path.join(ROOT, "include", "daqp_amd.h")]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
 def _stale():
     if not os.path.exists(LIBPATH):
         return True
-    t = os.path.getmtime(LIBPATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(ROOT, "include", "daqp_amd.h")]
-    if any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps):
+    if any(_unit_stale(u) or os.path.getmtime(os.path.join(OBJDIR, u + ".o")) > os.path.getmtime(LIBPATH) for u in UNITS):
         return True
     try:   # a development build (tools/devbuild.sh: fewer kernel variants) is never what build() should leave behind
         v = C.CDLL(LIBPATH).daqp_amd_version
@@ -85,8 +101,9 @@ def _stale():
         return True
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> daqp_amd/lib/libdaqp_amd.so (cross-compiles without a GPU)."""
+def build(force=False, verbose=False, extra_flags=()):
+    """hipcc --offload-arch=gfx950 -> daqp_amd/lib/libdaqp_amd.so (cross-compiles without a GPU).  One object per translation
+    unit (compiled side by side, only the stale ones), then one link."""
     if not force and not _stale():
         return LIBPATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -94,9 +111,18 @@ def build(force=False, verbose=False):
         if os.path.exists(LIBPATH):
             return LIBPATH
         raise RuntimeError("hipcc not found and no prebuilt libdaqp_amd.so")
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           os.path.join(CSRC, "daqp_amd.hip"), "-o", LIBPATH]
+    os.makedirs(OBJDIR, exist_ok=True)
+    procs = []
+    for unit in UNITS:
+        if force or _unit_stale(unit):
+            cmd = [hipcc, *HIPFLAGS, *extra_flags, "-c", os.path.join(CSRC, unit), "-o", os.path.join(OBJDIR, unit + ".o")]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *[os.path.join(OBJDIR, u + ".o") for u in UNITS], "-o", LIBPATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,60 @@
+// batch_dev.hip.h -- the device-side descriptor of a batch (what every kernel of the library receives)
+#pragma once
+#include "wave_ldp.hip.h"
+
+namespace daqp_amd {
+
+struct BatchDev {
+    int N, n, m, ms, cap, mA;
+    int npair, nblk, ldr, ltri, rtri;
+    int ldrc;   // row stride of the register kernel's active-row cache: == 2 (mod 4) doubles, >= 2*NP (16-B rows, conflict-free)
+    // problem data (device pointers; owned by the caller or by the batch's staging buffers)
+    const double *H, *f, *A, *bu, *bl;
+    const int *sense_in;
+    // LDP (persistent)
+    double *Mblk;      // [N][nblk][npair][64][2]
+    double *Rinv;      // [N][rtri]   packed upper R^-1, rows < ms normalised
+    double *v;         // [N][n]
+    double *scaling, *dupper, *dlower; // [N][m]
+    int *sense;        // [N][m]
+    double *xunc;      // [N][n]   unconstrained optimum when the shortcut fired
+    // iterate (persistent: warm start)
+    double *L;         // [N][ltri]
+    double *vecs;      // [N][5][cap]: D, xldl, zldl, lam buffer A, lam buffer B
+    int *WS;           // [N][cap]
+    QState *qs;        // [N]
+    double *rowc_g;    // [N][cap*ldr] only when the active-row cache / L spill out of LDS
+    double *setup_g;   // [N][2*rtri] only when the setup factors spill out of LDS
+    // outputs
+    double *x, *lam, *fval, *soft;
+    int *exitflag, *iter;
+    // debugging
+    int *trace; int trace_cap;
+    long long *prof;   // [N][8] phase cycle sums, or NULL
+    const DAQPSettings *st_dev;   // device copy of st (scalar-load friendly)
+    int exact_setup;              // 1: M = A R^-1 in the reference's operation order (VALU); 0: MFMA f64
+    int shared;                   // 1: one H, A for the whole batch (daqp_batch_setup_shared): Mblk, Rinv, scaling hold ONE problem's factors
+    DAQPSettings st;
+    // regularising re-runs of k_setup (utils.c:356-377): only the problems flagged DAQP_NEEDS_SHIFT, with H + hshift[q] on the diagonal
+    // (1), or the one setup pass of an LP batch (2): b.H is ONE identity matrix -- the reference's Rinv == RinvD == NULL
+    // branches are its RinvD branches with RinvD = 1 (utils.c:455-468,478-481, daqp.c:119-134), every direction proximal
+    int prox_pass;
+    const double *hshift;         // [N]
+    int *prox_mask;               // [N][n] coordinates that carry the shift (all of them for a dense H)
+    // workgroup-per-problem solve kernel (wg_kernel.hip.h): persistent workgroups, scratch per WORKGROUP
+    int *wg_counter;              // next problem to take
+    double *wg_rowc, *wg_rowcT;   // [grid][cap][ldr] active rows, [grid][n][wg_capT] the same transposed
+    int *fallback;                // [N] 1: the working set outgrew the LDS-resident L -- the one-wave kernel solves this problem
+    int wg_capL, wg_capT;
+};
+// internal setup flag: the Hessian is numerically singular and eps_prox != 0 -- the host re-runs the setup with a shifted
+// diagonal (never leaves the library: it ends as 1 or DAQP_EXIT_NONCONVEX)
+#define DAQP_NEEDS_SHIFT (-100)
+// internal setup flag while the proximal driver runs: this problem sits out the launch (any negative flag does that)
+#define DAQP_PROX_SKIP (-101)
+
+__host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+// index of problem q's factors (M, R^-1, scaling): its own, or the single shared set
+__device__ __forceinline__ size_t qf(const BatchDev &b, int q) { return b.shared ? (size_t)0 : (size_t)q; }
+
+} // namespace daqp_amd

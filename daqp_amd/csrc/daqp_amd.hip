@@ -14,7 +14,14 @@
 #include "kernels.hip.h"
 #include "setup_fast.hip.h"
 #include "prox.hip.h"
-#include "wg_kernel.hip.h"
+#include "wg_layout.hip.h"
+// the workgroup-per-problem solve kernel lives in its own translation unit (wg_kernel.hip): a change to it does not rebuild
+// everything else
+namespace daqp_amd {
+template <int C> __global__ void k_ldp_wg(BatchDev b, int mode);
+extern template __global__ void k_ldp_wg<2>(BatchDev, int);
+extern template __global__ void k_ldp_wg<4>(BatchDev, int);
+}
 
 using namespace daqp_amd;
 
@@ -426,13 +433,14 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         int W = d.nblk < 4 ? 4 : (d.nblk > kWgMaxWaves ? kWgMaxWaves : d.nblk);
         if (const char *we = getenv("DAQP_AMD_WG_WAVES")) { const int v = atoi(we); if (v >= 4 && v <= kWgMaxWaves) W = v; }
         const int lds_max = 160 * 1024 - 256;          // (the kernel's few static words come on top of the dynamic allocation)
+        const int Cw = cap <= 128 ? 2 : 4;
         int capL = cap;
-        while (capL > 16 && wg_lds(n, m, cap, capL, W).total_bytes > lds_max) --capL;
+        while (capL > 16 && wg_lds_bytes(Cw, m, capL) > lds_max) --capL;
         if (const char *ce = getenv("DAQP_AMD_WG_CAPL")) { const int v = atoi(ce); if (v >= 2 && v < capL) capL = v; }   // (tests: force the hand-over)
-        if (wg_lds(n, m, cap, capL, W).total_bytes <= lds_max && capL >= (cap < 48 ? cap : 48)) {
-            b->use_wg = true; b->wg_W = W; b->wg_C = cap <= 128 ? 2 : 4;
+        if (wg_lds_bytes(Cw, m, capL) <= lds_max && capL >= (cap < 48 ? cap : 48)) {
+            b->use_wg = true; b->wg_W = W; b->wg_C = Cw;
             d.wg_capL = capL; d.wg_capT = round_up(cap, 8);
-            b->lds_wg = (size_t)wg_lds(n, m, cap, capL, W).total_bytes;
+            b->lds_wg = (size_t)wg_lds_bytes(Cw, m, capL);
         }
     }
     b->fast_setup = (n <= 64) && !getenv("DAQP_AMD_SLOW_SETUP");

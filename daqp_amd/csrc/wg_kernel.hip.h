@@ -2,12 +2,10 @@
 // workgroups (wg_ldp.hip.h has the design).  Same global state layout as k_ldp, so the two are interchangeable: a problem
 // whose working set outgrows the LDS-resident L is flagged in b.fallback and solved by k_ldp<C, true> right after.
 #pragma once
-#include "kernels.hip.h"
+#include "batch_dev.hip.h"
 #include "wg_ldp.hip.h"
 
 namespace daqp_amd {
-
-constexpr int kWgMaxWaves = 10;
 
 // mode 0: daqp_solve; mode 1: only (re)build the working set from the ACTIVE bits (tail of daqp_update_ldp);
 // mode | 4: only the problems flagged in b.fallback are touched by the ONE-WAVE kernel (see k_ldp) -- not used here
@@ -18,17 +16,12 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
     __shared__ int q_sh;
     __shared__ int m_int[8];       // master -> everybody after the iteration: flag, iterations, na, reuse, sing, lam swapped, overflow
     __shared__ double m_dbl[2];    // fval, soft
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = wg_wave();   // (wave-uniform by construction: say so, or the master's whole body sits in a "divergent" branch)
     const int n = b.n, m = b.m, cap = b.cap, W = (int)(blockDim.x >> 6);
-    const WgLds o = wg_lds(n, m, cap, b.wg_capL, W);
-    int *ib = reinterpret_cast<int *>(smem + o.dbl);
     WgCtx c;
     c.n = n; c.m = m; c.ms = b.ms; c.cap = cap; c.capL = b.wg_capL; c.npair = b.npair; c.nblk = b.nblk; c.ldr = b.ldr; c.capT = b.wg_capT;
     c.W = W; c.exact = b.exact_setup;
-    c.L = smem + o.L; c.D = smem + o.D; c.xl = smem + o.xl; c.zl = smem + o.zl; c.lamA = smem + o.lamA; c.lamB = smem + o.lamB;
-    c.pend_lam = smem + o.pend_lam; c.u = smem + o.u; c.mnew = smem + o.mnew; c.gram = smem + o.gram; c.red = smem + o.red; c.cand = smem + o.cand;
-    c.ws = ib + o.ws; c.slot = ib + o.slot; c.slot_id = ib + o.slot_id; c.freestk = ib + o.freestk; c.pend_id = ib + o.pend_id;
-    c.sense = ib + o.sense; c.cmd = ib + o.cmd;
+    c.oL = wg_lds_L(C, m); c.lmax = wg_round_up(b.wg_capL * (b.wg_capL + 1) / 2, 2) - 1;
     c.rowc = b.wg_rowc + (size_t)blockIdx.x * cap * b.ldr;
     c.rowcT = b.wg_rowcT + (size_t)blockIdx.x * n * b.wg_capT;
     const int T = (int)blockDim.x;
@@ -37,20 +30,20 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
         __syncthreads();                       // the previous problem is completely done with LDS
         if (tid == 0) q_sh = atomicAdd(b.wg_counter, 1);
         __syncthreads();
-        const int q = q_sh;
+        const int q = uni(q_sh);
         if (q >= b.N) break;
         QState *qs = b.qs + q;
-        const int sflag = qs->setup_flag;
-        if (mode == 1) { if (sflag < 0 || !qs->need_activate) continue; }
+        const int sflag = uni(qs->setup_flag), need_act = uni(qs->need_activate), uflag = uni(qs->upd_flag);
+        if (mode == 1) { if (sflag < 0 || !need_act) continue; }
         if (sflag < 0) {   // setup failed: x/lam untouched, no solve (api.c:70-78)
             if (tid == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; b.fallback[q] = 0; }
             continue;
         }
-        if (mode == 0 && qs->upd_flag < 0) {   // the last update failed its bound check: report that, keep the state (see k_update)
-            if (tid == 0) { b.exitflag[q] = qs->upd_flag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; b.fallback[q] = 0; }
+        if (mode == 0 && uflag < 0) {   // the last update failed its bound check: report that, keep the state (see k_update)
+            if (tid == 0) { b.exitflag[q] = uflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; b.fallback[q] = 0; }
             continue;
         }
-        const int sing0 = qs->sing_ind;
+        const int sing0 = uni(qs->sing_ind);
         if (sing0 == DAQP_UNCONSTRAINED_OPTIMAL && mode == 0) {   // api.c:40-45: x = unconstrained optimum, no multipliers
             const double *xu = b.xunc + (size_t)q * n, *vq = b.v + (size_t)q * n;
             if (b.x) for (int i = tid; i < n; i += T) b.x[(size_t)q * n + i] = xu[i];
@@ -67,7 +60,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
             }
             continue;
         }
-        const int na0 = qs->n_active;
+        const int na0 = uni(qs->n_active);
         if (na0 > c.capL) {        // a warm start that does not fit: the one-wave kernel takes the problem as it is
             if (tid == 0) b.fallback[q] = 1;
             continue;
@@ -78,27 +71,27 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
         // ---- load the persistent iterate
         int *gsense = b.sense + (size_t)q * m;
         int softbits = 0;
-        for (int i = tid; i < m; i += T) { const int s = gsense[i]; c.sense[i] = s; softbits |= s & DAQP_SOFT; }
-        const int has_soft = __syncthreads_or(softbits) ? 1 : 0;
+        for (int i = tid; i < m; i += T) { const int s = gsense[i]; SI(c, sense)[i] = s; softbits |= s & DAQP_SOFT; }
+        const int has_soft = uni(__syncthreads_or(softbits) ? 1 : 0);
         double *gv = b.vecs + (size_t)q * 5 * cap;
         int *gws = b.WS + (size_t)q * cap;
         for (int i = tid; i < cap; i += T) {
-            c.D[i] = gv[i]; c.xl[i] = gv[cap + i]; c.zl[i] = gv[2 * cap + i];
-            c.lamA[i] = gv[3 * cap + i]; c.lamB[i] = gv[4 * cap + i];
-            c.ws[i] = gws[i];
-            c.slot[i] = i;
-            c.freestk[i] = cap - 1 - i;             // slots 0 .. na0-1 are taken: the stack holds cap-1 ... na0 (top = lowest free)
+            SD(c, D)[i] = gv[i]; SD(c, xl)[i] = gv[cap + i]; SD(c, zl)[i] = gv[2 * cap + i];
+            SD(c, lamA)[i] = gv[3 * cap + i]; SD(c, lamB)[i] = gv[4 * cap + i];
+            SI(c, ws)[i] = gws[i];
+            SI(c, slot)[i] = i;
+            SI(c, freestk)[i] = cap - 1 - i;             // slots 0 .. na0-1 are taken: the stack holds cap-1 ... na0 (top = lowest free)
         }
         {
             const int used = tri(na0);
             const double *gL = b.L + (size_t)q * b.ltri;
-            for (int e = tid; e < used; e += T) c.L[e] = gL[e];
+            for (int e = tid; e < used; e += T) SDL(c)[e] = gL[e];
         }
-        for (int e = tid; e < wg_round_up(n, 2) + 2; e += T) c.u[e] = 0;
+        for (int e = tid; e < wg_round_up(n, 2) + 2; e += T) SD(c, u)[e] = 0;
         __syncthreads();
         for (int i = wv; i < na0; i += W) {         // rebuild the active-row scratch (both orientations), a row per wave and trip
-            const int id = c.ws[i];
-            if (lane == 0) c.slot_id[i] = id;
+            const int id = SI(c, ws)[i];
+            if (lane == 0) SI(c, slot_id)[i] = id;
             const double2 *src = reinterpret_cast<const double2 *>(c.Mblk) + ((size_t)(id >> 6) * c.npair) * 64 + (id & 63);
             for (int t = lane; t < c.npair; t += 64) {
                 const double2 v = src[(size_t)t * 64];
@@ -117,75 +110,64 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
             w.c = c;
             w.t_start = __builtin_amdgcn_s_memrealtime();
             w.profiling = (b.prof != nullptr) && mode == 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w.prof[i] = 0;
-            w.st = b.st;
+            if (w.profiling && lane < 16) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[lane] = 0;
+            w.stp = b.st_dev;
             w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
             w.trace_cap = b.trace_cap; w.trace_len = 0;
-            w.na = na0; w.reuse = qs->reuse_ind; w.sing = sing0;
-            w.fval = qs->fval; w.soft = qs->soft_slack;
+            w.na = na0; w.reuse = uni(qs->reuse_ind); w.sing = sing0;
+            w.fval = und(qs->fval); w.soft = und(qs->soft_slack);
             w.has_soft = has_soft;
             w.nfree = cap - na0; w.hi_slot = na0 - 1; w.overflow = 0;
-            const int swapped = qs->lam_swapped;
-            w.lam = swapped ? c.lamB : c.lamA; w.lams = swapped ? c.lamA : c.lamB;
-            int flag = 1, iters = 0;
-            if (mode == 1) {
-                wreset_ws(w);
-                flag = wactivate_marked(w);
-            } else {
-                if (qs->need_activate) {   // defensive: setup/update normally runs mode 1 itself
-                    wreset_ws(w);
-                    flag = wactivate_marked(w);
-                }
-                if (flag >= 0 && !w.overflow) flag = wldp_loop(w, iters);
-            }
+            w.lam_b = uni(qs->lam_swapped) ? 1 : 0;
+            int iters = 0;
+            const int flag = wrun(w, mode, need_act != 0, iters);   // (need_activate at mode 0: defensive, setup/update runs mode 1 itself)
             if (lane == 0) {
                 m_int[0] = flag; m_int[1] = iters; m_int[2] = w.na; m_int[3] = w.reuse; m_int[4] = w.sing;
-                m_int[5] = (w.lam == c.lamB) ? 1 : 0; m_int[6] = w.overflow; m_int[7] = w.trace_len;
+                m_int[5] = w.lam_b; m_int[6] = w.overflow; m_int[7] = w.trace_len;
                 m_dbl[0] = w.fval; m_dbl[1] = w.soft;
-                c.cmd[0] = WG_EXIT;
-                if (w.profiling) for (int i = 0; i < 8; ++i) b.prof[(size_t)q * 32 + i] = w.prof[i];
+                SI(c, cmd)[0] = WG_EXIT;
+                if (w.profiling) for (int i = 0; i < 16; ++i) b.prof[(size_t)q * 32 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];
             }
             __syncthreads();
-        } else wg_serve(c, b.st.primal_tol);
+        } else wg_serve<C>(c, b.st.primal_tol);
         __syncthreads();
 
         // ---- everybody: outputs and the persistent iterate
-        const int flag = m_int[0], iters = m_int[1], na = m_int[2];
-        if (m_int[6]) {            // overflow: nothing of the problem's state in HBM has been touched; the one-wave kernel redoes it
+        const int flag = uni(m_int[0]), iters = uni(m_int[1]), na = uni(m_int[2]);
+        if (uni(m_int[6])) {            // overflow: nothing of the problem's state in HBM has been touched; the one-wave kernel redoes it
             if (tid == 0) b.fallback[q] = 1;
             continue;
         }
-        double *lams = m_int[5] ? c.lamA : c.lamB;
+        double *lams = uni(m_int[5]) ? SD(c, lamA) : SD(c, lamB);
         if (mode == 1) {
             if (tid == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
         } else {
             // ldp2qp_solution (daqp.c:111-139) + daqp_extract_result (api.c:455-495)
             const double *Rq = b.Rinv + qfac * b.rtri, *vq = b.v + (size_t)q * n;
-            double *vl = c.mnew;                                    // v staged in LDS (the new-row buffer is free now)
+            double *vl = SD(c, mnew);                                    // v staged in LDS (the new-row buffer is free now)
             for (int i = tid; i < n; i += T) vl[i] = vq[i];
             __syncthreads();
             if (flag > 0) {
-                for (int i = tid; i < n; i += T) c.u[i] = c.u[i] - vl[i];
-                for (int i = tid; i < na; i += T) lams[i] *= c.scaling[c.ws[i]];
+                for (int i = tid; i < n; i += T) SD(c, u)[i] = SD(c, u)[i] - vl[i];
+                for (int i = tid; i < na; i += T) lams[i] *= c.scaling[SI(c, ws)[i]];
             }
             __syncthreads();
             if (flag > 0) {
                 const int diag = qs->diag_h;
                 for (int i = tid; i < n; i += T) {
                     const double *row = Rq + roff(i, n);
-                    double xi = c.u[i] * row[i];
-                    for (int j = i + 1; j < n; ++j) xi += row[j] * c.u[j];
+                    double xi = SD(c, u)[i] * row[i];
+                    for (int j = i + 1; j < n; ++j) xi += row[j] * SD(c, u)[j];
                     if (i < b.ms && !diag) xi /= c.scaling[i];   // daqp.c:124-134: no division in the RinvD branch
                     if (b.x) b.x[(size_t)q * n + i] = xi;
                 }
             } else if (b.x) {
-                for (int i = tid; i < n; i += T) b.x[(size_t)q * n + i] = c.u[i];
+                for (int i = tid; i < n; i += T) b.x[(size_t)q * n + i] = SD(c, u)[i];
             }
             if (b.lam) {
                 for (int i = tid; i < m; i += T) b.lam[(size_t)q * m + i] = 0;
                 __syncthreads();
-                for (int i = tid; i < na; i += T) b.lam[(size_t)q * m + c.ws[i]] = lams[i];
+                for (int i = tid; i < na; i += T) b.lam[(size_t)q * m + SI(c, ws)[i]] = lams[i];
             }
             if (tid == 0) {
                 double fv = m_dbl[0];
@@ -198,15 +180,15 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
             }
         }
         for (int i = tid; i < cap; i += T) {
-            gv[i] = c.D[i]; gv[cap + i] = c.xl[i]; gv[2 * cap + i] = c.zl[i];
-            gv[3 * cap + i] = c.lamA[i]; gv[4 * cap + i] = c.lamB[i];
-            gws[i] = (i < na) ? c.ws[i] : -1;
+            gv[i] = SD(c, D)[i]; gv[cap + i] = SD(c, xl)[i]; gv[2 * cap + i] = SD(c, zl)[i];
+            gv[3 * cap + i] = SD(c, lamA)[i]; gv[4 * cap + i] = SD(c, lamB)[i];
+            gws[i] = (i < na) ? SI(c, ws)[i] : -1;
         }
-        for (int i = tid; i < m; i += T) gsense[i] = c.sense[i];
+        for (int i = tid; i < m; i += T) gsense[i] = SI(c, sense)[i];
         {
             const int used = tri(na);
             double *gL = b.L + (size_t)q * b.ltri;
-            for (int e = tid; e < used; e += T) gL[e] = c.L[e];
+            for (int e = tid; e < used; e += T) gL[e] = SDL(c)[e];
         }
         if (tid == 0) {
             qs->n_active = na; qs->reuse_ind = m_int[3]; qs->sing_ind = m_int[4];

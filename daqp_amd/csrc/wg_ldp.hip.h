@@ -17,88 +17,96 @@
 // command word in LDS (post, s_barrier, everybody works, s_barrier).
 #pragma once
 #include "wave_ldp.hip.h"
+#include "wave_ldp_reg.hip.h"   // static_for
+#include "wg_layout.hip.h"
 
 namespace daqp_amd {
 
 enum : int { WG_EXIT = 0, WG_PRIMAL = 1, WG_SCAN = 2, WG_FETCH_GRAM = 3, WG_COMPACT = 4 };
 
-struct WgLds { int L, D, xl, zl, lamA, lamB, pend_lam, u, mnew, gram, red, cand, dbl; int ws, slot, slot_id, freestk, pend_id, sense, cmd, ints; int total_bytes; };
-__host__ __device__ inline int wg_round_up(int a, int b) { return (a + b - 1) / b * b; }
-__host__ __device__ inline WgLds wg_lds(int n, int m, int cap, int capL, int W)
-{
-    WgLds s;
-    const int cp = wg_round_up(cap, 2);
-    int o = 0;
-    s.L = o; o += wg_round_up(capL * (capL + 1) / 2, 2);
-    s.D = o; o += cp; s.xl = o; o += cp; s.zl = o; o += cp; s.lamA = o; o += cp; s.lamB = o; o += cp; s.pend_lam = o; o += cp;
-    s.u = o; o += wg_round_up(n, 2) + 2;
-    s.mnew = o; o += wg_round_up(n, 2) + 2;
-    s.gram = o; o += cp;
-    s.red = o; o += 64 * W;            // partial sums of the split primal / Gram passes (W waves x 64 lanes)
-    s.cand = o; o += 2 * W;            // per-wave scan candidates: value | (index, side)
-    s.dbl = o;
-    int oi = 0;
-    s.ws = oi; oi += wg_round_up(cap, 4);
-    s.slot = oi; oi += wg_round_up(cap, 4);
-    s.slot_id = oi; oi += wg_round_up(cap, 4);
-    s.freestk = oi; oi += wg_round_up(cap, 4);
-    s.pend_id = oi; oi += wg_round_up(cap, 4);
-    s.sense = oi; oi += wg_round_up(m, 4);
-    s.cmd = oi; oi += 16;
-    s.ints = oi;
-    s.total_bytes = o * 8 + oi * 4;
-    return s;
-}
-
-// what every thread of the workgroup knows (pointers and sizes; no iterate state)
+// LDS layout for working sets of up to 64*C rows.  Everything but the packed L sits at COMPILE-TIME offsets (vectors sized
+// for 64*C rows, u / m_new for n <= 256): an LDS address is then "immediate + 8*index", and nothing about the layout has to
+// be kept in registers across the master's state machine (twenty region pointers did not fit the scalar file and came back
+// as VGPR-lane and scratch spills).  Only L, behind the m sense words, starts at a run-time offset.
+template <int C>
+struct WgL {
+    static constexpr int CAP = 64 * C;
+    // doubles
+    static constexpr int D = 0, xl = CAP, zl = 2 * CAP, lamA = 3 * CAP, lamB = 4 * CAP, pend_lam = 5 * CAP, gram = 6 * CAP, u = 7 * CAP,
+                         mnew = u + 258, red = mnew + 258, cand = red + 64 * kWgMaxWaves, prof = cand + 2 * kWgMaxWaves, dend = prof + 16;
+    // ints, counted from double offset dend
+    static constexpr int ws = 0, slot = CAP, slot_id = 2 * CAP, freestk = 3 * CAP, pend_id = 4 * CAP, cmd = 5 * CAP, sense = 5 * CAP + 16;
+};
+// what every thread of the workgroup knows (sizes, HBM pointers; no iterate state)
 struct WgCtx {
-    int n, m, ms, cap, capL, npair, nblk, ldr, capT, W, exact;
-    double *L, *D, *xl, *zl, *lamA, *lamB, *pend_lam, *u, *mnew, *gram, *red, *cand;
-    int *ws, *slot, *slot_id, *freestk, *pend_id, *sense, *cmd;
+    int n, m, ms, cap, capL, npair, nblk, ldr, capT, W, exact, oL, lmax;   // lmax: last valid index of packed L
     double *rowc, *rowcT;                 // this workgroup's scratch in HBM: [cap][ldr] and [n][capT]
     const double *Mblk, *dupper, *dlower, *scaling;
 };
+__device__ __forceinline__ double *wg_sm() { extern __shared__ __attribute__((aligned(16))) double wg_dyn_lds[]; return wg_dyn_lds; }
+#define SD(c, name) (wg_sm() + WgL<C>::name)
+#define SDL(c) (wg_sm() + (c).oL)
+#define SI(c, name) (reinterpret_cast<int *>(wg_sm() + WgL<C>::dend) + WgL<C>::name)
+
+// Thread coordinates as values the optimizer cannot see through.  Everything below runs inside two nested loops (the
+// persistent workgroup's problem loop and the master's state machine); addresses of the form "base + f(lane)" are loop
+// invariant, LICM hoists every one of them (tri(lane + 64 c), 8 * lane, row pointers ...) to the top of the kernel, the
+// register file cannot hold them and they come back as scratch reloads -- a trip to memory to save a multiply.  Built from
+// these, an address is recomputed where it is used.
+__device__ __forceinline__ int wg_tid() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+__device__ __forceinline__ int wg_wave() { return __builtin_amdgcn_readfirstlane(wg_tid() >> 6); }
+__device__ __forceinline__ int wg_lane() { return wg_tid() & 63; }
+// Values that are the same in every lane but come out of LDS / HBM loads are VGPRs to the compiler: a branch on one makes
+// the master's whole control flow "divergent" (exec-masked, with readfirstlane waterfalls around every v_readlane of the
+// substitution chains).  Anything that steers control flow or indexes a cross-lane read goes through these first.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool ub(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
+__device__ __forceinline__ double und(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 // the master's iterate
 template <int C>
 struct WgWave {
     WgCtx c;
-    double *lam, *lams;
+    int lam_b;                            // 1: lam lives in buffer B and lam* in buffer A (the reference swaps the two pointers on every add)
     int na, reuse, sing, has_soft, nfree, hi_slot, overflow;
     double fval, soft;
-    DAQPSettings st;
+    const DAQPSettings *stp;              // device copy of the settings: scalar loads at the point of use
     int *trace; int trace_cap, trace_len;
     unsigned long long t_start;
-    long long prof[8]; bool profiling;
+    bool profiling;                       // phase cycle counters in LDS (WgL::prof)
 };
+#define WLAM(w) (wg_sm() + ((w).lam_b ? WgL<C>::lamB : WgL<C>::lamA))
+#define WLAMS(w) (wg_sm() + ((w).lam_b ? WgL<C>::lamA : WgL<C>::lamB))
 #define WPROF_T0(w) long long wprof_t0_ = (w).profiling ? (long long)__builtin_readcyclecounter() : 0
-#define WPROF_ACC(w, slot) do { if ((w).profiling) { const long long t1_ = (long long)__builtin_readcyclecounter(); (w).prof[slot] += t1_ - wprof_t0_; wprof_t0_ = t1_; } } while (0)
+#define WPROF_ACC(w, slot) do { if ((w).profiling) { const long long t1_ = (long long)__builtin_readcyclecounter(); if (wg_lane() == 0) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[slot] += t1_ - wprof_t0_; wprof_t0_ = t1_; } } while (0)
 
 template <int C>
 __device__ __forceinline__ void wtrace(WgWave<C> &w, int ev)
 {
     if (w.trace) {
-        if (lane_id() == 0 && w.trace_len < w.trace_cap) w.trace[w.trace_len] = ev;
+        if (wg_lane() == 0 && w.trace_len < w.trace_cap) w.trace[w.trace_len] = ev;
         w.trace_len++;
     }
 }
 
-__device__ __forceinline__ int wg_wave() { return (int)(threadIdx.x >> 6); }
-__device__ __forceinline__ int wg_lane() { return (int)(threadIdx.x & 63); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // the parallel phases: executed by EVERY wave of the workgroup with the same arguments (barriers inside are workgroup-wide)
 // ---------------------------------------------------------------------------------------------------------------------
 
 // row `id` of the LDP constraint matrix -> LDS (mnew) and both orientations of the scratch at `slot`
+template <int C>
 __device__ __forceinline__ void wg_fetch_row(const WgCtx &c, int id, int slot, bool to_lds)
 {
-    const int t = (int)threadIdx.x;
+    const int t = wg_tid();
     if (t < c.npair) {
         const double2 *src = reinterpret_cast<const double2 *>(c.Mblk) + ((size_t)(id >> 6) * c.npair) * 64 + (id & 63);
         const double2 v = src[(size_t)t * 64];
         const bool two = 2 * t + 1 < c.n;
-        if (to_lds) { c.mnew[2 * t] = v.x; c.mnew[2 * t + 1] = two ? v.y : 0.0; }
+        if (to_lds) { SD(c, mnew)[2 * t] = v.x; SD(c, mnew)[2 * t + 1] = two ? v.y : 0.0; }
         double *rw = c.rowc + (size_t)slot * c.ldr + 2 * t;
         rw[0] = v.x;
         if (two) rw[1] = v.y;
@@ -110,6 +118,7 @@ __device__ __forceinline__ void wg_fetch_row(const WgCtx &c, int id, int slot, b
 // u = -sum_i lam*_i row(ws[i])  (auxiliary.c:46-88): lane <-> column, rows in working-set order.  Exact mode: one sweep per
 // column block; otherwise the working set is cut into contiguous segments, one per wave, and the partial sums are added
 // in segment order.
+template <int C>
 __device__ __forceinline__ void wg_primal(const WgCtx &c, int na, const double *lams)
 {
     const int wv = wg_wave(), lane = wg_lane();
@@ -124,28 +133,29 @@ __device__ __forceinline__ void wg_primal(const WgCtx &c, int na, const double *
     const int jj = j < c.n ? j : 0;
     double acc = 0;
     if (seg < segs) {
-        for (int i = i0; i < i1; i += 8) {
-            double rv[8], li[8];
+        constexpr int PB = 24;     // rows in flight per lane: the scratch rows come from L2 / HBM, a batch costs one round trip
+        for (int i = i0; i < i1; i += PB) {
+            double rv[PB], li[PB];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < PB; ++q) {
                 const int ii = (i + q < i1) ? i + q : i1 - 1;
-                rv[q] = c.rowc[(size_t)c.slot[ii] * c.ldr + jj];
-                li[q] = lams[ii];
+                rv[q] = c.rowc[(size_t)SI(c, slot)[ii] * c.ldr + jj];
+                li[q] = (i + q < i1) ? lams[ii] : 0.0;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) if (i + q < i1) acc -= rv[q] * li[q];
+            for (int q = 0; q < PB; ++q) if (i + q < i1) acc -= rv[q] * li[q];
         }
     }
     if (segs == 1) {
-        if (wv < CB && j < c.n) c.u[j] = acc;
+        if (wv < CB && j < c.n) SD(c, u)[j] = acc;
     } else {
-        if (seg < segs) c.red[seg * 64 * CB + cb * 64 + lane] = acc;    // segs * CB <= W waves of 64 lanes
+        if (seg < segs) SD(c, red)[seg * 64 * CB + cb * 64 + lane] = acc;    // segs * CB <= W waves of 64 lanes
         __syncthreads();
-        const int t = (int)threadIdx.x;
+        const int t = wg_tid();
         if (t < c.n) {
-            double s = c.red[t];
-            for (int g = 1; g < segs; ++g) s += c.red[g * 64 * CB + t];
-            c.u[t] = s;
+            double s = SD(c, red)[t];
+            for (int g = 1; g < segs; ++g) s += SD(c, red)[g * 64 * CB + t];
+            SD(c, u)[t] = s;
         }
     }
 }
@@ -153,17 +163,34 @@ __device__ __forceinline__ void wg_primal(const WgCtx &c, int na, const double *
 // feasibility scan + most-violated pick (auxiliary.c:89-198): lane <-> constraint row, wave w takes the 64-row blocks
 // w, w + W, ...; M streams from HBM, DEPTH x 16 bytes per lane in flight ahead of the k-ordered chain.  Every wave leaves
 // its candidate (value, row, side) in LDS; the master picks among them (lowest value, then lowest row).
+template <int C>
 __device__ __forceinline__ void wg_scan(const WgCtx &c, double primal_tol)
 {
     const int wv = wg_wave(), lane = wg_lane(), n = c.n;
     const double ep = -primal_tol;
     double bv = 0.0;
     int bi = kBig, bup = 0;
-    const double2 *u2 = reinterpret_cast<const double2 *>(c.u);
+    const double2 *u2 = reinterpret_cast<const double2 *>(SD(c, u));
     const bool odd = (n & 1) != 0;
     const int full = odd ? c.npair - 1 : c.npair;
-    constexpr int DEPTH = 16;
-    for (int blk = wv; blk < c.nblk; blk += c.W) {
+    constexpr int DEPTH = 32;   // 16-byte loads in flight per lane: 32 KiB per wave (two waves per SIMD leave 256 registers)
+    // candidate of row r given mu = M_r . u (auxiliary.c:126-150)
+    auto consider = [&](int r, double mu, double du, double dl, double sc) __attribute__((always_inline)) {
+        const int sn = SI(c, sense)[r];
+        if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
+            const double bound = ep * sc;
+            double cand = du - mu;
+            if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 1; }
+            else {
+                cand = mu - dl;
+                if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 0; }
+            }
+        }
+    };
+    // one 64-row block per wave and trip, each lane its row's k-ordered chain.  (Measured on C4, 10 blocks over 8 waves: sharing
+    // the two left-over blocks between all waves -- k-slices, partial sums through LDS -- is slower, 40 k instead of 31 k cycles
+    // per scan: the scan runs at what the CU can pull from L2 / MALL, not at the waves' load depth.)
+    for (int blk = (wv + c.W - 1) % c.W; blk < c.nblk; blk += c.W) {   // (wave 0, the master, takes its blocks last)
         const int r = blk * 64 + lane;
         const bool own = r < c.m;
         const int rr = own ? r : 0;
@@ -173,40 +200,39 @@ __device__ __forceinline__ void wg_scan(const WgCtx &c, double primal_tol)
         double mu = 0;
         int t = 0;
         for (; t + DEPTH <= full; t += DEPTH) {
-            double2 mm[DEPTH], uk[DEPTH];
+            double2 mm[DEPTH];
 #pragma unroll
             for (int q = 0; q < DEPTH; ++q) mm[q] = src[(size_t)(t + q) * 64];
 #pragma unroll
-            for (int q = 0; q < DEPTH; ++q) uk[q] = u2[t + q];
+            for (int g = 0; g < DEPTH / 8; ++g) {      // u from LDS eight pairs at a time (broadcast reads), k-ordered chain
+                double2 uk[8];
 #pragma unroll
-            for (int q = 0; q < DEPTH; ++q) { mu += mm[q].x * uk[q].x; mu += mm[q].y * uk[q].y; }
-        }
-        if (t < full) {
-            double2 mm[DEPTH], uk[DEPTH];
+                for (int h = 0; h < 8; ++h) uk[h] = u2[t + 8 * g + h];
 #pragma unroll
-            for (int q = 0; q < DEPTH; ++q) { const int tt = (t + q < full) ? t + q : full - 1; mm[q] = src[(size_t)tt * 64]; uk[q] = u2[tt]; }
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) if (t + q < full) { mu += mm[q].x * uk[q].x; mu += mm[q].y * uk[q].y; }
-        }
-        if (odd) mu += src[(size_t)full * 64].x * c.u[n - 1];
-        if (own) {
-            const int sn = c.sense[r];
-            if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
-                const double bound = ep * sc;
-                double cand = du - mu;
-                if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 1; }
-                else {
-                    cand = mu - dl;
-                    if (cand < bv && cand < bound) { bv = cand; bi = r; bup = 0; }
-                }
+                for (int h = 0; h < 8; ++h) { mu += mm[8 * g + h].x * uk[h].x; mu += mm[8 * g + h].y * uk[h].y; }
             }
         }
+        if (t < full) {
+            double2 mm[DEPTH];
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) { const int tt = (t + q < full) ? t + q : full - 1; mm[q] = src[(size_t)tt * 64]; }
+#pragma unroll
+            for (int g = 0; g < DEPTH / 8; ++g) {
+                double2 uk[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h) { const int tt = (t + 8 * g + h < full) ? t + 8 * g + h : full - 1; uk[h] = u2[tt]; }
+#pragma unroll
+                for (int h = 0; h < 8; ++h) if (t + 8 * g + h < full) { mu += mm[8 * g + h].x * uk[h].x; mu += mm[8 * g + h].y * uk[h].y; }
+            }
+        }
+        if (odd) mu += src[(size_t)full * 64].x * SD(c, u)[n - 1];
+        if (own) consider(r, mu, du, dl, sc);
     }
     wave_argmin(bv, bi, bup);
     if (lane == 0) {
-        c.cand[2 * wv] = bv;
-        reinterpret_cast<int *>(c.cand + 2 * wv + 1)[0] = bi;
-        reinterpret_cast<int *>(c.cand + 2 * wv + 1)[1] = bup;
+        SD(c, cand)[2 * wv] = bv;
+        reinterpret_cast<int *>(SD(c, cand) + 2 * wv + 1)[0] = bi;
+        reinterpret_cast<int *>(SD(c, cand) + 2 * wv + 1)[1] = bup;
     }
 }
 
@@ -214,6 +240,7 @@ __device__ __forceinline__ void wg_scan(const WgCtx &c, double primal_tol)
 // (free slots hold stale rows: finite, unused).  lane <-> slot, rows read from the transposed scratch (coalesced).
 // Exact mode: the reference's dot_row (four interleaved partial sums from the row's start column, (s0+s1)+(s2+s3));
 // otherwise the columns are cut into segments, one per wave, combined in segment order.
+template <int C>
 __device__ __forceinline__ void wg_gram(const WgCtx &c, int id, int hi)
 {
     const int wv = wg_wave(), lane = wg_lane(), n = c.n;
@@ -227,14 +254,14 @@ __device__ __forceinline__ void wg_gram(const WgCtx &c, int id, int hi)
     if (c.exact) {
         if (wv < RG) {
             const int c0 = id < c.ms ? id : 0;
-            const int idk = c.slot_id[ss];
+            const int idk = SI(c, slot_id)[ss];
             const int j0 = (idk < c.ms) ? (c0 > idk ? c0 : idk) : c0;       // factorization.c:64-72
             const int len = n - j0, body = j0 + (len & ~3);
             double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
             for (int jb = 0; jb < n; jb += 8) {
                 double rv[8], mv[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { const int j = (jb + q < n) ? jb + q : n - 1; rv[q] = col[(size_t)j * c.capT]; mv[q] = c.mnew[j]; }
+                for (int q = 0; q < 8; ++q) { const int j = (jb + q < n) ? jb + q : n - 1; rv[q] = col[(size_t)j * c.capT]; mv[q] = SD(c, mnew)[j]; }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int j = jb + q;
@@ -245,7 +272,7 @@ __device__ __forceinline__ void wg_gram(const WgCtx &c, int id, int hi)
                     }
                 }
             }
-            if (s < hi) c.gram[s] = (s0 + s1) + (s2 + s3);
+            if (s < hi) SD(c, gram)[s] = (s0 + s1) + (s2 + s3);
         }
         return;
     }
@@ -253,24 +280,25 @@ __device__ __forceinline__ void wg_gram(const WgCtx &c, int id, int hi)
     const int ja = seg * per, jb_ = (ja + per < n) ? ja + per : n;
     double acc = 0;
     if (seg < segs) {
-        for (int j = ja; j < jb_; j += 8) {
-            double rv[8], mv[8];
+        constexpr int GB = 24;     // columns in flight per lane
+        for (int j = ja; j < jb_; j += GB) {
+            double rv[GB], mv[GB];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int jj = (j + q < jb_) ? j + q : jb_ - 1; rv[q] = col[(size_t)jj * c.capT]; mv[q] = c.mnew[jj]; }
+            for (int q = 0; q < GB; ++q) { const int jj = (j + q < jb_) ? j + q : jb_ - 1; rv[q] = col[(size_t)jj * c.capT]; mv[q] = SD(c, mnew)[jj]; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) if (j + q < jb_) acc += rv[q] * mv[q];
+            for (int q = 0; q < GB; ++q) if (j + q < jb_) acc += rv[q] * mv[q];
         }
     }
     if (segs == 1) {
-        if (wv < RG && s < hi) c.gram[s] = acc;
+        if (wv < RG && s < hi) SD(c, gram)[s] = acc;
     } else {
-        if (seg < segs) c.red[seg * 64 * RG + rg * 64 + lane] = acc;     // segs * RG <= W
+        if (seg < segs) SD(c, red)[seg * 64 * RG + rg * 64 + lane] = acc;     // segs * RG <= W
         __syncthreads();
-        const int t = (int)threadIdx.x;
+        const int t = wg_tid();
         if (t < hi) {
-            double g = c.red[t];
-            for (int q = 1; q < segs; ++q) g += c.red[q * 64 * RG + t];
-            c.gram[t] = g;
+            double g = SD(c, red)[t];
+            for (int q = 1; q < segs; ++q) g += SD(c, red)[q * 64 * RG + t];
+            SD(c, gram)[t] = g;
         }
     }
 }
@@ -278,6 +306,7 @@ __device__ __forceinline__ void wg_gram(const WgCtx &c, int id, int hi)
 // factorization.c:121-129: move rows r+1.. of packed L up by one and drop column r, element-parallel over the
 // destination range [tri(r), tri(na-1)).  A destination always reads from a higher address, so ascending chunks with
 // "everybody reads, barrier, everybody writes, barrier" never clobber a live source.
+template <int C>
 __device__ __forceinline__ void wg_compact(const WgCtx &c, int r, int na)
 {
     const int e0 = tri(r), e1 = tri(na - 1);
@@ -287,38 +316,39 @@ __device__ __forceinline__ void wg_compact(const WgCtx &c, int r, int na)
         double tmp[U];
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const int e = cb + q * T + (int)threadIdx.x;
+            const int e = cb + q * T + wg_tid();
             tmp[q] = 0;
             if (e < e1) {
                 int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
                 while (tri(i + 1) <= e) ++i;
                 while (tri(i) > e) --i;
                 const int j = e - tri(i);
-                tmp[q] = c.L[tri(i + 1) + j + (j >= r ? 1 : 0)];
+                tmp[q] = SDL(c)[tri(i + 1) + j + (j >= r ? 1 : 0)];
             }
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const int e = cb + q * T + (int)threadIdx.x;
-            if (e < e1) c.L[e] = tmp[q];
+            const int e = cb + q * T + wg_tid();
+            if (e < e1) SDL(c)[e] = tmp[q];
         }
         __syncthreads();
     }
 }
 
 // one command, executed by every wave (the master included)
+template <int C>
 __device__ __forceinline__ void wg_do(const WgCtx &c, int code, double primal_tol)
 {
-    const int a0 = c.cmd[1], a1 = c.cmd[2], na = c.cmd[3], hi = c.cmd[4];
-    const double *lams = c.cmd[5] ? c.lamB : c.lamA;
-    if (code == WG_PRIMAL) wg_primal(c, na, lams);
-    else if (code == WG_SCAN) wg_scan(c, primal_tol);
+    const int a0 = uni(SI(c, cmd)[1]), a1 = uni(SI(c, cmd)[2]), na = uni(SI(c, cmd)[3]), hi = uni(SI(c, cmd)[4]);
+    const double *lams = uni(SI(c, cmd)[5]) ? SD(c, lamB) : SD(c, lamA);
+    if (code == WG_PRIMAL) wg_primal<C>(c, na, lams);
+    else if (code == WG_SCAN) wg_scan<C>(c, primal_tol);
     else if (code == WG_FETCH_GRAM) {
-        wg_fetch_row(c, a0, a1, true);
+        wg_fetch_row<C>(c, a0, a1, true);
         __syncthreads();
-        wg_gram(c, a0, hi);
-    } else if (code == WG_COMPACT) wg_compact(c, a0, na);
+        wg_gram<C>(c, a0, hi);
+    } else if (code == WG_COMPACT) wg_compact<C>(c, a0, na);
 }
 
 // master side: post a command, take part in it
@@ -326,22 +356,23 @@ template <int C>
 __device__ __forceinline__ void wg_run(WgWave<C> &w, int code, int a0 = 0, int a1 = 0)
 {
     const WgCtx &c = w.c;
-    if (lane_id() == 0) {
-        c.cmd[0] = code; c.cmd[1] = a0; c.cmd[2] = a1; c.cmd[3] = w.na; c.cmd[4] = w.hi_slot + 1;
-        c.cmd[5] = (w.lams == c.lamB) ? 1 : 0;
+    if (wg_lane() == 0) {
+        SI(c, cmd)[0] = code; SI(c, cmd)[1] = a0; SI(c, cmd)[2] = a1; SI(c, cmd)[3] = w.na; SI(c, cmd)[4] = w.hi_slot + 1;
+        SI(c, cmd)[5] = w.lam_b ? 0 : 1;   // which buffer holds lam*
     }
     __syncthreads();
-    wg_do(c, code, w.st.primal_tol);
+    wg_do<C>(c, code, w.stp->primal_tol);
     __syncthreads();
 }
 // everybody else: serve commands until the master says EXIT
+template <int C>
 __device__ __forceinline__ void wg_serve(const WgCtx &c, double primal_tol)
 {
     for (;;) {
         __syncthreads();
-        const int code = c.cmd[0];
+        const int code = uni(SI(c, cmd)[0]);
         if (code == WG_EXIT) break;
-        wg_do(c, code, primal_tol);
+        wg_do<C>(c, code, primal_tol);
         __syncthreads();
     }
 }
@@ -350,20 +381,74 @@ __device__ __forceinline__ void wg_serve(const WgCtx &c, double primal_tol)
 // master: the serial part of the iteration on wave 0 (lane + 64 c <-> working-set position), L and the vectors in LDS
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kWPre = 8;
+// index into packed L clamped to its LDS allocation: the chains below load a lane's entry whether or not the lane's row
+// exists (the result is discarded by a select or never read), so the address must stay inside the allocation
+#define WLIDX(c, e) ((e) < (c).lmax ? (e) : (c).lmax)
+
+// Cross-lane reads of a vector held as a[cc] in lane (idx & 63), chunk (idx >> 6).  A register array must never be indexed
+// with a run-time value -- "v = a[0]; if (chunk == 1) v = a[1]; ..." is folded into exactly that, the array moves to scratch
+// memory and every access of the chains below becomes a trip to it (measured: 600 cycles per substitution step).  Here
+// the chunk is chosen by a wave-uniform BRANCH around code whose array index is a compile-time constant.
+template <int C>
+__device__ __forceinline__ double wpick(const double (&a)[C], int idx)
+{
+    double v = 0;
+    static_for<C>([&](auto cc) __attribute__((always_inline)) { if ((idx >> 6) == cc) v = rl(a[cc], idx & 63); });
+    return v;
+}
+// f(cs, q, x) for the eight pivots 8*g8 + q, q = 0..7 (or 7..0 when `down`), x = the CURRENT value of that element of a
+// (f may update a between pivots); cs = the pivots' chunk as a compile-time constant
+template <int C, bool DOWN, class F>
+__device__ __forceinline__ void wpivots8(double (&a)[C], int g8, F &&f)
+{
+    const int l0 = (g8 & 7) * 8;
+    static_for<C>([&](auto cs) __attribute__((always_inline)) {
+        if ((g8 >> 3) == cs) {
+            static_for<8>([&](auto qq) __attribute__((always_inline)) {
+                constexpr int q = DOWN ? 7 - (int)qq : (int)qq;
+                f(cs, std::integral_constant<int, q>{}, rl(a[cs], l0 + q));
+            });
+        }
+    });
+}
+
+// A chain is a run of such groups; a taken branch costs as much as the arithmetic of a pivot (tools/ubench.hip: ~40
+// cycles), so the per-pivot end-of-range test exists only in the one partial group of a chain: body(cs, q, x, guard) with
+// guard a compile-time bool.
+template <int C, bool DOWN, class F>
+__device__ __forceinline__ void wgroup(double (&a)[C], int g8, bool full, F &&body)
+{
+    if (full) wpivots8<C, DOWN>(a, g8, [&](auto cs, auto q, double x) __attribute__((always_inline)) { body(cs, q, x, std::false_type{}); });
+    else wpivots8<C, DOWN>(a, g8, [&](auto cs, auto q, double x) __attribute__((always_inline)) { body(cs, q, x, std::true_type{}); });
+}
+// sum over the whole wave of a chunked vector (default arithmetic mode only: not the reference's order)
+template <int C>
+__device__ __forceinline__ double wsum(const double (&a)[C])
+{
+    double v = a[0];
+    static_for<C - 1>([&](auto cc) __attribute__((always_inline)) { v += a[cc + 1]; });
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
+}
 
 // LDL' row append (factorization.c:21-111)
 template <int C>
 __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
 {
     const WgCtx &c = w.c;
-    const int lane = lane_id(), na = w.na, n = c.n, base = tri(na);
+    const int lane = wg_lane(), na = w.na, n = c.n, base = tri(na);
     if (na >= c.capL) { w.overflow = 1; return; }          // packed L would outgrow its LDS: the one-wave kernel takes this problem
     // a free slot of the active-row scratch (lowest first: the slots in use stay dense)
-    const int newslot = c.freestk[w.nfree - 1];
+    const int newslot = uni(SI(c, freestk)[w.nfree - 1]);
     w.nfree--;
     if (newslot > w.hi_slot) w.hi_slot = newslot;
-    if (lane == 0) { c.slot[na] = newslot; c.slot_id[newslot] = id; }
+    if (lane == 0) { SI(c, slot)[na] = newslot; SI(c, slot_id)[newslot] = id; }
+    WPROF_T0(w);
     wg_run(w, WG_FETCH_GRAM, id, newslot);
+    WPROF_ACC(w, 8);
     w.sing = kEmpty;
     double g[C];
     int ns_act = 0;
@@ -373,42 +458,46 @@ __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
         g[cc] = 0;
         int soft_k = 0;
         if (k <= na) {
-            g[cc] = c.gram[c.slot[k]];
-            const int idk = (k < na) ? c.ws[k] : id;
-            soft_k = (c.sense[idk] & DAQP_SOFT) ? 1 : 0;
+            g[cc] = SD(c, gram)[SI(c, slot)[k]];
+            const int idk = (k < na) ? SI(c, ws)[k] : id;
+            soft_k = (SI(c, sense)[idk] & DAQP_SOFT) ? 1 : 0;
         }
         if (w.has_soft) ns_act += __popcll(__ballot(soft_k));
     }
-    double dnew = rlc<C>(g, na);
-    if (c.sense[id] & DAQP_SOFT) dnew += w.st.rho_soft;
+    double dnew = wpick<C>(g, na);
+    if (ub((SI(c, sense)[id] & DAQP_SOFT) != 0)) dnew += w.stp->rho_soft;
     if (na == 0) {
-        if (lane == 0) c.D[0] = dnew;
+        if (lane == 0) SD(c, D)[0] = dnew;
         WSYNC();
+        WPROF_ACC(w, 9);
         return;
     }
-    // forward substitution  l <- L \ g   (factorization.c:81-88)
-    for (int j0 = 0; j0 < na - 1; j0 += kWPre) {
+    // forward substitution  l <- L \ g   (factorization.c:81-88): pivots j ascending, eight at a time, the lane's own L entries
+    // of the group loaded before its chain
+    // (Rows of chunks above the pivots' own chunk take every update of the group unconditionally -- lanes beyond the working
+    //  set compute on whatever L holds there and are never read; only the pivots' chunk needs the k > j select.)
+    for (int g8 = 0; 8 * g8 < na - 1; ++g8) {
         double Lv[kWPre][C];
-#pragma unroll
-        for (int q = 0; q < kWPre; ++q)
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc) {
-                const int k = lane + 64 * cc, j = j0 + q;
-                Lv[q][cc] = c.L[(k > j && k < na) ? tri(k) + j : 0];
+        static_for<C>([&](auto cc) __attribute__((always_inline)) {   // (one uniform branch per chunk, not per load: a branch costs as much as four loads)
+            if (64 * (cc + 1) > 8 * g8 && 64 * cc < na) {
+                const int rowbase = tri(lane + 64 * cc) + 8 * g8;
+                static_for<kWPre>([&](auto q) __attribute__((always_inline)) { Lv[q][cc] = SDL(c)[WLIDX(c, rowbase + q)]; });
             }
-#pragma unroll
-        for (int q = 0; q < kWPre; ++q) {
-            const int j = j0 + q;
-            if (j < na - 1) {
-                const double lj = rlc<C>(g, j);
-#pragma unroll
-                for (int cc = 0; cc < C; ++cc) {
-                    const int k = lane + 64 * cc;
-                    if (k > j && k < na) g[cc] -= Lv[q][cc] * lj;
+        });
+        wgroup<C, false>(g, g8, 8 * g8 + 8 <= na - 1, [&](auto cs, auto q, double lj, auto guard) __attribute__((always_inline)) {
+            const int j = 8 * g8 + q;
+            if constexpr (guard) { if (j >= na - 1) return; }
+            static_for<C>([&](auto ct) __attribute__((always_inline)) {
+                if constexpr (ct == cs) {
+                    const double t = g[ct] - Lv[q][ct] * lj;
+                    g[ct] = (lane + 64 * ct > j) ? t : g[ct];
+                } else if constexpr (ct > cs) {
+                    if (64 * ct < na) g[ct] = g[ct] - Lv[q][ct] * lj;
                 }
-            }
-        }
+            });
+        });
     }
+    // l_k /= D_k ; d_new -= sum_k l_k^2 D_k, in k order (factorization.c:93-103)
     double p[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
@@ -416,18 +505,22 @@ __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
         p[cc] = 0;
         if (k < na) {
             const double t = g[cc];
-            const double lk = t / c.D[k];
-            c.L[base + k] = lk;
+            const double lk = t / SD(c, D)[k];
+            SDL(c)[base + k] = lk;
             p[cc] = t * lk;
         }
     }
     double acc = dnew;
-    for (int k = 0; k < na; ++k) acc -= rlc<C>(p, k);
+    if (c.exact) {   // the reference's order (p is exactly +0.0 beyond the working set: no end-of-range test)
+        for (int g8 = 0; 8 * g8 < na; ++g8)
+            wpivots8<C, false>(p, g8, [&](auto cs, auto q, double pk) __attribute__((always_inline)) { acc -= pk; });
+    } else acc -= wsum<C>(p);
     int sing = kEmpty;
-    if (acc < w.st.sing_tol || na >= n + ns_act) { sing = na; acc = 0; }
-    if (lane == 0) c.D[na] = acc;
+    if (ub(acc < w.stp->sing_tol) || na >= n + ns_act) { sing = na; acc = 0; }
+    if (lane == 0) SD(c, D)[na] = acc;
     w.sing = sing;
     WSYNC();
+    WPROF_ACC(w, 9);
 }
 
 // LDL' row delete (factorization.c:112-151)
@@ -435,62 +528,70 @@ template <int C>
 __device__ __forceinline__ void wldl_delete(WgWave<C> &w, int r)
 {
     const WgCtx &c = w.c;
-    const int lane = lane_id(), na = w.na;
+    const int lane = wg_lane(), na = w.na;
     if (na == r + 1) return;
     const int nupd = na - r - 1;
     double wv[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
         const int t = lane + 64 * cc;
-        wv[cc] = (t < nupd) ? c.L[tri(r + 1 + t) + r] : 0.0;
+        wv[cc] = (t < nupd) ? SDL(c)[tri(r + 1 + t) + r] : 0.0;
     }
     WSYNC();
+    WPROF_T0(w);
     wg_run(w, WG_COMPACT, r);
-    double alpha = c.D[r];
-    for (int j0 = 0; j0 < nupd; j0 += kWPre) {
-        // the lane's own L entries of kWPre columns (new numbering: row r+t, column r+j) before the chain, written back after
+    WPROF_ACC(w, 10);
+    double alpha = SD(c, D)[r];
+    for (int g8 = 0; 8 * g8 < nupd; ++g8) {
+        // the lane's own L entries of the group's eight columns (new numbering: row r+t, column r+j) before the chain, written back after
         double Lc[kWPre][C], Dv[kWPre];
-#pragma unroll
-        for (int q = 0; q < kWPre; ++q) {
-            const int j = j0 + q;
-            Dv[q] = c.D[(j < nupd) ? r + 1 + j : r];
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc) {
-                const int t = lane + 64 * cc;
-                Lc[q][cc] = c.L[(t > j && t < nupd) ? tri(r + t) + r + j : 0];
+        static_for<kWPre>([&](auto q) __attribute__((always_inline)) {
+            const int j = 8 * g8 + q;
+            Dv[q] = SD(c, D)[(j < nupd) ? r + 1 + j : r];
+        });
+        static_for<C>([&](auto cc) __attribute__((always_inline)) {
+            if (64 * (cc + 1) > 8 * g8 && 64 * cc < nupd) {
+                const int rowbase = tri(r + lane + 64 * cc) + r + 8 * g8;
+                static_for<kWPre>([&](auto q) __attribute__((always_inline)) { Lc[q][cc] = SDL(c)[WLIDX(c, rowbase + q)]; });
             }
-        }
-#pragma unroll
-        for (int q = 0; q < kWPre; ++q) {
-            const int j = j0 + q;
-            if (j < nupd) {
-                const double p = rlc<C>(wv, j);
+        });
+        wgroup<C, false>(wv, g8, 8 * g8 + 8 <= nupd, [&](auto cs, auto q, double p, auto guard) __attribute__((always_inline)) {
+            const int j = 8 * g8 + q;
+            if constexpr (guard) { if (j >= nupd) return; }
+            {
                 const double Di = Dv[q];
                 const double dbar = Di + alpha * p * p;
                 const double beta = p * alpha / dbar;
                 alpha = Di * alpha / dbar;
-                if (lane == 0) c.D[r + j] = dbar;
-#pragma unroll
-                for (int cc = 0; cc < C; ++cc) {
-                    const int t = lane + 64 * cc;
-                    if (t > j && t < nupd) {
-                        wv[cc] -= p * Lc[q][cc];
-                        Lc[q][cc] = Lc[q][cc] + beta * wv[cc];
+                if (lane == 0) SD(c, D)[r + j] = dbar;
+                static_for<C>([&](auto ct) __attribute__((always_inline)) {
+                    if constexpr (ct == cs) {
+                        const bool on = lane + 64 * ct > j;
+                        const double wn = wv[ct] - p * Lc[q][ct];
+                        wv[ct] = on ? wn : wv[ct];
+                        const double ln = Lc[q][ct] + beta * wv[ct];
+                        Lc[q][ct] = on ? ln : Lc[q][ct];
+                    } else if constexpr (ct > cs) {
+                        if (64 * ct < nupd) {
+                            wv[ct] = wv[ct] - p * Lc[q][ct];
+                            Lc[q][ct] = Lc[q][ct] + beta * wv[ct];
+                        }
                     }
-                }
+                });
             }
-        }
-#pragma unroll
-        for (int q = 0; q < kWPre; ++q) {
-            const int j = j0 + q;
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc) {
-                const int t = lane + 64 * cc;
-                if (j < nupd && t > j && t < nupd) c.L[tri(r + t) + r + j] = Lc[q][cc];
+        });
+        static_for<C>([&](auto cc) __attribute__((always_inline)) {
+            if (64 * (cc + 1) > 8 * g8 && 64 * cc < nupd) {
+                const int t = lane + 64 * cc, rowbase = tri(r + t) + r + 8 * g8;
+                static_for<kWPre>([&](auto q) __attribute__((always_inline)) {
+                    const int j = 8 * g8 + q;
+                    if (j < nupd && t > j && t < nupd) SDL(c)[rowbase + q] = Lc[q][cc];
+                });
             }
-        }
+        });
     }
     WSYNC();
+    WPROF_ACC(w, 11);
 }
 
 // auxiliary.c:3-22 without the trailing pivot; returns 1 if the factor became singular
@@ -498,10 +599,10 @@ template <int C>
 __device__ __forceinline__ int wdrop_core(WgWave<C> &w, int r)
 {
     const WgCtx &c = w.c;
-    const int lane = lane_id();
-    const int idr = c.ws[r];
+    const int lane = wg_lane();
+    const int idr = uni(SI(c, ws)[r]);
     wtrace(w, -(idr + 1));
-    if (lane == 0) { c.sense[idr] &= ~DAQP_ACTIVE; c.freestk[w.nfree] = c.slot[r]; }
+    if (lane == 0) { SI(c, sense)[idr] &= ~DAQP_ACTIVE; SI(c, freestk)[w.nfree] = SI(c, slot)[r]; }
     w.nfree++;
     wldl_delete(w, r);
     w.na--;
@@ -511,23 +612,23 @@ __device__ __forceinline__ int wdrop_core(WgWave<C> &w, int r)
     for (int cc = 0; cc < C; ++cc) {
         const int i = lane + 64 * cc;
         wsn[cc] = 0; sln[cc] = 0; lmn[cc] = 0;
-        if (i >= r && i < w.na) { wsn[cc] = c.ws[i + 1]; sln[cc] = c.slot[i + 1]; lmn[cc] = w.lam[i + 1]; }
+        if (i >= r && i < w.na) { wsn[cc] = SI(c, ws)[i + 1]; sln[cc] = SI(c, slot)[i + 1]; lmn[cc] = WLAM(w)[i + 1]; }
     }
     WSYNC();
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
         const int i = lane + 64 * cc;
-        if (i >= r && i < w.na) { c.ws[i] = wsn[cc]; c.slot[i] = sln[cc]; w.lam[i] = lmn[cc]; }
+        if (i >= r && i < w.na) { SI(c, ws)[i] = wsn[cc]; SI(c, slot)[i] = sln[cc]; WLAM(w)[i] = lmn[cc]; }
     }
     if (r < w.reuse) w.reuse = r;
     int took = 0;
     WSYNC();
-    if (w.na > 0 && c.D[w.na - 1] < w.st.sing_tol) {
+    if (w.na > 0 && ub(SD(c, D)[w.na - 1] < w.stp->sing_tol)) {
         w.sing = w.na - 1;
         took = 1;
     }
     WSYNC();
-    if (took && lane == 0) c.D[w.na - 1] = 0;
+    if (took && lane == 0) SD(c, D)[w.na - 1] = 0;
     WSYNC();
     return took;
 }
@@ -536,80 +637,43 @@ template <int C>
 __device__ __forceinline__ void wpush_core(WgWave<C> &w, int id, double lamv) // auxiliary.c:27-40
 {
     const WgCtx &c = w.c;
-    const int lane = lane_id();
+    const int lane = wg_lane();
     wtrace(w, id + 1);
-    if (lane == 0) c.sense[id] |= DAQP_ACTIVE;
+    if (lane == 0) SI(c, sense)[id] |= DAQP_ACTIVE;
     WSYNC();
     wldl_append(w, id);
     if (w.overflow) return;
-    if (lane == 0) { c.ws[w.na] = id; w.lam[w.na] = lamv; }
+    if (lane == 0) { SI(c, ws)[w.na] = id; WLAM(w)[w.na] = lamv; }
     w.na++;
     WSYNC();
 }
 
-// daqp_pivot_last (auxiliary.c:379-396) with its recursion as an explicit stack
-template <int C>
-__device__ __forceinline__ void wpivot_tail(WgWave<C> &w)
-{
-    const WgCtx &c = w.c;
-    const int lane = lane_id();
-    int depth = 0;
-    for (;;) {
-        if (w.overflow) break;
-        const int r = w.na - 2;
-        bool piv = false;
-        if (w.na > 1) {
-            const double dr = c.D[r], dl = c.D[w.na - 1];
-            piv = dr < w.st.pivot_tol && dr < dl;
-        }
-        if (piv) {
-            wtrace(w, kTracePivot);
-            if (lane == 0) { c.pend_id[depth] = c.ws[r]; c.pend_lam[depth] = w.lam[r]; }
-            depth++;
-            WSYNC();
-            if (wdrop_core(w, r)) break;
-            continue;
-        }
-        if (depth == 0) break;
-        if (w.sing != kEmpty) break;
-        depth--;
-        const int id = c.pend_id[depth];
-        const double lv = c.pend_lam[depth];
-        wpush_core(w, id, lv);
-    }
-}
-template <int C>
-__device__ __forceinline__ void wremove_constraint(WgWave<C> &w, int r) { if (!wdrop_core(w, r)) wpivot_tail(w); }
-template <int C>
-__device__ __forceinline__ void wadd_constraint(WgWave<C> &w, int id, double lamv) { wpush_core(w, id, lamv); if (!w.overflow) wpivot_tail(w); }
-
-// b <- L' \ b for the leading cnt rows (product order b_j * L[j][i])
+// b <- L' \ b for the leading cnt rows (product order b_j * L[j][i]): pivots j = cnt-1 ... 1, eight at a time
 template <int C>
 __device__ __forceinline__ void wbackward(WgWave<C> &w, double (&b)[C], int cnt)
 {
     const WgCtx &c = w.c;
-    const int lane = lane_id();
-    for (int j0 = cnt - 1; j0 >= 1; j0 -= kWPre) {
+    const int lane = wg_lane();
+    for (int g8 = (cnt - 1) >> 3; g8 >= 0; --g8) {
         double Lv[kWPre][C];
-#pragma unroll
-        for (int q = 0; q < kWPre; ++q)
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc) {
-                const int i = lane + 64 * cc, j = j0 - q;
-                Lv[q][cc] = c.L[(j >= 1 && i < j) ? tri(j) + i : 0];
-            }
-#pragma unroll
-        for (int q = 0; q < kWPre; ++q) {
-            const int j = j0 - q;
-            if (j >= 1) {
-                const double bj = rlc<C>(b, j);
-#pragma unroll
-                for (int cc = 0; cc < C; ++cc) {
-                    const int i = lane + 64 * cc;
-                    if (i < j) b[cc] -= bj * Lv[q][cc];
-                }
-            }
-        }
+        WPROF_T0(w);
+        static_for<C>([&](auto cc) __attribute__((always_inline)) {
+            if (64 * cc < 8 * g8 + 8)   // row j of L, lane <-> column (entries beyond the diagonal are loaded and never used)
+                static_for<kWPre>([&](auto q) __attribute__((always_inline)) { Lv[q][cc] = SDL(c)[WLIDX(c, tri(8 * g8 + q) + lane + 64 * cc)]; });
+        });
+        if (w.profiling) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        WPROF_ACC(w, 13);
+        wgroup<C, true>(b, g8, g8 >= 1 && 8 * g8 + 8 <= cnt, [&](auto cs, auto q, double bj, auto guard) __attribute__((always_inline)) {
+            const int j = 8 * g8 + q;
+            if constexpr (guard) { if (j < 1 || j >= cnt) return; }
+            static_for<C>([&](auto ct) __attribute__((always_inline)) {
+                if constexpr (ct == cs) {
+                    const double t = b[ct] - bj * Lv[q][ct];
+                    b[ct] = (lane + 64 * ct < j) ? t : b[ct];
+                } else if constexpr (ct < cs) b[ct] = b[ct] - bj * Lv[q][ct];   // whole chunks below the pivot
+            });
+        });
+        WPROF_ACC(w, 14);
     }
 }
 // x_i = rhs_i - sum_{j<i} L[i][j] x_j for rows i >= from (j ascending); rows < from are final in xl
@@ -617,7 +681,7 @@ template <int C>
 __device__ __forceinline__ void wforward(WgWave<C> &w, double (&acc)[C], int from)
 {
     const WgCtx &c = w.c;
-    const int lane = lane_id(), na = w.na;
+    const int lane = wg_lane(), na = w.na;
     if (from == na - 1 && na > 1) {
         // the usual case after an add: only the last row is open -- its products in parallel, then the j-ordered chain of
         // subtractions (the same operations, in the same order, as the sweep below performs for that row)
@@ -625,122 +689,166 @@ __device__ __forceinline__ void wforward(WgWave<C> &w, double (&acc)[C], int fro
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) {
             const int j = lane + 64 * cc;
-            p[cc] = (j < na - 1) ? c.L[tri(na - 1) + j] * c.xl[j] : 0.0;
+            p[cc] = (j < na - 1) ? SDL(c)[tri(na - 1) + j] * SD(c, xl)[j] : 0.0;
         }
-        double last = rlc<C>(acc, na - 1);
-        for (int j = 0; j < na - 1; ++j) last -= rlc<C>(p, j);
-#pragma unroll
-        for (int cc = 0; cc < C; ++cc) if (lane + 64 * cc == na - 1) acc[cc] = last;
+        double last = wpick<C>(acc, na - 1);
+        if (c.exact) {   // (p is exactly +0.0 from column na-1 on: no end-of-range test)
+            for (int g8 = 0; 8 * g8 < na - 1; ++g8)
+                wpivots8<C, false>(p, g8, [&](auto cs, auto q, double pj) __attribute__((always_inline)) { last -= pj; });
+        } else last -= wsum<C>(p);
+        static_for<C>([&](auto cc) __attribute__((always_inline)) { acc[cc] = (lane + 64 * cc == na - 1) ? last : acc[cc]; });
         return;
     }
-    for (int j0 = 0; j0 < na - 1; j0 += kWPre) {
+    if (w.profiling && lane == 0) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[15] += 1;   // general sweeps (after a removal)
+    // rows < from are final: the chunks that hold only such rows are skipped, the chunk that holds row `from` selects
+    const int cfrom = from >> 6;
+    // Pivots j < from are final values: their contribution to the open rows is a plain (row . x) accumulation with no
+    // cross-lane dependency -- every lane walks its own row of L, x_j comes as an LDS broadcast, j ascending (the reference's
+    // order for each row).  Rows < from compute on whatever they hold and are never read.  Only the pivots from `from` on
+    // form a triangular solve.
+    int g8 = 0;
+    for (; 8 * g8 + 8 <= from; ++g8) {
         double Lv[kWPre][C], xf[kWPre];
-#pragma unroll
-        for (int q = 0; q < kWPre; ++q) {
-            const int j = j0 + q;
-            xf[q] = c.xl[(j < from) ? j : 0];
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc) {
-                const int i = lane + 64 * cc;
-                Lv[q][cc] = c.L[(i >= from && i > j && i < na) ? tri(i) + j : 0];
+        static_for<kWPre>([&](auto q) __attribute__((always_inline)) { xf[q] = SD(c, xl)[8 * g8 + q]; });
+        static_for<C>([&](auto cc) __attribute__((always_inline)) {
+            if (64 * cc < na && cc >= cfrom) {
+                const int rowbase = tri(lane + 64 * cc) + 8 * g8;
+                static_for<kWPre>([&](auto q) __attribute__((always_inline)) { Lv[q][cc] = SDL(c)[WLIDX(c, rowbase + q)]; });
             }
-        }
-#pragma unroll
-        for (int q = 0; q < kWPre; ++q) {
-            const int j = j0 + q;
-            if (j < na - 1) {
-                const double xj = (j < from) ? xf[q] : rlc<C>(acc, j);
-#pragma unroll
-                for (int cc = 0; cc < C; ++cc) {
-                    const int i = lane + 64 * cc;
-                    if (i >= from && i > j && i < na) acc[cc] -= Lv[q][cc] * xj;
-                }
+        });
+        static_for<C>([&](auto cc) __attribute__((always_inline)) {
+            if (64 * cc < na && cc >= cfrom)
+                static_for<kWPre>([&](auto q) __attribute__((always_inline)) { acc[cc] = acc[cc] - Lv[q][cc] * xf[q]; });
+        });
+    }
+    for (; 8 * g8 < na - 1; ++g8) {
+        double Lv[kWPre][C], xf[kWPre];
+        static_for<kWPre>([&](auto q) __attribute__((always_inline)) {
+            const int j = 8 * g8 + q;
+            xf[q] = SD(c, xl)[(j < from) ? j : 0];
+        });
+        static_for<C>([&](auto cc) __attribute__((always_inline)) {
+            if (64 * (cc + 1) > 8 * g8 && 64 * cc < na && cc >= cfrom) {
+                const int rowbase = tri(lane + 64 * cc) + 8 * g8;
+                static_for<kWPre>([&](auto q) __attribute__((always_inline)) { Lv[q][cc] = SDL(c)[WLIDX(c, rowbase + q)]; });
             }
-        }
+        });
+        wgroup<C, false>(acc, g8, 8 * g8 + 8 <= na - 1, [&](auto cs, auto q, double aj, auto guard) __attribute__((always_inline)) {
+            const int j = 8 * g8 + q;
+            if constexpr (guard) { if (j >= na - 1) return; }
+            {
+                const double xj = (j < from) ? xf[q] : aj;
+                static_for<C>([&](auto ct) __attribute__((always_inline)) {
+                    if constexpr (ct >= cs) {
+                        if (64 * ct < na && ct >= cfrom) {
+                            const int i = lane + 64 * ct;
+                            const double t = acc[ct] - Lv[q][ct] * xj;
+                            if (ct == cs || ct == cfrom) acc[ct] = (i >= from && i > j) ? t : acc[ct];
+                            else acc[ct] = t;
+                        }
+                    }
+                });
+            }
+        });
     }
 }
 
+// lam* of the iteration: the constrained stationary point L D L' lam* = -d (auxiliary.c:314-354) or, with a singular factor,
+// the singular direction (auxiliary.c:357-376).  Both end in the one backward substitution of this kernel.
 template <int C>
-__device__ __forceinline__ void wsolve_csp(WgWave<C> &w) // auxiliary.c:314-354
+__device__ __forceinline__ void wdirection(WgWave<C> &w)
 {
     const WgCtx &c = w.c;
-    const int lane = lane_id(), na = w.na, from = w.reuse;
-    double acc[C];
-#pragma unroll
-    for (int cc = 0; cc < C; ++cc) {
-        const int i = lane + 64 * cc;
-        acc[cc] = 0;
-        if (i >= from && i < na) {
-            const int id = c.ws[i];
-            acc[cc] = (c.sense[id] & DAQP_LOWER) ? -c.dlower[id] : -c.dupper[id];
-        }
-    }
-    wforward<C>(w, acc, from);
+    const int lane = wg_lane(), na = w.na;
+    const bool regular = (w.sing == kEmpty);
     double b[C];
+    int cnt;
+    if (regular) {
+        const int from = w.reuse;
+        double acc[C];
 #pragma unroll
-    for (int cc = 0; cc < C; ++cc) {
-        const int i = lane + 64 * cc;
-        b[cc] = 0;
-        if (i < na) {
-            if (i >= from) {
-                c.xl[i] = acc[cc];
-                b[cc] = acc[cc] / c.D[i];
-                c.zl[i] = b[cc];
-            } else b[cc] = c.zl[i];
+        for (int cc = 0; cc < C; ++cc) {
+            const int i = lane + 64 * cc;
+            acc[cc] = 0;
+            if (i >= from && i < na) {
+                const int id = SI(c, ws)[i];
+                acc[cc] = (SI(c, sense)[id] & DAQP_LOWER) ? -c.dlower[id] : -c.dupper[id];
+            }
+        }
+        WPROF_T0(w);
+        wforward<C>(w, acc, from);
+        WPROF_ACC(w, 6);
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const int i = lane + 64 * cc;
+            b[cc] = 0;
+            if (i < na) {
+                if (i >= from) {
+                    SD(c, xl)[i] = acc[cc];
+                    b[cc] = acc[cc] / SD(c, D)[i];
+                    SD(c, zl)[i] = b[cc];
+                } else b[cc] = SD(c, zl)[i];
+            }
+        }
+        cnt = na;
+    } else {
+        const int s_ = w.sing, base = tri(s_);
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const int i = lane + 64 * cc;
+            b[cc] = (i < s_) ? -SDL(c)[base + i] : 0.0;
+        }
+        cnt = s_;
+    }
+    {
+        WPROF_T0(w);
+        wbackward<C>(w, b, cnt);
+        WPROF_ACC(w, 7);
+    }
+    double *lams = WLAMS(w);
+    if (regular) {
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const int i = lane + 64 * cc;
+            if (i < na) lams[i] = b[cc];
+        }
+        w.reuse = na;
+    } else {
+        const int s_ = w.sing;
+        const bool flip = (SI(c, sense)[SI(c, ws)[s_]] & DAQP_LOWER) != 0;
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const int i = lane + 64 * cc;
+            if (i <= s_) {
+                const double v = (i == s_) ? 1.0 : b[cc];
+                lams[i] = flip ? -v : v;
+            }
         }
     }
-    wbackward<C>(w, b, na);
-#pragma unroll
-    for (int cc = 0; cc < C; ++cc) {
-        const int i = lane + 64 * cc;
-        if (i < na) w.lams[i] = b[cc];
-    }
-    w.reuse = na;
     WSYNC();
 }
 
+// ratio test of auxiliary.c:277-311 (SOFT_WEIGHTS off): the position to drop (or kBig) after stepping lam towards lam*;
+// the removal itself is the state machine's single DROP site
 template <int C>
-__device__ __forceinline__ void wsingular_direction(WgWave<C> &w) // auxiliary.c:357-376
+__device__ __forceinline__ int wblocking_test(WgWave<C> &w)
 {
     const WgCtx &c = w.c;
-    const int lane = lane_id(), s = w.sing, base = tri(s);
-    double b[C];
-#pragma unroll
-    for (int cc = 0; cc < C; ++cc) {
-        const int i = lane + 64 * cc;
-        b[cc] = (i < s) ? -c.L[base + i] : 0.0;
-    }
-    wbackward<C>(w, b, s);
-    const bool flip = (c.sense[c.ws[s]] & DAQP_LOWER) != 0;
-#pragma unroll
-    for (int cc = 0; cc < C; ++cc) {
-        const int i = lane + 64 * cc;
-        if (i <= s) {
-            const double v = (i == s) ? 1.0 : b[cc];
-            w.lams[i] = flip ? -v : v;
-        }
-    }
-    WSYNC();
-}
-
-// auxiliary.c:277-311 (SOFT_WEIGHTS off)
-template <int C>
-__device__ __forceinline__ int wremove_blocking(WgWave<C> &w)
-{
-    const WgCtx &c = w.c;
-    const int lane = lane_id(), na = w.na;
-    const double dtol = w.st.dual_tol;
+    const int lane = wg_lane(), na = w.na;
+    const double dtol = w.stp->dual_tol;
     const bool regular = (w.sing == kEmpty);
     double bv = DAQP_INF;
     int bi = kBig, aux = 0;
     double lm[C], ls[C];
+    double *lam = WLAM(w);
+    const double *lams = WLAMS(w);
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
         const int i = lane + 64 * cc;
         lm[cc] = 0; ls[cc] = 0;
         if (i < na) {
-            lm[cc] = w.lam[i]; ls[cc] = w.lams[i];
-            const int sn = c.sense[c.ws[i]];
+            lm[cc] = lam[i]; ls[cc] = lams[i];
+            const int sn = SI(c, sense)[SI(c, ws)[i]];
             bool blocking = !(sn & DAQP_IMMUTABLE);
             if (sn & DAQP_LOWER) { if (ls[cc] < dtol) blocking = false; }
             else if (ls[cc] > -dtol) blocking = false;
@@ -751,17 +859,16 @@ __device__ __forceinline__ int wremove_blocking(WgWave<C> &w)
         }
     }
     wave_argmin(bv, bi, aux);
-    if (bi == kBig) return 0;
+    if (bi == kBig) return kBig;
     const double alpha = bv;
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
         const int i = lane + 64 * cc;
-        if (i < na) w.lam[i] = regular ? lm[cc] + alpha * (ls[cc] - lm[cc]) : lm[cc] + alpha * ls[cc];
+        if (i < na) lam[i] = regular ? lm[cc] + alpha * (ls[cc] - lm[cc]) : lm[cc] + alpha * ls[cc];
     }
     w.sing = kEmpty;
     WSYNC();
-    wremove_constraint(w, bi);
-    return 1;
+    return bi;
 }
 
 // primal step (all waves) + the soft part of the objective (auxiliary.c:46-88)
@@ -773,23 +880,28 @@ __device__ __forceinline__ void wprimal(WgWave<C> &w)
     double fv = 0;
     if (w.has_soft) {
         for (int i = 0; i < w.na; ++i)
-            if (c.sense[c.ws[i]] & DAQP_SOFT) { const double li = w.lams[i]; fv += li * li; }
+            if (ub((SI(c, sense)[SI(c, ws)[i]] & DAQP_SOFT) != 0)) { const double li = WLAMS(w)[i]; fv += li * li; }
     }
-    fv = fv * w.st.rho_soft;
-    w.soft = fv;
+    fv = fv * w.stp->rho_soft;
+    w.soft = und(fv);
 }
+// start + u_0^2 + u_1^2 + ... in index order (auxiliary.c:85-86): lane <-> component for the squares, then the ordered chain
+// over broadcast operands
 template <int C>
 __device__ __forceinline__ double wordered_norm2(WgWave<C> &w, double start)
 {
     const WgCtx &c = w.c;
-    double fv = start;
-    for (int j0 = 0; j0 < c.n; j0 += 8) {
-        double uj[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) uj[q] = c.u[(j0 + q < c.n) ? j0 + q : 0];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (j0 + q < c.n) fv += uj[q] * uj[q];
-    }
+    const int lane = wg_lane();
+    double sq[4];
+    static_for<4>([&](auto cc) __attribute__((always_inline)) {
+        const int j = lane + 64 * cc;
+        const double uj = (j < c.n) ? SD(c, u)[j] : 0.0;
+        sq[cc] = uj * uj;
+    });
+    if (!c.exact) return start + wsum<4>(sq);
+    double fv = start;     // (squares beyond n are exactly +0.0: no end-of-range test)
+    for (int g8 = 0; 8 * g8 < c.n; ++g8)
+        wpivots8<4, false>(sq, g8, [&](auto cs, auto q, double v) __attribute__((always_inline)) { fv += v; });
     return fv;
 }
 // scan (all waves), then the pick among the waves' candidates and, when asked, |u|^2 in index order
@@ -798,28 +910,17 @@ __device__ __forceinline__ int wscan(WgWave<C> &w, int &upper, bool with_fval)
 {
     const WgCtx &c = w.c;
     wg_run(w, WG_SCAN);
-    if (with_fval) w.fval = wordered_norm2(w, w.soft);
-    double bv = 0.0;
-    int bi = kBig, bup = 0;
-    for (int k = 0; k < c.W; ++k) {
-        const double v = c.cand[2 * k];
-        const int i = reinterpret_cast<const int *>(c.cand + 2 * k + 1)[0], up = reinterpret_cast<const int *>(c.cand + 2 * k + 1)[1];
-        if (i != kBig && (bi == kBig || v < bv || (v == bv && i < bi))) { bv = v; bi = i; bup = up; }
-    }
+    WPROF_T0(w);
+    if (with_fval) w.fval = und(wordered_norm2(w, w.soft));
+    // lane k <-> wave k's candidate; lowest value, then lowest row
+    const int lane = wg_lane(), kk = lane < c.W ? lane : 0;
+    double bv = SD(c, cand)[2 * kk];
+    int bi = (lane < c.W) ? reinterpret_cast<const int *>(SD(c, cand) + 2 * kk + 1)[0] : kBig;
+    int bup = reinterpret_cast<const int *>(SD(c, cand) + 2 * kk + 1)[1];
+    wave_argmin(bv, bi, bup);
     upper = bup;
+    WPROF_ACC(w, 12);
     return bi;
-}
-
-template <int C>
-__device__ __forceinline__ void wcommit_add(WgWave<C> &w, int pick, int upper) // auxiliary.c:152-166
-{
-    const WgCtx &c = w.c;
-    if (lane_id() == 0) {
-        if (upper) c.sense[pick] &= ~DAQP_LOWER; else c.sense[pick] |= DAQP_LOWER;
-    }
-    double *t = w.lam; w.lam = w.lams; w.lams = t;
-    WSYNC();
-    wadd_constraint(w, pick, upper ? 1.0 : -1.0);
 }
 
 // one step of iterative refinement on the active rows (auxiliary.c:498-593); rare, so the rows are read from the
@@ -828,7 +929,7 @@ template <int C>
 __device__ __forceinline__ void wrefine_active(WgWave<C> &w)
 {
     const WgCtx &c = w.c;
-    const int lane = lane_id(), na = w.na, n = c.n;
+    const int lane = wg_lane(), na = w.na, n = c.n;
     w.reuse = 0;
     double acc[C];
 #pragma unroll
@@ -836,13 +937,13 @@ __device__ __forceinline__ void wrefine_active(WgWave<C> &w)
         const int i = lane + 64 * cc;
         acc[cc] = 0;
         if (i < na) {
-            const int id = c.ws[i];
-            const double *row = c.rowc + (size_t)c.slot[i] * c.ldr;
+            const int id = SI(c, ws)[i];
+            const double *row = c.rowc + (size_t)SI(c, slot)[i] * c.ldr;
             double mu = 0;
-            for (int j = (id < c.ms ? id : 0); j < n; ++j) mu += row[j] * c.u[j];
-            const double d = (c.sense[id] & DAQP_LOWER) ? c.dlower[id] : c.dupper[id];
+            for (int j = (id < c.ms ? id : 0); j < n; ++j) mu += row[j] * SD(c, u)[j];
+            const double d = (SI(c, sense)[id] & DAQP_LOWER) ? c.dlower[id] : c.dupper[id];
             acc[cc] = mu - d;
-            if (c.sense[id] & DAQP_SOFT) acc[cc] -= w.st.rho_soft * w.lams[i];
+            if (SI(c, sense)[id] & DAQP_SOFT) acc[cc] -= w.stp->rho_soft * WLAMS(w)[i];
         }
     }
     wforward<C>(w, acc, 0);
@@ -851,24 +952,24 @@ __device__ __forceinline__ void wrefine_active(WgWave<C> &w)
     for (int cc = 0; cc < C; ++cc) {
         const int i = lane + 64 * cc;
         b[cc] = 0;
-        if (i < na) { c.xl[i] = acc[cc]; b[cc] = acc[cc] / c.D[i]; c.zl[i] = b[cc]; }
+        if (i < na) { SD(c, xl)[i] = acc[cc]; b[cc] = acc[cc] / SD(c, D)[i]; SD(c, zl)[i] = b[cc]; }
     }
     wbackward<C>(w, b, na);
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
         const int i = lane + 64 * cc;
-        if (i < na) { c.xl[i] = b[cc]; w.lams[i] += b[cc]; }
+        if (i < na) { SD(c, xl)[i] = b[cc]; WLAMS(w)[i] += b[cc]; }
     }
     WSYNC();
     double uu[C == 1 ? 2 : C + 1];   // columns: lane + 64 cc covers n <= 64 (C + 1) (n < cap <= 64 C)
     constexpr int CU = (C == 1 ? 2 : C + 1);
 #pragma unroll
-    for (int cc = 0; cc < CU; ++cc) { const int j = lane + 64 * cc; uu[cc] = (j < n) ? c.u[j] : 0.0; }
+    for (int cc = 0; cc < CU; ++cc) { const int j = lane + 64 * cc; uu[cc] = (j < n) ? SD(c, u)[j] : 0.0; }
     for (int i = 0; i < na; ++i) {
-        const double dl = c.xl[i];
-        const int id = c.ws[i];
+        const double dl = SD(c, xl)[i];
+        const int id = SI(c, ws)[i];
         const int j0 = id < c.ms ? id : 0;
-        const double *row = c.rowc + (size_t)c.slot[i] * c.ldr;
+        const double *row = c.rowc + (size_t)SI(c, slot)[i] * c.ldr;
 #pragma unroll
         for (int cc = 0; cc < CU; ++cc) {
             const int j = lane + 64 * cc;
@@ -877,9 +978,9 @@ __device__ __forceinline__ void wrefine_active(WgWave<C> &w)
     }
     WSYNC();
 #pragma unroll
-    for (int cc = 0; cc < CU; ++cc) { const int j = lane + 64 * cc; if (j < n) c.u[j] = uu[cc]; }
+    for (int cc = 0; cc < CU; ++cc) { const int j = lane + 64 * cc; if (j < n) SD(c, u)[j] = uu[cc]; }
     WSYNC();
-    w.fval = wordered_norm2(w, w.soft);
+    w.fval = und(wordered_norm2(w, w.soft));
 }
 
 template <int C>
@@ -888,140 +989,265 @@ __device__ __forceinline__ void wreset_ws(WgWave<C> &w)
     const WgCtx &c = w.c;
     w.sing = kEmpty; w.na = 0; w.reuse = 0;
     // every slot of the scratch is free again, lowest on top
-    for (int i = lane_id(); i < c.cap; i += 64) c.freestk[i] = c.cap - 1 - i;
+    for (int i = wg_lane(); i < c.cap; i += 64) SI(c, freestk)[i] = c.cap - 1 - i;
     w.nfree = c.cap; w.hi_slot = -1;
     WSYNC();
 }
 
-// (re)build the working set from the ACTIVE bits, in index order (auxiliary.c:399-479)
+// ---------------------------------------------------------------------------------------------------------------------
+// daqp_ldp (daqp.c:6-108) + daqp_activate_constraints (auxiliary.c:399-479) + daqp_pivot_last (auxiliary.c:379-396) as ONE
+// explicit state machine, as in wave_ldp_reg.hip.h: the reference reaches add_constraint / remove_constraint from a dozen
+// places and recurses through pivot_last; inlined, every primitive (and with it every parallel phase of the workgroup) was
+// instantiated up to ten times -- 69 k lines of ISA, 780 bytes of scratch per lane.  Here each primitive and each command
+// has exactly one call site and "who asked" is a continuation code.
+//   mode 1: only rebuild the working set from the ACTIVE bits (tail of daqp_update_ldp).
+// Returns the exit flag (mode 0) or the activation flag (mode 1).
+// ---------------------------------------------------------------------------------------------------------------------
+enum : int { WPC_START_LOOP, WPC_ITER, WPC_AFTER_DIR, WPC_SCAN, WPC_EDIT, WPC_ACT_BEGIN, WPC_ACT_NEXT, WPC_ACT_POST, WPC_ACT_POST2, WPC_DONE };
+enum : int { WAFTER_NEXT_ITER, WAFTER_CYCLE_GUARD, WAFTER_ACT_POST };
+enum : int { WACT_THEN_DONE, WACT_THEN_LOOP, WACT_THEN_NEXT_ITER, WACT_THEN_CYCLE_RESET };
+
 template <int C>
-__device__ __forceinline__ int wactivate_marked(WgWave<C> &w)
+__device__ __forceinline__ int wrun(WgWave<C> &w, int mode, bool need_activate, int &iterations)
 {
     const WgCtx &c = w.c;
-    const int lane = lane_id();
-    for (int blk = 0; blk * 64 < c.m; ++blk) {
-        const int r = blk * 64 + lane;
-        unsigned long long msk = __ballot(r < c.m && (c.sense[r] & DAQP_ACTIVE));
-        while (msk) {
-            const int i = blk * 64 + __ffsll((long long)msk) - 1;
-            msk &= msk - 1;
-            wadd_constraint(w, i, (c.sense[i] & DAQP_LOWER) ? -1.0 : 1.0);
-            if (w.overflow) return 1;
-            if (w.sing == kEmpty) continue;
-            const int last = c.ws[w.na - 1];
-            if (c.sense[last] & DAQP_IMMUTABLE) {
-                wsingular_direction(w);
-                double resid = 0.0, scale = 1.0;
-                for (int j = 0; j < w.na; ++j) {
-                    const int id = c.ws[j];
-                    const double bd = (c.sense[id] & DAQP_LOWER) ? c.dlower[id] : c.dupper[id];
-                    const double t = w.lams[j] * bd;
-                    resid += t;
-                    scale += t < 0 ? -t : t;
+    const int lane = wg_lane();
+    int flag = DAQP_EXIT_ITERLIMIT, it = 1, repaired = 0, stall = 0;
+    double best = -1;
+    const double fbound = 2 * w.stp->fval_bound;
+    const bool timed = w.stp->time_limit > 0;
+    int depth = 0, req_add = 1, req_id = 0, req_r = 0, after_edit = WAFTER_NEXT_ITER;
+    double req_lam = 0;
+    int act_then = WACT_THEN_DONE, act_blk = 0, act_i = 0, act_flag = 1;
+    unsigned long long act_msk = 0;
+    int tl_skip = 0, scan_first = 1, dir_then = WPC_AFTER_DIR, was_singular = 0;
+    int pc;
+    if (mode == 1 || need_activate) { wreset_ws(w); act_then = (mode == 1) ? WACT_THEN_DONE : WACT_THEN_LOOP; pc = WPC_ACT_BEGIN; }
+    else pc = WPC_START_LOOP;
+#define WTL_CHECK() (timed && !tl_skip && (it & 31) == 0 && time_is_up(w.t_start, w.stp->time_limit))
+#define WUNIFORM() do { w.na = uni(w.na); w.reuse = uni(w.reuse); w.sing = uni(w.sing); w.nfree = uni(w.nfree); w.hi_slot = uni(w.hi_slot); \
+                        w.lam_b = uni(w.lam_b); w.overflow = uni(w.overflow); } while (0)
+    while (pc != WPC_DONE && !w.overflow) {
+        // (belt and braces: the iterate's scalars are wave-uniform by construction; saying so once per state keeps every loop
+        //  bounded by them a scalar loop whatever the optimizer concluded about the joins of the previous state)
+        pc = uni(pc); it = uni(it); depth = uni(depth); req_add = uni(req_add); req_id = uni(req_id); req_r = uni(req_r); after_edit = uni(after_edit);
+        WUNIFORM();
+        WPROF_T0(w);
+        switch (pc) {
+        case WPC_START_LOOP:
+            if (act_flag < 0) { flag = act_flag; pc = WPC_DONE; break; }
+            it = 1;
+            pc = (it < w.stp->iter_limit) ? WPC_ITER : WPC_DONE;
+            break;
+        // ---- lam* (CSP or singular direction): one site for the iteration and for the dependent-equality test of the activation
+        case WPC_ITER:
+            tl_skip = 0;
+            was_singular = (w.sing != kEmpty);
+            if (was_singular && dir_then == WPC_AFTER_DIR) wtrace(w, kTraceSingular);   // (the activation's dependency test is not an iteration)
+            wdirection(w);
+            WPROF_ACC(w, 0);
+            pc = dir_then;
+            break;
+        case WPC_AFTER_DIR: {
+            const int blk = wblocking_test(w);
+            WPROF_ACC(w, 1);
+            if (blk != kBig) { req_add = 0; req_r = blk; depth = 0; after_edit = WAFTER_NEXT_ITER; pc = WPC_EDIT; break; }
+            if (was_singular) { flag = DAQP_EXIT_INFEASIBLE; pc = WPC_DONE; break; }
+            wprimal(w);
+            WPROF_ACC(w, 2);
+            scan_first = 1;
+            pc = WPC_SCAN;
+            break;
+        }
+        // ---- feasibility scan: the iteration's (with |u|^2) or the one after refine_active
+        case WPC_SCAN: {
+            int upper = 0;
+            const int pick = wscan(w, upper, scan_first != 0);
+            WPROF_ACC(w, 3);
+            if (scan_first) {
+                if (ub(w.fval > fbound)) { flag = DAQP_EXIT_INFEASIBLE; pc = WPC_DONE; break; }
+                after_edit = WAFTER_CYCLE_GUARD;
+                if (pick == kBig) {
+                    double dmin = SD(c, D)[0];
+                    for (int i = 1; i < w.na; ++i) { const double di = SD(c, D)[i]; dmin = di < dmin ? di : dmin; }
+                    dmin = und(dmin);
+                    if (w.na > 2 && repaired != 1 && ub(dmin < w.stp->refactor_tol)) {
+                        repaired = 1;
+                        tl_skip = 1;
+                        wtrace(w, kTraceRefactor);
+                        const double *lam = WLAM(w);
+                        for (int i = lane; i < w.na; i += 64) {
+                            const int id = SI(c, ws)[i];
+                            if (lam[i] >= 0) SI(c, sense)[id] &= ~DAQP_LOWER; else SI(c, sense)[id] |= DAQP_LOWER;
+                        }
+                        WSYNC();
+                        wreset_ws(w);
+                        act_then = WACT_THEN_NEXT_ITER; pc = WPC_ACT_BEGIN;
+                        break;
+                    }
+                    if (w.na > 0 && ub(dmin < w.stp->pivot_tol)) {
+                        wtrace(w, kTraceRefine);
+                        wrefine_active(w);
+                        scan_first = 0; after_edit = WAFTER_NEXT_ITER; tl_skip = 1;
+                        pc = WPC_SCAN;
+                        break;
+                    }
+                    flag = ub(w.soft > w.stp->primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
+                    pc = WPC_DONE;
+                    break;
                 }
-                WSYNC();
-                if (lane == 0) { c.sense[last] &= ~DAQP_ACTIVE; c.freestk[w.nfree] = c.slot[w.na - 1]; }
-                w.nfree++;
-                w.na--;
-                w.sing = kEmpty;
-                if (w.reuse > w.na) w.reuse = w.na;
-                WSYNC();
-                if (resid <= w.st.primal_tol * scale && resid >= -w.st.primal_tol * scale) continue;
-                return DAQP_EXIT_OVERDETERMINED_INITIAL;
+            } else if (pick == kBig) {
+                flag = ub(w.soft > w.stp->primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
+                pc = WPC_DONE;
+                break;
             }
-            int flag = 1;
-            for (int q = i; q < c.m; q += 1) {
-                const int sn = c.sense[q];
+            // auxiliary.c:152-166: fix the side, lam <-> lam*, then add with multiplier +-1
+            if (lane == 0) { if (upper) SI(c, sense)[pick] &= ~DAQP_LOWER; else SI(c, sense)[pick] |= DAQP_LOWER; }
+            w.lam_b ^= 1;
+            WSYNC();
+            req_add = 1; req_id = pick; req_lam = upper ? 1.0 : -1.0; depth = 0; pc = WPC_EDIT;
+            break;
+        }
+        // ---- add_constraint / remove_constraint with the pivot_last cascade (auxiliary.c:3-44, 379-396)
+        case WPC_EDIT: {
+            for (;;) {
+                bool settled = false;
+                WUNIFORM();
+                req_add = uni(req_add); req_id = uni(req_id); req_r = uni(req_r); depth = uni(depth);
+                if (req_add) { wpush_core(w, req_id, req_lam); if (w.overflow) break; WPROF_ACC(w, 4); }
+                else { settled = wdrop_core(w, req_r) != 0; WPROF_ACC(w, 5); }     // a removal that left a singular factor does not pivot
+                if (!settled) {
+                    const int r = w.na - 2;
+                    bool piv = false;
+                    if (w.na > 1) {
+                        const double dr = SD(c, D)[r], dlast = SD(c, D)[w.na - 1];
+                        piv = ub(dr < w.stp->pivot_tol && dr < dlast);
+                    }
+                    if (piv) {
+                        wtrace(w, kTracePivot);
+                        if (lane == 0) { SI(c, pend_id)[depth] = SI(c, ws)[r]; SD(c, pend_lam)[depth] = WLAM(w)[r]; }
+                        depth++;
+                        WSYNC();
+                        req_add = 0; req_r = r;
+                        continue;
+                    }
+                    if (depth > 0 && w.sing == kEmpty) {
+                        depth--;
+                        req_id = uni(SI(c, pend_id)[depth]); req_lam = und(SD(c, pend_lam)[depth]);
+                        req_add = 1;
+                        continue;
+                    }
+                }
+                break;
+            }
+            if (w.overflow) break;
+            if (after_edit == WAFTER_ACT_POST) { pc = WPC_ACT_POST; break; }
+            if (after_edit == WAFTER_CYCLE_GUARD) {   // daqp.c:66-85
+                if (ub(w.fval - best < w.stp->progress_tol)) {
+                    if (stall++ > w.stp->cycle_tol) {
+                        if (repaired == 1) { flag = DAQP_EXIT_CYCLE; pc = WPC_DONE; break; }
+                        repaired = 1;
+                        wtrace(w, kTraceCycleReset);
+                        wreset_ws(w);
+                        act_then = WACT_THEN_CYCLE_RESET; pc = WPC_ACT_BEGIN;
+                        break;
+                    }
+                } else { best = w.fval; stall = 0; }
+            }
+            if (WTL_CHECK()) { flag = DAQP_EXIT_TIMELIMIT; pc = WPC_DONE; break; }
+            ++it;
+            pc = (it < w.stp->iter_limit) ? WPC_ITER : WPC_DONE;   // falling out of the loop: flag stays ITERLIMIT
+            break;
+        }
+        // ---- daqp_activate_constraints: ACTIVE rows in index order (auxiliary.c:399-479)
+        case WPC_ACT_BEGIN:
+            act_blk = 0; act_flag = 1;
+            act_msk = __ballot(lane < c.m && (SI(c, sense)[lane < c.m ? lane : 0] & DAQP_ACTIVE));
+            pc = WPC_ACT_NEXT;
+            break;
+        case WPC_ACT_NEXT: {
+            while (act_msk == 0 && (act_blk + 1) * 64 < c.m) {
+                act_blk++;
+                const int r = act_blk * 64 + lane;
+                act_msk = __ballot(r < c.m && (SI(c, sense)[r < c.m ? r : 0] & DAQP_ACTIVE));
+            }
+            if (act_msk == 0) {   // done: continue where the activation was requested from
+                if (act_then == WACT_THEN_DONE) pc = WPC_DONE;
+                else if (act_then == WACT_THEN_LOOP) pc = WPC_START_LOOP;
+                else {
+                    if (act_then == WACT_THEN_CYCLE_RESET) { stall = 0; best = -1; }
+                    if (WTL_CHECK()) { flag = DAQP_EXIT_TIMELIMIT; pc = WPC_DONE; break; }
+                    ++it;
+                    pc = (it < w.stp->iter_limit) ? WPC_ITER : WPC_DONE;
+                }
+                break;
+            }
+            act_i = act_blk * 64 + __ffsll((long long)act_msk) - 1;
+            act_msk &= act_msk - 1;
+            req_add = 1; req_id = act_i; req_lam = ub((SI(c, sense)[act_i] & DAQP_LOWER) != 0) ? -1.0 : 1.0;
+            depth = 0; after_edit = WAFTER_ACT_POST; pc = WPC_EDIT;
+            break;
+        }
+        case WPC_ACT_POST: {
+            if (w.sing == kEmpty) { pc = WPC_ACT_NEXT; break; }
+            const int last = uni(SI(c, ws)[w.na - 1]);
+            if (ub((SI(c, sense)[last] & DAQP_IMMUTABLE) != 0)) {   // a new equality depends on the active ones: its direction first
+                dir_then = WPC_ACT_POST2;
+                pc = WPC_ITER;
+                break;
+            }
+            int fl = 1;
+            for (int q = act_i; q < c.m; q += 1) {   // rows >= i: unactivated equalities are an error, the rest are cleaned
+                const int sn = uni(SI(c, sense)[q]);
                 if (sn & DAQP_ACTIVE) {
-                    if (sn & DAQP_IMMUTABLE) flag = DAQP_EXIT_OVERDETERMINED_INITIAL;
-                    else if (lane == 0) c.sense[q] = sn & ~DAQP_ACTIVE;
+                    if (sn & DAQP_IMMUTABLE) fl = DAQP_EXIT_OVERDETERMINED_INITIAL;
+                    else if (lane == 0) SI(c, sense)[q] = sn & ~DAQP_ACTIVE;
                 }
             }
-            if (lane == 0) c.freestk[w.nfree] = c.slot[w.na - 1];
+            if (lane == 0) SI(c, freestk)[w.nfree] = SI(c, slot)[w.na - 1];
             w.nfree++;
             w.na--;
             w.sing = kEmpty;
+            act_flag = fl;
             WSYNC();
-            return flag;
+            act_msk = 0; act_blk = (c.m + 63) / 64;   // activation ends here (with act_flag)
+            pc = WPC_ACT_NEXT;
+            break;
+        }
+        case WPC_ACT_POST2: {   // consistent => ignore the dependent equality, else over-determined
+            dir_then = WPC_AFTER_DIR;
+            const int last = uni(SI(c, ws)[w.na - 1]);
+            const double *lams = WLAMS(w);
+            double resid = 0.0, scale = 1.0;
+            for (int j = 0; j < w.na; ++j) {
+                const int id = SI(c, ws)[j];
+                const double bd = (SI(c, sense)[id] & DAQP_LOWER) ? c.dlower[id] : c.dupper[id];
+                const double t = lams[j] * bd;
+                resid += t;
+                scale += t < 0 ? -t : t;
+            }
+            WSYNC();
+            if (lane == 0) { SI(c, sense)[last] &= ~DAQP_ACTIVE; SI(c, freestk)[w.nfree] = SI(c, slot)[w.na - 1]; }
+            w.nfree++;
+            w.na--;
+            w.sing = kEmpty;
+            if (w.reuse > w.na) w.reuse = w.na;
+            WSYNC();
+            if (ub(resid <= w.stp->primal_tol * scale && resid >= -w.stp->primal_tol * scale)) { pc = WPC_ACT_NEXT; break; }
+            act_flag = DAQP_EXIT_OVERDETERMINED_INITIAL;
+            act_msk = 0; act_blk = (c.m + 63) / 64;
+            pc = WPC_ACT_NEXT;
+            break;
+        }
+        default:
+            pc = WPC_DONE;
+            break;
         }
     }
-    return 1;
-}
-
-// daqp_ldp (daqp.c:6-108)
-template <int C>
-__device__ __forceinline__ int wldp_loop(WgWave<C> &w, int &iterations)
-{
-    const WgCtx &c = w.c;
-    const int lane = lane_id();
-    int flag = DAQP_EXIT_ITERLIMIT, it, repaired = 0, stall = 0;
-    double best = -1;
-    const double fbound = 2 * w.st.fval_bound;
-    const bool timed = w.st.time_limit > 0;
-    for (it = 1; it < w.st.iter_limit; ++it) {
-        if (w.overflow) break;
-        WPROF_T0(w);
-        if (w.sing == kEmpty) {
-            wsolve_csp(w);
-            WPROF_ACC(w, 0);
-            const int blocked = wremove_blocking(w);
-            if (blocked) WPROF_ACC(w, 5); else WPROF_ACC(w, 1);
-            if (blocked) {   // falls through to the end of the reference's loop body: the clock check applies
-                if (timed && (it & 31) == 0 && time_is_up(w.t_start, w.st.time_limit)) { flag = DAQP_EXIT_TIMELIMIT; break; }
-                continue;
-            }
-            wprimal(w);
-            WPROF_ACC(w, 2);
-            int upper = 0;
-            int pick = wscan(w, upper, true);
-            WPROF_ACC(w, 3);
-            if (w.fval > fbound) { flag = DAQP_EXIT_INFEASIBLE; break; }
-            if (pick == kBig) {
-                double dmin = c.D[0];
-                for (int i = 1; i < w.na; ++i) { const double di = c.D[i]; if (di < dmin) dmin = di; }
-                if (w.na > 2 && repaired != 1 && dmin < w.st.refactor_tol) {
-                    repaired = 1;
-                    wtrace(w, kTraceRefactor);
-                    for (int i = lane; i < w.na; i += 64) {
-                        const int id = c.ws[i];
-                        if (w.lam[i] >= 0) c.sense[id] &= ~DAQP_LOWER; else c.sense[id] |= DAQP_LOWER;
-                    }
-                    WSYNC();
-                    wreset_ws(w);
-                    wactivate_marked(w);
-                    continue;
-                }
-                if (w.na > 0 && dmin < w.st.pivot_tol) {
-                    wtrace(w, kTraceRefine);
-                    wrefine_active(w);
-                    pick = wscan(w, upper, false);
-                    if (pick != kBig) { wcommit_add(w, pick, upper); continue; }
-                }
-                flag = (w.soft > w.st.primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
-                break;
-            }
-            wcommit_add(w, pick, upper);
-            WPROF_ACC(w, 4);
-            if (w.fval - best < w.st.progress_tol) {
-                if (stall++ > w.st.cycle_tol) {
-                    if (repaired == 1) { flag = DAQP_EXIT_CYCLE; break; }
-                    repaired = 1;
-                    wtrace(w, kTraceCycleReset);
-                    wreset_ws(w);
-                    wactivate_marked(w);
-                    stall = 0;
-                    best = -1;
-                }
-            } else { best = w.fval; stall = 0; }
-        } else {
-            wtrace(w, kTraceSingular);
-            wsingular_direction(w);
-            if (!wremove_blocking(w)) { flag = DAQP_EXIT_INFEASIBLE; break; }
-        }
-        if (timed && (it & 31) == 0 && time_is_up(w.t_start, w.st.time_limit)) { flag = DAQP_EXIT_TIMELIMIT; break; }
-    }
+#undef WTL_CHECK
+#undef WUNIFORM
     iterations = it;
-    return flag;
+    return (mode == 1) ? act_flag : flag;
 }
 
 } // namespace daqp_amd

@@ -12,12 +12,25 @@
 #include <vector>
 
 #include "kernels.hip.h"
+#include "reg_kernel.hip.h"
 #include "setup_fast.hip.h"
 #include "prox.hip.h"
 #include "wg_layout.hip.h"
 // the workgroup-per-problem solve kernel lives in its own translation unit (wg_kernel.hip): a change to it does not rebuild
 // everything else
 namespace daqp_amd {
+// the register-centric solve kernels: reg_kernel.hip
+#define DAQP_REG_SHAPE(NB, NP) \
+    extern template __global__ void k_ldp_reg<NB, NP, false>(const BatchDev *__restrict__, int); \
+    extern template __global__ void k_ldp_reg<NB, NP, true>(const BatchDev *__restrict__, int);
+DAQP_REG_SHAPE(1, 8)
+DAQP_REG_SHAPE(3, 25)
+#ifndef DAQP_AMD_FEW_VARIANTS
+DAQP_REG_SHAPE(1, 16)
+DAQP_REG_SHAPE(2, 16)
+DAQP_REG_SHAPE(2, 32)
+#endif
+#undef DAQP_REG_SHAPE
 template <int C> __global__ void k_ldp_wg(BatchDev b, int mode);
 extern template __global__ void k_ldp_wg<2>(BatchDev, int);
 extern template __global__ void k_ldp_wg<4>(BatchDev, int);
@@ -80,6 +93,7 @@ struct DAQPBatch {
     int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
     bool fast_setup = false, setup_spill = false;
     // workgroup-per-problem solve kernel (wg_kernel.hip.h): shapes without a register variant and more than 64 working-set rows
+    bool in_prox_loop = false;      // launches of the proximal outer loop (solve_with_prox)
     bool use_wg = false;
     int wg_W = 0, wg_C = 0, wg_grid = 0;
     size_t lds_wg = 0;
@@ -124,15 +138,18 @@ const RegShape kRegShapes[] = {{1, 8}, {3, 25}};
 #else
 const RegShape kRegShapes[] = {{1, 8}, {1, 16}, {2, 16}, {3, 25}, {2, 32}};
 #endif
-ldp_reg_kernel_t pick_ldp_reg(const DAQPBatch *b)
+// exact: the reference's arithmetic (two roundings per multiply-add); otherwise fused multiply-adds (default mode)
+ldp_reg_kernel_t pick_ldp_reg(const DAQPBatch *b, bool exact)
 {
-    if (b->NB == 1 && b->NP == 8) return k_ldp_reg<1, 8>;
-    if (b->NB == 3 && b->NP == 25) return k_ldp_reg<3, 25>;
+#define DAQP_REG_PICK(nb, np) if (b->NB == nb && b->NP == np) return exact ? k_ldp_reg<nb, np, false> : k_ldp_reg<nb, np, true>;
+    DAQP_REG_PICK(1, 8)
+    DAQP_REG_PICK(3, 25)
 #ifndef DAQP_AMD_FEW_VARIANTS
-    if (b->NB == 1 && b->NP == 16) return k_ldp_reg<1, 16>;
-    if (b->NB == 2 && b->NP == 16) return k_ldp_reg<2, 16>;
-    if (b->NB == 2 && b->NP == 32) return k_ldp_reg<2, 32>;
+    DAQP_REG_PICK(1, 16)
+    DAQP_REG_PICK(2, 16)
+    DAQP_REG_PICK(2, 32)
 #endif
+#undef DAQP_REG_PICK
     return nullptr;
 }
 ldp_kernel_t pick_ldp(const DAQPBatch *b)
@@ -163,7 +180,9 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         wg_kernel_t kw = b->wg_C == 2 ? k_ldp_wg<2> : k_ldp_wg<4>;
         HIPCHK(hipMemsetAsync(b->d.wg_counter, 0, sizeof(int), b->stream));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg));
-        hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, b->d, mode);
+        BatchDev dd = b->d;
+        if (b->in_prox_loop) dd.exact_setup = 1;   // problems of the proximal outer loop keep the reference's arithmetic in both modes
+        hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, dd, mode);
         HIPCHK(hipGetLastError());
         ldp_kernel_t kf = pick_ldp(b);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
@@ -172,7 +191,8 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         return 0;
     }
     if (b->NB > 0) {
-        ldp_reg_kernel_t kr = pick_ldp_reg(b);
+        // problems that run the proximal outer loop keep the reference's arithmetic in both modes (their setup passes do as well)
+        ldp_reg_kernel_t kr = pick_ldp_reg(b, b->d.exact_setup != 0 || b->in_prox_loop);
         // the descriptor travels through device memory: stream-ordered copy, then the launch
         if (descriptor_changed) HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
@@ -334,6 +354,7 @@ int solve_with_prox(DAQPBatch *b, int mode)
         else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_gradient<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grad));
     }
     int rc = 0, outer = 0;
+    b->in_prox_loop = true;
     hipLaunchKernelGGL(k_prox_pre, dim3(d.N), dim3(64), 0, b->stream, d, b->px, f_user);
     if (hipGetLastError() != hipSuccess) rc = 1;
     for (; !rc; ++outer) {
@@ -351,6 +372,7 @@ int solve_with_prox(DAQPBatch *b, int mode)
         }
     }
     b->prox_outer = outer + 1;
+    b->in_prox_loop = false;
     d.f = f_user; d.fval = o_fval; d.soft = o_soft; d.exitflag = o_flag; d.iter = o_iter;
     hipLaunchKernelGGL(k_prox_mark, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 2);
     HIPCHK(hipGetLastError());

@@ -883,402 +883,4 @@ void k_ldp(BatchDev b, int mode_in)
     }
 }
 
-// LDS of the register-centric solve kernel.  Everything small sits at COMPILE-TIME offsets in front (u, the pivot
-// stack, the per-row bounds, packed L): their addresses are "immediate + 8*lane", nothing to keep in a register across
-// the state-machine loop (every loop-invariant base pointer is one more value that the full register file spills to
-// scratch).  Only the active-row cache, behind the run-time sized L, has a run-time base.
-template <int NB>
-struct RegLds {
-    static constexpr int u = 0, pend_lam = 68, pend_id = 132, prof = 164, rowv = 196, L = 196 + 192 * NB;   // doubles
-};
-__host__ __device__ inline int reg_lds_rowc_size(int n, int m, int cap, int ldrc)
-{
-    const int rows = round_up(cap * ldrc, 2), fin = round_up(n * (n + 1) / 2, 2) + 2 + round_up(m, 2);   // epilogue: staged R^-1 + lam
-    return rows > fin ? rows : fin;
-}
-__host__ __device__ inline int reg_lds_rowc(int NB, int cap) { return 196 + 192 * NB + round_up(cap * (cap + 1) / 2, 2); }
-__host__ __device__ inline int reg_lds_bytes(int NB, int n, int m, int cap, int ldrc) { return 8 * (reg_lds_rowc(NB, cap) + reg_lds_rowc_size(n, m, cap, ldrc)); }
-
-// ------------------------------------------------------------------------------------
-// k_ldp_reg: the register-centric solve kernel (wave_ldp_reg.hip.h) for n + n_soft + 1 <= 64 and
-// m <= 64*NB, n <= 2*NP.  Same global state layout as k_ldp, so the two are interchangeable.
-// ------------------------------------------------------------------------------------
-// Waves per SIMD: M alone takes 4*NB*NP registers per lane.  The large shapes own the whole unified 512-entry file (one
-// wave per SIMD); the small ones are held to a budget that lets 2 or 4 waves share a SIMD, where the other waves'
-// instructions fill this wave's issue gaps and LDS waits.
-#ifndef DAQP_AMD_SMALL_WAVES
-#define DAQP_AMD_SMALL_WAVES 3
-#endif
-constexpr int ldp_reg_waves(int NB, int NP) { return NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 32 ? 2 : 1); }
-template <int NB, int NP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_waves(NB, NP), ldp_reg_waves(NB, NP)))) void k_ldp_reg(const BatchDev *__restrict__ bp, int mode_in)
-{
-    // mode 0: daqp_solve; 1: only (re)build the working set from the ACTIVE bits; 2 | mask << 4: daqp_update_ldp(mask)
-    // for mask within UPDATE_v|UPDATE_d applied here, then daqp_solve -- the rows of M are in registers anyway, so the
-    // warm path of an MPC step reads them from HBM once instead of twice (k_update + solve)
-    const int upd = (mode_in & 3) == 2 ? (mode_in >> 4) : 0;
-    const int mode = (mode_in & 3) == 2 ? 0 : (mode_in & 3);
-    // The descriptor is read through a pointer (scalar loads at the point of use) instead of being a
-    // by-value kernel argument: ~60 SGPRs of pointers would otherwise stay live across the whole state
-    // machine and push its uniform state into VGPR-lane spills.
-    const BatchDev &b = *bp;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const long long t_start = (long long)__builtin_readcyclecounter();
-    const int q = blockIdx.x, lane = lane_id();
-    const int n = b.n, m = b.m, cap = b.cap;
-    QState *qs = b.qs + q;
-    // everything read from the per-QP record is wave-uniform; say so, or every loop bounded by
-    // n_active becomes a divergent (exec-masked) loop with readfirstlane waterfalls around v_readlane
-    const int sflag = __builtin_amdgcn_readfirstlane(qs->setup_flag);
-    int q_need_act = __builtin_amdgcn_readfirstlane(qs->need_activate);
-    const int qdiag = __builtin_amdgcn_readfirstlane(qs->diag_h);
-    if (mode == 1) { if (sflag < 0 || !q_need_act) return; }
-    if (sflag < 0) {
-        if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
-        return;
-    }
-    if (mode == 0 && !upd) {   // the last update failed its bound check: report that, keep the state (see k_update)
-        const int uflag = __builtin_amdgcn_readfirstlane(qs->upd_flag);
-        if (uflag < 0) {
-            if (lane == 0) { b.exitflag[q] = uflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
-            return;
-        }
-    }
-    typedef RegLds<NB> o;
-    if (lane == 0) reinterpret_cast<unsigned long long *>(smem + o::u)[66] = __builtin_amdgcn_s_memrealtime();   // time_limit stamp (rrun)
-    const int rowc_size = reg_lds_rowc_size(n, m, cap, b.ldrc);
-    RWave<NB, NP> w;
-    // phase counters live in the (otherwise unused) D/xl slots of the LDS carve-up
-    w.prof = (kProfile && (b.prof != nullptr) && mode == 0) ? reinterpret_cast<long long *>(smem + o::prof) : nullptr;
-    if (kProfile && w.prof && lane < 32) w.prof[lane] = 0;
-    w.n = n; w.m = m; w.ms = b.ms; w.ldr = b.ldrc;
-    w.L = smem + o::L; w.rowc = smem + reg_lds_rowc(NB, cap); w.u = smem + o::u; w.pend_lam = smem + o::pend_lam;
-    w.rowv = smem + o::rowv;
-    w.pend_id = reinterpret_cast<int *>(smem + o::pend_id);
-    w.stp = b.st_dev;
-    w.dual_tol = b.st.dual_tol; w.sing_tol = b.st.sing_tol; w.pivot_tol = b.st.pivot_tol; w.rho_soft = b.st.rho_soft;
-    w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
-    w.trace_cap = b.trace_cap; w.trace_len = 0;
-    w.na = __builtin_amdgcn_readfirstlane(qs->n_active);
-    w.reuse = __builtin_amdgcn_readfirstlane(qs->reuse_ind);
-    w.sing = __builtin_amdgcn_readfirstlane(qs->sing_ind);
-    w.fval = rl(qs->fval, 0); w.soft = rl(qs->soft_slack, 0);
-    const int swapped = __builtin_amdgcn_readfirstlane(qs->lam_swapped);
-    const size_t qfac = qf(b, q);
-    const double *gdu = b.dupper + (size_t)q * m, *gdl = b.dlower + (size_t)q * m, *gsc = b.scaling + qfac * m;
-    int *gsense = b.sense + (size_t)q * m;
-    double *gv = b.vecs + (size_t)q * 5 * cap;
-    int *gws = b.WS + (size_t)q * cap;
-
-    if (w.sing == DAQP_UNCONSTRAINED_OPTIMAL && mode == 0 && !upd) {   // api.c:40-45 (an update resets sing_ind first)
-        const double *xu = b.xunc + (size_t)q * n, *vq = b.v + (size_t)q * n;
-        if (b.x) for (int i = lane; i < n; i += 64) b.x[(size_t)q * n + i] = xu[i];
-        if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = 0;
-        double fv = 0;
-        for (int i = 0; i < n; ++i) { const double vi = vq[i]; fv -= vi * vi; }
-        fv *= 0.5;
-        if (lane == 0) {
-            b.exitflag[q] = DAQP_EXIT_OPTIMAL; b.iter[q] = 1;
-            if (b.fval) b.fval[q] = fv;
-            if (b.soft) b.soft[q] = 0;
-            qs->iterations = 1; qs->fval = 0; qs->soft_slack = 0; qs->exitflag = DAQP_EXIT_OPTIMAL;
-        }
-        return;
-    }
-    // a pending UPDATE_v needs R^-1 and f: their loads go out first and arrive together with the rows of M
-    const int rinv0 = rowc_size - round_up(b.rtri, 2) - 2;
-    double *Rl0 = w.rowc + rinv0;
-    double f_in = 0;
-    if (upd & DAQP_UPDATE_v) {
-        const double *Rq = b.Rinv + qfac * b.rtri, *f = b.f + (size_t)q * n;
-        const int odd8 = (int)(((size_t)Rq >> 3) & 1);
-        Rl0 += odd8;
-        if (odd8) copy_async_dwords(Rl0, Rq, 1);
-        const int body = (b.rtri - odd8) & ~1;
-        copy_async(Rl0 + odd8, Rq + odd8, body);
-        if (odd8 + body < b.rtri) copy_async_dwords(Rl0 + odd8 + body, Rq + odd8 + body, 1);
-        if (lane < n) f_in = (lane < b.ms && !qdiag) ? f[lane] / gsc[lane] : f[lane];
-    }
-    // ---- row view: bounds, tolerance, sense and the rows of M themselves -> registers
-    const double ep = -w.stp->primal_tol;
-    double scr[NB];
-    int softbits = 0;
-    w.rs = 0;
-    const double2 *msrc = reinterpret_cast<const double2 *>(b.Mblk + qfac * b.nblk * b.npair * 128);
-    const int npair_u = __builtin_amdgcn_readfirstlane(b.npair), nblk_u = __builtin_amdgcn_readfirstlane(b.nblk);
-    // the small per-row loads go out first: in-order return means whoever waits for them would otherwise wait for
-    // every row of M issued before them
-    double dur[NB], dlr[NB];
-    int snr[NB];
-    static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-        const int r = bb * 64 + lane;
-        const bool ok = r < m;
-        scr[bb] = ok ? gsc[r] : 0.0;
-        dur[bb] = ok ? gdu[r] : 0.0;
-        dlr[bb] = ok ? gdl[r] : 0.0;
-        snr[bb] = ok ? (gsense[r] & 0xff) : 0;
-    });
-    // a pending update also needs the new bounds: same early batch
-    double bur[NB], blr[NB];
-    if (upd) {
-        const double *nbu = b.bu + (size_t)q * m, *nbl = b.bl + (size_t)q * m;
-        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-            const int r = bb * 64 + lane;
-            bur[bb] = (r < m) ? nbu[r] : 0.0;
-            blr[bb] = (r < m) ? nbl[r] : 0.0;
-        });
-    }
-    // the warm-start state rides in the same early batch: working-set ids / vectors into registers, packed L and (as
-    // soon as the ids are there) the active rows straight into LDS -- all of it in flight together with the rows of M
-    const bool act = lane < w.na;
-    const int wsid_r = act ? gws[lane] : 0;
-    const double D_r = (lane < cap) ? gv[lane] : 0.0, xl_r = (lane < cap) ? gv[cap + lane] : 0.0, zl_r = (lane < cap) ? gv[2 * cap + lane] : 0.0;
-    const double la_r = (lane < cap) ? gv[3 * cap + lane] : 0.0, lb_r = (lane < cap) ? gv[4 * cap + lane] : 0.0;
-    copy_async(w.L, b.L + (size_t)q * b.ltri, round_up(tri(w.na), 2));
-    auto fetch_active_rows = [&]() __attribute__((always_inline)) {
-        for (int i = 0; i < w.na; ++i) {
-            const int id = rli(wsid_r, i);
-            const double2 *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63) + (size_t)lane * 64;
-            if (lane < b.npair)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(w.rowc + (size_t)i * w.ldr), 16, 0, 0);
-        }
-    };
-    const bool rows_early = !(upd & DAQP_UPDATE_v) || w.na * w.ldr <= rinv0;   // R^-1 is staged in the top of the row cache
-    if (rows_early) fetch_active_rows();
-    __builtin_amdgcn_sched_barrier(0);
-    if (nblk_u == NB && npair_u == NP) {
-        // the shape fills the template exactly (the benchmark's case): NB*NP unconditional loads in ONE basic block, each
-        // straight into its final (mostly accumulation) register -- all in flight, one wait at the first use
-        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-            static_for<NP>([&](auto t) __attribute__((always_inline)) {
-                const double2 v = msrc[((size_t)bb * NP + t) * 64 + lane];
-                w.Mx[bb][t] = v.x; w.My[bb][t] = v.y;
-            });
-        });
-    } else {
-        // smaller problems in the same register shape: lines beyond the problem's are zeros (a select per load keeps
-        // only a few of them in flight; these shapes are far from bandwidth-critical)
-        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-            static_for<NP>([&](auto t) __attribute__((always_inline)) {
-                const bool ok = bb < nblk_u && t < npair_u;
-                const double2 v = msrc[(ok ? ((size_t)bb * npair_u + t) : (size_t)0) * 64 + lane];
-                w.Mx[bb][t] = ok ? v.x : 0.0; w.My[bb][t] = ok ? v.y : 0.0;
-            });
-        });
-    }
-    static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-        const int r = bb * 64 + lane;
-        w.rowv[r] = dur[bb];
-        w.rowv[(64 * NB) + r] = dlr[bb];
-        w.rowv[2 * (64 * NB) + r] = ep * scr[bb];
-        w.rs |= (unsigned)snr[bb] << (8 * bb);
-        softbits |= snr[bb] & DAQP_SOFT;
-    });
-    w.has_soft = __any(softbits) ? 1 : 0;
-    const long long tp1 = kProfile ? (long long)__builtin_readcyclecounter() : 0;
-    if (upd) {
-        // ---- daqp_update_ldp(UPDATE_v|UPDATE_d) on the resident factors (utils.c:58-221 without Rinv/M), cf. k_update
-        // check_bounds (utils.c:546-567) on the stored sense: the first crossed pair (in index order) ends the update with
-        // -1; unmarked equalities before it have been marked by then, nothing else changes (see k_update)
-        int first_bad = kBig;
-        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-            const int r = bb * 64 + lane;
-            if (r < m && !(rsense_get(w, bb) & DAQP_IMMUTABLE) && bur[bb] - blr[bb] < -w.stp->primal_tol && first_bad == kBig) first_bad = r;
-        });
-        first_bad = (int)wave_min((double)first_bad);
-        int bad = 0;
-        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-            const int r = bb * 64 + lane;
-            const int sn = rsense_get(w, bb);
-            if (r < m && r < first_bad && !(sn & DAQP_IMMUTABLE) && !(sn & DAQP_SOFT) && bur[bb] - blr[bb] < w.stp->zero_tol) {
-                w.rs |= (unsigned)(DAQP_ACTIVE | DAQP_IMMUTABLE) << (8 * bb); bad |= 4;
-            }
-        });
-        if (first_bad != kBig) {
-            static_for<NB>([&](auto bb) __attribute__((always_inline)) { const int r = bb * 64 + lane; if (r < m) gsense[r] = rsense_get(w, bb); });
-            if (lane == 0) {
-                qs->upd_flag = DAQP_EXIT_INFEASIBLE; qs->sing_ind = kEmpty;
-                b.exitflag[q] = DAQP_EXIT_INFEASIBLE; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0;
-            }
-            copy_wait();   // nothing may still be landing in LDS when the workgroup ends
-            return;
-        }
-        if (lane == 0) qs->upd_flag = 0;
-        if (__any(bad & 4)) q_need_act = 1;
-        double *vv = w.u, *fl = w.pend_lam;       // both regions are free until the loop starts (u is zeroed below)
-        for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) vv[e] = 0;
-        if (upd & DAQP_UPDATE_v) {   // v = R^-T f (utils.c:474-497), rows < ms of R^-1 are the normalised ones
-            const double *Rl = Rl0;
-            if (lane < n) fl[lane] = f_in;
-            copy_wait();
-            WSYNC();
-            if (lane < n) {
-                const int i = lane;
-                double acc = Rl[roff(i, n) + i] * fl[i];
-                for (int j0 = i - 1; j0 >= 0; j0 -= kChunk) {
-                    double rr[kChunk], ff[kChunk];
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) { const int j = (j0 - k >= 0) ? j0 - k : 0; rr[k] = Rl[roff(j, n) + i]; ff[k] = fl[j]; }
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) if (j0 - k >= 0) acc += rr[k] * ff[k];
-                }
-                vv[i] = acc;
-                b.v[(size_t)q * n + i] = acc;
-            }
-        } else if (lane < n) vv[lane] = b.v[(size_t)q * n + lane];
-        WSYNC();
-        // d = b*scaling + (row . v) for every row of the dense image (utils.c:499-544); rows stay in registers
-        {
-            const double2 *v2 = reinterpret_cast<const double2 *>(vv);
-            double sm[NB];
-            static_for<NB>([&](auto bb) __attribute__((always_inline)) { sm[bb] = 0; });
-            static_for<NP>([&](auto tt) __attribute__((always_inline)) {
-                const double2 vk = v2[tt];
-                static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-                    sm[bb] += w.Mx[bb][tt] * vk.x;
-                    sm[bb] += w.My[bb][tt] * vk.y;     // odd n: the last pair's partner is 0 * 0 (both zero padding), an exact no-op
-                });
-            });
-            static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-                const int r = bb * 64 + lane;
-                if (r < m) {
-                    const double nu = bur[bb] * scr[bb] + sm[bb], nl = blr[bb] * scr[bb] + sm[bb];
-                    dur[bb] = nu; dlr[bb] = nl;
-                    w.rowv[r] = nu; w.rowv[(64 * NB) + r] = nl;
-                    b.dupper[(size_t)q * m + r] = nu;
-                    b.dlower[(size_t)q * m + r] = nl;
-                }
-            });
-        }
-        w.reuse = 0; w.sing = kEmpty;     // utils.c:80-81
-        WSYNC();
-    }
-    // ---- working-set view
-    w.wsid = wsid_r;
-    w.slot = lane;
-    w.slotmask = (w.na >= 64) ? ~0ull : ((1ull << w.na) - 1ull);
-    w.hi_slot = w.na - 1;
-    const int rinv_off = rowc_size - round_up(b.rtri, 2) - 2;
-    w.D = D_r; w.xl = xl_r; w.zl = zl_r;
-    w.lam = swapped ? lb_r : la_r;
-    w.lams = swapped ? la_r : lb_r;
-    {   // sense and bound of each working-set row are already in registers (row view): fetch them across lanes
-        // (ds_bpermute) instead of a second, dependent trip to HBM
-        const int src = w.wsid & 63, blk = w.wsid >> 6;
-        int fl = 0;
-        double bu = 0, bl = 0;
-        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-            const int s8 = (int)((__shfl((int)w.rs, src) >> (8 * bb)) & 0xff);
-            const double u_ = __shfl(dur[bb], src), l_ = __shfl(dlr[bb], src);
-            if (blk == bb) { fl = s8; bu = u_; bl = l_; }
-        });
-        w.wflag = act ? fl : 0;
-        w.drhs = act ? -((fl & DAQP_LOWER) ? bl : bu) : 0.0;
-    }
-    {
-        // warm start: packed L and the active-row cache come straight from HBM into LDS (global_load_lds, no VGPRs),
-        // every instruction in flight at once -- one memory round trip instead of one per row
-        for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) w.u[e] = 0;
-        if (!rows_early) fetch_active_rows();
-        if (kProfile && w.prof && lane == 0) { w.prof[26] = tp1 - t_start; w.prof[27] = (long long)__builtin_readcyclecounter() - tp1; }
-        copy_wait();
-        if (kProfile && w.prof && lane == 0) w.prof[31] = (long long)__builtin_readcyclecounter() - tp1;
-    }
-    WSYNC();
-
-    int iters = 0;
-    const long long t_loop = (long long)__builtin_readcyclecounter();
-    int flag = rrun(w, mode, q_need_act != 0, iters);
-    const long long t_done = (long long)__builtin_readcyclecounter();
-    if (mode == 1) {
-        if (lane == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
-    } else {
-        const double *Rq = b.Rinv + qfac * b.rtri;
-        // Everything that needs LDS hand-offs (x from the staged R^-1, lam assembled by working-set scatter) comes
-        // first; the stores to HBM are issued together at the very end, so no fence ever waits for a store.
-        // Packed R^-1 comes into the top of the (now dead) active-row cache in one HBM round trip; v and the scalings ride along.
-        // (16 bytes per lane; the packed rows of odd QPs start 8 bytes off a 16-byte boundary, so the LDS image is
-        // shifted by one double for them and that first double goes separately)
-        const int odd8 = (int)(((size_t)Rq >> 3) & 1);
-        double *Rl = w.rowc + rinv_off + odd8;
-        if (flag > 0) {
-            if (odd8) copy_async_dwords(Rl, Rq, 1);
-            const int body = (b.rtri - odd8) & ~1;
-            copy_async(Rl + odd8, Rq + odd8, body);
-            if (odd8 + body < b.rtri) copy_async_dwords(Rl + odd8 + body, Rq + odd8 + body, 1);
-        }
-        const double *vq = b.v + (size_t)q * n;
-        const double vl = (lane < n) ? vq[lane] : 0.0;
-        const double sc_ws = (flag > 0 && lane < w.na) ? gsc[w.wsid] : 1.0;
-        const double sc_sb = (flag > 0 && lane < b.ms) ? gsc[lane] : 1.0;
-        double *lamq = w.rowc;                                          // m doubles at the (dead) bottom of the row cache
-        double xi = (lane < n) ? w.u[lane] : 0.0;
-        if (b.lam) for (int i = lane; i < m; i += 64) lamq[i] = 0;     // daqp_extract_result (api.c:455-495): zero ...
-        const long long te1 = (long long)__builtin_readcyclecounter();
-        copy_wait();
-        if (flag > 0) {   // ldp2qp_solution (daqp.c:111-139)
-            if (lane < n) w.u[lane] = w.u[lane] - vl;
-            if (lane < w.na) w.lams *= sc_ws;
-        }
-        WSYNC();
-        const long long te2 = (long long)__builtin_readcyclecounter();
-        if (b.lam && lane < w.na) lamq[w.wsid] = w.lams;                // ... then scatter by WS
-        if (flag > 0 && lane < n) {
-            const double *row = Rl + roff(lane, n);
-            xi = w.u[lane] * row[lane];
-            for (int j0 = lane + 1; j0 < n; j0 += kChunk) {
-                double rr[kChunk], uu[kChunk];
-#pragma unroll
-                for (int k = 0; k < kChunk; ++k) { const int j = (j0 + k < n) ? j0 + k : n - 1; rr[k] = row[j]; uu[k] = w.u[j]; }
-#pragma unroll
-                for (int k = 0; k < kChunk; ++k) if (j0 + k < n) xi += rr[k] * uu[k];
-            }
-            if (lane < b.ms && !qdiag) xi /= sc_sb;   // daqp.c:124-134: no division in the RinvD branch
-        }
-        WSYNC();
-        const long long te3 = (long long)__builtin_readcyclecounter();
-        if (kProfile && w.prof && lane == 0) { w.prof[20] = te1 - t_done; w.prof[21] = te2 - te1; w.prof[22] = te3 - te2; }
-        if (b.x && lane < n) b.x[(size_t)q * n + lane] = xi;
-        if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = lamq[i];
-        double fv = w.fval;                      // fval - |v|^2 in index order, v_i broadcast from its lane
-        static_for<8>([&](auto c) __attribute__((always_inline)) {
-            if (8 * c < n) static_for<8>([&](auto k) __attribute__((always_inline)) { const double vi = rl(vl, 8 * c + k); fv -= vi * vi; });
-        });
-        fv *= 0.5;
-        if (lane == 0) {
-            b.exitflag[q] = flag; b.iter[q] = iters;
-            if (b.fval) b.fval[q] = fv;
-            if (b.soft) b.soft[q] = w.soft;
-            qs->iterations = iters; qs->exitflag = flag; qs->need_activate = 0;
-        }
-    }
-    // ---- store the persistent iterate (lam in buffer A, lam* in buffer B)
-    if (lane < cap) {
-        gv[lane] = w.D; gv[cap + lane] = w.xl; gv[2 * cap + lane] = w.zl;
-        gv[3 * cap + lane] = w.lam; gv[4 * cap + lane] = w.lams;
-        gws[lane] = (lane < w.na) ? w.wsid : -1;
-    }
-    static_for<NB>([&](auto bb) __attribute__((always_inline)) { const int r = bb * 64 + lane; if (r < m) gsense[r] = rsense_get(w, bb); });
-    {
-        const int used = tri(w.na);
-        double *gL = b.L + (size_t)q * b.ltri;
-        for (int e = lane; e < used; e += 64) gL[e] = w.L[e];
-    }
-    if (lane == 0) {
-        qs->n_active = w.na; qs->reuse_ind = w.reuse; qs->sing_ind = w.sing;
-        qs->lam_swapped = 0;
-        qs->fval = w.fval; qs->soft_slack = w.soft;
-        if (b.trace) b.trace[(size_t)q * b.trace_cap + b.trace_cap - 1] = w.trace_len;
-        if (kProfile && w.prof) {
-            const long long te4 = (long long)__builtin_readcyclecounter();
-            w.prof[23] = te4 - t_done;
-            for (int i = 0; i < 32; ++i) b.prof[(size_t)q * 32 + i] = w.prof[i];
-            b.prof[(size_t)q * 32 + 28] = t_loop - t_start;                                    // prologue
-            b.prof[(size_t)q * 32 + 29] = (long long)__builtin_readcyclecounter() - t_done;   // epilogue
-            b.prof[(size_t)q * 32 + 30] = t_done - t_loop;                                     // the loop
-        }
-    }
-}
-
 } // namespace daqp_amd

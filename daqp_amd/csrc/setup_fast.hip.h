@@ -13,7 +13,7 @@
 //     all n accumulators of the row in registers (terms arrive diagonal first, then decreasing r).
 #pragma once
 #include "wave_ldp_reg.hip.h"
-#include "kernels.hip.h"
+#include "batch_dev.hip.h"
 
 namespace daqp_amd {
 

@@ -29,7 +29,7 @@ __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-template <int NB, int NP>
+template <int NB, int NP, bool FM>
 struct RWave {
     int n, m, ms, ldr;
     double *L, *rowc, *u, *pend_lam;   // LDS
@@ -77,8 +77,15 @@ constexpr bool kProfile = false;
 
 __device__ __forceinline__ int rli(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
-template <int NB, int NP>
-__device__ __forceinline__ void rtrace(RWave<NB, NP> &w, int ev)
+// x - a*b and x + a*b.  FM = false: two roundings, the reference's arithmetic (the file is compiled with -ffp-contract=off).
+// FM = true (default arithmetic mode of the library, where M = A R^-1 already comes from the matrix cores): one v_fma_f64,
+// i.e. one rounding -- results differ from the reference's in the last bits, decisions are compared at the north_star bar
+// (tests/test_gpu_fast_mode.py); one instruction less per term of every chain and of the feasibility scan.
+template <bool FM> __device__ __forceinline__ double msub(double x, double a, double b) { if constexpr (FM) return __builtin_fma(-a, b, x); else return x - a * b; }
+template <bool FM> __device__ __forceinline__ double madd(double x, double a, double b) { if constexpr (FM) return __builtin_fma(a, b, x); else return x + a * b; }
+
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ void rtrace(RWave<NB, NP, FM> &w, int ev)
 {
     if (w.trace) {
         if (lane_id() == 0 && w.trace_len < w.trace_cap) w.trace[w.trace_len] = ev;
@@ -88,15 +95,15 @@ __device__ __forceinline__ void rtrace(RWave<NB, NP> &w, int ev)
 
 // --- row-view accessors ----------------------------------------------------------------------
 // sense words are < 256 (bits ACTIVE..SLACK_FIXED): block bb of this lane sits in byte bb of w.rs
-template <int NB, int NP>
-__device__ __forceinline__ int rsense_get(const RWave<NB, NP> &w, int bb) { return (int)((w.rs >> (8 * bb)) & 0xffu); }
-template <int NB, int NP>
-__device__ __forceinline__ int sense_of(const RWave<NB, NP> &w, int id)   // id wave-uniform
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ int rsense_get(const RWave<NB, NP, FM> &w, int bb) { return (int)((w.rs >> (8 * bb)) & 0xffu); }
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ int sense_of(const RWave<NB, NP, FM> &w, int id)   // id wave-uniform
 {
     return rli(rsense_get(w, id >> 6), id & 63);
 }
-template <int NB, int NP>
-__device__ __forceinline__ void sense_set(RWave<NB, NP> &w, int id, int set_bits, int clear_bits)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ void sense_set(RWave<NB, NP, FM> &w, int id, int set_bits, int clear_bits)
 {
     if (lane_id() == (id & 63)) {
         const int sh = 8 * (id >> 6);
@@ -105,16 +112,16 @@ __device__ __forceinline__ void sense_set(RWave<NB, NP> &w, int id, int set_bits
 }
 // bound of constraint id: broadcast every block's candidate first, THEN pick (selecting between
 // array elements before the readlane gets folded into a dynamic index => scratch)
-template <int NB, int NP>
-__device__ __forceinline__ double bound_of(const RWave<NB, NP> &w, int id, bool lower)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ double bound_of(const RWave<NB, NP, FM> &w, int id, bool lower)
 {
     return w.rowv[(lower ? (64 * NB) : 0) + id];     // wave-uniform address: an LDS broadcast
 }
 
 // rowc[slot] <- row id: the owning lane stores its registers, NP unconditional 16-byte writes (the row
 // stride is >= 2*NP and rows are 16-byte aligned; entries beyond n are the zero padding of M)
-template <int NB, int NP>
-__device__ __forceinline__ void rfetch_row(RWave<NB, NP> &w, int id, int slot)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ void rfetch_row(RWave<NB, NP, FM> &w, int id, int slot)
 {
     const int lane = lane_id();
     double2 *dst = reinterpret_cast<double2 *>(w.rowc + (size_t)slot * w.ldr);
@@ -130,6 +137,7 @@ __device__ __forceinline__ void rfetch_row(RWave<NB, NP> &w, int id, int slot)
 }
 
 // factorization.c:4-15 with the loads of each group of 8 issued before its arithmetic
+template <bool FM>
 __device__ __forceinline__ double dot4_pipelined(const double *a, const double *b, int len)
 {
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -138,8 +146,8 @@ __device__ __forceinline__ double dot4_pipelined(const double *a, const double *
         double x[8], y[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) { x[q] = a[i + q]; y[q] = b[i + q]; }
-        s0 += x[0] * y[0]; s1 += x[1] * y[1]; s2 += x[2] * y[2]; s3 += x[3] * y[3];
-        s0 += x[4] * y[4]; s1 += x[5] * y[5]; s2 += x[6] * y[6]; s3 += x[7] * y[7];
+        s0 = madd<FM>(s0, x[0], y[0]); s1 = madd<FM>(s1, x[1], y[1]); s2 = madd<FM>(s2, x[2], y[2]); s3 = madd<FM>(s3, x[3], y[3]);
+        s0 = madd<FM>(s0, x[4], y[4]); s1 = madd<FM>(s1, x[5], y[5]); s2 = madd<FM>(s2, x[6], y[6]); s3 = madd<FM>(s3, x[7], y[7]);
     }
     for (; i + 3 < len; i += 4) {
         double x[4], y[4];
@@ -163,8 +171,8 @@ __device__ __forceinline__ double dot4_pipelined(const double *a, const double *
 
 // b <- L' \ b over the leading cnt positions (column-oriented; product order b_j * L[j][i]).
 // Lanes >= cnt must hold b == 0.
-template <int NB, int NP>
-__device__ __forceinline__ double rbackward(RWave<NB, NP> &w, double b, int cnt)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ double rbackward(RWave<NB, NP, FM> &w, double b, int cnt)
 {
     const int lane = lane_id();
     const double *Ll = w.L + lane_now();
@@ -185,7 +193,7 @@ __device__ __forceinline__ double rbackward(RWave<NB, NP> &w, double b, int cnt)
                 constexpr int j = 8 * c + 7 - q;
                 if constexpr (j >= 1) {
                     const double bj = rl(b, j);
-                    const double t = b - bj * Lb[q];
+                    const double t = msub<FM>(b, bj, Lb[q]);
                     b = ((unsigned)(j + nlane) < room) ? t : b;
                 }
             });
@@ -204,8 +212,8 @@ __device__ __forceinline__ double ordered_sub(double acc, double p, int cnt)
 // x_i = rhs_i - sum_{j<i} L[i][j] x_j for rows i >= from (j ascending), column-oriented: lane <-> row, the
 // lane's own L entries for 8 columns preloaded, x_j broadcast by v_readlane once final.
 // In: x = final values for lanes < from; rhs for lanes in [from, na); 0 beyond.
-template <int NB, int NP>
-__device__ __forceinline__ double rforward(RWave<NB, NP> &w, double x, double rhs, int from)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ double rforward(RWave<NB, NP, FM> &w, double x, double rhs, int from)
 {
     const int lane = lane_id(), na = w.na;
     const bool pending = lane >= from && lane < na;
@@ -226,7 +234,7 @@ __device__ __forceinline__ double rforward(RWave<NB, NP> &w, double x, double rh
             static_for<8>([&](auto q) __attribute__((always_inline)) {
                 constexpr int j = 8 * c + q;
                 const double xj = rl(x, j);
-                const double t = x - Lk[q] * xj;
+                const double t = msub<FM>(x, Lk[q], xj);
                 x = (pl > j) ? t : x;     // rows > j that are still open; steps j >= na-1 select nothing (pl < na)
             });
         }
@@ -239,8 +247,8 @@ __device__ __forceinline__ double rforward(RWave<NB, NP> &w, double x, double rh
 // every other 16-byte pair of its row and of the new row: half the LDS instructions and a quarter of the VALU work
 // of one lane per row.  Element e < 4*(n/4) goes to chain e%4 in ascending order, the n%4 tail elements go to s0 one
 // after the other, and the result is (s0+s1)+(s2+s3) -- exactly the reference's dot_row.  Row na is the new row itself.
-template <int NB, int NP>
-__device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP> &w, int newslot, const double *Mi)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP, FM> &w, int newslot, const double *Mi)
 {
     const int lane = lane_id(), na = w.na, n = w.n, nq = n >> 2, h = lane & 1;
     const double2 *rb = reinterpret_cast<const double2 *>(Mi) + h;
@@ -256,7 +264,7 @@ __device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP> &w, int newslot,
             if (4 * G + 3 < nq) {
                 double2 x[4], y[4];
                 static_for<4>([&](auto q) __attribute__((always_inline)) { x[q] = ra[2 * (4 * G + q)]; y[q] = rb[2 * (4 * G + q)]; });
-                static_for<4>([&](auto q) __attribute__((always_inline)) { sa += x[q].x * y[q].x; sb += x[q].y * y[q].y; });
+                static_for<4>([&](auto q) __attribute__((always_inline)) { sa = madd<FM>(sa, x[q].x, y[q].x); sb = madd<FM>(sb, x[q].y, y[q].y); });
             } else if (4 * G < nq) {
                 static_for<4>([&](auto q) __attribute__((always_inline)) {
                     if (4 * G + q < nq) {
@@ -281,8 +289,8 @@ __device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP> &w, int newslot,
 // ---------------------------------------------------------------------------------------
 // LDL' row append (factorization.c:21-111); returns the new pivot D[na]
 // ---------------------------------------------------------------------------------------
-template <int NB, int NP>
-__device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int newslot, int sn_id)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ double rldl_append(RWave<NB, NP, FM> &w, int id, int newslot, int sn_id)
 {
     const int lane = lane_id(), na = w.na, n = w.n, base = tri(na);
     rfetch_row(w, id, newslot);
@@ -294,7 +302,7 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
         const int idk = (lane < na) ? w.wsid : id;
         const int sk = (lane < na) ? w.slot : newslot;
         const int j = (lane < na && idk < w.ms) ? (c0 > idk ? c0 : idk) : c0;
-        if (w.ms != 0) g = dot4_pipelined(w.rowc + (size_t)sk * w.ldr + j, Mi + j, n - j);
+        if (w.ms != 0) g = dot4_pipelined<FM>(w.rowc + (size_t)sk * w.ldr + j, Mi + j, n - j);
     }
     if (w.ms == 0) g = rdots_two_lanes(w, newslot, Mi);
     int ns_act = 0;
@@ -313,7 +321,7 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
                 static_for<8>([&](auto q) __attribute__((always_inline)) {
                     constexpr int j = 8 * c + q;
                     const double lj = rl(g, j);
-                    const double t = g - Lk[q] * lj;
+                    const double t = msub<FM>(g, Lk[q], lj);
                     g = (pl > j) ? t : g;
                 });
             }
@@ -335,8 +343,8 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP> &w, int id, int news
 // ---------------------------------------------------------------------------------------
 // LDL' row delete (factorization.c:112-151)
 // ---------------------------------------------------------------------------------------
-template <int NB, int NP>
-__device__ __forceinline__ void rldl_delete(RWave<NB, NP> &w, int r)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM> &w, int r)
 {
     const int lane = lane_id(), na = w.na;
     if (na == r + 1) return;
@@ -395,8 +403,8 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP> &w, int r)
                     alpha = Di * alpha / dbar;
                     if (lane == r + j) Dn = dbar;
                     if (pl > j) {
-                        wv -= p * Lc[q];
-                        Lc[q] = Lc[q] + beta * wv;
+                        wv = msub<FM>(wv, p, Lc[q]);
+                        Lc[q] = madd<FM>(Lc[q], beta, wv);
                     }
                 }
             });
@@ -421,8 +429,8 @@ __device__ __forceinline__ double shift_from(double v, int r)
     return lane_id() >= r ? __hiloint2double(hi, lo) : v;
 }
 
-template <int NB, int NP>
-__device__ __forceinline__ int rdrop_core(RWave<NB, NP> &w, int r) // auxiliary.c:3-22
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ int rdrop_core(RWave<NB, NP, FM> &w, int r) // auxiliary.c:3-22
 {
     const int lane = lane_id();
     const int idr = rli(w.wsid, r);
@@ -445,8 +453,8 @@ __device__ __forceinline__ int rdrop_core(RWave<NB, NP> &w, int r) // auxiliary.
     return 0;
 }
 
-template <int NB, int NP>
-__device__ __forceinline__ void rpush_core(RWave<NB, NP> &w, int id, double lamv) // auxiliary.c:27-40
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ void rpush_core(RWave<NB, NP, FM> &w, int id, double lamv) // auxiliary.c:27-40
 {
     const int lane = lane_id();
     rtrace(w, id + 1);
@@ -467,8 +475,8 @@ __device__ __forceinline__ void rpush_core(RWave<NB, NP> &w, int id, double lamv
 // ---------------------------------------------------------------------------------------
 // per-iteration kernels
 // ---------------------------------------------------------------------------------------
-template <int NB, int NP>
-__device__ __forceinline__ void rsolve_csp(RWave<NB, NP> &w) // auxiliary.c:314-354
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ void rsolve_csp(RWave<NB, NP, FM> &w) // auxiliary.c:314-354
 {
     const int lane = lane_id(), na = w.na, from = w.reuse;
     long long tq = (kProfile && w.prof) ? (long long)__builtin_readcyclecounter() : 0;
@@ -481,8 +489,8 @@ __device__ __forceinline__ void rsolve_csp(RWave<NB, NP> &w) // auxiliary.c:314-
     w.reuse = na;
 }
 
-template <int NB, int NP>
-__device__ __forceinline__ void rsingular_direction(RWave<NB, NP> &w) // auxiliary.c:357-376
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ void rsingular_direction(RWave<NB, NP, FM> &w) // auxiliary.c:357-376
 {
     const int lane = lane_id(), s = w.sing;
     double b = (lane < s) ? -w.L[tri(s) + lane] : 0.0;
@@ -496,8 +504,8 @@ __device__ __forceinline__ void rsingular_direction(RWave<NB, NP> &w) // auxilia
 
 // ratio test of auxiliary.c:277-311 (SOFT_WEIGHTS off): returns the position to drop (or kBig)
 // after stepping lam towards lam*; the removal itself is the caller's single DROP site
-template <int NB, int NP>
-__device__ __forceinline__ int rblocking_test(RWave<NB, NP> &w)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ int rblocking_test(RWave<NB, NP, FM> &w)
 {
     const int lane = lane_id(), na = w.na;
     const double dtol = w.dual_tol;
@@ -522,8 +530,8 @@ __device__ __forceinline__ int rblocking_test(RWave<NB, NP> &w)
 }
 
 // u = -M_k' lam*  (auxiliary.c:46-88): lane <-> component j, working-set order, rows preloaded 8 ahead
-template <int NB, int NP>
-__device__ __forceinline__ void rprimal_u(RWave<NB, NP> &w)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ void rprimal_u(RWave<NB, NP, FM> &w)
 {
     const int lane = lane_id(), na = w.na, n = w.n;
     double uu = 0;
@@ -540,7 +548,7 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP> &w)
                 li[q] = rl(lz, i);
                 rv[q] = rc[rli(soff, i)];
             });
-            static_for<8>([&](auto q) __attribute__((always_inline)) { uu -= rv[q] * li[q]; });
+            static_for<8>([&](auto q) __attribute__((always_inline)) { uu = msub<FM>(uu, rv[q], li[q]); });
         }
     });
     WSYNC();
@@ -560,8 +568,8 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP> &w)
 // the value is materialised in a VGPR at this point of the program (an optimisation barrier for that value only)
 __device__ __forceinline__ void pin_vgpr(double &x) { asm volatile("" : "+v"(x)); }
 
-template <int NB, int NP>
-__device__ __forceinline__ int rscan_rows(RWave<NB, NP> &w, int &upper, bool with_fval)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ int rscan_rows(RWave<NB, NP, FM> &w, int &upper, bool with_fval)
 {
     const int lane = lane_id();
     double bv = 0.0;
@@ -586,10 +594,10 @@ __device__ __forceinline__ int rscan_rows(RWave<NB, NP> &w, int &upper, bool wit
             if constexpr (t < NP) {
                 const double ux = ub[g & 1][h].x, uy = ub[g & 1][h].y;
                 static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-                    mu[bb] += w.Mx[bb][t] * ux;
-                    mu[bb] += w.My[bb][t] * uy;
+                    mu[bb] = madd<FM>(mu[bb], w.Mx[bb][t], ux);
+                    mu[bb] = madd<FM>(mu[bb], w.My[bb][t], uy);
                 });
-                if (with_fval) { fv += ux * ux; fv += uy * uy; }   // j-ordered |u|^2 (auxiliary.c:85-86)
+                if (with_fval) { fv = madd<FM>(fv, ux, ux); fv = madd<FM>(fv, uy, uy); }   // j-ordered |u|^2 (auxiliary.c:85-86)
             }
         });
         // pin this group's partial sums here: without it the optimizer sinks whole chains below the loop (towards
@@ -619,8 +627,8 @@ __device__ __forceinline__ int rscan_rows(RWave<NB, NP> &w, int &upper, bool wit
     return bi;
 }
 
-template <int NB, int NP>
-__device__ __forceinline__ void rrefine_active(RWave<NB, NP> &w) // auxiliary.c:498-593
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ void rrefine_active(RWave<NB, NP, FM> &w) // auxiliary.c:498-593
 {
     const int lane = lane_id(), na = w.na, n = w.n;
     w.reuse = 0;
@@ -651,11 +659,11 @@ __device__ __forceinline__ void rrefine_active(RWave<NB, NP> &w) // auxiliary.c:
     w.fval = fv;
 }
 
-template <int NB, int NP>
-__device__ __forceinline__ void rreset_ws(RWave<NB, NP> &w) { w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0; }
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ void rreset_ws(RWave<NB, NP, FM> &w) { w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0; }
 
-template <int NB, int NP>
-__device__ __forceinline__ unsigned long long active_mask(const RWave<NB, NP> &w, int bb)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ unsigned long long active_mask(const RWave<NB, NP, FM> &w, int bb)
 {
     return __ballot(bb * 64 + lane_id() < w.m && (rsense_get(w, bb) & DAQP_ACTIVE));
 }
@@ -673,8 +681,8 @@ enum : int { PC_START_LOOP, PC_ITER, PC_EDIT, PC_ACT_BEGIN, PC_ACT_NEXT, PC_ACT_
 enum : int { AFTER_NEXT_ITER, AFTER_CYCLE_GUARD, AFTER_ACT_POST };   // what follows a completed working-set edit
 enum : int { ACT_THEN_DONE, ACT_THEN_LOOP, ACT_THEN_NEXT_ITER, ACT_THEN_CYCLE_RESET };
 
-template <int NB, int NP>
-__device__ __forceinline__ int rrun(RWave<NB, NP> &w, int mode, bool need_activate, int &iterations)
+template <int NB, int NP, bool FM>
+__device__ __forceinline__ int rrun(RWave<NB, NP, FM> &w, int mode, bool need_activate, int &iterations)
 {
     const int lane = lane_id();
     int flag = DAQP_EXIT_ITERLIMIT, it = 1, repaired = 0, stall = 0;

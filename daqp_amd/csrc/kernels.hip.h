@@ -18,6 +18,9 @@ namespace daqp_amd {
 #define DAQP_AMD_SETUP_ROWS 8
 #endif
 constexpr int kSetupRows = DAQP_AMD_SETUP_ROWS;
+#ifndef DAQP_AMD_CHOL_DEPTH
+#define DAQP_AMD_CHOL_DEPTH 8
+#endif
 struct SetupLds { int R, Rout, fv, vv, xu, sc, du, dl, tile, sens, total_bytes; };
 __host__ __device__ inline SetupLds setup_lds(int n, int m, bool gs = false)
 {
@@ -204,9 +207,10 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                         acc[r][jb] = (i < n && j >= i && j < n) ? R[pi + j] : 0.0;
                     });
                 });
-                for (int k0 = 0; k0 < i0; k0 += 2) {      // two finished rows in flight (i0 is a multiple of KR)
-                    double rk[2][NBK], ru[2][KR];
-                    static_for<2>([&](auto tt) __attribute__((always_inline)) {
+                constexpr int KD = DAQP_AMD_CHOL_DEPTH;   // finished rows in flight (i0 is a multiple of KR, KR of KD)
+                for (int k0 = 0; k0 < i0; k0 += KD) {
+                    double rk[KD][NBK], ru[KD][KR];
+                    static_for<KD>([&](auto tt) __attribute__((always_inline)) {
                         constexpr int t = tt;
                         const int pk = roff(k0 + t, n);
                         static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                             ru[t][r] = R[pk + ((i0 + r < n) ? i0 + r : i0)];
                         });
                     });
-                    static_for<2>([&](auto tt) __attribute__((always_inline)) {
+                    static_for<KD>([&](auto tt) __attribute__((always_inline)) {
                         constexpr int t = tt;
                         static_for<KR>([&](auto rr) __attribute__((always_inline)) {
                             constexpr int r = rr;
@@ -323,24 +327,32 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                         ri[u][jb] = (jb >= bi && j > i && j < n) ? R[pi + j] : 0.0;
                     }
                 }
+                // (The column block of i picked by a wave-uniform branch around code with compile-time block numbers: blocks
+                //  left of it are skipped, blocks right of it take the update without a select -- all their columns are > i --
+                //  and x_i comes out of a register that is never indexed at run time.  The per-row "has this row started" test
+                //  exists only in the first steps of a group and in the last group.)
                 static_for<4>([&](auto uu) __attribute__((always_inline)) {
                     constexpr int u = uu;
                     const int i = i0 + u;
                     if (i < n) {
                         const int bi = i >> 6, li = i & 63;
-                        static_for<KR>([&](auto rr) __attribute__((always_inline)) {
-                            constexpr int r = rr;
-                            const int k = k0 + r;
-                            if (k < i && k < n) {       // (rows of the group that have not started yet sit this step out)
-                                double xi = x[r][0];
-                                if (bi == 1) xi = x[r][1];
-                                if (bi == 2) xi = x[r][2];
-                                if (bi == 3) xi = x[r][3];
-                                const double t = rl(xi, li) * rii[u];          // utils.c:386
-                                static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
-                                    constexpr int jb = jj;
-                                    const int j = jb * 64 + lane;
-                                    if (jb >= bi) x[r][jb] = (j == i) ? t : ((j > i) ? x[r][jb] - ri[u][jb] * t : x[r][jb]);   // utils.c:387-388
+                        const bool all_rows = (i >= k0 + KR) && (k0 + KR <= n);
+                        static_for<NBK>([&](auto bb) __attribute__((always_inline)) {
+                            if (bi == bb) {
+                                auto row_step = [&](auto rr) __attribute__((always_inline)) {
+                                    constexpr int r = rr;
+                                    const double t = rl(x[r][bb], li) * rii[u];          // utils.c:386
+                                    static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
+                                        constexpr int jb = jj;
+                                        const int j = jb * 64 + lane;
+                                        if constexpr (jb == bb) x[r][jb] = (j == i) ? t : ((j > i) ? x[r][jb] - ri[u][jb] * t : x[r][jb]);   // utils.c:387-388
+                                        else if constexpr (jb > bb) x[r][jb] = x[r][jb] - ri[u][jb] * t;
+                                    });
+                                };
+                                if (all_rows) static_for<KR>([&](auto rr) __attribute__((always_inline)) { row_step(rr); });
+                                else static_for<KR>([&](auto rr) __attribute__((always_inline)) {
+                                    const int k = k0 + rr;
+                                    if (k < i && k < n) row_step(rr);                   // (rows of the group that have not started yet sit this step out)
                                 });
                             }
                         });
@@ -413,13 +425,86 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     // per term any more.  Phase B (lane <-> row, the blocked image read back coalesced) normalises and forms d.
     int feasible = 1;
     double *Mq = b.Mblk + (size_t)q * b.nblk * b.npair * 128;
+    // Default arithmetic mode: phase A on the matrix cores (v_mfma_f64_16x16x4_f64), 16 rows of A at a time.  The A operand of
+    // a row tile (lane l: A[l&15][4kt + (l>>4)], every k step) is loaded from HBM once and stays in registers; the fragments of
+    // R^-1 (lane l: R^-1[4kt + (l>>4)][16ct + (l&15)], zero below the diagonal) stream past it eight k steps ahead of the
+    // matrix instructions that consume them, column tile by column tile, only up to each tile's last row (R^-1 is upper
+    // triangular).  Nothing of A is staged in LDS.  The sums are fp64 fused in a different order than the reference's: M agrees
+    // to ~1e-16 relative (the exact mode keeps the chain below).
+    const bool mfma_m = !b.exact_setup;
+    if (flag > 0 && mfma_m) {
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        constexpr int KB = 16, NKT = 64;          // n <= 255: at most 64 k steps
+        double *ob = smem + o.tile;               // [16][64] one column block of results on its way to the blocked image
+        double2 *Mq2 = reinterpret_cast<double2 *>(Mq);
+        const int lr = lane & 15, lk = lane >> 4;
+        for (int kb = 0; kb < mA; kb += KB) {
+            const int rows = (mA - kb) < KB ? (mA - kb) : KB;
+            const bool rowok = lr < rows;
+            const double *arow = A + (size_t)(kb + (rowok ? lr : 0)) * n;
+            double av[NKT];
+            static_for<NKT / 8>([&](auto c8) __attribute__((always_inline)) {
+                static_for<8>([&](auto u) __attribute__((always_inline)) { av[8 * c8 + u] = 0.0; });
+                if (32 * c8 < n) {
+                    static_for<8>([&](auto u) __attribute__((always_inline)) {
+                        const int kk = 4 * (8 * c8 + u) + lk;
+                        const double a = arow[kk < n ? kk : 0];
+                        av[8 * c8 + u] = (rowok && kk < n) ? a : 0.0;
+                    });
+                }
+            });
+            for (int cb = 0; cb < n; cb += 64) {
+                const int rtop = (n - 1 < cb + 63) ? n - 1 : cb + 63;
+                WSYNC();   // the previous block's readers are done with ob
+                for (int ct = 0; ct < 4 && cb + 16 * ct < n; ++ct) {
+                    const int col = cb + 16 * ct + lr;
+                    const bool colok = col < n;
+                    const int klast = (n - 1 < cb + 16 * ct + 15) ? n - 1 : cb + 16 * ct + 15;
+                    auto fetch = [&](double (&bv)[8], int c8) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int kk = 4 * (8 * c8 + u) + lk;
+                            const bool ok = colok && kk <= col;
+                            const double v = Ro[ok ? roff(kk, n) + col : 0];
+                            bv[u] = ok ? v : 0.0;
+                        }
+                    };
+                    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+                    constexpr int AHEAD = 3;          // blocks of eight k steps in flight ahead of the matrix instructions
+                    double bq[AHEAD + 1][8];
+                    static_for<AHEAD>([&](auto c8) __attribute__((always_inline)) { fetch(bq[c8], c8); });
+                    static_for<NKT / 8>([&](auto c8) __attribute__((always_inline)) {
+                        if (32 * c8 <= klast) {
+                            if constexpr (c8 + AHEAD < NKT / 8) fetch(bq[(c8 + AHEAD) % (AHEAD + 1)], c8 + AHEAD);   // (all lanes masked off beyond klast: a cached dummy address)
+                            static_for<8>([&](auto u) __attribute__((always_inline)) {
+                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[8 * c8 + u], bq[c8 % (AHEAD + 1)][u], acc, 0, 0, 0);
+                            });
+                        }
+                    });
+                    static_for<4>([&](auto r) __attribute__((always_inline)) { ob[(lk + 4 * r) * 64 + 16 * ct + lr] = acc[(int)r]; });   // D: row (l>>4) + 4 reg, column l&15
+                }
+                WSYNC();
+                const int pairs = ((rtop - cb) >> 1) + 1;
+                for (int idx = lane; idx < pairs * KB; idx += 64) {
+                    const int k = idx & (KB - 1), t = idx / KB;
+                    if (k < rows) {
+                        const int gi = ms + kb + k;
+                        double2 vpair;
+                        vpair.x = ob[k * 64 + 2 * t];
+                        vpair.y = (cb + 2 * t + 1 < n) ? ob[k * 64 + 2 * t + 1] : 0.0;
+                        Mq2[((size_t)(gi >> 6) * b.npair + (cb >> 1) + t) * 64 + (gi & 63)] = vpair;
+                    }
+                }
+            }
+        }
+    }
     if (flag > 0) {
         constexpr int KB = kSetupRows;
         const int np2 = round_up(n, 2);
         double *at = smem + o.tile;               // [KB][np2] rows of A
         double *ob = at + KB * np2;               // [KB][64] one column block of results on its way to the blocked image
         double2 *Mq2 = reinterpret_cast<double2 *>(Mq);
-        for (int kb = 0; kb < mA; kb += KB) {
+        for (int kb = 0; kb < mA && !mfma_m; kb += KB) {
             const int rows = (mA - kb) < KB ? (mA - kb) : KB;
             WSYNC();
             stage_rows(at, A + (size_t)kb * n, rows, n, np2);
@@ -517,7 +602,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                         if (!(sens[gi] & DAQP_IMMUTABLE) && !(sens[gi] & DAQP_SOFT)) rowbad = 1;
                     sens[gi] = DAQP_IMMUTABLE;
                 } else scal = 1 / sqrt(s);
-                double dsum = 0;
+                double dsum = 0, sraw = 0;
                 for (int t0 = 0; t0 < b.npair; t0 += 8) {
                     double2 v8[8];
 #pragma unroll
@@ -527,6 +612,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                         const int t = t0 + u;
                         if (t < b.npair) {
                             double2 w = v8[u];
+                            if (unc && mfma_m) { sraw += w.x * vv[2 * t]; if (2 * t + 1 < n) sraw += w.y * vv[2 * t + 1]; }
                             if (scale_it) { w.x *= scal; if (2 * t + 1 < n) w.y *= scal; }
                             if (!unc) { dsum += w.x * vv[2 * t]; if (2 * t + 1 < n) dsum += w.y * vv[2 * t + 1]; }
                             if (scale_it) rowp[(size_t)t * 64] = w;
@@ -535,7 +621,9 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                 }
                 sc[gi] = scal;
                 if (unc) {
-                    const double sunc = du[gi];
+                    // A_k . x_unc: parked by the exact phase A; the matrix-core phase has no row of A in LDS and uses
+                    // A x_unc = -(A R^-1) v, the unnormalised row against v (equal up to rounding)
+                    const double sunc = mfma_m ? -sraw : du[gi];
                     const double u0 = bu[gi] - sunc, l0 = bl[gi] - sunc;
                     if (u0 < -st.primal_tol || l0 > st.primal_tol) feasible = 0;
                     du[gi] = u0 * scal; dl[gi] = l0 * scal;

@@ -25,6 +25,7 @@ struct BatchDev {
     QState *qs;        // [N]
     double *rowc_g;    // [N][cap*ldr] only when the active-row cache / L spill out of LDS
     double *setup_g;   // [N][2*rtri] only when the setup factors spill out of LDS
+    double *setup_sq;  // [N][round_up(n,32)][round_up(n,16)] generic setup, default mode: R^-1 as a zero-padded square (the matrix cores' B operand)
     // outputs
     double *x, *lam, *fval, *soft;
     int *exitflag, *iter;

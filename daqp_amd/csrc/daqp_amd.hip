@@ -494,6 +494,11 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &d.qs, Nn);
     if (b->spill) rc |= dev_alloc(b, &d.rowc_g, Nn * cap * d.ldr);
     if (b->setup_spill) rc |= dev_alloc(b, &d.setup_g, Nn * 2 * (size_t)round_up(d.rtri, 2));
+    if (!b->fast_setup) {   // zeroed once: the kernel only ever writes the upper triangle
+        const size_t sq = Nn * (size_t)round_up(n, 32) * (size_t)round_up(n, 16);
+        rc |= dev_alloc(b, &d.setup_sq, sq);
+        if (!rc) HIPCHK(hipMemset(d.setup_sq, 0, sq * sizeof(double)));
+    }
     rc |= dev_alloc(b, &b->ox, Nn * n);
     rc |= dev_alloc(b, &b->olam, Nn * m);
     rc |= dev_alloc(b, &b->ofval, Nn);

@@ -99,6 +99,10 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     const bool force = st.eps_prox > 0.0 && pp != 2;
     const int shift_code = (!pp && st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;   // eps == 0: utils.c:357,367
     int nprox = 0;
+    // default arithmetic mode: M = A R^-1 on the matrix cores (below), which read R^-1 from a zero-padded square image
+    bool mfma_m = !b.exact_setup && b.setup_sq != nullptr;
+    const int sq_ld = round_up(n, 16);
+    double *Rsq = b.setup_sq ? b.setup_sq + (size_t)q * round_up(n, 32) * sq_ld : nullptr;
     // optional phase cycle counters -> b.prof[q][16..21]: checks, Cholesky, inverse, v/x_unc, M rows, simple bounds + write-back
     long long gpt[6] = {0, 0, 0, 0, 0, 0};
     long long gt0 = b.prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -168,6 +172,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                 }
             }
             diag = 1;
+            mfma_m = false;   // (M = A D^-1/2: the chain below; the square image is not written on this path)
             if (pp == 2) nprox = n;
             WSYNC();
         }
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
 #pragma unroll
                     for (int jb = 0; jb < NBK; ++jb) {
                         const int j = jb * 64 + lane;
-                        if (j >= k && j < n) Ro[pk + j] = x[r][jb];
+                        if (j >= k && j < n) { Ro[pk + j] = x[r][jb]; if (mfma_m) Rsq[(size_t)k * sq_ld + j] = x[r][jb]; }
                     }
                 }
             }
@@ -431,28 +436,34 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     // matrix instructions that consume them, column tile by column tile, only up to each tile's last row (R^-1 is upper
     // triangular).  Nothing of A is staged in LDS.  The sums are fp64 fused in a different order than the reference's: M agrees
     // to ~1e-16 relative (the exact mode keeps the chain below).
-    const bool mfma_m = !b.exact_setup;
     if (flag > 0 && mfma_m) {
         typedef double v4d __attribute__((ext_vector_type(4)));
         constexpr int KB = 16, NKT = 64;          // n <= 255: at most 64 k steps
         double *ob = smem + o.tile;               // [16][64] one column block of results on its way to the blocked image
         double2 *Mq2 = reinterpret_cast<double2 *>(Mq);
         const int lr = lane & 15, lk = lane >> 4;
+        long long mp[3] = {0, 0, 0}, mt0 = b.prof ? (long long)__builtin_readcyclecounter() : 0;
+#define MPROF(slot) do { if (b.prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t1 = (long long)__builtin_readcyclecounter(); mp[slot] += t1 - mt0; mt0 = t1; } } while (0)
         for (int kb = 0; kb < mA; kb += KB) {
             const int rows = (mA - kb) < KB ? (mA - kb) : KB;
             const bool rowok = lr < rows;
             const double *arow = A + (size_t)(kb + (rowok ? lr : 0)) * n;
             double av[NKT];
-            static_for<NKT / 8>([&](auto c8) __attribute__((always_inline)) {
-                static_for<8>([&](auto u) __attribute__((always_inline)) { av[8 * c8 + u] = 0.0; });
-                if (32 * c8 < n) {
-                    static_for<8>([&](auto u) __attribute__((always_inline)) {
-                        const int kk = 4 * (8 * c8 + u) + lk;
-                        const double a = arow[kk < n ? kk : 0];
-                        av[8 * c8 + u] = (rowok && kk < n) ? a : 0.0;
+            // (straight-line per number of 32-column blocks of A, as for R^-1 below: all loads in flight, then the masks)
+            static_for<NKT / 8>([&](auto nb) __attribute__((always_inline)) {
+                if ((n + 31) / 32 == nb + 1) {
+                    static_for<8 * (nb + 1)>([&](auto kt) __attribute__((always_inline)) {
+                        const int kk = 4 * kt + lk;
+                        av[kt] = arow[kk < n ? kk : 0];
                     });
+                    static_for<8 * (nb + 1)>([&](auto kt) __attribute__((always_inline)) {
+                        const int kk = 4 * kt + lk;
+                        av[kt] = (rowok && kk < n) ? av[kt] : 0.0;
+                    });
+                    static_for<NKT - 8 * (nb + 1)>([&](auto kt) __attribute__((always_inline)) { av[8 * (nb + 1) + kt] = 0.0; });
                 }
             });
+            MPROF(0);
             for (int cb = 0; cb < n; cb += 64) {
                 const int rtop = (n - 1 < cb + 63) ? n - 1 : cb + 63;
                 WSYNC();   // the previous block's readers are done with ob
@@ -460,30 +471,31 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                     const int col = cb + 16 * ct + lr;
                     const bool colok = col < n;
                     const int klast = (n - 1 < cb + 16 * ct + 15) ? n - 1 : cb + 16 * ct + 15;
-                    auto fetch = [&](double (&bv)[8], int c8) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int kk = 4 * (8 * c8 + u) + lk;
-                            const bool ok = colok && kk <= col;
-                            const double v = Ro[ok ? roff(kk, n) + col : 0];
-                            bv[u] = ok ? v : 0.0;
-                        }
-                    };
+                    // (rows up to round_up(n,32) and columns up to round_up(n,16) of the square image exist and are zero outside
+                    //  the upper triangle: no masks, no per-load address arithmetic beyond base + k step.  One straight-line
+                    //  sequence per number of 32-row blocks this tile needs, chosen by a wave-uniform branch: with no control
+                    //  flow between the loads and the matrix instructions the waits count exactly, all loads of the tile
+                    //  are in flight before the first matrix instruction and each waits for its own operand only.)
+                    const double *bcol = Rsq + (size_t)lk * sq_ld + col;
+                    const int nblk = klast / 32 + 1;
                     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-                    constexpr int AHEAD = 3;          // blocks of eight k steps in flight ahead of the matrix instructions
-                    double bq[AHEAD + 1][8];
-                    static_for<AHEAD>([&](auto c8) __attribute__((always_inline)) { fetch(bq[c8], c8); });
-                    static_for<NKT / 8>([&](auto c8) __attribute__((always_inline)) {
-                        if (32 * c8 <= klast) {
-                            if constexpr (c8 + AHEAD < NKT / 8) fetch(bq[(c8 + AHEAD) % (AHEAD + 1)], c8 + AHEAD);   // (all lanes masked off beyond klast: a cached dummy address)
-                            static_for<8>([&](auto u) __attribute__((always_inline)) {
-                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[8 * c8 + u], bq[c8 % (AHEAD + 1)][u], acc, 0, 0, 0);
+                    static_for<NKT / 8>([&](auto nb) __attribute__((always_inline)) {
+                        if (nblk == nb + 1) {
+                            double bq[nb + 1][8];
+                            static_for<nb + 1>([&](auto c8) __attribute__((always_inline)) {
+                                static_for<8>([&](auto u) __attribute__((always_inline)) { bq[c8][u] = bcol[(size_t)(32 * c8 + 4 * u) * sq_ld]; });
+                            });
+                            static_for<nb + 1>([&](auto c8) __attribute__((always_inline)) {
+                                static_for<8>([&](auto u) __attribute__((always_inline)) {
+                                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[8 * c8 + u], bq[c8][u], acc, 0, 0, 0);
+                                });
                             });
                         }
                     });
                     static_for<4>([&](auto r) __attribute__((always_inline)) { ob[(lk + 4 * r) * 64 + 16 * ct + lr] = acc[(int)r]; });   // D: row (l>>4) + 4 reg, column l&15
                 }
                 WSYNC();
+                MPROF(1);
                 const int pairs = ((rtop - cb) >> 1) + 1;
                 for (int idx = lane; idx < pairs * KB; idx += 64) {
                     const int k = idx & (KB - 1), t = idx / KB;
@@ -495,8 +507,11 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                         Mq2[((size_t)(gi >> 6) * b.npair + (cb >> 1) + t) * 64 + (gi & 63)] = vpair;
                     }
                 }
+                MPROF(2);
             }
         }
+        if (b.prof && lane == 0) for (int i = 0; i < 3; ++i) b.prof[(size_t)q * 32 + 22 + i] = mp[i];
+#undef MPROF
     }
     if (flag > 0) {
         constexpr int KB = kSetupRows;
@@ -575,6 +590,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             }
         }
         __threadfence();   // phase B reads the image back through other lanes
+        GPROF(3);
         WSYNC();
         for (int tb = 0; tb < mA && flag > 0; tb += 64) {
             const int k = tb + lane;

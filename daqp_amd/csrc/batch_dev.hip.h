@@ -13,6 +13,8 @@ struct BatchDev {
     const int *sense_in;
     // LDP (persistent)
     double *Mblk;      // [N][nblk][npair][64][2]
+    float *M32;        // [N][nblk][nquad][64][4] the same image rounded to fp32 (workgroup kernel's screening scan), or null
+    int nquad;         // (npair + 1) / 2
     double *Rinv;      // [N][rtri]   packed upper R^-1, rows < ms normalised
     double *v;         // [N][n]
     double *scaling, *dupper, *dlower; // [N][m]

@@ -430,7 +430,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); delete b; return DAQP_EXIT_UNSUPPORTED; }
     BatchDev &d = b->d;
     d.N = N; d.n = n; d.m = m; d.ms = ms; d.cap = cap; d.mA = m - ms;
-    d.npair = (n + 1) / 2; d.nblk = (m + 63) / 64; d.ldr = n | 1;
+    d.npair = (n + 1) / 2; d.nblk = (m + 63) / 64; d.ldr = n | 1; d.nquad = (d.npair + 1) / 2;
     d.ltri = round_up(cap * (cap + 1) / 2, 2); d.rtri = n * (n + 1) / 2;   // even stride: 16-byte aligned rows for the direct HBM->LDS copy
     if (settings) d.st = *settings; else default_settings(&d.st);
     b->C = cap <= 64 ? 1 : (cap <= 128 ? 2 : 4);
@@ -494,6 +494,12 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &d.qs, Nn);
     if (b->spill) rc |= dev_alloc(b, &d.rowc_g, Nn * cap * d.ldr);
     if (b->setup_spill) rc |= dev_alloc(b, &d.setup_g, Nn * 2 * (size_t)round_up(d.rtri, 2));
+    // fp32 image of M for the workgroup kernel's screening scan (generic setup kernel only: it is the one that writes it)
+    if (b->use_wg && !b->fast_setup && !getenv("DAQP_AMD_NO_SCAN32")) {
+        const size_t cnt = Nn * (size_t)d.nblk * d.nquad * 256;
+        rc |= dev_alloc(b, &d.M32, cnt);
+        if (!rc) HIPCHK(hipMemset(d.M32, 0, cnt * sizeof(float)));
+    }
     if (!b->fast_setup) {   // zeroed once: the kernel only ever writes the upper triangle
         const size_t sq = Nn * (size_t)round_up(n, 32) * (size_t)round_up(n, 16);
         rc |= dev_alloc(b, &d.setup_sq, sq);

@@ -597,6 +597,8 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
             const bool own = k < mA;
             const int gi = ms + (own ? k : 0);
             double2 *rowp = Mq2 + ((size_t)(gi >> 6) * b.npair) * 64 + (gi & 63);
+            // fp32 image [row/64][col/4][row%64][col%4] for the workgroup kernel's screening scan, as float2 halves
+            float2 *row32 = b.M32 ? reinterpret_cast<float2 *>(b.M32 + (size_t)q * b.nblk * b.nquad * 256) + (((size_t)(gi >> 6) * b.nquad) * 64 + (gi & 63)) * 2 : nullptr;
             int rowbad = 0;
             if (own) {
                 double s = 0;
@@ -632,6 +634,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                             if (scale_it) { w.x *= scal; if (2 * t + 1 < n) w.y *= scal; }
                             if (!unc) { dsum += w.x * vv[2 * t]; if (2 * t + 1 < n) dsum += w.y * vv[2 * t + 1]; }
                             if (scale_it) rowp[(size_t)t * 64] = w;
+                            if (row32) row32[((size_t)(t >> 1) * 64) * 2 + (t & 1)] = make_float2((float)w.x, (2 * t + 1 < n) ? (float)w.y : 0.0f);
                         }
                     }
                 }
@@ -687,6 +690,10 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
                         vpair.y = (2 * t + 1 >= i && 2 * t + 1 < n) ? Ro[pi + 2 * t + 1] : 0.0;
                     }
                     dst[(size_t)t * 64] = vpair;
+                    if (b.M32) {
+                        float2 *d32 = reinterpret_cast<float2 *>(b.M32 + (size_t)q * b.nblk * b.nquad * 256) + (((size_t)(i >> 6) * b.nquad) * 64 + (i & 63)) * 2;
+                        d32[((size_t)(t >> 1) * 64) * 2 + (t & 1)] = make_float2((float)vpair.x, (float)vpair.y);
+                    }
                 }
             }
         }

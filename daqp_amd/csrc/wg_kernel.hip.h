@@ -67,6 +67,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
         }
         const size_t qfac = qf(b, q);
         c.Mblk = b.Mblk + qfac * b.nblk * b.npair * 128;
+        c.M32 = b.M32 ? b.M32 + qfac * b.nblk * b.nquad * 256 : nullptr; c.nquad = b.nquad;
         c.dupper = b.dupper + (size_t)q * m; c.dlower = b.dlower + (size_t)q * m; c.scaling = b.scaling + qfac * m;
         // ---- load the persistent iterate
         int *gsense = b.sense + (size_t)q * m;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
             w.c = c;
             w.t_start = __builtin_amdgcn_s_memrealtime();
             w.profiling = (b.prof != nullptr) && mode == 0;
-            if (w.profiling && lane < 16) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[lane] = 0;
+            if (w.profiling && lane < 20) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[lane] = 0;
             w.stp = b.st_dev;
             w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
             w.trace_cap = b.trace_cap; w.trace_len = 0;
@@ -126,7 +127,10 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
                 m_int[5] = w.lam_b; m_int[6] = w.overflow; m_int[7] = w.trace_len;
                 m_dbl[0] = w.fval; m_dbl[1] = w.soft;
                 SI(c, cmd)[0] = WG_EXIT;
-                if (w.profiling) for (int i = 0; i < 16; ++i) b.prof[(size_t)q * 32 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];
+                if (w.profiling) {
+                    for (int i = 0; i < 16; ++i) b.prof[(size_t)q * 32 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];
+                    for (int i = 16; i < 20; ++i) b.prof[(size_t)q * 32 + 9 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];   // [25..28]: scans, fp64 re-scans
+                }
             }
             __syncthreads();
         } else wg_serve<C>(c, b.st.primal_tol);

@@ -22,7 +22,7 @@
 
 namespace daqp_amd {
 
-enum : int { WG_EXIT = 0, WG_PRIMAL = 1, WG_SCAN = 2, WG_FETCH_GRAM = 3, WG_COMPACT = 4 };
+enum : int { WG_EXIT = 0, WG_PRIMAL = 1, WG_SCAN = 2, WG_FETCH_GRAM = 3, WG_COMPACT = 4, WG_SCAN32 = 5 };
 
 // LDS layout for working sets of up to 64*C rows.  Everything but the packed L sits at COMPILE-TIME offsets (vectors sized
 // for 64*C rows, u / m_new for n <= 256): an LDS address is then "immediate + 8*index", and nothing about the layout has to
@@ -33,7 +33,7 @@ struct WgL {
     static constexpr int CAP = 64 * C;
     // doubles
     static constexpr int D = 0, xl = CAP, zl = 2 * CAP, lamA = 3 * CAP, lamB = 4 * CAP, pend_lam = 5 * CAP, gram = 6 * CAP, u = 7 * CAP,
-                         mnew = u + 258, red = mnew + 258, cand = red + 64 * kWgMaxWaves, prof = cand + 2 * kWgMaxWaves, dend = prof + 16;
+                         mnew = u + 258, red = mnew + 258, cand = red + 64 * kWgMaxWaves, prof = cand + 8 * kWgMaxWaves, dend = prof + 20;
     // ints, counted from double offset dend
     static constexpr int ws = 0, slot = CAP, slot_id = 2 * CAP, freestk = 3 * CAP, pend_id = 4 * CAP, cmd = 5 * CAP, sense = 5 * CAP + 16;
 };
@@ -42,6 +42,8 @@ struct WgCtx {
     int n, m, ms, cap, capL, npair, nblk, ldr, capT, W, exact, oL, lmax;   // lmax: last valid index of packed L
     double *rowc, *rowcT;                 // this workgroup's scratch in HBM: [cap][ldr] and [n][capT]
     const double *Mblk, *dupper, *dlower, *scaling;
+    const float *M32;                     // fp32 image of M for the screening scan (null: every scan in fp64)
+    int nquad;
 };
 __device__ __forceinline__ double *wg_sm() { extern __shared__ __attribute__((aligned(16))) double wg_dyn_lds[]; return wg_dyn_lds; }
 #define SD(c, name) (wg_sm() + WgL<C>::name)
@@ -230,9 +232,92 @@ __device__ __forceinline__ void wg_scan(const WgCtx &c, double primal_tol)
     }
     wave_argmin(bv, bi, bup);
     if (lane == 0) {
-        SD(c, cand)[2 * wv] = bv;
-        reinterpret_cast<int *>(SD(c, cand) + 2 * wv + 1)[0] = bi;
-        reinterpret_cast<int *>(SD(c, cand) + 2 * wv + 1)[1] = bup;
+        SD(c, cand)[8 * wv] = bv;
+        reinterpret_cast<int *>(SD(c, cand) + 8 * wv + 1)[0] = bi;
+        reinterpret_cast<int *>(SD(c, cand) + 8 * wv + 1)[1] = bup;
+    }
+}
+
+// Screening scan in fp32 (default arithmetic mode): the same pass over an fp32 image of M, half the bytes.  It does not decide
+// anything the fp64 scan would decide differently: with E a rigorous bound on |M_r.u (fp32) - M_r.u (exact)| (unit rows:
+// E = (n/4 + 8) 2^-24 |u|), the master accepts its pick only if that row is the most violated one by more than 2E, violates
+// its own threshold by more than E and its side is unambiguous, accepts "nothing violated" only if every row clears its
+// threshold by more than E, and otherwise runs the fp64 scan above.  Each wave leaves in LDS: its best value s1 (as the
+// fp64 scan's candidate value, du - mu or mu - dl), row, side, the runner-up value s2, the smallest margin to the threshold
+// over its rows, the winner's own margin and side gap, and whether anything was not finite.
+template <int C>
+__device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol)
+{
+    const int wv = wg_wave(), lane = wg_lane(), n = c.n;
+    float *u32 = reinterpret_cast<float *>(SD(c, red));     // the reduction area is idle during a scan
+    for (int j = wg_tid(); j < 4 * c.nquad; j += 64 * c.W) u32[j] = (j < n) ? (float)SD(c, u)[j] : 0.0f;
+    __syncthreads();
+    const double ep = -primal_tol;
+    double s1 = DAQP_INF, s2 = DAQP_INF, minq = DAQP_INF, q1 = DAQP_INF, gap1 = 0.0;
+    int i1 = kBig, up1 = 0, bad = 0;
+    const float4 *u4 = reinterpret_cast<const float4 *>(u32);
+    constexpr int DEPTH = 32;   // 16-byte loads in flight per lane
+    for (int blk = (wv + c.W - 1) % c.W; blk < c.nblk; blk += c.W) {
+        const int r = blk * 64 + lane;
+        const bool own = r < c.m;
+        const int rr = own ? r : 0;
+        const float4 *src = reinterpret_cast<const float4 *>(c.M32) + ((size_t)blk * c.nquad) * 64 + lane;
+        const double du = c.dupper[rr], dl = c.dlower[rr], sc = c.scaling[rr];
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int t = 0;
+        for (; t + DEPTH <= c.nquad; t += DEPTH) {
+            float4 mm[DEPTH];
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) mm[q] = src[(size_t)(t + q) * 64];
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) {
+                const float4 uk = u4[t + q];
+                a0 = __builtin_fmaf(mm[q].x, uk.x, a0); a1 = __builtin_fmaf(mm[q].y, uk.y, a1);
+                a2 = __builtin_fmaf(mm[q].z, uk.z, a2); a3 = __builtin_fmaf(mm[q].w, uk.w, a3);
+            }
+        }
+        if (t < c.nquad) {
+            float4 mm[DEPTH];
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) { const int tt = (t + q < c.nquad) ? t + q : c.nquad - 1; mm[q] = src[(size_t)tt * 64]; }
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) {
+                const bool in = t + q < c.nquad;
+                const float4 uk = u4[in ? t + q : 0];
+                const float z = in ? 1.0f : 0.0f;       // (a repeated last load counts zero times)
+                a0 = __builtin_fmaf(mm[q].x * z, uk.x, a0); a1 = __builtin_fmaf(mm[q].y * z, uk.y, a1);
+                a2 = __builtin_fmaf(mm[q].z * z, uk.z, a2); a3 = __builtin_fmaf(mm[q].w * z, uk.w, a3);
+            }
+        }
+        const double mu = (double)((a0 + a1) + (a2 + a3));
+        if (own) {
+            const int sn = SI(c, sense)[r];
+            if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
+                if (!(mu - mu == 0.0)) bad = 1;
+                const double cu = du - mu, cl = mu - dl;
+                const bool isup = cu <= cl;
+                const double s = isup ? cu : cl, q = s - ep * sc, gap = isup ? cl - cu : cu - cl;
+                if (q < minq) minq = q;
+                if (s < s1) { s2 = s1; s1 = s; i1 = r; up1 = isup ? 1 : 0; q1 = q; gap1 = gap; }
+                else if (s < s2) s2 = s;
+            }
+        }
+    }
+    // the wave's best, runner-up and smallest margin
+    double bv = s1;
+    int bi = i1, aux = lane;
+    wave_argmin(bv, bi, aux);                       // aux: the lane that holds the winner
+    const double other = (lane == aux && bi != kBig) ? s2 : s1;
+    const double w2 = wave_min(other), wq = wave_min(minq);
+    const unsigned long long anybad = __ballot(bad);
+    const int src_lane = (bi == kBig) ? 0 : aux;
+    const double wq1 = rl(q1, src_lane), wgap = rl(gap1, src_lane);
+    const int wup = __builtin_amdgcn_readlane(up1, src_lane);
+    if (lane == 0) {
+        double *o = SD(c, cand) + 8 * wv;
+        o[0] = bv; o[1] = w2; o[2] = wq; o[3] = wq1; o[4] = wgap;
+        reinterpret_cast<int *>(o + 5)[0] = bi; reinterpret_cast<int *>(o + 5)[1] = wup;
+        reinterpret_cast<int *>(o + 6)[0] = anybad ? 1 : 0;
     }
 }
 
@@ -344,6 +429,7 @@ __device__ __forceinline__ void wg_do(const WgCtx &c, int code, double primal_to
     const double *lams = uni(SI(c, cmd)[5]) ? SD(c, lamB) : SD(c, lamA);
     if (code == WG_PRIMAL) wg_primal<C>(c, na, lams);
     else if (code == WG_SCAN) wg_scan<C>(c, primal_tol);
+    else if (code == WG_SCAN32) wg_scan32<C>(c, primal_tol);
     else if (code == WG_FETCH_GRAM) {
         wg_fetch_row<C>(c, a0, a1, true);
         __syncthreads();
@@ -909,14 +995,48 @@ template <int C>
 __device__ __forceinline__ int wscan(WgWave<C> &w, int &upper, bool with_fval)
 {
     const WgCtx &c = w.c;
+    const int lane = wg_lane(), kk = lane < c.W ? lane : 0;
+    if (c.M32 != nullptr && !c.exact) {
+        // fp32 screening pass first (see wg_scan32): its verdict stands only when it is certain
+        if (w.profiling && lane == 0) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[16] += 1;
+        wg_run(w, WG_SCAN32);
+        WPROF_T0(w);
+        if (with_fval) w.fval = und(wordered_norm2(w, w.soft));
+        double sq[4];
+        static_for<4>([&](auto cc) __attribute__((always_inline)) {
+            const int j = lane + 64 * cc;
+            const double uj = (j < c.n) ? SD(c, u)[j] : 0.0;
+            sq[cc] = uj * uj;
+        });
+        // |fl32(M_r . u) - M_r . u| <= (K + 5) 2^-24 sum_j |M_rj u_j| for fma chains of at most K terms, two rounded operands per
+        // term and a short tree of final additions; sum_j |M_rj u_j| <= |M_r| |u| and the rows are unit vectors.  K <= nquad.
+        const double E = 1.001 * (double)(c.nquad + 8) * 5.9604644775390625e-08 * sqrt(wsum<4>(sq)) + 1e-300;
+        const double *o = SD(c, cand) + 8 * kk;
+        double bv = o[0];
+        int bi = (lane < c.W) ? reinterpret_cast<const int *>(o + 5)[0] : kBig;
+        int aux = lane;
+        const int wbad = (lane < c.W) ? reinterpret_cast<const int *>(o + 6)[0] : 0;
+        const double mq = (lane < c.W) ? o[2] : (double)DAQP_INF;
+        wave_argmin(bv, bi, aux);
+        const double other = (lane < c.W) ? ((lane == aux && bi != kBig) ? o[1] : o[0]) : (double)DAQP_INF;
+        const double s2 = wave_min(other), minq = wave_min(mq);
+        const bool anybad = __ballot(wbad != 0) != 0;
+        const int wl = (bi == kBig) ? 0 : aux;
+        const double q1 = rl(o[3], wl), gap1 = rl(o[4], wl);
+        const int up1 = __builtin_amdgcn_readlane(reinterpret_cast<const int *>(o + 5)[1], wl);
+        if (!anybad && minq >= E) { upper = 0; WPROF_ACC(w, 12); return kBig; }                  // certainly nothing violated
+        if (!anybad && bi != kBig && bv + 2.0 * E < s2 && q1 < -E && gap1 > 2.0 * E) { upper = up1; WPROF_ACC(w, 12); return bi; }
+        with_fval = false;      // (already done above)
+        WPROF_ACC(w, 12);
+        if (w.profiling && lane == 0) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[17] += 1;
+    }
     wg_run(w, WG_SCAN);
     WPROF_T0(w);
     if (with_fval) w.fval = und(wordered_norm2(w, w.soft));
     // lane k <-> wave k's candidate; lowest value, then lowest row
-    const int lane = wg_lane(), kk = lane < c.W ? lane : 0;
-    double bv = SD(c, cand)[2 * kk];
-    int bi = (lane < c.W) ? reinterpret_cast<const int *>(SD(c, cand) + 2 * kk + 1)[0] : kBig;
-    int bup = reinterpret_cast<const int *>(SD(c, cand) + 2 * kk + 1)[1];
+    double bv = SD(c, cand)[8 * kk];
+    int bi = (lane < c.W) ? reinterpret_cast<const int *>(SD(c, cand) + 8 * kk + 1)[0] : kBig;
+    int bup = reinterpret_cast<const int *>(SD(c, cand) + 8 * kk + 1)[1];
     wave_argmin(bv, bi, bup);
     upper = bup;
     WPROF_ACC(w, 12);

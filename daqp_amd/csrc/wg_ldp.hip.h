@@ -447,8 +447,15 @@ __device__ __forceinline__ void wg_run(WgWave<C> &w, int code, int a0 = 0, int a
         SI(c, cmd)[5] = w.lam_b ? 0 : 1;   // which buffer holds lam*
     }
     __syncthreads();
+    const long long tA = w.profiling ? (long long)__builtin_readcyclecounter() : 0;
     wg_do<C>(c, code, w.stp->primal_tol);
+    const long long tB = w.profiling ? (long long)__builtin_readcyclecounter() : 0;
     __syncthreads();
+    if (w.profiling && (code == WG_SCAN32) && wg_lane() == 0) {
+        const long long tC = (long long)__builtin_readcyclecounter();
+        reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[18] += tB - tA;
+        reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[19] += tC - tB;
+    }
 }
 // everybody else: serve commands until the master says EXIT
 template <int C>

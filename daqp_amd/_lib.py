@@ -60,7 +60,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 EXPORTS = [
     "daqp_quadprog", "daqp_solve", "setup_daqp", "setup_daqp_main", "daqp_update_ldp", "daqp_default_settings",
     "allocate_daqp_settings", "free_daqp_workspace", "free_daqp_ldp", "daqp_primal_init_active",
-    "daqp_dual_init_active", "daqp_set_primal_start", "daqp_minrep", "allocate_daqp_workspace", "allocate_daqp_ldp", "daqp_first_violating", "daqp_batch_create", "daqp_batch_free", "daqp_batch_set_stream",
+    "daqp_dual_init_active", "daqp_set_primal_start", "daqp_minrep", "allocate_daqp_workspace", "allocate_daqp_ldp", "daqp_first_violating", "daqp_batch_create", "daqp_batch_free", "daqp_amd_release_pool", "daqp_batch_set_stream",
     "daqp_batch_set_settings", "daqp_batch_set_exact", "daqp_batch_setup", "daqp_batch_setup_shared", "daqp_batch_update", "daqp_batch_solve",
     "daqp_batch_setup_flags", "daqp_batch_working_sets", "daqp_batch_set_primal_start", "daqp_batch_prox_info", "daqp_quadprog_batch", "daqp_batch_kernel_ms",
     "daqp_batch_device_bytes", "daqp_amd_last_error", "daqp_amd_device_count", "daqp_amd_version",
@@ -147,6 +147,8 @@ def lib():
     L.daqp_batch_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci, C.POINTER(DAQPSettings), ci]
     L.daqp_batch_free.argtypes = [vp]
     L.daqp_batch_free.restype = None
+    L.daqp_amd_release_pool.argtypes = []
+    L.daqp_amd_release_pool.restype = None
     L.daqp_batch_set_stream.argtypes = [vp, vp]
     L.daqp_batch_set_stream.restype = None
     L.daqp_batch_set_settings.argtypes = [vp, C.POINTER(DAQPSettings)]

@@ -10,6 +10,8 @@
 #include <cstring>
 #include <mutex>
 #include <vector>
+#include <string>
+#include <mutex>
 
 #include "kernels.hip.h"
 #include "reg_kernel.hip.h"
@@ -112,6 +114,14 @@ struct DAQPBatch {
     int prox_outer = 0;            // outer iterations of the last solve (the longest loop of the batch)
     double *ident = nullptr;       // LP batches (H == NULL): the one n x n identity the setup pass reads as H
     // single-problem workspaces: results of the last daqp_ldp, waiting for daqp_extract_result
+    // single-problem batches (N == 1, the daqp_quadprog / setup_daqp path): one pinned host slab and one device slab each for
+    // the inputs and the results (one copy each way instead of six), and the pool key of a parked batch
+    char *pin_in = nullptr, *dev_in = nullptr, *pin_out = nullptr;
+    size_t in_cap = 0, out_bytes = 0;
+    double *dev_mir = nullptr, *pin_mir = nullptr;   // host mirrors of a single-problem workspace: gathered slab (k_mirror) and its pinned landing zone
+    hipEvent_t ev_in = nullptr;     // the last packed host->device copy (the pinned slab is free again once it has run)
+    std::string env_key;
+    int ns_max = 0;
     std::vector<double> one_lam;
     double one_fval = 0, one_soft = 0;
     int one_flag = 0, one_iter = 0;
@@ -393,6 +403,36 @@ int check_problem(const DAQPBatch *b, const DAQPBatchProblem *p)
 
 } // namespace
 
+namespace {
+// Parked single-problem batches.  daqp_quadprog creates and frees a workspace per call (api.c:61-104); on the GPU that is
+// ~40 hipMalloc / hipFree and four events per call, an order of magnitude more than the solve itself.  A freed batch of ONE
+// problem is parked here instead and handed to the next create with the same shape, device and environment switches.
+std::mutex g_pool_mu;
+std::vector<DAQPBatch *> g_pool;
+constexpr size_t kPoolMax = 8;
+bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && atoi(e) != 0); }
+std::string env_signature()
+{
+    static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32"};
+    std::string k;
+    for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
+    return k;
+}
+void destroy_batch(DAQPBatch *b)
+{
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    for (void *p : b->owned) (void)hipFree(p);
+    if (b->pin_in) (void)hipHostFree(b->pin_in);
+    if (b->pin_out) (void)hipHostFree(b->pin_out);
+    if (b->pin_mir) (void)hipHostFree(b->pin_mir);
+    if (b->ev_in) (void)hipEventDestroy(b->ev_in);
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+} // namespace
+
 extern "C" {
 
 const char *daqp_amd_last_error(void) { return g_err; }
@@ -424,9 +464,36 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         set_err("no HIP device: libdaqp_amd has no CPU path");
         return DAQP_EXIT_UNSUPPORTED;
     }
-    DAQPBatch *b = new DAQPBatch();
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    const std::string env_key = env_signature();
+    if (N == 1 && pool_enabled()) {
+        DAQPBatch *hit = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            for (size_t i = 0; i < g_pool.size(); ++i) {
+                DAQPBatch *c = g_pool[i];
+                if (c->device == device && c->d.n == n && c->d.m == m && c->d.ms == ms && c->ns_max == ns_max && c->env_key == env_key) {
+                    hit = c; g_pool.erase(g_pool.begin() + i); break;
+                }
+            }
+        }
+        if (hit) {
+            if (hipSetDevice(device) != hipSuccess) { destroy_batch(hit); set_err("hipSetDevice(%d) failed", device); return DAQP_EXIT_UNSUPPORTED; }
+            BatchDev &hd = hit->d;
+            if (settings) hd.st = *settings; else default_settings(&hd.st);
+            const char *ex = getenv("DAQP_AMD_EXACT");
+            hd.exact_setup = (ex && atoi(ex) != 0) ? 1 : 0;
+            // the iterate of the previous owner: gone (a fresh batch starts from zeros too)
+            if (hipMemcpyAsync(hit->st_dev, &hd.st, sizeof(DAQPSettings), hipMemcpyHostToDevice, hit->stream) != hipSuccess ||
+                hipMemsetAsync(hd.vecs, 0, (size_t)5 * hd.cap * sizeof(double), hit->stream) != hipSuccess ||
+                hipMemsetAsync(hd.qs, 0, sizeof(QState), hit->stream) != hipSuccess) { destroy_batch(hit); set_err("reset of a pooled workspace failed"); return DAQP_EXIT_UNSUPPORTED; }
+            *out = hit;
+            return 0;
+        }
+    }
+    DAQPBatch *b = new DAQPBatch();
     b->device = device;
+    b->env_key = env_key; b->ns_max = ns_max;
     if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); delete b; return DAQP_EXIT_UNSUPPORTED; }
     BatchDev &d = b->d;
     d.N = N; d.n = n; d.m = m; d.ms = ms; d.cap = cap; d.mA = m - ms;
@@ -505,12 +572,23 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         rc |= dev_alloc(b, &d.setup_sq, sq);
         if (!rc) HIPCHK(hipMemset(d.setup_sq, 0, sq * sizeof(double)));
     }
-    rc |= dev_alloc(b, &b->ox, Nn * n);
-    rc |= dev_alloc(b, &b->olam, Nn * m);
-    rc |= dev_alloc(b, &b->ofval, Nn);
-    rc |= dev_alloc(b, &b->osoft, Nn);
-    rc |= dev_alloc(b, &b->oflag, Nn);
-    rc |= dev_alloc(b, &b->oiter, Nn);
+    if (N == 1) {   // one slab: x[n] lam[m] fval soft | flag iter  -> one device->host copy per solve
+        double *slab = nullptr;
+        rc |= dev_alloc(b, &slab, (size_t)n + m + 3);
+        if (!rc) {
+            b->ox = slab; b->olam = slab + n; b->ofval = slab + n + m; b->osoft = slab + n + m + 1;
+            b->oflag = reinterpret_cast<int *>(slab + n + m + 2); b->oiter = b->oflag + 1;
+            b->out_bytes = ((size_t)n + m + 3) * sizeof(double);
+            if (hipHostMalloc(reinterpret_cast<void **>(&b->pin_out), b->out_bytes, hipHostMallocDefault) != hipSuccess) { b->pin_out = nullptr; b->out_bytes = 0; }
+        }
+    } else {
+        rc |= dev_alloc(b, &b->ox, Nn * n);
+        rc |= dev_alloc(b, &b->olam, Nn * m);
+        rc |= dev_alloc(b, &b->ofval, Nn);
+        rc |= dev_alloc(b, &b->osoft, Nn);
+        rc |= dev_alloc(b, &b->oflag, Nn);
+        rc |= dev_alloc(b, &b->oiter, Nn);
+    }
     rc |= dev_alloc(b, &b->st_dev, 1);
     rc |= dev_alloc(b, &b->d_dev, 1);
     rc |= dev_alloc(b, &b->px.counter, 4);
@@ -550,11 +628,32 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
 void daqp_batch_free(DAQPBatch *b)
 {
     if (!b) return;
-    (void)hipSetDevice(b->device);
-    (void)hipStreamSynchronize(b->stream);
-    for (void *p : b->owned) (void)hipFree(p);
-    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
-    delete b;
+    if (b->d.N == 1 && b->ev[3] != nullptr && pool_enabled()) {   // (fully constructed single-problem batch: park it)
+        (void)hipSetDevice(b->device);
+        (void)hipStreamSynchronize(b->stream);
+        b->stream = nullptr;
+        b->d.trace = nullptr; b->d.trace_cap = 0; b->d.prof = nullptr;
+        b->d.shared = 0; b->d.prox_pass = 0;
+        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->is_setup = false;
+        b->timed_setup = b->timed_solve = false; b->n_prox_qps = 0; b->prox_outer = 0;
+        b->one_fval = b->one_soft = 0; b->one_flag = b->one_iter = 0;
+        DAQPBatch *evict = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            g_pool.push_back(b);
+            if (g_pool.size() > kPoolMax) { evict = g_pool.front(); g_pool.erase(g_pool.begin()); }
+        }
+        if (evict) destroy_batch(evict);
+        return;
+    }
+    destroy_batch(b);
+}
+// really release every parked single-problem workspace (tests; a host that wants its device memory back)
+void daqp_amd_release_pool(void)
+{
+    std::vector<DAQPBatch *> all;
+    { std::lock_guard<std::mutex> lk(g_pool_mu); all.swap(g_pool); }
+    for (DAQPBatch *c : all) destroy_batch(c);
 }
 
 void daqp_batch_set_exact(DAQPBatch *b, int exact) { if (b) b->d.exact_setup = exact ? 1 : 0; }
@@ -662,12 +761,41 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
             HIPCHK(hipMemcpy(b->ident, eye.data(), eye.size() * sizeof(double), hipMemcpyHostToDevice));
         }
         d.H = b->ident;
-    } else rc |= stage(b, p->H, p->memory, N * d.n * d.n, &b->sH, &b->nH, &d.H);
-    rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &b->nf, &d.f);
-    rc |= stage(b, p->A, p->memory, N * d.mA * d.n, &b->sA, &b->nA, &d.A);
-    rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &b->nbu, &d.bu);
-    rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &b->nbl, &d.bl);
-    rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &b->nsense, &d.sense_in);
+    } else if (!(N == 1 && p->memory == DAQP_MEM_HOST)) rc |= stage(b, p->H, p->memory, N * d.n * d.n, &b->sH, &b->nH, &d.H);
+    if (N == 1 && p->memory == DAQP_MEM_HOST) {
+        // one problem from host memory: everything through ONE pinned slab and ONE copy (six pageable copies cost more than
+        // the kernels of a small problem)
+        const size_t nH = (lp ? 0 : (size_t)d.n * d.n), nf = d.n, nA = (size_t)d.mA * d.n, nb = d.m;
+        const size_t dbl = nH + nf + nA + 2 * nb, bytes = dbl * sizeof(double) + (p->sense ? nb * sizeof(int) : 0);
+        if (b->in_cap < bytes || b->pin_in == nullptr) {
+            if (b->ev_in) HIPCHK(hipEventSynchronize(b->ev_in));
+            if (b->pin_in) { (void)hipHostFree(b->pin_in); b->pin_in = nullptr; }
+            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&b->pin_in), bytes ? bytes : 8, hipHostMallocDefault));
+            if (slot_reserve(b, &b->dev_in, &b->in_cap, bytes ? bytes : 8)) return DAQP_EXIT_UNSUPPORTED;
+        }
+        if (b->ev_in == nullptr) HIPCHK(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
+        else HIPCHK(hipEventSynchronize(b->ev_in));      // the previous copy out of the slab has run
+        double *hp = reinterpret_cast<double *>(b->pin_in);
+        const double *dp = reinterpret_cast<const double *>(b->dev_in);
+        size_t o = 0;
+        if (!lp) { memcpy(hp + o, p->H, nH * sizeof(double)); d.H = dp + o; o += nH; }
+        if (p->f) { memcpy(hp + o, p->f, nf * sizeof(double)); d.f = dp + o; } else d.f = nullptr;
+        o += nf;
+        if (nA) memcpy(hp + o, p->A, nA * sizeof(double));
+        d.A = dp + o; o += nA;
+        if (nb) { memcpy(hp + o, p->bupper, nb * sizeof(double)); memcpy(hp + o + nb, p->blower, nb * sizeof(double)); }
+        d.bu = dp + o; d.bl = dp + o + nb; o += 2 * nb;
+        if (p->sense) { memcpy(hp + o, p->sense, nb * sizeof(int)); d.sense_in = reinterpret_cast<const int *>(dp + o); }
+        else d.sense_in = nullptr;
+        HIPCHK(hipMemcpyAsync(b->dev_in, b->pin_in, bytes, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipEventRecord(b->ev_in, b->stream));
+    } else {
+        rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &b->nf, &d.f);
+        rc |= stage(b, p->A, p->memory, N * d.mA * d.n, &b->sA, &b->nA, &d.A);
+        rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &b->nbu, &d.bu);
+        rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &b->nbl, &d.bl);
+        rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &b->nsense, &d.sense_in);
+    }
     if (rc) return DAQP_EXIT_UNSUPPORTED;
     b->was_shared = false;
     // DAQP_UPDATE_eliminate (daqp_quadprog, eq_elim.c): the reference projects many equalities out of the LDP first.  That
@@ -851,7 +979,19 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
     if (rc) return rc;
     HIPCHK(hipEventRecord(b->ev[3], b->stream));
     b->timed_solve = true;
-    if (!dev) {
+    if (!dev && d.N == 1 && b->pin_out != nullptr) {   // one problem: the result slab in one copy
+        HIPCHK(hipMemcpyAsync(b->pin_out, b->ox, b->out_bytes, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        const double *o = reinterpret_cast<const double *>(b->pin_out);
+        if (r->x) memcpy(r->x, o, d.n * sizeof(double));
+        if (r->lam && d.m) memcpy(r->lam, o + d.n, d.m * sizeof(double));
+        if (r->fval) *r->fval = o[d.n + d.m];
+        if (r->soft_slack) *r->soft_slack = o[d.n + d.m + 1];
+        const int *oi = reinterpret_cast<const int *>(o + d.n + d.m + 2);
+        if (r->exitflag) *r->exitflag = oi[0];
+        if (r->iter) *r->iter = oi[1];
+        r->solve_time = now_s() - t0;
+    } else if (!dev) {
         const size_t N = d.N;
         if (r->x) HIPCHK(hipMemcpyAsync(r->x, b->ox, N * d.n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
         if (r->lam) HIPCHK(hipMemcpyAsync(r->lam, b->olam, N * d.m * sizeof(double), hipMemcpyDeviceToHost, b->stream));
@@ -995,43 +1135,55 @@ static DAQPBatchProblem one_problem(const DAQPProblem *qp)
 // Host mirrors of the device state behind a single-problem workspace.  `ldp`: also the LDP itself (M, R^-1, v, d, scaling:
 // after a setup or an update; read-only copies for bindings that inspect them -- interfaces/daqp-eigen/daqp.cpp:250-271
 // reads Rinv / RinvD / v / sense -- writing to them does not reach the device).
-static void refresh_mirrors(DAQPWorkspace *w, bool ldp = false)
+static void refresh_mirrors(DAQPWorkspace *w, bool ldp = false, bool full = true)
 {
+    if (!ldp) full = false;
     DAQPBatch *b = ws_batch(w);
     if (!b) return;
-    QState qs;
     (void)hipSetDevice(b->device);
-    (void)hipStreamSynchronize(b->stream);
-    if (hipMemcpy(&qs, b->d.qs, sizeof(QState), hipMemcpyDeviceToHost) != hipSuccess) return;
+    const BatchDev &d = b->d;
+    const size_t dbl = mirror_doubles(d.n, d.m, d.ms, d.cap, d.rtri);
+    if (b->dev_mir == nullptr) {
+        if (dev_alloc(b, &b->dev_mir, dbl) || hipHostMalloc(reinterpret_cast<void **>(&b->pin_mir), dbl * sizeof(double), hipHostMallocDefault) != hipSuccess) return;
+    }
+    // one gather launch + one or two copies: the LDP part only when it may have changed (after a setup or an update), and
+    // of it R^-1 and M only when the caller says those changed too
+    const int blocks = full ? (int)(((size_t)(d.m - d.ms) * d.n + 255) / 256 > 64 ? 64 : ((size_t)(d.m - d.ms) * d.n + 255) / 256 + 1) : 1;
+    hipLaunchKernelGGL(k_mirror, dim3(blocks), dim3(256), 0, b->stream, d, b->dev_mir, ldp ? (full ? 2 : 1) : 0);
+    const size_t io = mirror_int_off(d.n, d.m, d.ms, d.cap, d.rtri);
+    if (ldp && full) {
+        if (hipMemcpyAsync(b->pin_mir, b->dev_mir, dbl * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return;
+    } else {   // head (scalars, lam_star and, with ldp, v / d / scaling) and tail (WS, sense)
+        const size_t head = mirror_ldp_off(d.cap) + (ldp ? (size_t)d.n + 3 * (size_t)d.m : 0);
+        if (hipMemcpyAsync(b->pin_mir, b->dev_mir, head * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return;
+        if (hipMemcpyAsync(b->pin_mir + io, b->dev_mir + io, (dbl - io) * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return;
+    }
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return;
+    QState qs;
+    memcpy(&qs, b->pin_mir, sizeof(QState));
     w->n_active = qs.n_active; w->reuse_ind = qs.reuse_ind; w->sing_ind = qs.sing_ind;
     w->iterations = qs.iterations; w->fval = qs.fval; w->soft_slack = qs.soft_slack;
-    if (w->WS) (void)hipMemcpy(w->WS, b->d.WS, sizeof(int) * b->d.cap, hipMemcpyDeviceToHost);
-    if (w->sense) (void)hipMemcpy(w->sense, b->d.sense, sizeof(int) * b->d.m, hipMemcpyDeviceToHost);
-    if (w->lam_star) {
-        const double *src = b->d.vecs + (qs.lam_swapped ? 3 : 4) * (size_t)b->d.cap;
-        (void)hipMemcpy(w->lam_star, src, sizeof(double) * b->d.cap, hipMemcpyDeviceToHost);
-    }
+    const int *ints = reinterpret_cast<const int *>(b->pin_mir + io);
+    if (w->WS) memcpy(w->WS, ints, sizeof(int) * d.cap);
+    if (w->sense) memcpy(w->sense, ints + d.cap, sizeof(int) * d.m);
+    if (w->lam_star) memcpy(w->lam_star, b->pin_mir + 16, sizeof(double) * d.cap);
     if (!ldp || qs.setup_flag < 0) return;
-    const BatchDev &d = b->d;
     const bool lp = b->ident && d.H == b->ident;
-    if (w->v) (void)hipMemcpy(w->v, d.v, sizeof(double) * d.n, hipMemcpyDeviceToHost);
-    if (w->dupper) (void)hipMemcpy(w->dupper, d.dupper, sizeof(double) * d.m, hipMemcpyDeviceToHost);
-    if (w->dlower) (void)hipMemcpy(w->dlower, d.dlower, sizeof(double) * d.m, hipMemcpyDeviceToHost);
-    if (w->scaling) (void)hipMemcpy(w->scaling, d.scaling, sizeof(double) * d.m, hipMemcpyDeviceToHost);
-    std::vector<double> R(d.rtri);
-    if (!lp && hipMemcpy(R.data(), d.Rinv, sizeof(double) * d.rtri, hipMemcpyDeviceToHost) == hipSuccess) {
+    const double *o = b->pin_mir + mirror_ldp_off(d.cap);
+    if (w->v) memcpy(w->v, o, sizeof(double) * d.n);
+    o += d.n;
+    if (w->dupper) memcpy(w->dupper, o, sizeof(double) * d.m);
+    if (w->dlower) memcpy(w->dlower, o + d.m, sizeof(double) * d.m);
+    if (w->scaling) memcpy(w->scaling, o + 2 * (size_t)d.m, sizeof(double) * d.m);
+    o += 3 * (size_t)d.m;
+    if (!full) return;
+    if (!lp) {
         if (qs.diag_h) {   // the reference's RinvD branch (utils.c:245-312): Rinv == NULL, RinvD = 1/sqrt(H_ii)
-            if (w->RinvD) for (int i = 0; i < d.n; ++i) w->RinvD[i] = R[((2 * d.n - i - 1) * i) / 2 + i];
-        } else if (w->Rinv) memcpy(w->Rinv, R.data(), sizeof(double) * d.rtri);
+            if (w->RinvD) for (int i = 0; i < d.n; ++i) w->RinvD[i] = o[((2 * d.n - i - 1) * i) / 2 + i];
+        } else if (w->Rinv) memcpy(w->Rinv, o, sizeof(double) * d.rtri);
     }
-    if (w->M && d.mA > 0) {   // the reference's layout: (m - ms) x n row-major, rows normalised
-        const size_t per = (size_t)d.nblk * d.npair * 128;
-        std::vector<double> blk(per);
-        if (hipMemcpy(blk.data(), d.Mblk, per * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess)
-            for (int r = d.ms; r < d.m; ++r)
-                for (int k = 0; k < d.n; ++k)
-                    w->M[(size_t)(r - d.ms) * d.n + k] = blk[(((size_t)(r >> 6) * d.npair + (k >> 1)) * 64 + (r & 63)) * 2 + (k & 1)];
-    }
+    o += d.rtri;
+    if (w->M && d.mA > 0) memcpy(w->M, o, sizeof(double) * (size_t)d.mA * d.n);   // (m - ms) x n row-major, rows normalised
 }
 
 void allocate_daqp_settings(DAQPWorkspace *work)
@@ -1117,7 +1269,7 @@ int daqp_update_ldp(const int mask, DAQPWorkspace *work, DAQPProblem *qp)
     int flag = 1;
     rc = daqp_batch_setup_flags(b, &flag);
     if (rc < 0) return rc;
-    refresh_mirrors(work, true);
+    refresh_mirrors(work, true, (m & (DAQP_UPDATE_Rinv | DAQP_UPDATE_M)) != 0);
     return flag < 0 ? flag : 0;
 }
 
@@ -1191,20 +1343,44 @@ void free_daqp_ldp(DAQPWorkspace *work)   // api.c:243-275
     work->M = work->dupper = work->dlower = work->scaling = work->v = work->Rinv = work->RinvD = nullptr;
 }
 
+// api.c:61-104.  One-shot: no workspace survives the call, so none of its host mirrors are built -- a (parked) single-problem
+// batch, one packed copy in, setup + solve launches, one packed copy out, one synchronisation.
 void daqp_quadprog(DAQPResult *res, DAQPProblem *qp, DAQPSettings *settings)
 {
-    DAQPWorkspace work;
-    memset(&work, 0, sizeof(work));
-    work.settings = settings;
     res->setup_time = 0; res->solve_time = 0;
-    const int flag = setup_daqp_main(qp, &work, &res->setup_time, DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate);
-    res->exitflag = flag;
-    if (flag >= 0) {
-        daqp_solve(res, &work);
-        if (settings != nullptr) work.settings = nullptr;
-        free_daqp_workspace(&work);
-        free_daqp_ldp(&work);
+    if (qp->problem_type != 0 || qp->nh > 1 || qp->break_points != nullptr || qp->f == nullptr) {
+        set_err("AVI / hierarchical problems and problems without a linear term are outside this path");
+        res->exitflag = DAQP_EXIT_UNSUPPORTED;
+        return;
     }
+    int ns = 0;
+    if (qp->sense)
+        for (int i = 0; i < qp->m; ++i) {
+            if (qp->sense[i] & DAQP_SOFT) ns++;
+            if (qp->sense[i] & DAQP_BINARY) { set_err("binary constraints are outside this path"); res->exitflag = DAQP_EXIT_UNSUPPORTED; return; }
+        }
+    const double t0 = now_s();
+    DAQPBatch *b = nullptr;
+    int rc = daqp_batch_create(&b, 1, qp->n, qp->m, qp->ms, ns, settings, -1);
+    if (rc < 0) { res->exitflag = rc; return; }
+    DAQPBatchProblem p = one_problem(qp);
+    rc = daqp_batch_setup(b, &p, DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate);
+    int flag = 1;
+    if (rc == 0) rc = daqp_batch_setup_flags(b, &flag);
+    res->setup_time = now_s() - t0;
+    if (rc < 0 || flag < 0) { res->exitflag = rc < 0 ? rc : flag; daqp_batch_free(b); return; }   // api.c:74-77: no solve after a failed setup
+    const double t1 = now_s();
+    DAQPBatchResult r;
+    memset(&r, 0, sizeof(r));
+    int iters = 0, eflag = 0;
+    r.x = res->x; r.lam = res->lam; r.fval = &res->fval; r.soft_slack = &res->soft_slack; r.exitflag = &eflag; r.iter = &iters;
+    r.memory = DAQP_MEM_HOST;
+    rc = daqp_batch_solve(b, &r);
+    res->exitflag = rc < 0 ? rc : eflag;
+    res->iter = iters;
+    res->nodes = b->n_prox_qps > 0 ? b->prox_outer : 1;
+    res->solve_time = now_s() - t1;
+    daqp_batch_free(b);
 }
 
 // warm-start helpers: pure host code on the caller's sense array (api.c:579-633)

@@ -720,6 +720,42 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
 }
 
 // ------------------------------------------------------------------------------------
+// k_mirror: everything a single-problem workspace shows its caller on the host (types.h:187-264: the iterate's scalars,
+// WS, sense, lam_star and, with `ldp`, v, d, scaling, R^-1 and M in the reference's row-major layout) gathered into ONE
+// slab, so that the host takes it in one copy instead of ten.  Problem 0 of the batch.
+//   doubles: [0,16) QState bytes | lam_star[cap] | v[n] dupper[m] dlower[m] scaling[m] Rinv[rtri] M[(m-ms) n] | ints: WS[cap] sense[m]
+// ------------------------------------------------------------------------------------
+__host__ __device__ inline size_t mirror_ldp_off(int cap) { return 16 + (size_t)cap; }
+__host__ __device__ inline size_t mirror_int_off(int n, int m, int ms, int cap, int rtri) { return mirror_ldp_off(cap) + n + 3 * (size_t)m + rtri + (size_t)(m - ms) * n; }
+__host__ __device__ inline size_t mirror_doubles(int n, int m, int ms, int cap, int rtri) { return mirror_int_off(n, m, ms, cap, rtri) + (size_t)(cap + m + 1) / 2 + 1; }
+__global__ __launch_bounds__(256) void k_mirror(BatchDev b, double *slab, int ldp)
+{
+    const int T = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = b.n, m = b.m, ms = b.ms, cap = b.cap;
+    const QState *qs = b.qs;
+    if (t0 < (int)(sizeof(QState) / sizeof(int))) reinterpret_cast<int *>(slab)[t0] = reinterpret_cast<const int *>(qs)[t0];
+    const double *lam = b.vecs + (qs->lam_swapped ? 3 : 4) * (size_t)cap;
+    for (int i = t0; i < cap; i += T) slab[16 + i] = lam[i];
+    int *io = reinterpret_cast<int *>(slab + mirror_int_off(n, m, ms, cap, b.rtri));
+    for (int i = t0; i < cap; i += T) io[i] = b.WS[i];
+    for (int i = t0; i < m; i += T) io[cap + i] = b.sense[i];
+    if (!ldp) return;
+    double *o = slab + mirror_ldp_off(cap);
+    for (int i = t0; i < n; i += T) o[i] = b.v[i];
+    o += n;
+    for (int i = t0; i < m; i += T) { o[i] = b.dupper[i]; o[m + i] = b.dlower[i]; o[2 * m + i] = b.scaling[i]; }
+    o += 3 * (size_t)m;
+    if (ldp < 2) return;
+    for (int i = t0; i < b.rtri; i += T) o[i] = b.Rinv[i];
+    o += b.rtri;
+    const int mA = m - ms;
+    for (size_t e = t0; e < (size_t)mA * n; e += T) {
+        const int r = ms + (int)(e / n), k = (int)(e % n);
+        o[e] = b.Mblk[(((size_t)(r >> 6) * b.npair + (k >> 1)) * 64 + (r & 63)) * 2 + (k & 1)];
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_update: DAQP_UPDATE_v and/or DAQP_UPDATE_d on an existing LDP (utils.c:58-221 with those masks)
 // ------------------------------------------------------------------------------------
 // daqp_batch_setup_shared: per-problem state after the ONE factorisation (done with wide-open bounds, so the sense it

@@ -189,6 +189,11 @@ typedef struct DAQPBatch DAQPBatch; /* device-resident workspaces of N problems 
 int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max,
                       const DAQPSettings *settings, int device);
 void daqp_batch_free(DAQPBatch *b);
+/* A freed batch of ONE problem (what daqp_quadprog and setup_daqp / free_daqp_workspace create and free per call -- reference
+ * api.c:61-104) is parked and handed to the next daqp_batch_create of the same shape, device and environment switches, so that
+ * repeated single solves do not pay ~40 hipMalloc / hipFree each.  At most 8 are kept; this releases them all now.
+ * Environment DAQP_AMD_NO_POOL=1 switches the parking off. */
+void daqp_amd_release_pool(void);
 /* hipStream_t the batch launches on (NULL: the legacy default stream). */
 void daqp_batch_set_stream(DAQPBatch *b, void *hip_stream);
 void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings);

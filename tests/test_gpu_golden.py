@@ -398,3 +398,35 @@ def test_two_batches_on_one_device_from_two_host_threads(oracle, gpu_lib, monkey
         q = qs[t]
         ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
         assert out[t] is not None and np.array_equal(out[t]["iter"], ref[4]) and bits_equal(out[t]["x"], ref[0])
+
+
+def test_quadprog_one_shot_reuses_parked_workspaces(oracle, gpu_lib, monkeypatch):
+    """daqp_quadprog creates and frees a workspace per call; here the freed single-problem batch is parked and reused.
+    Interleaved shapes, soft constraints, a settings change and an infeasible problem in between must all come out as
+    from fresh workspaces (bit-identical to the oracle), with and without the pool."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    shapes = [(10, 25, 5, 4), (7, 30, 0, 3), (10, 25, 5, 4), (20, 40, 8, 6), (7, 30, 0, 3)]
+    for pool in ("0", "1", "0"):
+        monkeypatch.setenv("DAQP_AMD_NO_POOL", "1" if pool == "0" else "0")
+        for rep in range(3):
+            for k, (n, m, ms, na) in enumerate(shapes):
+                q = O.generate_qp(n, m, ms, na, rng=[4400 + rep, k])
+                sense = np.zeros(m, np.int32)
+                if k == 3:
+                    sense[ms + 1] = 8   # one soft constraint: ns changes the workspace key
+                kw = {"iter_limit": 3} if (rep == 1 and k == 0) else {}
+                x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], sense, **kw)
+                ref = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], sense, settings=O.default_settings(**kw) if kw else None)
+                assert flag == ref[3] and info["iterations"] == ref[4], (pool, rep, k)
+                assert bits_equal(x, ref[0]) and bits_equal(info["lam"], ref[1]) and fval == ref[2]
+            # crossed bounds: the setup fails (-1), nothing is solved, and the parked workspace must stay usable
+            q = O.generate_qp(10, 25, 5, 4, rng=[4490, rep])
+            bu = q["bupper"].copy(); bu[7] = q["blower"][7] - 1.0
+            x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], bu, q["blower"], np.zeros(25, np.int32))
+            assert flag == -1
+    gpu_lib.daqp_amd_release_pool()
+    q = O.generate_qp(10, 25, 5, 4, rng=[4499, 0])
+    x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], np.zeros(25, np.int32))
+    ref = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], np.zeros(25, np.int32))
+    assert flag == ref[3] and bits_equal(x, ref[0])

@@ -10,7 +10,7 @@ for cfg in ("C1", "C2"):
     n, m, ms, na, seed, _ = O.CONFIGS[cfg]
     q = O.generate_qp(n, m, ms, na, rng=[seed, 0])
     args = (q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
-    for _ in range(5):
+    for _ in range(300):    # (the first few hundred calls of a process run slower: clocks, lazy loading)
         daqp_amd.solve(*args)
     t0 = time.perf_counter()
     K = 100
@@ -19,8 +19,8 @@ for cfg in ("C1", "C2"):
     t1 = time.perf_counter()
     mdl = daqp_amd.Model()
     mdl.setup(*args)
-    for _ in range(5):
-        mdl.solve()
+    for _ in range(300):
+        mdl.update(f=q["f"]); mdl.solve()
     t2 = time.perf_counter()
     for _ in range(K):
         mdl.update(f=q["f"]); mdl.solve()

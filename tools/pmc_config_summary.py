@@ -1,0 +1,60 @@
+"""profiles/r*_pmc_summary.json from the per-config PMC aggregates of tools/pmc_json.py:
+   python tools/pmc_config_summary.py <out.json> pmc_raw_C2.json pmc_raw_C3.json pmc_raw_C4.json pmc_raw_C5.json
+Per config: the solve launch's HBM bytes (FETCH_SIZE in KiB units, doubled for 16-byte coalesced reads on gfx950 as
+MI355X_MICROARCH.md prescribes, + WRITE_SIZE) and the issue-side counters that say what binds the kernel; the same for
+the setup launch.  bench.py quotes `traffic_bytes_per_launch` and `binding` of the newest summary."""
+import json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import CONFIGS
+
+out = sys.argv[1]
+SOLVE = {"C2": r"k_ldp_reg<3, 25", "C3": r"k_ldp_reg<1, 8", "C4": r"k_ldp_wg<4>", "C5": r"k_ldp_reg<3, 25"}
+SETUP = {"C2": r"k_setup_fast<56", "C3": r"k_setup_fast<16", "C4": r"k_setup<true>", "C5": r"k_setup_fast<56"}
+
+
+def pick(raw, pat):
+    for k, v in raw.items():
+        if re.search(pat, k):
+            return k, {c: x["mean"] for c, x in v.items()}
+    return None, {}
+
+
+def describe(c):
+    g = lambda k: c.get(k, 0.0)
+    d = {}
+    if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+        d["hbm_read_bytes"] = g("FETCH_SIZE") * 1024 * 2
+        d["hbm_written_bytes"] = g("WRITE_SIZE") * 1024
+    wc = g("SQ_WAVE_CYCLES")
+    if wc:
+        d["issue"] = {"active_inst_any_over_wave_cycles": g("SQ_ACTIVE_INST_ANY") / wc, "wait_any_over_wave_cycles": g("SQ_WAIT_ANY") / wc,
+                      "wait_inst_any_over_wave_cycles": g("SQ_WAIT_INST_ANY") / wc, "active_inst_valu_over_wave_cycles": g("SQ_ACTIVE_INST_VALU") / wc,
+                      "wait_inst_lds_over_wave_cycles": g("SQ_WAIT_INST_LDS") / wc, "active_inst_lds_over_wave_cycles": g("SQ_ACTIVE_INST_LDS") / wc}
+        d["instructions"] = {k: g("SQ_INSTS_" + k) for k in ("VALU", "SALU", "LDS", "VMEM")}
+        d["waves"] = g("SQ_WAVES")
+        if g("SQ_LDS_IDX_ACTIVE"):
+            d["lds_bank_conflict_over_lds_active"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+    return d
+
+
+res = {}
+for path in sys.argv[2:]:
+    cfg = re.search(r"(C\d)", os.path.basename(path)).group(1)
+    raw = json.load(open(path))
+    ks, cs = pick(raw, SOLVE[cfg])
+    kt, ct = pick(raw, SETUP[cfg])
+    s, t = describe(cs), describe(ct)
+    entry = {"batch": CONFIGS[cfg]["per_gpu"], "solve_kernel": ks, "setup_kernel": kt, "solve": s, "setup": t}
+    if "hbm_read_bytes" in s:
+        entry["traffic_bytes_per_launch"] = s["hbm_read_bytes"] + s["hbm_written_bytes"]
+    if "issue" in s:
+        i = s["issue"]
+        insts = sum(s["instructions"].values())
+        entry["binding"] = {"resource": "instruction issue + dependent-operation latency (one wave per SIMD holds the iterate in registers)" if cfg != "C4"
+                            else "per-CU memory pipeline (scan / row-cache reads at ~30 B/clk/CU) + the master wave's substitution chains",
+                            "frac": i["active_inst_any_over_wave_cycles"], "frac_is": "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of the solve launch",
+                            "wait_any_frac": i["wait_any_over_wave_cycles"], "valu_frac": i["active_inst_valu_over_wave_cycles"],
+                            "wave_instructions_per_qp": insts / entry["batch"]}
+    res[cfg] = entry
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))

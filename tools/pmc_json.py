@@ -19,8 +19,13 @@ for d in dirs:
 res = {}
 for k, cs in acc.items():
     name = re.sub(r"^void daqp_amd::|\(.*$", "", k)
-    # (the solve kernels are also launched as activation passes that return at once: keep the heavy dispatches of each counter)
-    heavy = {c: [x for x in v if x >= 0.5 * max(v)] for c, v in cs.items()}
+    # (the solve kernels are also launched as activation passes that return at once, and a warm-started sequence starts with one
+    #  cold solve: drop the near-empty dispatches of each counter, then keep those around the median of the rest)
+    def typical(v):
+        w = sorted(x for x in v if x >= 0.02 * max(v)) if max(v) > 0 else list(v)
+        med = w[len(w) // 2]
+        return [x for x in w if 0.5 * med <= x <= 1.5 * med] or w
+    heavy = {c: typical(v) for c, v in cs.items()}
     res[name] = {c: {"mean": sum(v) / len(v), "dispatches": len(v)} for c, v in sorted(heavy.items())}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: {c: round(v["mean"]) for c, v in cs.items()} for k, cs in res.items()}, indent=1))

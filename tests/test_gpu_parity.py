@@ -204,6 +204,48 @@ def test_degenerate_cases(oracle, gpu_lib):
     assert not mism, mism[:10]
 
 
+@pytest.mark.parametrize("exact", ["1", "0"])
+def test_degenerate_cases_workgroup_kernel(oracle, gpu_lib, monkeypatch, exact):
+    """the same families at n = 65 ... 130 (working sets beyond 64 rows: the workgroup kernel with two- and four-chunk
+    masters): near-duplicate rows at relative distance 1e-13 ... 1e-2, equalities (some dependent), soft rows.  Exact mode: bit
+    for bit; default mode: exit flag and iterations identical, x to 1e-9, the multipliers' combined effect A'lam to 1e-7.  The trace markers say which branches ran."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", exact)
+    mism, marks = [], set()
+    for trial in range(36):
+        rng = np.random.default_rng([199, trial])
+        eps = 10.0 ** rng.uniform(-13, -2)
+        n = int(rng.integers(65, 131)); m = int(rng.integers(n + 20, 3 * n)); ms = int(rng.integers(0, n // 3))
+        na = int(rng.integers(n // 4, n - 4))
+        q = O.generate_nasty(n, m, ms, na, eps, rng, n_dup=int(rng.integers(0, 6)), n_eq=int(rng.integers(0, 4)),
+                             n_soft=int(rng.integers(0, 4)), dep_eq=bool(rng.integers(0, 2)))
+        ns = int((q["sense"] & 8).astype(bool).sum())
+        bm = daqp_amd.BatchModel(1, n, m, ms, ns_max=ns)
+        bm.enable_trace(1 << 15)
+        bm.setup(q["H"][None], q["f"][None], q["A"][None], q["bupper"][None], q["blower"][None], q["sense"][None],
+                 init_mask=daqp_amd.UPDATE_unconstrained)
+        g = bm.solve()
+        tr = bm.read_trace(marks=True)[0]
+        marks |= {int(e) for e in tr if abs(int(e)) >= daqp_amd.api.TRACE_MARK}
+        bm.close()
+        r = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        flag, it = int(g["exitflag"][0]), int(g["iter"][0])
+        ok = flag == r[3] and it == r[4]
+        if ok and flag > 0:
+            if exact == "1":
+                ok = bits_equal(g["x"][0], r[0]) and bits_equal(g["lam"][0], r[1])
+            else:
+                # (near-duplicate active rows at relative distance down to 1e-13 share their multiplier in an ill-determined
+                #  way: lam may differ between two arithmetics by O(1) on such a pair while x agrees to 1e-14 -- compare x and
+                #  the multipliers' effect  sum_i lam_i [I; A]_i  =  -(H x + f))
+                G = np.vstack([np.eye(n)[:ms], q["A"]])
+                ok = np.abs(g["x"][0] - r[0]).max() < 1e-9 and np.abs(G.T @ (g["lam"][0] - r[1])).max() < 1e-7
+        if not ok:
+            mism.append((trial, n, m, ms, ns, flag, r[3], it, r[4]))
+    assert not mism, mism[:10]
+    assert len(marks) >= 1, "no degenerate branch was taken: the generator parameters no longer reach them"
+
+
 def test_warm_sequence(oracle, gpu_lib):
     """config 5: setup + cold solve, then f <- f + 0.05 N(0,I): update(v) + solve reusing the LDL' on the device"""
     import daqp_amd

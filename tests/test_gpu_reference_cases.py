@@ -150,7 +150,7 @@ def test_concurrent_host_threads(oracle, gpu_lib):
         assert same(out[t]["x"], r[0]) and same(out[t]["lam"], r[1])
 
 
-@pytest.mark.parametrize("shape", [(50, 150, 0, 20), (12, 48, 12, 6), (20, 40, 0, 8)])
+@pytest.mark.parametrize("shape", [(50, 150, 0, 20), (12, 48, 12, 6), (20, 40, 0, 8), (80, 200, 5, 30)])   # (the last one: generic setup + workgroup kernel)
 def test_shared_structure_batch(oracle, gpu_lib, shape):
     """condensed-MPC batches: ONE H and A, per-problem f and bounds.  daqp_batch_setup_shared is the
     reference's own MPC usage batched: factor once (setup_daqp with open bounds), then per problem

@@ -376,3 +376,37 @@ def test_full_size_properties(gpu_lib):
         assert bool((ax <= q["bupper"] + 1e-5).all()) and bool((ax >= q["blower"] - 1e-5).all())
         del q, g, Afull, kkt, ax
         torch.cuda.empty_cache()
+
+
+def test_full_size_warm_sequence(gpu_lib):
+    """config C5 at full size (100 000 QPs x 10 warm steps, f <- f + 0.05 N(0, I), factors and working sets kept on the
+    device): every step every QP optimal, KKT stationarity and primal feasibility for that step's f, and the warm
+    solves far cheaper than the cold one"""
+    import torch
+    import daqp_amd
+    from daqp_amd.synthetic import generate_batch_torch
+    N, n, m, ms, na, T = 100_000, 50, 150, 0, 20, 10
+    q = generate_batch_torch(N, n, m, ms, na, seed=11)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=daqp_amd.UPDATE_unconstrained)
+    g = bm.solve(out="torch")
+    assert bool((g["exitflag"] == 1).all())
+    cold = float(g["iter"].double().mean())
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    f = q["f"].clone()
+    warm = []
+    for t in range(T):
+        f = f + 0.05 * torch.randn(f.shape, dtype=torch.float64, device="cuda", generator=gen)
+        bm.update(f=f)
+        g = bm.solve(out="torch")
+        assert bool((g["exitflag"] == 1).all()), t
+        warm.append(float(g["iter"].double().mean()))
+        kkt = (q["H"] @ g["x"][:, :, None])[:, :, 0] + f + (q["A"].transpose(1, 2) @ g["lam"][:, :, None])[:, :, 0]
+        assert float(kkt.abs().max()) < 1e-5, t
+        ax = (q["A"] @ g["x"][:, :, None])[:, :, 0]
+        assert bool((ax <= q["bupper"] + 1e-5).all()) and bool((ax >= q["blower"] - 1e-5).all()), t
+        # complementarity: a non-zero multiplier sits on its bound
+        onb = torch.minimum((ax - q["bupper"]).abs(), (ax - q["blower"]).abs())
+        assert float((onb * (g["lam"] != 0)).max()) < 1e-5, t
+    assert max(warm) < 0.5 * cold, (cold, warm)
+    bm.close()

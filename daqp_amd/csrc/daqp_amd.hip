@@ -414,7 +414,7 @@ bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && 
 std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
-                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32"};
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -528,6 +528,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         if (const char *ce = getenv("DAQP_AMD_WG_CAPL")) { const int v = atoi(ce); if (v >= 2 && v < capL) capL = v; }   // (tests: force the hand-over)
         if (wg_lds_bytes(Cw, m, capL) <= lds_max && capL >= (cap < 48 ? cap : 48)) {
             b->use_wg = true; b->wg_W = W; b->wg_C = Cw;
+            { const char *iv = getenv("DAQP_AMD_WG_INVERSE"); d.wg_inverse = (iv && atoi(iv) == 0) ? 0 : 1; }   // default mode: L^-1 instead of L (wg_ldp.hip.h)
             d.wg_capL = capL; d.wg_capT = round_up(cap, 8);
             b->lds_wg = (size_t)wg_lds_bytes(Cw, m, capL);
         }

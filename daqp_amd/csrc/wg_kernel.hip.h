@@ -120,8 +120,11 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
             w.has_soft = has_soft;
             w.nfree = cap - na0; w.hi_slot = na0 - 1; w.overflow = 0;
             w.lam_b = uni(qs->lam_swapped) ? 1 : 0;
+            // inverse-factor representation: default arithmetic, cold start, no soft rows (wg_ldp.hip.h)
+            w.use_w = (b.wg_inverse && !c.exact && mode == 0 && na0 == 0 && !need_act && !has_soft) ? 1 : 0;
             int iters = 0;
-            const int flag = wrun(w, mode, need_act != 0, iters);   // (need_activate at mode 0: defensive, setup/update runs mode 1 itself)
+            const int flag = wrun(w, mode, need_act != 0, iters);
+            if (!w.overflow) wleave_w(w, w.na);                          // the stored iterate is always L   // (need_activate at mode 0: defensive, setup/update runs mode 1 itself)
             if (lane == 0) {
                 m_int[0] = flag; m_int[1] = iters; m_int[2] = w.na; m_int[3] = w.reuse; m_int[4] = w.sing;
                 m_int[5] = w.lam_b; m_int[6] = w.overflow; m_int[7] = w.trace_len;

@@ -22,7 +22,7 @@
 
 namespace daqp_amd {
 
-enum : int { WG_EXIT = 0, WG_PRIMAL = 1, WG_SCAN = 2, WG_FETCH_GRAM = 3, WG_COMPACT = 4, WG_SCAN32 = 5 };
+enum : int { WG_EXIT = 0, WG_PRIMAL = 1, WG_SCAN = 2, WG_FETCH_GRAM = 3, WG_COMPACT = 4, WG_SCAN32 = 5, WG_WCSP = 6, WG_WAPPEND = 7, WG_WDELETE = 8, WG_W2L = 9 };
 
 // LDS layout for working sets of up to 64*C rows.  Everything but the packed L sits at COMPILE-TIME offsets (vectors sized
 // for 64*C rows, u / m_new for n <= 256): an LDS address is then "immediate + 8*index", and nothing about the layout has to
@@ -32,7 +32,7 @@ template <int C>
 struct WgL {
     static constexpr int CAP = 64 * C;
     // doubles
-    static constexpr int D = 0, xl = CAP, zl = 2 * CAP, lamA = 3 * CAP, lamB = 4 * CAP, pend_lam = 5 * CAP, gram = 6 * CAP, u = 7 * CAP,
+    static constexpr int D = 0, xl = CAP, zl = 2 * CAP, lamA = 3 * CAP, lamB = 4 * CAP, pend_lam = 5 * CAP, gram = 6 * CAP, rhs = 7 * CAP, u = 8 * CAP,
                          mnew = u + 258, red = mnew + 258, cand = red + 64 * kWgMaxWaves, prof = cand + 8 * kWgMaxWaves, dend = prof + 20;
     // ints, counted from double offset dend
     static constexpr int ws = 0, slot = CAP, slot_id = 2 * CAP, freestk = 3 * CAP, pend_id = 4 * CAP, cmd = 5 * CAP, sense = 5 * CAP + 16;
@@ -48,6 +48,9 @@ struct WgCtx {
 __device__ __forceinline__ double *wg_sm() { extern __shared__ __attribute__((aligned(16))) double wg_dyn_lds[]; return wg_dyn_lds; }
 #define SD(c, name) (wg_sm() + WgL<C>::name)
 #define SDL(c) (wg_sm() + (c).oL)
+// index into packed L clamped to its LDS allocation: lanes whose row does not exist load anyway (the value is discarded),
+// so the address must stay inside the allocation
+#define WLIDX(c, e) ((e) < (c).lmax ? (e) : (c).lmax)
 #define SI(c, name) (reinterpret_cast<int *>(wg_sm() + WgL<C>::dend) + WgL<C>::name)
 
 // Thread coordinates as values the optimizer cannot see through.  Everything below runs inside two nested loops (the
@@ -74,6 +77,7 @@ struct WgWave {
     WgCtx c;
     int lam_b;                            // 1: lam lives in buffer B and lam* in buffer A (the reference swaps the two pointers on every add)
     int na, reuse, sing, has_soft, nfree, hi_slot, overflow;
+    int use_w;                            // 1: the LDS factor area holds W = L^-1 (default arithmetic, regular factor), see "inverse factor" below
     double fval, soft;
     const DAQPSettings *stp;              // device copy of the settings: scalar loads at the point of use
     int *trace; int trace_cap, trace_len;
@@ -421,6 +425,180 @@ __device__ __forceinline__ void wg_compact(const WgCtx &c, int r, int na)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Inverse factor (default arithmetic mode).  With L in LDS every iteration pays three or four substitution CHAINS on the
+// master wave -- na dependent readlane/fma steps each, ~60 k of the 111 k cycles of a C4 iteration, with seven waves
+// watching.  Carrying W = L^-1 (unit lower triangular, same packed storage) instead turns each of them into matrix-vector
+// products that the whole workgroup shares, with no cross-lane dependency at all:
+//   CSP          x = W rhs (only the rows that changed), z = x / D, lam* = W' z
+//   append       y = W g, l = y / D, d_new = g_nn - sum y_i l_i, new row of W = -l' W
+//   delete row r p = -W[r+1.., r] (the column IS L22^-1 l_r), the rank-one recurrences as prefix sums over
+//                t_j = 1/alpha_j (t' = t + p^2/D), then  new rows = K^-1 [W21 + p w_r' | W22]  as one sweep down each column:
+//                x = x0 - p_t s,  s += beta_t x  (s: the column's running sum; columns are independent)
+// Same mathematics, different rounding (results agree to ~1e-14; the exact mode keeps L and the reference's chains).
+// Anything irregular -- a singular or ill-conditioned pivot, pivot_last, refinement, re-activation -- first converts W back
+// to L (wg_w2l) and continues on the chains; so does the end of a solve, because the stored iterate is always L.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wred_sum(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
+}
+// rows from..na-1 of (W v) + v, one row per wave and trip: lanes <-> columns (adjacent lanes, adjacent addresses)
+template <int C, class F>
+__device__ __forceinline__ void wg_w_rows(const WgCtx &c, const double *vec, int from, int na, F &&out)
+{
+    const int wv = wg_wave(), lane = wg_lane();
+    double vr[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) { const int j = lane + 64 * cc; vr[cc] = (j < na) ? vec[j] : 0.0; }
+    for (int i = from + wv; i < na; i += c.W) {
+        double acc = 0;
+        const int base = tri(i);
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const int j = lane + 64 * cc;
+            if (64 * cc < i) { const double wij = SDL(c)[WLIDX(c, base + j)]; acc = __builtin_fma((j < i) ? wij : 0.0, vr[cc], acc); }
+        }
+        acc = wred_sum(acc);
+        out(i, acc + vec[i]);
+    }
+}
+// column j of (W' v): v_j + sum_{i > j} W[i][j] v_i, one thread per column
+template <int C>
+__device__ __forceinline__ double wg_w_col(const WgCtx &c, const double *vec, int j, int na)
+{
+    double a0 = vec[j], a1 = 0, a2 = 0, a3 = 0;
+    int i = j + 1;
+    for (; i + 3 < na; i += 4) {
+        a0 = __builtin_fma(SDL(c)[tri(i) + j], vec[i], a0);
+        a1 = __builtin_fma(SDL(c)[tri(i + 1) + j], vec[i + 1], a1);
+        a2 = __builtin_fma(SDL(c)[tri(i + 2) + j], vec[i + 2], a2);
+        a3 = __builtin_fma(SDL(c)[tri(i + 3) + j], vec[i + 3], a3);
+    }
+    for (; i < na; ++i) a0 = __builtin_fma(SDL(c)[tri(i) + j], vec[i], a0);
+    return (a0 + a1) + (a2 + a3);
+}
+template <int C>
+__device__ __forceinline__ void wg_wcsp(const WgCtx &c, int from, int na, double *lams)
+{
+    wg_w_rows<C>(c, SD(c, rhs), from, na, [&](int i, double xi) __attribute__((always_inline)) {
+        if (wg_lane() == 0) { SD(c, xl)[i] = xi; SD(c, zl)[i] = xi / SD(c, D)[i]; }
+    });
+    __syncthreads();
+    const int j = wg_tid();
+    if (j < na) lams[j] = wg_w_col<C>(c, SD(c, zl), j, na);
+}
+// after the Gram column: l and the new row of W; leaves sum_i y_i l_i in cand[0]
+template <int C>
+__device__ __forceinline__ void wg_wappend(const WgCtx &c, int na)
+{
+    const int tid = wg_tid();
+    double *gp = SD(c, pend_lam), *lv = SD(c, mnew), *pv = SD(c, red);
+    if (tid < na) gp[tid] = SD(c, gram)[SI(c, slot)[tid]];
+    __syncthreads();
+    wg_w_rows<C>(c, gp, 0, na, [&](int i, double yi) __attribute__((always_inline)) {
+        if (wg_lane() == 0) { const double li = yi / SD(c, D)[i]; lv[i] = li; pv[i] = yi * li; }
+    });
+    __syncthreads();
+    if (tid < na) SDL(c)[tri(na) + tid] = -wg_w_col<C>(c, lv, tid, na);
+    if (wg_wave() == c.W - 1) {
+        double s = 0;
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) { const int i = wg_lane() + 64 * cc; s += (i < na) ? pv[i] : 0.0; }
+        s = wred_sum(s);
+        if (wg_lane() == 0) SD(c, cand)[0] = s;
+    }
+}
+// delete row / column r (nupd = na - r - 1 >= 1 trailing rows; D[r] and the trailing D checked > 0 by the master)
+template <int C>
+__device__ __forceinline__ void wg_wdelete(const WgCtx &c, int r, int na)
+{
+    const int wv = wg_wave(), lane = wg_lane(), tid = wg_tid(), nupd = na - r - 1;
+    double *pvec = SD(c, gram), *bvec = SD(c, pend_lam), *wr = SD(c, mnew);
+    double *bnd0 = SD(c, xl) + r + 1, *bnd1 = SD(c, zl) + r + 1, *bnd2 = SD(c, red);
+    // phase 0: wave 0 -- p, the recurrences by prefix sums, the new pivots; the others -- row r and the columns at the chunk seams
+    if (wv == 0) {
+        double carry = 1.0 / SD(c, D)[r];            // t_0 = 1 / alpha_0
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            if (64 * cc < nupd) {
+                const int t = lane + 64 * cc;
+                const bool in = t < nupd;
+                const double p = in ? -SDL(c)[WLIDX(c, tri(r + 1 + t) + r)] : 0.0;
+                const double Dt = in ? SD(c, D)[r + 1 + t] : 1.0;
+                double sc = p * p / Dt;                                   // s_t
+                // inclusive prefix sum over the wave (Hillis-Steele through ds_bpermute: six steps)
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const double up = __shfl_up(sc, d); sc += (lane >= d) ? up : 0.0; }
+                const double tnext = carry + sc;                           // t_{t+1}
+                const double tprev = carry + __shfl_up(sc, 1) * (lane > 0 ? 1.0 : 0.0);   // t_t
+                const double tcur = (lane > 0) ? tprev : carry;
+                const double an = 1.0 / tnext, ac = 1.0 / tcur;
+                if (in) {
+                    pvec[t] = p;
+                    bvec[t] = p * an / Dt;                                 // beta_t
+                    SD(c, D)[r + t] = __builtin_fma(ac * p, p, Dt);        // dbar_t (position r + t in the new numbering)
+                }
+                carry = rl(tnext, 63);
+            }
+        }
+    } else {
+        for (int cidx = tid - 64; cidx < r; cidx += 64 * (c.W - 1)) wr[cidx] = SDL(c)[tri(r) + cidx];
+        for (int t = tid - 64; t < nupd; t += 64 * (c.W - 1)) {
+            const int ro = r + 1 + t;                                      // old row
+            static_for<C - 1>([&](auto k) __attribute__((always_inline)) {
+                constexpr int cb = 64 * (k + 1);                           // old column read by the last lane of chunk k
+                const double v = (cb < ro) ? SDL(c)[tri(ro) + cb] : 0.0;
+                if (k == 0) bnd0[t] = v; else if (k == 1) bnd1[t] = v; else bnd2[t] = v;
+            });
+        }
+    }
+    __syncthreads();
+    // phase 1: one thread per NEW column c' (old column c' or c' + 1), sweeping down the trailing rows
+    const int cn = tid;
+    if (cn < na - 1) {
+        const bool shift = cn >= r;
+        const int co = shift ? cn + 1 : cn;
+        const double wrc = shift ? 0.0 : wr[cn];
+        const bool seam = shift && (cn & 63) == 63;
+        const int k = cn >> 6;
+        const double *bnd = (k == 0) ? bnd0 : (k == 1 ? bnd1 : bnd2);
+        // (a column of W22 enters the sweep at its own unit diagonal: x = 1 there, so the running sum starts at beta of that row)
+        double s = shift ? bvec[cn - r] : 0.0;
+        int t = shift ? cn - r + 1 : 0;                                    // first new row below this column's diagonal: r + t > cn
+        for (; t < nupd; ++t) {
+            const int ro = r + 1 + t, rn = r + t;
+            const double w0 = seam ? bnd[t] : SDL(c)[tri(ro) + co];
+            const double pt = pvec[t], bt = bvec[t];
+            const double x0 = __builtin_fma(pt, wrc, w0);
+            const double x = __builtin_fma(-pt, s, x0);
+            s = __builtin_fma(bt, x, s);
+            SDL(c)[tri(rn) + cn] = x;
+        }
+    }
+}
+// W -> L in place (rows top to bottom: L[i][j] = -W[i][j] - sum_{j<k<i} W[i][k] L[k][j]), nrows rows
+template <int C>
+__device__ __forceinline__ void wg_w2l(const WgCtx &c, int nrows)
+{
+    const int tid = wg_tid();
+    double *wrow = SD(c, mnew);
+    for (int i = 1; i < nrows; ++i) {
+        if (tid < i) wrow[tid] = SDL(c)[tri(i) + tid];
+        __syncthreads();
+        if (tid < i) {
+            double acc = -wrow[tid];
+            for (int k = tid + 1; k < i; ++k) acc = __builtin_fma(-wrow[k], SDL(c)[tri(k) + tid], acc);
+            SDL(c)[tri(i) + tid] = acc;
+        }
+        __syncthreads();
+    }
+}
+
 // one command, executed by every wave (the master included)
 template <int C>
 __device__ __forceinline__ void wg_do(const WgCtx &c, int code, double primal_tol)
@@ -435,6 +613,15 @@ __device__ __forceinline__ void wg_do(const WgCtx &c, int code, double primal_to
         __syncthreads();
         wg_gram<C>(c, a0, hi);
     } else if (code == WG_COMPACT) wg_compact<C>(c, a0, na);
+    else if (code == WG_WCSP) wg_wcsp<C>(c, a0, na, const_cast<double *>(lams));
+    else if (code == WG_WAPPEND) {
+        wg_fetch_row<C>(c, a0, a1, true);
+        __syncthreads();
+        wg_gram<C>(c, a0, hi);
+        __syncthreads();
+        wg_wappend<C>(c, na);
+    } else if (code == WG_WDELETE) wg_wdelete<C>(c, a0, na);
+    else if (code == WG_W2L) wg_w2l<C>(c, a0);
 }
 
 // master side: post a command, take part in it
@@ -474,9 +661,6 @@ __device__ __forceinline__ void wg_serve(const WgCtx &c, double primal_tol)
 // master: the serial part of the iteration on wave 0 (lane + 64 c <-> working-set position), L and the vectors in LDS
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kWPre = 8;
-// index into packed L clamped to its LDS allocation: the chains below load a lane's entry whether or not the lane's row
-// exists (the result is discarded by a select or never read), so the address must stay inside the allocation
-#define WLIDX(c, e) ((e) < (c).lmax ? (e) : (c).lmax)
 
 // Cross-lane reads of a vector held as a[cc] in lane (idx & 63), chunk (idx >> 6).  A register array must never be indexed
 // with a run-time value -- "v = a[0]; if (chunk == 1) v = a[1]; ..." is folded into exactly that, the array moves to scratch
@@ -527,10 +711,45 @@ __device__ __forceinline__ double wsum(const double (&a)[C])
     return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
 }
 
+// leave the inverse-factor representation: W -> L over the first `rows` rows, then the chains take over for the rest of the solve
+template <int C>
+__device__ __forceinline__ void wleave_w(WgWave<C> &w, int rows)
+{
+    if (!w.use_w) return;
+    wg_run(w, WG_W2L, rows);
+    w.use_w = 0;
+}
+
 // LDL' row append (factorization.c:21-111)
 template <int C>
 __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
 {
+    if (w.use_w) {   // inverse factor: Gram column, l = D^-1 W g, new row of W = -l' W, all in one command
+        const WgCtx &c = w.c;
+        const int lane = wg_lane(), na = w.na;
+        if (na >= c.capL) { w.overflow = 1; return; }
+        const int newslot = uni(SI(c, freestk)[w.nfree - 1]);
+        w.nfree--;
+        if (newslot > w.hi_slot) w.hi_slot = newslot;
+        if (lane == 0) {
+            SI(c, slot)[na] = newslot; SI(c, slot_id)[newslot] = id;
+            SD(c, rhs)[na] = (SI(c, sense)[id] & DAQP_LOWER) ? -c.dlower[id] : -c.dupper[id];
+        }
+        WPROF_T0(w);
+        wg_run(w, WG_WAPPEND, id, newslot);
+        WPROF_ACC(w, 8);
+        w.sing = kEmpty;
+        const double dnew = und(SD(c, gram)[newslot] - SD(c, cand)[0]);
+        if (ub(dnew < w.stp->sing_tol) || na >= c.n) {
+            // a singular pivot: back to L (the new row included: its L entries are l), then as the chains would leave it
+            wleave_w(w, na + 1);
+            if (lane == 0) SD(c, D)[na] = 0;
+            w.sing = na;
+        } else if (lane == 0) SD(c, D)[na] = dnew;
+        WSYNC();
+        WPROF_ACC(w, 9);
+        return;
+    }
     const WgCtx &c = w.c;
     const int lane = wg_lane(), na = w.na, n = c.n, base = tri(na);
     if (na >= c.capL) { w.overflow = 1; return; }          // packed L would outgrow its LDS: the one-wave kernel takes this problem
@@ -624,6 +843,22 @@ __device__ __forceinline__ void wldl_delete(WgWave<C> &w, int r)
     const int lane = wg_lane(), na = w.na;
     if (na == r + 1) return;
     const int nupd = na - r - 1;
+    if (w.use_w) {
+        // the prefix-sum form of the recurrences needs D[r] > 0 and a positive trailing block
+        double dmin = SD(c, D)[r];
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const int t = lane + 64 * cc;
+            if (t < nupd) { const double dt = SD(c, D)[r + 1 + t]; dmin = dt < dmin ? dt : dmin; }
+        }
+        if (ub(wave_min(dmin) > 1e-200)) {
+            WPROF_T0(w);
+            wg_run(w, WG_WDELETE, r);
+            WPROF_ACC(w, 11);
+            return;
+        }
+        wleave_w(w, na);
+    }
     double wv[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
@@ -700,23 +935,24 @@ __device__ __forceinline__ int wdrop_core(WgWave<C> &w, int r)
     wldl_delete(w, r);
     w.na--;
     int wsn[C], sln[C];
-    double lmn[C];
+    double lmn[C], rhn[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
         const int i = lane + 64 * cc;
-        wsn[cc] = 0; sln[cc] = 0; lmn[cc] = 0;
-        if (i >= r && i < w.na) { wsn[cc] = SI(c, ws)[i + 1]; sln[cc] = SI(c, slot)[i + 1]; lmn[cc] = WLAM(w)[i + 1]; }
+        wsn[cc] = 0; sln[cc] = 0; lmn[cc] = 0; rhn[cc] = 0;
+        if (i >= r && i < w.na) { wsn[cc] = SI(c, ws)[i + 1]; sln[cc] = SI(c, slot)[i + 1]; lmn[cc] = WLAM(w)[i + 1]; rhn[cc] = SD(c, rhs)[i + 1]; }
     }
     WSYNC();
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
         const int i = lane + 64 * cc;
-        if (i >= r && i < w.na) { SI(c, ws)[i] = wsn[cc]; SI(c, slot)[i] = sln[cc]; WLAM(w)[i] = lmn[cc]; }
+        if (i >= r && i < w.na) { SI(c, ws)[i] = wsn[cc]; SI(c, slot)[i] = sln[cc]; WLAM(w)[i] = lmn[cc]; SD(c, rhs)[i] = rhn[cc]; }
     }
     if (r < w.reuse) w.reuse = r;
     int took = 0;
     WSYNC();
     if (w.na > 0 && ub(SD(c, D)[w.na - 1] < w.stp->sing_tol)) {
+        wleave_w(w, w.na);
         w.sing = w.na - 1;
         took = 1;
     }
@@ -854,6 +1090,13 @@ __device__ __forceinline__ void wdirection(WgWave<C> &w)
     const WgCtx &c = w.c;
     const int lane = wg_lane(), na = w.na;
     const bool regular = (w.sing == kEmpty);
+    if (w.use_w) {    // (regular by construction: a singular pivot leaves the inverse-factor representation at once)
+        WPROF_T0(w);
+        wg_run(w, WG_WCSP, w.reuse);
+        WPROF_ACC(w, 7);
+        w.reuse = na;
+        return;
+    }
     double b[C];
     int cnt;
     if (regular) {
@@ -1115,6 +1358,7 @@ __device__ __forceinline__ void wreset_ws(WgWave<C> &w)
 {
     const WgCtx &c = w.c;
     w.sing = kEmpty; w.na = 0; w.reuse = 0;
+    w.use_w = 0;   // (an empty factor is an empty factor; what follows -- re-activation -- stays on the chains)
     // every slot of the scratch is free again, lowest on top
     for (int i = wg_lane(); i < c.cap; i += 64) SI(c, freestk)[i] = c.cap - 1 - i;
     w.nfree = c.cap; w.hi_slot = -1;
@@ -1214,6 +1458,7 @@ __device__ __forceinline__ int wrun(WgWave<C> &w, int mode, bool need_activate, 
                     }
                     if (w.na > 0 && ub(dmin < w.stp->pivot_tol)) {
                         wtrace(w, kTraceRefine);
+                        wleave_w(w, w.na);
                         wrefine_active(w);
                         scan_first = 0; after_edit = WAFTER_NEXT_ITER; tl_skip = 1;
                         pc = WPC_SCAN;
@@ -1251,6 +1496,7 @@ __device__ __forceinline__ int wrun(WgWave<C> &w, int mode, bool need_activate, 
                         piv = ub(dr < w.stp->pivot_tol && dr < dlast);
                     }
                     if (piv) {
+                        wleave_w(w, w.na);
                         wtrace(w, kTracePivot);
                         if (lane == 0) { SI(c, pend_id)[depth] = SI(c, ws)[r]; SD(c, pend_lam)[depth] = WLAM(w)[r]; }
                         depth++;

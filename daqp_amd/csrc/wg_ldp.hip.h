@@ -447,7 +447,8 @@ __device__ __forceinline__ double wred_sum(double v)
     v += dpp_f64<0x140>(v);
     return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
 }
-// rows from..na-1 of (W v) + v, one row per wave and trip: lanes <-> columns (adjacent lanes, adjacent addresses)
+// rows from..na-1 of (W v) + v: four rows per wave and trip (their reductions overlap), lanes <-> columns (adjacent lanes,
+// adjacent addresses)
 template <int C, class F>
 __device__ __forceinline__ void wg_w_rows(const WgCtx &c, const double *vec, int from, int na, F &&out)
 {
@@ -455,71 +456,119 @@ __device__ __forceinline__ void wg_w_rows(const WgCtx &c, const double *vec, int
     double vr[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) { const int j = lane + 64 * cc; vr[cc] = (j < na) ? vec[j] : 0.0; }
-    for (int i = from + wv; i < na; i += c.W) {
-        double acc = 0;
-        const int base = tri(i);
+    for (int i0 = from + 4 * wv; i0 < na; i0 += 4 * c.W) {
+        double acc[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) {
-            const int j = lane + 64 * cc;
-            if (64 * cc < i) { const double wij = SDL(c)[WLIDX(c, base + j)]; acc = __builtin_fma((j < i) ? wij : 0.0, vr[cc], acc); }
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q;
+            const int base = tri(i);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                const int j = lane + 64 * cc;
+                if (64 * cc < i && i < na) { const double wij = SDL(c)[WLIDX(c, base + j)]; acc[q] = __builtin_fma((j < i) ? wij : 0.0, vr[cc], acc[q]); }
+            }
         }
-        acc = wred_sum(acc);
-        out(i, acc + vec[i]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = wred_sum(acc[q]);
+        // lane q finishes row i0 + q (whatever `out` does -- a division, a store -- happens once for the four rows)
+        const double mine = (lane == 0) ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+        const int irow = i0 + (lane & 3);
+        if (lane < 4 && irow < na) out(irow, mine + vec[irow]);
     }
 }
-// column j of (W' v): v_j + sum_{i > j} W[i][j] v_i, one thread per column
-template <int C>
-__device__ __forceinline__ double wg_w_col(const WgCtx &c, const double *vec, int j, int na)
+// (W' v)_j = v_j + sum_{i > j} W[i][j] v_i for every column: thread <-> column (adjacent lanes, adjacent addresses), the rows cut
+// into slices over the waves that the columns leave idle; partial sums meet in `red`.  All threads; two barriers inside.
+template <int C, class F>
+__device__ __forceinline__ void wg_w_cols(const WgCtx &c, const double *vec, int na, F &&out)
 {
-    double a0 = vec[j], a1 = 0, a2 = 0, a3 = 0;
-    int i = j + 1;
-    for (; i + 3 < na; i += 4) {
-        a0 = __builtin_fma(SDL(c)[tri(i) + j], vec[i], a0);
-        a1 = __builtin_fma(SDL(c)[tri(i + 1) + j], vec[i + 1], a1);
-        a2 = __builtin_fma(SDL(c)[tri(i + 2) + j], vec[i + 2], a2);
-        a3 = __builtin_fma(SDL(c)[tri(i + 3) + j], vec[i + 3], a3);
+    const int wv = wg_wave(), lane = wg_lane(), tid = wg_tid();
+    const int chunks = (na + 63) >> 6;              // <= 3: the inverse factor is only carried while na <= 192
+    // waves per 64-column chunk in proportion to the rows below the chunk's first diagonal entry (chunk 0 of a 135-row W has
+    // 134 rows to sum, chunk 2 has six): waves [0,b1) serve chunk 0, [b1,b2) chunk 1, [b2,W) chunk 2 (scalars only: a
+    // run-time indexed table would live in scratch memory)
+    int b1 = c.W, b2 = c.W;
+    if (chunks == 2) {
+        b1 = (na * c.W + (2 * na - 64) / 2) / (2 * na - 64);
+        b1 = b1 < 1 ? 1 : (b1 > c.W - 1 ? c.W - 1 : b1);
+    } else if (chunks >= 3) {
+        const int total = 3 * na - 192;
+        b1 = (na * c.W + total / 2) / total;
+        b1 = b1 < 1 ? 1 : (b1 > c.W - 2 ? c.W - 2 : b1);
+        b2 = ((2 * na - 64) * c.W + total / 2) / total;
+        b2 = b2 < b1 + 1 ? b1 + 1 : (b2 > c.W - 1 ? c.W - 1 : b2);
     }
-    for (; i < na; ++i) a0 = __builtin_fma(SDL(c)[tri(i) + j], vec[i], a0);
-    return (a0 + a1) + (a2 + a3);
+    const int chunk = wv < b1 ? 0 : (wv < b2 ? 1 : 2);
+    const int wfirst = chunk == 0 ? 0 : (chunk == 1 ? b1 : b2), wend = chunk == 0 ? b1 : (chunk == 1 ? b2 : c.W);
+    const int nsl = wend - wfirst, slice = wv - wfirst;
+    double *part = SD(c, red);                      // [wave][64]
+    if (chunk < chunks) {
+        const int j = chunk * 64 + lane;
+        const int rows0 = 64 * chunk + 1, span = na - rows0;          // rows rows0 .. na-1 concern this chunk
+        const int per = (span + nsl - 1) / (nsl > 0 ? nsl : 1);
+        int lo = rows0 + slice * per, hi = lo + per < na ? lo + per : na;
+        if (lo < j + 1) lo = j + 1;
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (j < na) {
+            int i = lo;
+            const double *wp = SDL(c) + tri(i) + j;          // W[i][j]; the next row is i + 1 doubles further
+            for (; i + 7 < hi; i += 8) {                     // eight rows in flight per trip
+                double wv8[8], vv8[8];
+                const double *q = wp;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { wv8[k] = *q; vv8[k] = vec[i + k]; q += i + k + 1; }
+                wp = q;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = __builtin_fma(wv8[k], vv8[k], a[k]);
+            }
+            for (; i < hi; ++i) { a[0] = __builtin_fma(*wp, vec[i], a[0]); wp += i + 1; }
+        }
+        part[wv * 64 + lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    __syncthreads();
+    if (tid < na) {
+        const int ck = tid >> 6;
+        const int f0 = ck == 0 ? 0 : (ck == 1 ? b1 : b2), f1 = ck == 0 ? b1 : (ck == 1 ? b2 : c.W);
+        double sum = vec[tid];
+        for (int g = f0; g < f1; ++g) sum += part[g * 64 + (tid & 63)];
+        out(tid, sum);
+    }
+    __syncthreads();
 }
 template <int C>
 __device__ __forceinline__ void wg_wcsp(const WgCtx &c, int from, int na, double *lams)
 {
     wg_w_rows<C>(c, SD(c, rhs), from, na, [&](int i, double xi) __attribute__((always_inline)) {
-        if (wg_lane() == 0) { SD(c, xl)[i] = xi; SD(c, zl)[i] = xi / SD(c, D)[i]; }
+        SD(c, xl)[i] = xi; SD(c, zl)[i] = xi / SD(c, D)[i];
     });
     __syncthreads();
-    const int j = wg_tid();
-    if (j < na) lams[j] = wg_w_col<C>(c, SD(c, zl), j, na);
+    wg_w_cols<C>(c, SD(c, zl), na, [&](int j, double v) __attribute__((always_inline)) { lams[j] = v; });
 }
-// after the Gram column: l and the new row of W; leaves sum_i y_i l_i in cand[0]
+// after the Gram column: l and the new row of W; leaves each wave's part of sum_i y_i l_i in cand[wave]
 template <int C>
 __device__ __forceinline__ void wg_wappend(const WgCtx &c, int na)
 {
     const int tid = wg_tid();
-    double *gp = SD(c, pend_lam), *lv = SD(c, mnew), *pv = SD(c, red);
+    double *gp = SD(c, pend_lam), *lv = SD(c, mnew);
     if (tid < na) gp[tid] = SD(c, gram)[SI(c, slot)[tid]];
     __syncthreads();
+    double dpart = 0;                      // (lanes 0..3 of every wave each carry the rows they finished)
     wg_w_rows<C>(c, gp, 0, na, [&](int i, double yi) __attribute__((always_inline)) {
-        if (wg_lane() == 0) { const double li = yi / SD(c, D)[i]; lv[i] = li; pv[i] = yi * li; }
+        const double li = yi / SD(c, D)[i];
+        dpart = __builtin_fma(yi, li, dpart);
+        lv[i] = li;
     });
+    dpart = wred_sum(wg_lane() < 4 ? dpart : 0.0);
+    if (wg_lane() == 0) SD(c, cand)[wg_wave()] = dpart;
     __syncthreads();
-    if (tid < na) SDL(c)[tri(na) + tid] = -wg_w_col<C>(c, lv, tid, na);
-    if (wg_wave() == c.W - 1) {
-        double s = 0;
-#pragma unroll
-        for (int cc = 0; cc < C; ++cc) { const int i = wg_lane() + 64 * cc; s += (i < na) ? pv[i] : 0.0; }
-        s = wred_sum(s);
-        if (wg_lane() == 0) SD(c, cand)[0] = s;
-    }
+    wg_w_cols<C>(c, lv, na, [&](int j, double v) __attribute__((always_inline)) { SDL(c)[tri(na) + j] = -v; });
 }
 // delete row / column r (nupd = na - r - 1 >= 1 trailing rows; D[r] and the trailing D checked > 0 by the master)
 template <int C>
-__device__ __forceinline__ void wg_wdelete(const WgCtx &c, int r, int na)
+__device__ __forceinline__ void wg_wdelete(const WgCtx &c, int r, int na, bool xvalid)
 {
     const int wv = wg_wave(), lane = wg_lane(), tid = wg_tid(), nupd = na - r - 1;
     double *pvec = SD(c, gram), *bvec = SD(c, pend_lam), *wr = SD(c, mnew);
-    double *bnd0 = SD(c, xl) + r + 1, *bnd1 = SD(c, zl) + r + 1, *bnd2 = SD(c, red);
+    double *bnd0 = SD(c, red), *bnd1 = SD(c, red) + 256;      // (two seams: the inverse factor is only carried while na <= 192)
     // phase 0: wave 0 -- p, the recurrences by prefix sums, the new pivots; the others -- row r and the columns at the chunk seams
     if (wv == 0) {
         double carry = 1.0 / SD(c, D)[r];            // t_0 = 1 / alpha_0
@@ -550,23 +599,36 @@ __device__ __forceinline__ void wg_wdelete(const WgCtx &c, int r, int na)
         for (int cidx = tid - 64; cidx < r; cidx += 64 * (c.W - 1)) wr[cidx] = SDL(c)[tri(r) + cidx];
         for (int t = tid - 64; t < nupd; t += 64 * (c.W - 1)) {
             const int ro = r + 1 + t;                                      // old row
-            static_for<C - 1>([&](auto k) __attribute__((always_inline)) {
+            static_for<(C - 1 < 2 ? C - 1 : 2)>([&](auto k) __attribute__((always_inline)) {
                 constexpr int cb = 64 * (k + 1);                           // old column read by the last lane of chunk k
                 const double v = (cb < ro) ? SDL(c)[tri(ro) + cb] : 0.0;
-                if (k == 0) bnd0[t] = v; else if (k == 1) bnd1[t] = v; else bnd2[t] = v;
+                if (k == 0) bnd0[t] = v; else bnd1[t] = v;
             });
         }
     }
     __syncthreads();
-    // phase 1: one thread per NEW column c' (old column c' or c' + 1), sweeping down the trailing rows
+    // phase 1: one thread per NEW column c' (old column c' or c' + 1), sweeping down the trailing rows; the last thread of
+    // the workgroup takes the CSP's x = W rhs along as one more column: x~_2 = K^-1 (x_2 + p x_r) (x_2 + p x_r is what W21 rhs_1
+    // + p w_r' rhs_1 + W22 rhs_2 comes to), so that the next CSP has no rows to redo after a removal
     const int cn = tid;
+    if (xvalid && tid == 64 * c.W - 1) {
+        const double xr = SD(c, xl)[r];
+        double s = 0;
+        for (int t = 0; t < nupd; ++t) {
+            const double pt = pvec[t], bt = bvec[t];
+            const double x = __builtin_fma(-pt, s, __builtin_fma(pt, xr, SD(c, xl)[r + 1 + t]));
+            s = __builtin_fma(bt, x, s);
+            SD(c, xl)[r + t] = x;
+            SD(c, zl)[r + t] = x / SD(c, D)[r + t];
+        }
+    }
     if (cn < na - 1) {
         const bool shift = cn >= r;
         const int co = shift ? cn + 1 : cn;
         const double wrc = shift ? 0.0 : wr[cn];
         const bool seam = shift && (cn & 63) == 63;
         const int k = cn >> 6;
-        const double *bnd = (k == 0) ? bnd0 : (k == 1 ? bnd1 : bnd2);
+        const double *bnd = (k == 0) ? bnd0 : bnd1;
         // (a column of W22 enters the sweep at its own unit diagonal: x = 1 there, so the running sum starts at beta of that row)
         double s = shift ? bvec[cn - r] : 0.0;
         int t = shift ? cn - r + 1 : 0;                                    // first new row below this column's diagonal: r + t > cn
@@ -620,7 +682,7 @@ __device__ __forceinline__ void wg_do(const WgCtx &c, int code, double primal_to
         wg_gram<C>(c, a0, hi);
         __syncthreads();
         wg_wappend<C>(c, na);
-    } else if (code == WG_WDELETE) wg_wdelete<C>(c, a0, na);
+    } else if (code == WG_WDELETE) wg_wdelete<C>(c, a0, na, a1 != 0);
     else if (code == WG_W2L) wg_w2l<C>(c, a0);
 }
 
@@ -739,7 +801,9 @@ __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
         wg_run(w, WG_WAPPEND, id, newslot);
         WPROF_ACC(w, 8);
         w.sing = kEmpty;
-        const double dnew = und(SD(c, gram)[newslot] - SD(c, cand)[0]);
+        double dsum = 0;
+        for (int k = 0; k < c.W; ++k) dsum += SD(c, cand)[k];
+        const double dnew = und(SD(c, gram)[newslot] - dsum);
         if (ub(dnew < w.stp->sing_tol) || na >= c.n) {
             // a singular pivot: back to L (the new row included: its L entries are l), then as the chains would leave it
             wleave_w(w, na + 1);
@@ -852,9 +916,11 @@ __device__ __forceinline__ void wldl_delete(WgWave<C> &w, int r)
             if (t < nupd) { const double dt = SD(c, D)[r + 1 + t]; dmin = dt < dmin ? dt : dmin; }
         }
         if (ub(wave_min(dmin) > 1e-200)) {
+            const int xvalid = (w.reuse >= na) ? 1 : 0;     // x = W rhs complete (the removal follows a CSP): updated by the sweep
             WPROF_T0(w);
-            wg_run(w, WG_WDELETE, r);
+            wg_run(w, WG_WDELETE, r, xvalid);
             WPROF_ACC(w, 11);
+            if (xvalid) w.reuse = na;                       // (wdrop_core lowers it to na - 1 = all rows of the new factor)
             return;
         }
         wleave_w(w, na);
@@ -948,7 +1014,8 @@ __device__ __forceinline__ int wdrop_core(WgWave<C> &w, int r)
         const int i = lane + 64 * cc;
         if (i >= r && i < w.na) { SI(c, ws)[i] = wsn[cc]; SI(c, slot)[i] = sln[cc]; WLAM(w)[i] = lmn[cc]; SD(c, rhs)[i] = rhn[cc]; }
     }
-    if (r < w.reuse) w.reuse = r;
+    if (w.use_w && w.reuse > w.na) w.reuse = w.na;        // inverse factor: x was carried through the removal
+    else if (r < w.reuse) w.reuse = r;
     int took = 0;
     WSYNC();
     if (w.na > 0 && ub(SD(c, D)[w.na - 1] < w.stp->sing_tol)) {

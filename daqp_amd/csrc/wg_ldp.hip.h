@@ -786,6 +786,7 @@ __device__ __forceinline__ void wleave_w(WgWave<C> &w, int rows)
 template <int C>
 __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
 {
+    if (w.use_w && w.na >= 191) wleave_w(w, w.na);   // (the inverse-factor commands serve up to three 64-row chunks: 192 rows)
     if (w.use_w) {   // inverse factor: Gram column, l = D^-1 W g, new row of W = -l' W, all in one command
         const WgCtx &c = w.c;
         const int lane = wg_lane(), na = w.na;

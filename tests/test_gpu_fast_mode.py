@@ -44,12 +44,14 @@ def test_fast_mode_shapes(oracle, gpu_lib, shape):
     assert np.abs(g["x"] - ref[0]).max() < XTOL
 
 
-@pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (129, 200, 10, 30), (229, 400, 20, 60)])
+@pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (129, 200, 10, 30), (229, 400, 20, 60), (229, 420, 0, 205)])
 def test_fast_mode_workgroup_kernel_shapes(oracle, gpu_lib, shape):
-    """the workgroup solve kernel in the default arithmetic: primal step and Gram column summed in per-wave segments"""
+    """the workgroup solve kernel in the default arithmetic: the inverse factor W = L^-1 (CSP / append / delete as matrix-vector
+    products over all waves), primal step and Gram column summed in per-wave segments, fp32-screened scan.  The last shape's
+    working sets pass 191 rows, where the kernel converts W back to L and continues on the substitution chains."""
     import daqp_amd
     n, m, ms, na = shape
-    q = O.generate_batch(12, n, m, ms, na, 1900 + n)
+    q = O.generate_batch(12 if na < 100 else 3, n, m, ms, na, 1900 + n + na)
     ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
     g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
     assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4])
@@ -100,3 +102,33 @@ def test_fast_mode_warm_sequence(oracle, gpu_lib):
             assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4]
             assert np.array_equal(np.sign(g["lam"][k]), np.sign(r[1])) and np.abs(g["x"][k] - r[0]).max() < XTOL
     bm.close()
+
+
+def test_inverse_factor_matches_chains(oracle, gpu_lib, monkeypatch):
+    """default mode with and without the inverse factor (DAQP_AMD_WG_INVERSE=0: L and the substitution chains): the same add /
+    remove sequence step for step, x and lam equal to rounding -- on a shape with removals in most problems, with a warm
+    update afterwards (the stored iterate is always L: the warm solve starts on the chains)"""
+    import daqp_amd
+    n, m, ms, na = 90, 220, 6, 35
+    N = 16
+    q = O.generate_batch(N, n, m, ms, na, 7700)
+    res = {}
+    for inv in ("1", "0"):
+        monkeypatch.setenv("DAQP_AMD_WG_INVERSE", inv)
+        bm = daqp_amd.BatchModel(N, n, m, ms)
+        bm.enable_trace(8192)
+        bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=daqp_amd.UPDATE_unconstrained)
+        g = bm.solve()
+        tr = bm.read_trace()
+        bm.update(f=q["f"] * 1.05)
+        g2 = bm.solve()
+        res[inv] = (g, tr, g2)
+        bm.close()
+    a, b = res["1"], res["0"]
+    assert np.array_equal(a[0]["iter"], b[0]["iter"]) and np.array_equal(a[0]["exitflag"], b[0]["exitflag"])
+    assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1])), "add / remove sequences differ"
+    assert any((np.asarray(t) < 0).any() for t in a[1]), "no removal in the sample: the delete sweep was not exercised"
+    assert np.abs(a[0]["x"] - b[0]["x"]).max() < 1e-11 and np.abs(a[0]["lam"] - b[0]["lam"]).max() < 1e-9
+    assert np.array_equal(a[2]["iter"], b[2]["iter"]) and np.abs(a[2]["x"] - b[2]["x"]).max() < 1e-11
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert np.array_equal(a[0]["iter"], ref[4]) and np.abs(a[0]["x"] - ref[0]).max() < XTOL

@@ -132,3 +132,39 @@ def test_inverse_factor_matches_chains(oracle, gpu_lib, monkeypatch):
     assert np.array_equal(a[2]["iter"], b[2]["iter"]) and np.abs(a[2]["x"] - b[2]["x"]).max() < 1e-11
     ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
     assert np.array_equal(a[0]["iter"], ref[4]) and np.abs(a[0]["x"] - ref[0]).max() < XTOL
+
+
+def test_fast_mode_shared_structure_large(oracle, gpu_lib):
+    """shared-structure batch at n = 80 in the default arithmetic: generic setup on the matrix cores, workgroup kernel with the
+    fp32-screened scan and the inverse factor on the first (cold) solve, warm updates afterwards on the stored L"""
+    import daqp_amd
+    n, m, ms, na = 80, 200, 5, 30
+    N = 24
+    q0 = O.generate_qp(n, m, ms, na, rng=[821, n])
+    rng = np.random.default_rng([822, n])
+    # (small perturbations of the generator's QP: its optimum stays well conditioned -- large ones produce multipliers of 1e4
+    #  and an x that moves by 1e-7 relative under ANY change of rounding, which says nothing about the kernels)
+    f = q0["f"][None, :] + 0.02 * rng.standard_normal((N, n))
+    shift = 0.005 * rng.standard_normal((N, m))
+    bu, bl = q0["bupper"][None, :] + shift, q0["blower"][None, :] + shift
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup_shared(q0["H"], f, q0["A"], bu, bl, None)
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q0["H"], f[k], q0["A"], np.full(m, 1e30), np.full(m, -1e30), None)
+        assert om.update(O.UPDATE_v | O.UPDATE_d, f=f[k], bupper=bu[k], blower=bl[k]) == 0
+        models.append(om)
+    for t in range(3):
+        if t > 0:
+            f = f + 0.01 * rng.standard_normal((N, n))
+            bm.update(f=f)
+            for k in range(N):
+                assert models[k].update(O.UPDATE_v, f=f[k]) == 0
+        g = bm.solve()
+        for k in range(N):
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (t, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            assert np.array_equal(np.sign(g["lam"][k]), np.sign(r[1])), (t, k)
+            assert np.abs(g["x"][k] - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max(), np.abs(r[1]).max()), (t, k, np.abs(g["x"][k] - r[0]).max(), np.abs(r[1]).max())
+    bm.close()

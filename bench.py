@@ -276,6 +276,8 @@ class Runner:
         prof = committed_counters(cfg, N, n, m)
         if prof:
             out["roofline"].update(prof)
+            if prof.get("traffic"):     # what the launch really moves through the memory side, against the peak: the honest HBM utilisation
+                out["roofline"]["traffic_frac"] = prof["traffic"] / max(t_ldp, 1e-12) / 1e9 / HBM_PEAK_GBS
         elif headline:
             out["roofline"]["traffic"] = None
         if cpu_sample > 0 and self.world == 1:

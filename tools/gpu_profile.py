@@ -7,7 +7,7 @@ import daqp_amd
 from daqp_amd.synthetic import generate_batch_torch
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-n, m, ms, na = 50, 150, 0, 20
+n, m, ms, na = (int(v) for v in sys.argv[2:6]) if len(sys.argv) > 5 else (50, 150, 0, 20)
 q = generate_batch_torch(N, n, m, ms, na, seed=42)
 for prof in (False, True):
     bm = daqp_amd.BatchModel(N, n, m, ms)

@@ -19,7 +19,7 @@ namespace daqp_amd {
 #endif
 constexpr int kSetupRows = DAQP_AMD_SETUP_ROWS;
 #ifndef DAQP_AMD_CHOL_DEPTH
-#define DAQP_AMD_CHOL_DEPTH 8
+#define DAQP_AMD_CHOL_DEPTH 4
 #endif
 struct SetupLds { int R, Rout, fv, vv, xu, sc, du, dl, tile, sens, total_bytes; };
 __host__ __device__ inline SetupLds setup_lds(int n, int m, bool gs = false)
@@ -70,7 +70,7 @@ __host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill, int
 // GS = true: the packed Cholesky factor and R^-1 live in per-QP HBM scratch (b.setup_g)
 // instead of LDS -- the n = 200 class of problems, where 2 x 160 KB of factors cannot be staged.
 template <bool GS>
-__global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_setup(BatchDev b, int mask)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = lane_id();
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     const int shift_code = (!pp && st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;   // eps == 0: utils.c:357,367
     int nprox = 0;
     // default arithmetic mode: M = A R^-1 on the matrix cores (below), which read R^-1 from a zero-padded square image
-    bool mfma_m = !b.exact_setup && b.setup_sq != nullptr;
+    bool mfma_m = !b.exact_setup && b.setup_sq != nullptr && b.n <= 208;   // (52 k steps of A in registers)
     const int sq_ld = round_up(n, 16);
     double *Rsq = b.setup_sq ? b.setup_sq + (size_t)q * round_up(n, 32) * sq_ld : nullptr;
     // optional phase cycle counters -> b.prof[q][16..21]: checks, Cholesky, inverse, v/x_unc, M rows, simple bounds + write-back
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64) void k_setup(BatchDev b, int mask)
     // to ~1e-16 relative (the exact mode keeps the chain below).
     if (flag > 0 && mfma_m) {
         typedef double v4d __attribute__((ext_vector_type(4)));
-        constexpr int KB = 16, NKT = 64;          // n <= 255: at most 64 k steps
+        constexpr int KB = 16, NKT = 56;          // n <= 208: 52 k steps (56: whole blocks of eight)
         double *ob = smem + o.tile;               // [16][64] one column block of results on its way to the blocked image
         double2 *Mq2 = reinterpret_cast<double2 *>(Mq);
         const int lr = lane & 15, lk = lane >> 4;

@@ -83,7 +83,7 @@ __host__ __device__ inline FastLds fast_lds(int n, int m, int exact)
 // code with H + hshift[q] on the diagonal (a diagonal H: in its singular coordinates only), the stricter pivot ratio and
 // the list of shifted coordinates written out.  A separate instantiation, so that the ordinary pass keeps its code.
 template <int NMAX, bool PROX = false>
-__global__ __launch_bounds__(64) void k_setup_fast(BatchDev b, int mask)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ? 2 : 1, NMAX >= 56 ? 2 : 8))) void k_setup_fast(BatchDev b, int mask)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = lane_id();

@@ -15,7 +15,7 @@ namespace daqp_amd {
 // ------------------------------------------------------------------------------------
 // rows of A per pass of k_setup's M phase (LDS: this many rows of A plus as many rows of one 64-column result block)
 #ifndef DAQP_AMD_SETUP_ROWS
-#define DAQP_AMD_SETUP_ROWS 8
+#define DAQP_AMD_SETUP_ROWS 4
 #endif
 constexpr int kSetupRows = DAQP_AMD_SETUP_ROWS;
 #ifndef DAQP_AMD_CHOL_DEPTH
@@ -30,7 +30,10 @@ __host__ __device__ inline SetupLds setup_lds(int n, int m, bool gs = false)
     s.R = o; if (!gs) o += rt; s.Rout = o; if (!gs) o += rt;
     s.fv = o; o += np; s.vv = o; o += np; s.xu = o; o += np;
     s.sc = s.du = s.dl = o;   // (not in LDS any more)
-    s.tile = o; o += kSetupRows * np + kSetupRows * 64;   // the block of rows of A and the result block of the M phase
+    {   // the block of rows of A and the result block of the exact M phase; the matrix-core phase needs 16 x 64 results
+        const int t = kSetupRows * np + kSetupRows * 64;
+        s.tile = o; o += t > 1024 ? t : 1024;
+    }
     s.sens = o;
     s.total_bytes = o * 8 + round_up(m, 4) * 4;
     return s;

@@ -308,7 +308,7 @@ int regularise(DAQPBatch *b, int mask, bool lp)
     size_t lds = (size_t)setup_lds(d.n, d.m, gs).total_bytes;
     if (b->fast_setup && !lp) {
         ks = (d.n <= 16) ? k_setup_fast<16, true> : (d.n <= 32 ? k_setup_fast<32, true> : (d.n <= 56 ? k_setup_fast<56, true> : k_setup_fast<64, true>));
-        lds = (size_t)fast_lds(d.n, d.m, 1).total_bytes;
+        lds = (size_t)fast_lds(d.n, d.m, 1, d.mA).total_bytes;
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int exact_saved = d.exact_setup;
@@ -539,7 +539,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.exact_setup = (ex && atoi(ex) != 0) ? 1 : 0;
     }
     b->setup_spill = !b->fast_setup && (setup_lds(n, m).total_bytes > 150 * 1024 || getenv("DAQP_AMD_FORCE_SPILL"));
-    b->lds_setup = b->fast_setup ? (size_t)fast_lds(n, m, 1).total_bytes : (size_t)setup_lds(n, m, b->setup_spill).total_bytes;
+    b->lds_setup = b->fast_setup ? (size_t)fast_lds(n, m, 1, m - ms).total_bytes : (size_t)setup_lds(n, m, b->setup_spill).total_bytes;
     b->lds_update = (size_t)round_up(n, 2) * 16;
     if (b->lds_ldp > 160 * 1024 || b->lds_setup > 160 * 1024) {
         set_err("problem too large for the LDS-staged setup (needs %zu / %zu bytes)", b->lds_setup, b->lds_ldp);
@@ -808,7 +808,7 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
     size_t lds_setup = b->lds_setup;
     if (b->fast_setup) {
         ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : (d.n <= 56 ? k_setup_fast<56> : k_setup_fast<64>));
-        lds_setup = (size_t)fast_lds(d.n, d.m, d.exact_setup).total_bytes;   // the MFMA path overlays the A tile on R^-1
+        lds_setup = (size_t)fast_lds(d.n, d.m, d.exact_setup, d.mA).total_bytes;   // the MFMA path overlays the A tile on R^-1
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
@@ -871,7 +871,7 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     size_t lds_setup = b->lds_setup;
     if (b->fast_setup) {
         ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : (d.n <= 56 ? k_setup_fast<56> : k_setup_fast<64>));
-        lds_setup = (size_t)fast_lds(d.n, d.m, d.exact_setup).total_bytes;
+        lds_setup = (size_t)fast_lds(d.n, d.m, d.exact_setup, d.mA).total_bytes;
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
     HIPCHK(hipEventRecord(b->ev[0], b->stream));

@@ -63,17 +63,24 @@ __device__ __forceinline__ double chain_add8(double acc, int cnt, FA A, FB B)
 // fragments live in registers during the M phase, so the tile aliases Rsq and four workgroups fit a CU.
 struct FastLds { int R, fv, vv, xu, sc, du, dl, tile, sens, nsq, total_bytes; };
 __host__ __device__ inline int fast_nsq(int n) { int q = n < 2 ? 2 : n; while ((q & 3) != 2) ++q; return q; }
-__host__ __device__ inline FastLds fast_lds(int n, int m, int exact)
+// rows of A per LDS tile: 56 when that does not add a tile (150 general rows: 56 + 56 + 38 like 64 + 64 + 22).  With d and the
+// scalings of the general rows written straight to HBM it brings a C2 workgroup from 31 KB of LDS to 24 KB: 6 per CU instead of
+// 5 -- the kernel's phases are latency-bound per wave, resident waves are what counts.  (Measured: balanced tiles of 52 rows,
+// 7 workgroups per CU, are slower again -- 8.3 against 8.0 ms per 100 k QPs.)
+__host__ __device__ inline int fast_tile_rows(int mA) { return (mA > 0 && (mA + 55) / 56 == (mA + 63) / 64) ? 56 : 64; }
+__host__ __device__ inline FastLds fast_lds(int n, int m, int exact, int mA = -1)
 {
     FastLds s;
     const int nsq = fast_nsq(n), np = round_up(n, 2), mp = round_up(m, 2), ldr = n | 1;   // tile stride: n | 1 (staged) or n (direct copy)
-    const int rsz = round_up(n * nsq + 8, 2), tsz = round_up(64 * ldr, 2);
+    const int TR = mA < 0 ? 64 : fast_tile_rows(mA);
+    const int rsz = round_up(n * nsq + 8, 2), tsz = round_up(TR * ldr, 2);
+    (void)mp;
     int o = 0;
     s.nsq = nsq;
     s.R = 0;
     if (exact) { s.tile = rsz; o = rsz + tsz; } else { s.tile = 0; o = rsz > tsz ? rsz : tsz; }
     s.fv = o; o += np; s.vv = o; o += np; s.xu = o; o += np;
-    s.sc = o; o += mp; s.du = o; o += mp; s.dl = o; o += mp;
+    s.sc = o; o += (mA < 0) ? np : round_up(m - mA < np ? m - mA : np, 2); s.du = s.dl = o;   // (scaling of the simple bounds only: ms <= n entries)
     s.sens = o;
     s.total_bytes = o * 8 + round_up(m, 4) * 4;
     return s;
@@ -88,10 +95,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ?
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = lane_id();
     const int n = b.n, m = b.m, ms = b.ms, mA = b.mA;
-    const FastLds o = fast_lds(n, m, b.exact_setup);
+    const FastLds o = fast_lds(n, m, b.exact_setup, mA);
+    const int TR = fast_tile_rows(mA);
     const int nsq = o.nsq;
     double *Rsq = smem + o.R, *fl = smem + o.fv, *vv = smem + o.vv, *xu = smem + o.xu;
-    double *sc = smem + o.sc, *du = smem + o.du, *dl = smem + o.dl, *tile = smem + o.tile;
+    double *scs = smem + o.sc, *tile = smem + o.tile;
+    double *sc = b.scaling + (size_t)q * m, *du = b.dupper + (size_t)q * m, *dl = b.dlower + (size_t)q * m;   // HBM
     int *sens = reinterpret_cast<int *>(smem + o.sens);
     const double *H = b.H + (size_t)q * n * n, *f = b.f + (size_t)q * n, *A = b.A + (size_t)q * mA * n;
     const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ?
                 for (int j = i; j < n; ++j) s += Ri[j] * Ri[j];
                 s = 1 / sqrt(s);
             }
-            sc[i] = s;
+            sc[i] = s; scs[i] = s;
             if (unc) {
                 const double u0 = bu[i] - xu[i], l0 = bl[i] - xu[i];
                 if (u0 < -st.primal_tol || l0 > st.primal_tol) feasible = 0;
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ?
             const int j = i + lane;
             if (j < n) {
                 double val = Rsq[i * nsq + j];
-                if (i < ms && !diag) val *= sc[i];
+                if (i < ms && !diag) val *= scs[i];
                 Rp[roff(i, n) + j] = val;
             }
         }
@@ -357,9 +366,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ?
     // --- general rows, 64 at a time through the LDS tile; lane <-> row
     if (flag > 0) {
         WSYNC();   // Rsq (under the tile unless exact_setup) has no readers left
-        if (direct && mA > 0) copy_async(tile, A, (mA < 64 ? mA : 64) * n);
-        for (int tb = 0; tb < mA && flag > 0; tb += 64) {
-            const int rows = (mA - tb) < 64 ? (mA - tb) : 64;
+        if (direct && mA > 0) copy_async(tile, A, (mA < TR ? mA : TR) * n);
+        for (int tb = 0; tb < mA && flag > 0; tb += TR) {
+            const int rows = (mA - tb) < TR ? (mA - tb) : TR;
             if (direct) copy_wait();
             else { WSYNC(); stage_rows(tile, A + (size_t)tb * n, rows, n, ldr); }
             WSYNC();
@@ -438,9 +447,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ?
                 }
             }
             SPROF(3);
-            if (direct && tb + 64 < mA) {   // this tile lives in registers now: the next one loads during the normalisation
+            if (direct && tb + TR < mA) {   // this tile lives in registers now: the next one loads during the normalisation
                 WSYNC();
-                copy_async(tile, A + (size_t)(tb + 64) * n, ((mA - tb - 64) < 64 ? (mA - tb - 64) : 64) * n);
+                copy_async(tile, A + (size_t)(tb + TR) * n, ((mA - tb - TR) < TR ? (mA - tb - TR) : TR) * n);
             }
             // normalise (utils.c:586-613), d (utils.c:499-544 / 664-676 + 151-159), blocked store
             double s = 0;
@@ -487,11 +496,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ?
     if (flag > 0 && unc && all_feasible) { sing = DAQP_UNCONSTRAINED_OPTIMAL; activate = 0; }
     if (flag > 0) {
         if (lane < n) { b.v[(size_t)q * n + lane] = vv[lane]; if (unc) b.xunc[(size_t)q * n + lane] = xu[lane]; }
-        for (int i = lane; i < m; i += 64) {
-            b.scaling[(size_t)q * m + i] = sc[i];
-            b.dupper[(size_t)q * m + i] = du[i];
-            b.dlower[(size_t)q * m + i] = dl[i];
-        }
     }
     for (int i = lane; i < m; i += 64) b.sense[(size_t)q * m + i] = sens[i];
     SPROF(5);

@@ -218,6 +218,7 @@ __device__ __forceinline__ double rforward(RWave<NB, NP, FM> &w, double x, doubl
     const int lane = lane_id(), na = w.na;
     const bool pending = lane >= from && lane < na;
     x = pending ? rhs : (lane < na ? x : 0.0);
+    if (from >= na) return x;          // nothing open (x was carried through a removal)
     if (from == na - 1 && na > 1) {
         // the usual case after an add: only the last row is open.  Its products in parallel, then the j-ordered
         // chain of subtractions on broadcast operands -- the same operations as the sweep below for that row
@@ -384,6 +385,12 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM> &w, int r)
     double alpha = rl(w.D, r);
     double Dn = w.D;
     const double Drot = __shfl(w.D, (lane + r + 1) & 63);     // D_{r+1+j} in lane j: compile-time lane numbers below
+    // Default arithmetic: the CSP's x = L^-1 rhs rides through the update (x~_2 = K^-1 (x_2 + p x_r), the same recurrence the rows
+    // of L go through, on one more scalar per pivot), so that the next CSP has no rows to re-solve after a removal -- provided x was
+    // complete (the removal follows a CSP).  The reference re-solves rows >= r; same mathematics, other rounding.
+    const double Xrot = FM ? __shfl(w.xl, (lane + r + 1) & 63) : 0.0;
+    const double xr = FM ? rl(w.xl, r) : 0.0;
+    double sx = 0, Xn = w.xl;
     const int pl = lane < nupd ? lane : -1;
     double *Lr = w.L + tri(r + lane_now()) + r;
     static_for<8>([&](auto c) __attribute__((always_inline)) {
@@ -402,6 +409,11 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM> &w, int r)
                     const double beta = p * alpha / dbar;
                     alpha = Di * alpha / dbar;
                     if (lane == r + j) Dn = dbar;
+                    if constexpr (FM) {
+                        const double xt = __builtin_fma(-p, sx, __builtin_fma(p, xr, rl(Xrot, j)));
+                        sx = __builtin_fma(beta, xt, sx);
+                        if (lane == r + j) Xn = xt;
+                    }
                     if (pl > j) {
                         wv = msub<FM>(wv, p, Lc[q]);
                         Lc[q] = madd<FM>(Lc[q], beta, wv);
@@ -415,6 +427,13 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM> &w, int r)
         }
     });
     w.D = Dn;
+    if constexpr (FM) {
+        if (w.reuse >= na) {          // x was complete: keep it so (rdrop_core sets reuse to the new na)
+            w.xl = Xn;
+            if (lane >= r && lane < na - 1) w.zl = Xn / Dn;
+            w.reuse = na + 64;        // marker: "carried"
+        }
+    }
     WSYNC();
     RPROF_ACC(w, 25);
 }
@@ -444,7 +463,8 @@ __device__ __forceinline__ int rdrop_core(RWave<NB, NP, FM> &w, int r) // auxili
     w.wflag = shift_from(w.wflag, r);
     w.lam = shift_from(w.lam, r);
     w.drhs = shift_from(w.drhs, r);
-    if (r < w.reuse) w.reuse = r;
+    if (w.reuse > w.na + 32) w.reuse = w.na;       // (x carried through the removal: nothing to re-solve)
+    else if (r < w.reuse) w.reuse = r;
     if (w.na > 0 && rl(w.D, w.na - 1) < w.sing_tol) {
         w.sing = w.na - 1;
         if (lane == w.na - 1) w.D = 0;

@@ -201,6 +201,15 @@ __device__ __forceinline__ double rbackward(RWave<NB, NP, FM> &w, double b, int 
     });
     return b;
 }
+// sum over the wave by tree (default arithmetic mode only: not the reference's order): 4 DPP steps inside each row of 16, then 4 readlanes
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
+}
 // ordered sum: acc - p_0 - p_1 - ... - p_{cnt-1} (p must be 0 in lanes >= cnt)
 __device__ __forceinline__ double ordered_sub(double acc, double p, int cnt)
 {
@@ -223,7 +232,7 @@ __device__ __forceinline__ double rforward(RWave<NB, NP, FM> &w, double x, doubl
         // the usual case after an add: only the last row is open.  Its products in parallel, then the j-ordered
         // chain of subtractions on broadcast operands -- the same operations as the sweep below for that row
         const double p = (lane < na - 1) ? w.L[tri(na - 1) + lane_now()] * x : 0.0;
-        const double last = ordered_sub(rl(rhs, na - 1), p, na - 1);
+        const double last = FM ? rl(rhs, na - 1) - wave_sum(p) : ordered_sub(rl(rhs, na - 1), p, na - 1);   // (default mode: a tree instead of the k-ordered chain)
         return (lane == na - 1) ? last : x;
     }
     const int pl = pending ? lane : -1;
@@ -335,7 +344,7 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP, FM> &w, int id, int 
         w.L[base + lane_now()] = lk;
         p = t * lk;
     }
-    double acc = ordered_sub(dnew, p, na);
+    double acc = FM ? dnew - wave_sum(p) : ordered_sub(dnew, p, na);
     if (acc < w.sing_tol || na >= n + ns_act) { w.sing = na; acc = 0; }
     WSYNC();
     return acc;

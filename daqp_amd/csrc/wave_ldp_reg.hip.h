@@ -541,14 +541,16 @@ __device__ __forceinline__ int rblocking_test(RWave<NB, NP, FM> &w)
     const bool regular = (w.sing == kEmpty);
     double bv = DAQP_INF;
     int bi = kBig, aux = 0;
+    bool blocking = false;
     if (lane < na) {
-        bool blocking = !(w.wflag & DAQP_IMMUTABLE);
+        blocking = !(w.wflag & DAQP_IMMUTABLE);
         if (w.wflag & DAQP_LOWER) { if (w.lams < dtol) blocking = false; }
         else if (w.lams > -dtol) blocking = false;
-        if (blocking) {
-            const double cand = regular ? -w.lam / (w.lams - w.lam) : -w.lam / w.lams;
-            if (cand < bv) { bv = cand; bi = lane; }
-        }
+    }
+    if (!__any(blocking)) return kBig;      // the usual case (two iterations out of three): no division, no wave-wide minimum
+    if (blocking) {
+        const double cand = regular ? -w.lam / (w.lams - w.lam) : -w.lam / w.lams;
+        if (cand < bv) { bv = cand; bi = lane; }
     }
     wave_argmin(bv, bi, aux);
     if (bi == kBig) return kBig;

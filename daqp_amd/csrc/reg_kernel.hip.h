@@ -365,8 +365,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         if (kProfile && w.prof && lane == 0) { w.prof[20] = te1 - t_done; w.prof[21] = te2 - te1; w.prof[22] = te3 - te2; }
         if (b.x && lane < n) b.x[(size_t)q * n + lane] = xi;
         if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = lamq[i];
-        double fv = w.fval;                      // fval - |v|^2 in index order, v_i broadcast from its lane
-        static_for<8>([&](auto c) __attribute__((always_inline)) {
+        double fv = w.fval;                      // fval - |v|^2: in index order, v_i broadcast from its lane -- or, default mode, by tree
+        if constexpr (FM) fv -= wave_sum(vl * vl);
+        else static_for<8>([&](auto c) __attribute__((always_inline)) {
             if (8 * c < n) static_for<8>([&](auto k) __attribute__((always_inline)) { const double vi = rl(vl, 8 * c + k); fv -= vi * vi; });
         });
         fv *= 0.5;

@@ -169,6 +169,24 @@ __device__ __forceinline__ double dot4_pipelined(const double *a, const double *
 // (s_add + SGPR-index hazard, tools/ubench2.hip), and a constant column turns every L address into
 // "lane base + immediate offset".
 
+// The chains below run over eight static chunks of eight lanes, each behind its own "is this chunk live" branch (~18 cycles
+// whether taken or not).  Working sets of up to 16 rows pay for the upper six chunks with ONE branch, those of up to 32 rows for the upper four.
+template <class F> __device__ __forceinline__ void chunks_up(int live, F &&f)
+{
+    static_for<2>([&](auto c) __attribute__((always_inline)) { f(c); });
+    if (live > 16) {
+        static_for<2>([&](auto c) __attribute__((always_inline)) { f(std::integral_constant<int, c + 2>{}); });
+        if (live > 32) static_for<4>([&](auto c) __attribute__((always_inline)) { f(std::integral_constant<int, c + 4>{}); });
+    }
+}
+template <class F> __device__ __forceinline__ void chunks_down(int live, F &&f)   // f(cc), chunk 7 - cc: top chunks first
+{
+    if (live > 16) {
+        if (live > 32) static_for<4>([&](auto cc) __attribute__((always_inline)) { f(cc); });
+        static_for<2>([&](auto cc) __attribute__((always_inline)) { f(std::integral_constant<int, cc + 4>{}); });
+    }
+    static_for<2>([&](auto cc) __attribute__((always_inline)) { f(std::integral_constant<int, cc + 6>{}); });
+}
 // b <- L' \ b over the leading cnt positions (column-oriented; product order b_j * L[j][i]).
 // Lanes >= cnt must hold b == 0.
 template <int NB, int NP, bool FM>
@@ -181,7 +199,7 @@ __device__ __forceinline__ double rbackward(RWave<NB, NP, FM> &w, double b, int 
     // spilled SGPR pairs).  Lanes >= cnt may pick up unused values; nothing reads them.
     const unsigned room = (unsigned)(cnt - 1 - lane);
     const int nlane = -1 - lane;
-    static_for<8>([&](auto cc) __attribute__((always_inline)) {
+    chunks_down(cnt, [&](auto cc) __attribute__((always_inline)) {
         constexpr int c = 7 - cc;
         if (8 * c < cnt && cnt > 1) {
             double Lb[8];
@@ -213,7 +231,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // ordered sum: acc - p_0 - p_1 - ... - p_{cnt-1} (p must be 0 in lanes >= cnt)
 __device__ __forceinline__ double ordered_sub(double acc, double p, int cnt)
 {
-    static_for<8>([&](auto c) __attribute__((always_inline)) {
+    chunks_up(cnt, [&](auto c) __attribute__((always_inline)) {
         if (8 * c < cnt) static_for<8>([&](auto q) __attribute__((always_inline)) { acc -= rl(p, 8 * c + q); });
     });
     return acc;
@@ -237,7 +255,7 @@ __device__ __forceinline__ double rforward(RWave<NB, NP, FM> &w, double x, doubl
     }
     const int pl = pending ? lane : -1;
     const double *Lr = w.L + tri(lane_now());
-    static_for<8>([&](auto c) __attribute__((always_inline)) {
+    chunks_up(na - 1, [&](auto c) __attribute__((always_inline)) {
         if (8 * c < na - 1) {
             double Lk[8];
             static_for<8>([&](auto q) __attribute__((always_inline)) { Lk[q] = Lr[8 * c + q]; });
@@ -324,7 +342,7 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP, FM> &w, int id, int 
     {
         const int pl = lane < na ? lane : -1;
         const double *Lr = w.L + tri(lane_now());
-        static_for<8>([&](auto c) __attribute__((always_inline)) {
+        chunks_up(na - 1, [&](auto c) __attribute__((always_inline)) {
             if (8 * c < na - 1) {
                 double Lk[8];
                 static_for<8>([&](auto q) __attribute__((always_inline)) { Lk[q] = Lr[8 * c + q]; });
@@ -402,7 +420,7 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM> &w, int r)
     double sx = 0, Xn = w.xl;
     const int pl = lane < nupd ? lane : -1;
     double *Lr = w.L + tri(r + lane_now()) + r;
-    static_for<8>([&](auto c) __attribute__((always_inline)) {
+    chunks_up(nupd, [&](auto c) __attribute__((always_inline)) {
         if (8 * c < nupd) {
             double Lc[8];
             static_for<8>([&](auto q) __attribute__((always_inline)) {
@@ -571,7 +589,7 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP, FM> &w)
     const int soff = (lane < na) ? w.slot * w.ldr : 0;
     const double lz = (lane < na) ? w.lams : 0.0;
     const double *rc = w.rowc + lane_now();
-    static_for<8>([&](auto c) __attribute__((always_inline)) {
+    chunks_up(na, [&](auto c) __attribute__((always_inline)) {
         if (8 * c < na) {
             double rv[8], li[8];
             static_for<8>([&](auto q) __attribute__((always_inline)) {

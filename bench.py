@@ -102,33 +102,68 @@ def cpu_baseline(q_host, ms, gpu_res, threads_options):
                        f"({S * 1.0 / dt / cores:.0f} QPs/s per thread), wall {dt:.2f} s" + (f" [best of: {tried.strip()}]" if tried else "")), parity, cores
 
 
-def cpu_baseline_warm(q_host, fs_host, ms, gpu_x, gpu_iter):
-    """C5 on one host core: the reference's setup_daqp -> solve -> {update_ldp(UPDATE_v) -> solve}* per QP (oracle/_ref through
-    ctypes, else the C restatement) over the same walk of f; only the warm steps are timed."""
+def cpu_baseline_warm(q_host, fs_host, ms, thread_options):
+    """C5 on the host cores, all in C (oracle/ref_batch.c::ref_warm_run): per QP the reference's setup_daqp -> daqp_solve
+    (untimed), then T x {daqp_update_ldp(UPDATE_v) -> daqp_solve} over the first T steps of the walk of f, P pthreads with one
+    contiguous slice each; only the warm phase is timed (first thread in to last thread out).  Best of the thread counts tried.
+    Without oracle/_ref: the C restatement through ctypes on one thread (kind "port")."""
     from oracle import oracle as O
-    S, P = q_host["f"].shape[0], fs_host.shape[0]
+    T, S = fs_host.shape[0], q_host["f"].shape[0]
     n, m = q_host["f"].shape[1], q_host["bupper"].shape[1]
-    kind = "reference" if O.reference_available() else "port"
-    drv = O.Reference() if kind == "reference" else O.Oracle(fast=True)
-    dt = 0.0
-    same_iter, max_dx = 0, 0.0
-    for k in range(S):
-        md = drv.model(n, m, ms)
-        md.setup(q_host["H"][k], q_host["f"][k], q_host["A"][k], q_host["bupper"][k], q_host["blower"][k], None)
-        md.solve()
-        t0 = time.perf_counter()
-        for t in range(P):
-            md.update(O.UPDATE_v, f=fs_host[t, k])
-            r = md.solve()
-        dt += time.perf_counter() - t0
-        same_iter += int(r[4] == gpu_iter[k])
-        max_dx = max(max_dx, float(np.abs(r[0] - gpu_x[k]).max()))
-        if hasattr(md, "close"):
-            md.close()
-    return dict(value=S * P / dt, unit="warm solves/s", cores=1, kind=kind,
-                sample=f"first {S} QPs x {P} warm steps (the whole walk of f), daqp_update_ldp(UPDATE_v) + daqp_solve per step on one "
-                       f"host thread (python/ctypes call overhead included), wall {dt:.2f} s"), \
-        dict(sample=int(S), identical_iter_last_step=same_iter / S, max_abs_dx_last_step=max_dx)
+    if O.reference_available():
+        libpath = os.path.join(O.HERE, "_ref", "libdaqp_ref.so")
+        best, tried = None, ""
+        for th in thread_options:
+            r = O.timed_cpu_warm(libpath, th, q_host["H"], q_host["f"], q_host["A"], q_host["bupper"], q_host["blower"], fs_host, ms)
+            tried += f"{th} threads: {S * T / r[0]:.0f}/s; "
+            if best is None or r[0] < best[1][0]:
+                best = (th, r)
+        cores, (dt, x, lam, flag, it) = best
+        kind = "reference"
+        how = f"C driver, {cores} pthreads, no Python in the timed loop [best of: {tried.strip()}]"
+    else:
+        drv = O.Oracle(fast=True)
+        x, lam = np.zeros((T, S, n)), np.zeros((T, S, m))
+        flag, it = np.zeros((T, S), np.int32), np.zeros((T, S), np.int32)
+        dt = 0.0
+        for k in range(S):
+            md = drv.model(n, m, ms)
+            md.setup(q_host["H"][k], q_host["f"][k], q_host["A"][k], q_host["bupper"][k], q_host["blower"][k], None)
+            md.solve()
+            t0 = time.perf_counter()
+            for t in range(T):
+                md.update(O.UPDATE_v, f=fs_host[t, k])
+                r = md.solve()
+                x[t, k], lam[t, k], flag[t, k], it[t, k] = r[0], r[1], r[3], r[4]
+            dt += time.perf_counter() - t0
+        cores, kind, how = 1, "port", "C restatement through ctypes on one thread (oracle/_ref did not travel)"
+    return dict(value=S * T / dt, unit="warm solves/s", cores=int(cores), kind=kind,
+                sample=f"first {S} QPs x the first {T} warm steps of the walk of f: daqp_update_ldp(UPDATE_v) + daqp_solve per step, "
+                       f"setup_daqp + cold solve untimed; {how}; wall {dt:.2f} s"), dict(x=x, lam=lam, flag=flag, iter=it)
+
+
+def warm_parity(bm_factory, q, fs, S, T, cpu):
+    """the GPU's warm sequence replayed on the first S QPs from a fresh setup, compared with the CPU run at EVERY step:
+    iteration count, exit flag, active set (index and side) and |dx|"""
+    import daqp_amd
+    bm = bm_factory(S)
+    sl = {k: q[k][:S].contiguous() for k in ("H", "f", "A", "bupper", "blower")}
+    bm.setup(sl["H"], sl["f"], sl["A"], sl["bupper"], sl["blower"], None, init_mask=0)
+    bm.solve(out="torch")
+    same_it = same_flag = same_as = 0.0
+    dx = 0.0
+    for t in range(T):
+        bm.update(f=fs[t, :S].contiguous())
+        g = bm.solve(out="torch")
+        gi, gf = g["iter"].cpu().numpy(), g["exitflag"].cpu().numpy()
+        same_it += float(np.mean(gi == cpu["iter"][t]))
+        same_flag += float(np.mean(gf == cpu["flag"][t]))
+        same_as += float(np.mean(np.all(np.sign(g["lam"].cpu().numpy()) == np.sign(cpu["lam"][t]), axis=1)))
+        dx = max(dx, float(np.abs(g["x"].cpu().numpy() - cpu["x"][t]).max()))
+    bm.close()
+    return dict(sample=int(S), steps=int(T), identical_iter=same_it / T, identical_exitflag=same_flag / T,
+                identical_active_set=same_as / T, max_abs_dx=dx,
+                identical_iter_last_step=float(np.mean(gi == cpu["iter"][T - 1])), max_abs_dx_last_step=float(np.abs(g["x"].cpu().numpy() - cpu["x"][T - 1]).max()))
 
 
 class Runner:
@@ -143,13 +178,23 @@ class Runner:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
         torch.cuda.set_device(self.local_rank)
-        if self.world > 1:
+        # under a torch.distributed launcher (RANK / MASTER_ADDR set) the process group is created even for ONE rank, so that
+        # the RCCL communicator, the barrier and the MAX all-reduce on the device are the same code at every world size
+        self.grouped = self.world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+        self.comm = None
+        if self.grouped:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if args.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                try:
+                    ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception:
+                    ver = "?"
+                self.comm = "nccl (RCCL %s)" % ver
             else:
                 dist.init_process_group(args.backend)
-        self.red_device = "cuda" if (self.world > 1 and args.backend == "nccl") else "cpu"
+                self.comm = args.backend
+        self.red_device = "cuda" if (self.grouped and args.backend == "nccl") else "cpu"
         cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         # the fastest of {all, 1/2, 1/4, 1/8 of} the host threads: with every hardware thread busy the per-thread rate
         # collapses on these hosts (SMT + memory), and the baseline should be the CPU's best, not its most crowded
@@ -157,7 +202,7 @@ class Runner:
 
     def sync(self):
         self.torch.cuda.synchronize()
-        if self.world > 1:
+        if self.grouped:
             self.dist.barrier()
             self.torch.cuda.synchronize()
 
@@ -283,8 +328,10 @@ class Runner:
         if cpu_sample > 0 and self.world == 1:
             S = min(N, cpu_sample)
             if warm:
+                import daqp_amd
                 qh = {k: q[k][:S].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}
-                base, parity = cpu_baseline_warm(qh, info["fs"][:, :S].cpu().numpy(), ms, res["x"][:S].cpu().numpy(), iters[:S])
+                base, cpu = cpu_baseline_warm(qh, info["fs"][:T, :S].cpu().numpy(), ms, self.side_threads)
+                parity = warm_parity(lambda S_: daqp_amd.BatchModel(S_, n, m, ms, device=self.local_rank), q, info["fs"], S, T, cpu)
             else:
                 qh = {k: q[k][:S].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}
                 gh = {k: res[k][:S].cpu().numpy() for k in ("x", "lam", "iter", "exitflag")}
@@ -329,7 +376,7 @@ def main():
 
     R = Runner(args)
     R.side_threads = R.thread_options[-2:-1] or R.thread_options
-    auto_sample = {"C2": 65536, "C3": 262144, "C4": 1024, "C5": 256}   # ~10-25 CPU-seconds each on one core-group
+    auto_sample = {"C2": 65536, "C3": 262144, "C4": 1024, "C5": 8192}   # ~10-25 CPU-seconds each on one core-group
     sample = lambda cfg: 0 if (args.cpu_sample == 0 or R.world > 1) else (auto_sample[cfg] if args.cpu_sample < 0 else args.cpu_sample)
 
     q, res, bm, info = R.run(args.config, args.steps, args.warmup, batch=args.batch or None, strong=args.strong)
@@ -341,7 +388,8 @@ def main():
             "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": h["workload"], "batch_per_gpu": h["batch_per_gpu"], "mean_iterations": h["mean_iterations"],
-                       "parallelism": f"independent shards x{R.world}, no collective"},
+                       "parallelism": f"independent shards x{R.world}, no collective in the data path"
+                                      + (f"; barrier + MAX(elapsed) over {R.comm}" if R.comm else "")},
             "roofline": h["roofline"], "checks": h["checks"],
         }
         for k in ("cpu_baseline", "parity_vs_cpu"):
@@ -371,7 +419,7 @@ def main():
             line["configs"] = cfgs
     if R.rank == 0:
         print(json.dumps(line))
-    if R.world > 1:
+    if R.grouped:
         R.dist.barrier()
         R.dist.destroy_process_group()
 

@@ -69,31 +69,46 @@ EXPORTS = [
 ]
 
 
-# translation units -> what each one includes (a unit is recompiled when any of these is newer than its object)
+# translation units -> what each one includes (a unit is recompiled when any of these is newer than its object, or when the
+# object was compiled with other flags)
 UNITS = {
     "daqp_amd.hip": ["daqp_amd.hip", "kernels.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h", "setup_fast.hip.h", "prox.hip.h",
-                     "wg_layout.hip.h", "batch_dev.hip.h", "reg_kernel.hip.h"],
+                     "wg_layout.hip.h", "batch_dev.hip.h", "reg_kernel.hip.h", "tiny_kernel.hip.h", "multi.hip.h"],
     "reg_kernel.hip": ["reg_kernel.hip", "reg_kernel.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
     "wg_kernel.hip": ["wg_kernel.hip", "wg_kernel.hip.h", "wg_ldp.hip.h", "wg_layout.hip.h", "batch_dev.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h"],
+    "tiny_kernel.hip": ["tiny_kernel.hip", "tiny_kernel.hip.h", "tiny_ldp.hip.h", "tiny_setup.hip.h", "batch_dev.hip.h", "wave_ldp.hip.h"],
 }
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 OBJDIR = os.path.join(LIBDIR, "obj")
+UNITS = {u: d for u, d in UNITS.items() if os.path.exists(os.path.join(CSRC, u))}
+
+
+def _flag_key(extra_flags=()):
+    return " ".join([*HIPFLAGS, *extra_flags])
 
 
 def _unit_stale(unit, extra_flags=()):
     obj = os.path.join(OBJDIR, unit + ".o")
     if not os.path.exists(obj):
         return True
+    try:   # an object compiled with other flags (a development build's -DDAQP_AMD_FEW_VARIANTS, say) is not this build's object
+        with open(obj + ".flags") as fh:
+            if fh.read() != _flag_key(extra_flags):
+                return True
+    except OSError:
+        return True
     t = os.path.getmtime(obj)
     deps = [os.path.join(CSRC, d) for d in UNITS[unit]] + [os.path.join(ROOT, "include", "daqp_amd.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def _stale():
+def _stale(extra_flags=()):
     if not os.path.exists(LIBPATH):
         return True
-    if any(_unit_stale(u) or os.path.getmtime(os.path.join(OBJDIR, u + ".o")) > os.path.getmtime(LIBPATH) for u in UNITS):
+    if any(_unit_stale(u, extra_flags) or os.path.getmtime(os.path.join(OBJDIR, u + ".o")) > os.path.getmtime(LIBPATH) for u in UNITS):
         return True
+    if extra_flags:
+        return False
     try:   # a development build (tools/devbuild.sh: fewer kernel variants) is never what build() should leave behind
         v = C.CDLL(LIBPATH).daqp_amd_version
         v.restype = C.c_char_p
@@ -104,8 +119,11 @@ def _stale():
 
 def build(force=False, verbose=False, extra_flags=()):
     """hipcc --offload-arch=gfx950 -> daqp_amd/lib/libdaqp_amd.so (cross-compiles without a GPU).  One object per translation
-    unit (compiled side by side, only the stale ones), then one link."""
-    if not force and not _stale():
+    unit (compiled side by side, only the stale ones: older than a source, or compiled with other flags), then one link.
+    Compile and link run under an exclusive file lock and the library is moved into place atomically, so the eight ranks of
+    a torchrun launch that import a stale tree build it once, not eight times on top of each other."""
+    extra_flags = tuple(extra_flags)
+    if not force and not _stale(extra_flags):
         return LIBPATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -113,20 +131,35 @@ def build(force=False, verbose=False, extra_flags=()):
             return LIBPATH
         raise RuntimeError("hipcc not found and no prebuilt libdaqp_amd.so")
     os.makedirs(OBJDIR, exist_ok=True)
-    procs = []
-    for unit in UNITS:
-        if force or _unit_stale(unit):
-            cmd = [hipcc, *HIPFLAGS, *extra_flags, "-c", os.path.join(CSRC, unit), "-o", os.path.join(OBJDIR, unit + ".o")]
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale(extra_flags):      # another process built it while this one waited
+                return LIBPATH
+            procs = []
+            for unit in UNITS:
+                if force or _unit_stale(unit, extra_flags):
+                    obj = os.path.join(OBJDIR, unit + ".o")
+                    cmd = [hipcc, *HIPFLAGS, *extra_flags, "-c", os.path.join(CSRC, unit), "-o", obj + ".tmp"]
+                    if verbose:
+                        print(" ".join(cmd))
+                    procs.append((cmd, obj, subprocess.Popen(cmd)))
+            for cmd, obj, pr in procs:
+                if pr.wait() != 0:
+                    raise subprocess.CalledProcessError(pr.returncode, cmd)
+            for cmd, obj, pr in procs:
+                os.replace(obj + ".tmp", obj)
+                with open(obj + ".flags", "w") as fh:
+                    fh.write(_flag_key(extra_flags))
+            tmp = LIBPATH + ".tmp.%d" % os.getpid()
+            cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *[os.path.join(OBJDIR, u + ".o") for u in UNITS], "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
-            procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *[os.path.join(OBJDIR, u + ".o") for u in UNITS], "-o", LIBPATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIBPATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIBPATH
 
 

@@ -50,6 +50,10 @@ struct BatchDev {
     double *wg_rowc, *wg_rowcT;   // [grid][cap][ldr] active rows, [grid][n][wg_capT] the same transposed
     int *fallback;                // [N] 1: the working set outgrew the LDS-resident L -- the one-wave kernel solves this problem
     int wg_capL, wg_capT;
+    // settings->time_limit (daqp.c:95-103): per-problem start stamp of the current daqp_batch_solve (null: not armed) and the
+    // period of the device's constant clock (s_memrealtime) in seconds
+    unsigned long long *tstart;
+    double tick_s;
 };
 // internal setup flag: the Hessian is numerically singular and eps_prox != 0 -- the host re-runs the setup with a shifted
 // diagonal (never leaves the library: it ends as 1 or DAQP_EXIT_NONCONVEX)

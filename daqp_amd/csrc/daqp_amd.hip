@@ -122,6 +122,7 @@ struct DAQPBatch {
     hipEvent_t ev_in = nullptr;     // the last packed host->device copy (the pinned slab is free again once it has run)
     std::string env_key;
     int ns_max = 0;
+    unsigned long long *tstart = nullptr;   // [N] start stamps of the current daqp_batch_solve (allocated when a time limit is first armed)
     std::vector<double> one_lam;
     double one_fval = 0, one_soft = 0;
     int one_flag = 0, one_iter = 0;
@@ -593,6 +594,11 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &b->st_dev, 1);
     rc |= dev_alloc(b, &b->d_dev, 1);
     rc |= dev_alloc(b, &b->px.counter, 4);
+    {   // period of the constant device clock behind s_memrealtime (settings->time_limit): asked of the runtime, not assumed
+        int khz = 0;
+        d.tick_s = (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) ? 1.0 / (1e3 * (double)khz) : 1e-8;
+        d.tstart = nullptr;
+    }
     if (b->use_wg && !rc) {
         typedef void (*wg_kernel_t)(BatchDev, int);
         wg_kernel_t kw = b->wg_C == 2 ? k_ldp_wg<2> : k_ldp_wg<4>;
@@ -973,6 +979,14 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
     d.exitflag = (dev && r->exitflag) ? r->exitflag : b->oflag;
     d.iter = (dev && r->iter) ? r->iter : b->oiter;
     const double t0 = now_s();
+    // settings->time_limit (daqp.c:95-103: ONE timer per daqp_solve): every problem's start stamp of this call is cleared here;
+    // the first launch that reaches a problem sets it, later launches of the same solve (one-wave fallback behind the workgroup
+    // kernel, the launches of the proximal outer loop) inherit it
+    if (d.st.time_limit > 0) {
+        if (!b->tstart && dev_alloc(b, &b->tstart, (size_t)d.N)) return DAQP_EXIT_UNSUPPORTED;
+        HIPCHK(hipMemsetAsync(b->tstart, 0, (size_t)d.N * sizeof(unsigned long long), b->stream));
+        d.tstart = b->tstart;
+    } else d.tstart = nullptr;
     HIPCHK(hipEventRecord(b->ev[2], b->stream));
     const int mode = b->pending_mask ? (2 | (b->pending_mask << 4)) : 0;
     b->pending_mask = 0;

@@ -899,7 +899,7 @@ void k_ldp(BatchDev b, int mode_in)
     const LdpLds o = ldp_lds(n, m, cap, SPILL);
     int *ibase = reinterpret_cast<int *>(smem + o.dbl);
     Wave<C, NB, NP> w;
-    w.t_start = __builtin_amdgcn_s_memrealtime();
+    w.t_start = solve_stamp(b.tstart, q); w.tick_s = b.tick_s;
     w.profiling = (b.prof != nullptr) && mode == 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) w.prof[i] = 0;

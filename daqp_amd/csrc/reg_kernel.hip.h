@@ -69,7 +69,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         }
     }
     typedef RegLds<NB> o;
-    if (lane == 0) reinterpret_cast<unsigned long long *>(smem + o::u)[66] = __builtin_amdgcn_s_memrealtime();   // time_limit stamp (rrun)
+    {   // time_limit stamp and seconds per tick (rrun reads them from u[66], u[67])
+        const unsigned long long ts = solve_stamp(b.tstart, q);
+        if (lane == 0) { reinterpret_cast<unsigned long long *>(smem + o::u)[66] = ts; smem[o::u + 67] = b.tick_s; }
+    }
     const int rowc_size = reg_lds_rowc_size(n, m, cap, b.ldrc);
     RWave<NB, NP, FM> w;
     // phase counters live in the (otherwise unused) D/xl slots of the LDS carve-up

@@ -172,15 +172,31 @@ struct Wave {
     // optional phase cycle counters (s_memtime): csp, blocking, primal, scan, add, remove, other
     long long prof[8];
     bool profiling;
-    // settings->time_limit > 0 (daqp.c:95-103): ticks of the 100 MHz constant clock at the start of this problem's solve
+    // settings->time_limit > 0 (daqp.c:95-103): ticks of the constant device clock at the start of this problem's daqp_solve
+    // (solve_stamp: one stamp per problem and daqp_batch_solve, shared by every launch of that solve) and seconds per tick
     unsigned long long t_start;
+    double tick_s;
 };
 
-// seconds -> ticks of s_memrealtime (constant 100 MHz on gfx950)
-__device__ __forceinline__ bool time_is_up(unsigned long long t_start, double limit_s)
+// s_memrealtime ticks since t_start against the limit; tick_s = seconds per tick (hipDeviceAttributeWallClockRate, queried by
+// the host at batch creation: 100 MHz on gfx950)
+__device__ __forceinline__ bool time_is_up(unsigned long long t_start, double limit_s, double tick_s)
 {
     const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-    return (double)(now - t_start) * 1e-8 > limit_s;
+    return (double)(now - t_start) * tick_s > limit_s;
+}
+// The reference starts ONE timer per daqp_solve and shares it across everything that solve does -- the proximal outer loop
+// included (daqp.c:95-103, api.c:8-59).  Here a solve may take several launches (workgroup kernel -> one-wave fallback; two
+// launches per outer iteration of the proximal loop): the first launch that touches problem q in a daqp_batch_solve stamps
+// tstart[q] (zeroed by the host at the start of the call when the limit is armed), the later ones inherit it.
+__device__ __forceinline__ unsigned long long solve_stamp(unsigned long long *tstart, int q)
+{
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (tstart == nullptr) return now;
+    const unsigned long long t = __hip_atomic_load(tstart + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != 0) return t;
+    if (lane_id() == 0) __hip_atomic_store(tstart + q, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return now;
 }
 
 #define PROF_T0(w) long long prof_t0_ = (w).profiling ? (long long)__builtin_readcyclecounter() : 0
@@ -904,7 +920,7 @@ __device__ __forceinline__ int ldp_loop(Wave<C, NB, NP> &w, int &iterations)
             const int blocked = remove_blocking(w);
             if (blocked) PROF_ACC(w, 5); else PROF_ACC(w, 1);
             if (blocked) {   // falls through to the end of the reference's loop body: the clock check applies
-                if (w.st.time_limit > 0 && (it & 31) == 0 && time_is_up(w.t_start, w.st.time_limit)) { flag = DAQP_EXIT_TIMELIMIT; break; }
+                if (w.st.time_limit > 0 && (it & 31) == 0 && time_is_up(w.t_start, w.st.time_limit, w.tick_s)) { flag = DAQP_EXIT_TIMELIMIT; break; }
                 continue;
             }
             primal_u(w);
@@ -956,7 +972,7 @@ __device__ __forceinline__ int ldp_loop(Wave<C, NB, NP> &w, int &iterations)
             if (!remove_blocking(w)) { flag = DAQP_EXIT_INFEASIBLE; break; }
         }
         // daqp.c:95-103: every 32nd iteration that reaches the end of the loop body looks at the clock
-        if (w.st.time_limit > 0 && (it & 31) == 0 && time_is_up(w.t_start, w.st.time_limit)) { flag = DAQP_EXIT_TIMELIMIT; break; }
+        if (w.st.time_limit > 0 && (it & 31) == 0 && time_is_up(w.t_start, w.st.time_limit, w.tick_s)) { flag = DAQP_EXIT_TIMELIMIT; break; }
     }
     iterations = it;
     return flag;

@@ -746,7 +746,7 @@ __device__ __forceinline__ int rrun(RWave<NB, NP, FM> &w, int mode, bool need_ac
     // at the clock; the start stamp sits in LDS (u[66], see k_ldp_reg) so that it costs no register across the loop
     const bool tl_armed = rl(w.stp->time_limit, 0) > 0.0;
     int tl_skip = 0;   // this iteration ends with one of the reference's `continue`s: no clock check
-#define RTL_CHECK() (tl_armed && !tl_skip && (it & 31) == 0 && time_is_up(reinterpret_cast<const unsigned long long *>(w.u)[66], rl(w.stp->time_limit, 0)))
+#define RTL_CHECK() (tl_armed && !tl_skip && (it & 31) == 0 && time_is_up(reinterpret_cast<const unsigned long long *>(w.u)[66], rl(w.stp->time_limit, 0), rl(w.u[67], 0)))
     // edit request (add / drop, then the pivot_last cascade) and its continuation
     int depth = 0, req_add = 1, req_id = 0, req_r = 0, after_edit = AFTER_NEXT_ITER;
     double req_lam = 0;

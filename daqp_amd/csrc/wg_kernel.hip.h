@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
         if (wv == 0) {
             WgWave<C> w;
             w.c = c;
-            w.t_start = __builtin_amdgcn_s_memrealtime();
+            w.t_start = solve_stamp(b.tstart, q); w.tick_s = b.tick_s;
             w.profiling = (b.prof != nullptr) && mode == 0;
             if (w.profiling && lane < 20) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[lane] = 0;
             w.stp = b.st_dev;

@@ -82,6 +82,7 @@ struct WgWave {
     const DAQPSettings *stp;              // device copy of the settings: scalar loads at the point of use
     int *trace; int trace_cap, trace_len;
     unsigned long long t_start;
+    double tick_s;
     bool profiling;                       // phase cycle counters in LDS (WgL::prof)
 };
 #define WLAM(w) (wg_sm() + ((w).lam_b ? WgL<C>::lamB : WgL<C>::lamA))
@@ -1463,7 +1464,7 @@ __device__ __forceinline__ int wrun(WgWave<C> &w, int mode, bool need_activate, 
     int pc;
     if (mode == 1 || need_activate) { wreset_ws(w); act_then = (mode == 1) ? WACT_THEN_DONE : WACT_THEN_LOOP; pc = WPC_ACT_BEGIN; }
     else pc = WPC_START_LOOP;
-#define WTL_CHECK() (timed && !tl_skip && (it & 31) == 0 && time_is_up(w.t_start, w.stp->time_limit))
+#define WTL_CHECK() (timed && !tl_skip && (it & 31) == 0 && time_is_up(w.t_start, w.stp->time_limit, w.tick_s))
 #define WUNIFORM() do { w.na = uni(w.na); w.reuse = uni(w.reuse); w.sing = uni(w.sing); w.nfree = uni(w.nfree); w.hi_slot = uni(w.hi_slot); \
                         w.lam_b = uni(w.lam_b); w.overflow = uni(w.overflow); } while (0)
     while (pc != WPC_DONE && !w.overflow) {

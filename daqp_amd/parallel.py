@@ -27,9 +27,9 @@ def is_distributed():
 
 def max_over_ranks(value, device="cpu"):
     """MAX all-reduce of a python float (the bench contract's elapsed time)."""
-    if not is_distributed() or dist.get_world_size() == 1:
+    if not is_distributed():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)   # (also with one rank: the same collective at every size)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

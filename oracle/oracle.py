@@ -47,7 +47,9 @@ def default_settings(**kw):
 def build(force=False):
     """Compile liboracle*.so (and oracle/_ref when /root/reference is present)."""
     need = force or not os.path.exists(os.path.join(HERE, "liboracle.so")) \
-        or os.path.getmtime(os.path.join(HERE, "liboracle.so")) < os.path.getmtime(os.path.join(HERE, "daqp_oracle.c"))
+        or os.path.getmtime(os.path.join(HERE, "liboracle.so")) < os.path.getmtime(os.path.join(HERE, "daqp_oracle.c")) \
+        or (os.path.exists(os.path.join(HERE, "librefbatch.so"))
+            and os.path.getmtime(os.path.join(HERE, "librefbatch.so")) < os.path.getmtime(os.path.join(HERE, "ref_batch.c")))
     ref_missing = os.path.isdir("/root/reference/src") and not os.path.exists(os.path.join(HERE, "_ref", "libdaqp_ref.so"))
     if need or ref_missing or not os.path.exists(os.path.join(HERE, "liboracle_fast.so")) \
             or not os.path.exists(os.path.join(HERE, "librefbatch.so")):
@@ -397,6 +399,26 @@ def timed_cpu_batch(libpath, threads, H, f, A, bupper, blower, ms=0):
     if dt < 0:
         raise RuntimeError(f"could not load daqp_quadprog from {libpath}")
     return dt, x, lam, fval, flag, it
+
+
+def timed_cpu_warm(libpath, threads, H, f, A, bupper, blower, fs, ms=0):
+    """config C5 on `threads` host threads, all in C (oracle/ref_batch.c::ref_warm_run): setup_daqp + cold daqp_solve per QP
+    (untimed), then the T = fs.shape[0] warm steps daqp_update_ldp(UPDATE_v) + daqp_solve of every QP (timed).
+    Returns (seconds of the warm phase, x [T,N,n], lam [T,N,m], exitflag [T,N], iter [T,N])."""
+    build()
+    L = C.CDLL(os.path.join(HERE, "librefbatch.so"))
+    L.ref_warm_run.restype = C.c_double
+    L.ref_warm_run.argtypes = [C.c_char_p] + [C.c_int] * 6 + [c_double_p] * 8 + [c_int_p] * 2
+    H, f, A, bupper, blower, fs = _f64(H), _f64(f), _f64(A), _f64(bupper), _f64(blower), _f64(fs)
+    N, n = f.shape
+    m, T = bupper.shape[1], fs.shape[0]
+    x, lam = np.zeros((T, N, n)), np.zeros((T, N, m))
+    flag, it = np.zeros((T, N), np.int32), np.zeros((T, N), np.int32)
+    dt = L.ref_warm_run(libpath.encode(), threads, N, n, m, ms, T, _dp(H), _dp(f), _dp(A), _dp(bupper), _dp(blower), _dp(fs),
+                        _dp(x), _dp(lam), _ip(flag), _ip(it))
+    if dt < 0:
+        raise RuntimeError(f"could not load the workspace API from {libpath}")
+    return dt, x, lam, flag, it
 
 
 CONFIGS = {  # SURVEY.md section 8(d): name -> (n, m, ms, n_active, seed, full N)

@@ -125,6 +125,19 @@ def main():
     a, b = check("iter_limit_1", q, O.default_settings(iter_limit=1))
     print(f"  iter_limit=1           flag {b[3]} iter {b[4]}")
 
+    # the two branches of daqp_ldp that ordinary data never reaches, forced through settings (tests/test_gpu_branches.py):
+    # refactor repair (daqp.c:33-46) and cycle guard (daqp.c:66-85, exit flag -2)
+    forced = {"refactor": dict(refactor_tol=10.0), "cycle": dict(progress_tol=1e30, cycle_tol=0)}
+    for (n, m, ms, na), N in (((20, 40, 0, 8), 20), ((12, 48, 12, 6), 40), ((24, 60, 6, 8), 8), ((50, 150, 0, 20), 6), ((70, 160, 5, 25), 8)):
+        qs = O.generate_batch(N, n, m, ms, na, 4242 + n, start=100)
+        for name, kw in forced.items():
+            flags = set()
+            for k in range(N):
+                q = {key: qs[key][k] for key in ("H", "f", "A", "bupper", "blower")}
+                a, b = check(f"forced_{name}[{n},{k}]", q, O.default_settings(**kw))
+                flags.add(b[3])
+            print(f"  forced {name:9s} n={n:3d} m={m:3d}: {N} QPs, exit flags {sorted(flags)}")
+
     for cfg, (n, m, ms, na, seed, _) in O.CONFIGS.items():
         N = args.n_per_config if n < 100 else max(10, args.n_per_config // 15)
         nfast_same = 0

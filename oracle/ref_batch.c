@@ -68,3 +68,100 @@ double ref_batch_run(const char *libpath, int threads, int N, int n, int m, int 
     free(tid); free(sl);
     return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- config C5: setup_daqp -> daqp_solve -> {daqp_update_ldp(UPDATE_v) -> daqp_solve} x T per QP on P threads ------------
+ * Phase 1 (untimed): every thread sets up and cold-solves the QPs of its slice, keeping the workspaces.  Phase 2 (timed,
+ * between two barriers): the T warm steps of every QP of the slice -- no Python in the loop.  fs: [T][N][n] (the walk of f),
+ * outputs per step: x [T][N][n], lam [T][N][m], iter / flag [T][N]. */
+typedef int (*setup_fn)(DAQPProblem *, DAQPWorkspace *, double *);
+typedef void (*solve_fn)(DAQPResult *, DAQPWorkspace *);
+typedef int (*update_fn)(const int, DAQPWorkspace *, DAQPProblem *);
+typedef void (*freews_fn)(DAQPWorkspace *);
+
+typedef struct {
+    setup_fn setup; solve_fn solve; update_fn update; freews_fn free_ws, free_ldp;
+    int lo, hi, N, n, m, ms, T;
+    const double *H, *f, *A, *bu, *bl, *fs;
+    double *x, *lam;
+    int *flag, *iter;
+    pthread_barrier_t *bar;
+    double warm_s;
+} warm_slice_t;
+
+static void *run_warm_slice(void *arg)
+{
+    warm_slice_t *s = (warm_slice_t *)arg;
+    const size_t n = s->n, m = s->m, mA = s->m - s->ms, N = s->N;
+    const int cnt = s->hi - s->lo;
+    DAQPWorkspace *ws = (DAQPWorkspace *)calloc(cnt > 0 ? cnt : 1, sizeof(DAQPWorkspace));
+    DAQPProblem *qps = (DAQPProblem *)calloc(cnt > 0 ? cnt : 1, sizeof(DAQPProblem));
+    double *x0 = (double *)malloc(sizeof(double) * n), *l0 = (double *)malloc(sizeof(double) * (m ? m : 1));
+    for (int k = 0; k < cnt; k++) {
+        const size_t q = s->lo + k;
+        DAQPProblem *qp = &qps[k];
+        qp->n = s->n; qp->m = s->m; qp->ms = s->ms;
+        qp->H = (double *)s->H + q * n * n; qp->f = (double *)s->f + q * n; qp->A = (double *)s->A + q * mA * n;
+        qp->bupper = (double *)s->bu + q * m; qp->blower = (double *)s->bl + q * m; qp->sense = NULL;
+        s->setup(qp, &ws[k], NULL);
+        DAQPResult r;
+        memset(&r, 0, sizeof(r));
+        r.x = x0; r.lam = l0;
+        s->solve(&r, &ws[k]);
+    }
+    pthread_barrier_wait(s->bar);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int k = 0; k < cnt; k++) {
+        const size_t q = s->lo + k;
+        for (int t = 0; t < s->T; t++) {
+            qps[k].f = (double *)s->fs + ((size_t)t * N + q) * n;
+            s->update(DAQP_UPDATE_v, &ws[k], &qps[k]);
+            DAQPResult r;
+            memset(&r, 0, sizeof(r));
+            r.x = s->x + ((size_t)t * N + q) * n; r.lam = s->lam + ((size_t)t * N + q) * m;
+            s->solve(&r, &ws[k]);
+            s->flag[(size_t)t * N + q] = r.exitflag; s->iter[(size_t)t * N + q] = r.iter;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    s->warm_s = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    pthread_barrier_wait(s->bar);
+    for (int k = 0; k < cnt; k++) { s->free_ws(&ws[k]); s->free_ldp(&ws[k]); }
+    free(ws); free(qps); free(x0); free(l0);
+    return NULL;
+}
+
+/* returns the wall seconds of the warm phase (first thread in to last thread out), or -1 */
+double ref_warm_run(const char *libpath, int threads, int N, int n, int m, int ms, int T, const double *H, const double *f,
+                    const double *A, const double *bu, const double *bl, const double *fs, double *x, double *lam, int *flag,
+                    int *iter)
+{
+    void *h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return -1;
+    setup_fn su = (setup_fn)dlsym(h, "setup_daqp");
+    solve_fn so = (solve_fn)dlsym(h, "daqp_solve");
+    update_fn up = (update_fn)dlsym(h, "daqp_update_ldp");
+    freews_fn fw = (freews_fn)dlsym(h, "free_daqp_workspace"), fl = (freews_fn)dlsym(h, "free_daqp_ldp");
+    if (!su || !so || !up || !fw || !fl) return -1;
+    if (threads < 1) threads = 1;
+    if (threads > N) threads = N;
+    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    warm_slice_t *sl = (warm_slice_t *)malloc(sizeof(warm_slice_t) * threads);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, threads + 1);
+    for (int t = 0; t < threads; t++) {
+        warm_slice_t s = {su, so, up, fw, fl, (int)((long long)N * t / threads), (int)((long long)N * (t + 1) / threads), N, n, m, ms, T,
+                          H, f, A, bu, bl, fs, x, lam, flag, iter, &bar, 0.0};
+        sl[t] = s;
+        pthread_create(&tid[t], NULL, run_warm_slice, &sl[t]);
+    }
+    struct timespec t0, t1;
+    pthread_barrier_wait(&bar);                 /* every workspace is set up and cold-solved */
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    pthread_barrier_wait(&bar);                 /* every thread has finished its warm steps */
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    pthread_barrier_destroy(&bar);
+    free(tid); free(sl);
+    return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}

@@ -69,3 +69,19 @@ def test_bench_two_ranks_one_device_weak_and_strong(gpu_lib):
     s = run_bench(common + ["--config", "C3", "--strong", "--batch", "10001"], launcher)
     assert s["n_gpus"] == 2 and s["scaling"] == "strong" and s["config"]["batch_per_gpu"] == 5001   # rank 0 of 10001 interleaved
     assert "n=12 m=48" in s["metric"] and abs(s["value"] - 10001 * 2 / (s["ms_per_step"] * 2e-3)) < 1e-6 * s["value"]
+
+
+def test_bench_rccl_process_group_on_the_device(gpu_lib):
+    """the driver's launch shape with the REAL collective backend: torch.distributed.run, backend nccl (= RCCL on ROCm),
+    init_process_group(device_id=cuda:0), barrier and MAX all-reduce of the elapsed time on the device -- one rank, because
+    the box has one GPU (two RCCL ranks cannot share a device); the code path is the one every world size takes"""
+    port = 29900 + os.getpid() % 90
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    d = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--backend", "nccl", "--cpu-sample", "0", "--batch", "2048",
+                   "--side-configs", "none"], launcher)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["checks"]["all_optimal"]
+    assert "RCCL" in d["config"]["parallelism"], d["config"]["parallelism"]
+    s = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--backend", "nccl", "--cpu-sample", "0", "--config", "C3", "--strong",
+                   "--batch", "4099", "--side-configs", "none"], launcher)
+    assert s["scaling"] == "strong" and s["config"]["batch_per_gpu"] == 4099 and "RCCL" in s["config"]["parallelism"]

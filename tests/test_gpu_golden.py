@@ -126,13 +126,17 @@ def _nasty(trial):
 
 def test_degenerate_cases_fast_mode(oracle, gpu_lib, monkeypatch):
     """the 400 near-degenerate problems of test_gpu_parity (duplicate rows at 1e-13..1e-2, dependent equalities, soft rows)
-    in the DEFAULT arithmetic mode.  M differs from the reference's in the last bit there, and these problems sit on the
-    solver's thresholds on purpose, so a decision may legitimately fall the other way: the bar is the exit flag class
-    for every problem, and identical iterations / active set / x within 1e-9 relative for (nearly) all of them."""
+    in the DEFAULT arithmetic mode.  These problems sit on the solver's thresholds on purpose; the reference's own release
+    build (-fassociative-math) agrees with its strict build on 400/400 of them, so that is the bar here too: exit flag,
+    iteration count, active set (index and side) identical and x within 1e-9 relative on every one.  The count and every
+    differing trial (flags, iterations, fval of both) are written to gpurun_out/degenerate_fast_mode.json and committed as
+    profiles/r03_degenerate_fast_mode.json."""
+    import json
     import daqp_amd
     monkeypatch.setenv("DAQP_AMD_EXACT", "0")
     same = 0
     total = 0
+    differing = []
     for trial in range(400):
         q = _nasty(trial)
         x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
@@ -142,9 +146,19 @@ def test_degenerate_cases_fast_mode(oracle, gpu_lib, monkeypatch):
         if flag == r[3] and info["iterations"] == r[4] and (flag < 0 or (
                 np.array_equal(np.sign(info["lam"]), np.sign(r[1])) and np.abs(x - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max()))):
             same += 1
-        elif flag > 0:   # a different path must still end at the same optimum
-            assert abs(fval - r[2]) < 1e-6 * max(1.0, abs(r[2])), (trial, fval, r[2])
-    assert same >= 0.97 * total, (same, total)
+        else:
+            differing.append(dict(trial=trial, n=int(q["f"].size), m=int(q["bupper"].size), flag=int(flag), ref_flag=int(r[3]),
+                                  iter=int(info["iterations"]), ref_iter=int(r[4]), fval=float(fval), ref_fval=float(r[2]),
+                                  same_active_set=bool(flag > 0 and np.array_equal(np.sign(info["lam"]), np.sign(r[1]))),
+                                  dx=float(np.abs(x - r[0]).max()) if flag > 0 else None))
+            if flag > 0:   # a different path must still end at the same optimum
+                assert abs(fval - r[2]) < 1e-6 * max(1.0, abs(r[2])), (trial, fval, r[2])
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "degenerate_fast_mode.json"), "w") as fh:
+        json.dump(dict(same=same, total=total, differing=differing), fh, indent=1)
+    print(f"degenerate set, default arithmetic: {same}/{total} identical; differing trials: {[d['trial'] for d in differing]}")
+    assert same == total, (same, total, differing)
 
 
 def test_degenerate_branches_are_taken_on_the_gpu(oracle, gpu_lib, monkeypatch):

@@ -1,5 +1,10 @@
 #!/bin/bash
-# development build: fewer template instantiations (fast compile). Usage: tools/devbuild.sh [extra hipcc flags]
-cd "$(dirname "$0")/../daqp_amd/csrc" || exit 1
-mkdir -p ../lib
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DDAQP_AMD_FEW_VARIANTS "$@" daqp_amd.hip -o ../lib/libdaqp_amd.so 2>&1 | grep -E "error|Function Name|VGPRs:|AGPRs:|Scratch|Spill" | sed 's/\[-Rpass[^]]*\]//g; s/remark: //g; s#^[./a-z_]*.hip.h:[0-9]*:[0-9]*:##'
+# development build: fewer template instantiations (fast compile), every translation unit, same object cache and lock as
+# daqp_amd.build().  Usage: tools/devbuild.sh [extra hipcc flags]     (daqp_amd.build() rebuilds the full library afterwards:
+# objects are keyed on their flags and a "dev build" library always counts as stale)
+cd "$(dirname "$0")/.." || exit 1
+python - "$@" <<'PY'
+import sys
+import daqp_amd._lib as L
+L.build(force=False, verbose=True, extra_flags=["-DDAQP_AMD_FEW_VARIANTS", *sys.argv[1:]])
+PY

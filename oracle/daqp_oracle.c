@@ -1154,6 +1154,12 @@ int ora_get_state(const ora_work *w, int *n_active, int *WS, int *sense, double 
     if (sense) for (int i = 0; i < w->m; i++) sense[i] = w->sense[i];
     return w->sing_ind;
 }
+/* the raw iterate (positions 0..cnt-1 of lam / lam_star as the last iteration left them): for diagnosing which decision of a
+ * near-degenerate problem another arithmetic takes differently (tools/degenerate_report.py) */
+void ora_get_iterate(const ora_work *w, int cnt, double *lam, double *lam_star)
+{
+    for (int i = 0; i < cnt; i++) { if (lam) lam[i] = w->lam[i]; if (lam_star) lam_star[i] = w->lam_star[i]; }
+}
 void ora_get_ldp(const ora_work *w, double *M, double *R, double *v, double *dupper, double *dlower, double *scaling)
 {
     if (M) memcpy(M, w->M, sizeof(double) * (size_t)(w->m - w->ms) * w->n);

@@ -18,6 +18,7 @@
 #include "setup_fast.hip.h"
 #include "prox.hip.h"
 #include "wg_layout.hip.h"
+#include "tiny_kernel.hip.h"
 // the workgroup-per-problem solve kernel lives in its own translation unit (wg_kernel.hip): a change to it does not rebuild
 // everything else
 namespace daqp_amd {
@@ -33,6 +34,11 @@ DAQP_REG_SHAPE(2, 16)
 DAQP_REG_SHAPE(2, 32)
 #endif
 #undef DAQP_REG_SHAPE
+// the 16-problems-per-wave kernel of tiny shapes: tiny_kernel.hip
+extern template __global__ void k_ldp_tiny<4, 0, false>(const BatchDev *__restrict__, int);
+extern template __global__ void k_ldp_tiny<4, 0, true>(const BatchDev *__restrict__, int);
+extern template __global__ void k_ldp_tiny<4, 3, false>(const BatchDev *__restrict__, int);
+extern template __global__ void k_ldp_tiny<4, 3, true>(const BatchDev *__restrict__, int);
 template <int C> __global__ void k_ldp_wg(BatchDev b, int mode);
 extern template __global__ void k_ldp_wg<2>(BatchDev, int);
 extern template __global__ void k_ldp_wg<4>(BatchDev, int);
@@ -93,6 +99,8 @@ struct DAQPBatch {
     int C = 1;
     bool spill = false;
     int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
+    bool tiny = false;    // tiny shape (n <= 12, m <= 48, <= 13 working-set rows): 16 problems per wavefront (tiny_kernel.hip.h)
+    int tiny_tri = 0;     // its row slots that hold simple bounds only (zero prefix not stored: ms >= 12 -> 3)
     bool fast_setup = false, setup_spill = false;
     // workgroup-per-problem solve kernel (wg_kernel.hip.h): shapes without a register variant and more than 64 working-set rows
     bool in_prox_loop = false;      // launches of the proximal outer loop (solve_with_prox)
@@ -198,6 +206,16 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         ldp_kernel_t kf = pick_ldp(b);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
         hipLaunchKernelGGL(kf, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, b->d, mode | 4);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (b->tiny) {
+        const bool exact = b->d.exact_setup != 0 || b->in_prox_loop;
+        ldp_reg_kernel_t kt = b->tiny_tri == 3 ? (exact ? k_ldp_tiny<4, 3, false> : k_ldp_tiny<4, 3, true>)
+                                               : (exact ? k_ldp_tiny<4, 0, false> : k_ldp_tiny<4, 0, true>);
+        if (descriptor_changed) HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, TinyL<4>::bytes));
+        hipLaunchKernelGGL(kt, dim3((b->d.N + TinyL<4>::Q - 1) / TinyL<4>::Q), dim3(64), TinyL<4>::bytes, b->stream, (const BatchDev *)b->d_dev, mode);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -415,7 +433,7 @@ bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && 
 std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
-                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE"};
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -509,7 +527,9 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     const int lds_limit = env ? atoi(env) : 80 * 1024;
     b->spill = ldp_lds(n, m, cap, false).total_bytes > lds_limit;
     if (getenv("DAQP_AMD_FORCE_SPILL")) b->spill = true;
-    if (!b->spill && cap <= 64 && !getenv("DAQP_AMD_STREAM_M"))
+    b->tiny = !b->spill && tiny_shape_ok(n, m, cap) && !getenv("DAQP_AMD_STREAM_M") && !getenv("DAQP_AMD_NO_TINY");
+    b->tiny_tri = (b->tiny && ms >= 12) ? 3 : 0;
+    if (!b->tiny && !b->spill && cap <= 64 && !getenv("DAQP_AMD_STREAM_M"))
         for (const RegShape &rs : kRegShapes)
             if (d.nblk <= rs.nb && d.npair <= rs.np) { b->NB = rs.nb; b->NP = rs.np; break; }
     d.ldrc = 0;
@@ -594,6 +614,8 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &b->st_dev, 1);
     rc |= dev_alloc(b, &b->d_dev, 1);
     rc |= dev_alloc(b, &b->px.counter, 4);
+    d.tiny_pend = nullptr;
+    if (b->tiny) rc |= dev_alloc(b, &d.tiny_pend, Nn * 3 * TCAP);
     {   // period of the constant device clock behind s_memrealtime (settings->time_limit): asked of the runtime, not assumed
         int khz = 0;
         d.tick_s = (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) ? 1.0 / (1e3 * (double)khz) : 1e-8;

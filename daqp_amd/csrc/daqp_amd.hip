@@ -101,6 +101,7 @@ struct DAQPBatch {
     int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
     bool tiny = false;    // tiny shape (n <= 12, m <= 48, <= 13 working-set rows): 16 problems per wavefront (tiny_kernel.hip.h)
     int tiny_tri = 0;     // its row slots that hold simple bounds only (zero prefix not stored: ms >= 12 -> 3)
+    int tiny_grid = 1024; // persistent waves of that kernel: 4 per CU
     bool fast_setup = false, setup_spill = false;
     // workgroup-per-problem solve kernel (wg_kernel.hip.h): shapes without a register variant and more than 64 working-set rows
     bool in_prox_loop = false;      // launches of the proximal outer loop (solve_with_prox)
@@ -214,8 +215,11 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         ldp_reg_kernel_t kt = b->tiny_tri == 3 ? (exact ? k_ldp_tiny<4, 3, false> : k_ldp_tiny<4, 3, true>)
                                                : (exact ? k_ldp_tiny<4, 0, false> : k_ldp_tiny<4, 0, true>);
         if (descriptor_changed) HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemsetAsync(b->d.tiny_counter, 0, sizeof(int), b->stream));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, TinyL<4>::bytes));
-        hipLaunchKernelGGL(kt, dim3((b->d.N + TinyL<4>::Q - 1) / TinyL<4>::Q), dim3(64), TinyL<4>::bytes, b->stream, (const BatchDev *)b->d_dev, mode);
+        // persistent waves: one per SIMD (its 39 KB of LDS and the full register file allow no more), each takes problems off the counter
+        const int want = (b->d.N + TinyL<4>::Q - 1) / TinyL<4>::Q;
+        hipLaunchKernelGGL(kt, dim3(want < b->tiny_grid ? want : b->tiny_grid), dim3(64), TinyL<4>::bytes, b->stream, (const BatchDev *)b->d_dev, mode);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -614,8 +618,15 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &b->st_dev, 1);
     rc |= dev_alloc(b, &b->d_dev, 1);
     rc |= dev_alloc(b, &b->px.counter, 4);
-    d.tiny_pend = nullptr;
-    if (b->tiny) rc |= dev_alloc(b, &d.tiny_pend, Nn * 3 * TCAP);
+    d.tiny_pend = nullptr; d.tiny_counter = nullptr;
+    if (b->tiny) {
+        rc |= dev_alloc(b, &d.tiny_pend, Nn * 3 * TCAP);
+        rc |= dev_alloc(b, &d.tiny_counter, 1);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        b->tiny_grid = 4 * cus;
+        if (const char *ge = getenv("DAQP_AMD_TINY_GRID")) { const int v = atoi(ge); if (v >= 1) b->tiny_grid = v; }
+    }
     {   // period of the constant device clock behind s_memrealtime (settings->time_limit): asked of the runtime, not assumed
         int khz = 0;
         d.tick_s = (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) ? 1.0 / (1e3 * (double)khz) : 1e-8;

@@ -81,7 +81,7 @@ struct TW {
     double M[RPL][TNC];
     // d_upper, d_lower, scaling of the rows: read from HBM / L2 at the top of every scan (36 loads that complete behind the scan's
     // 132 multiply-adds) instead of 72 more registers held across the whole loop -- the register file is full: M alone is 264-288
-    const double *gdu, *gdl, *gsc;
+    const double *gdu, *gdl, *gsc;   // (rebuilt from the problem index where they are used: tptr)
     double ep;                  // -primal_tol
     unsigned long long rs;      // 4 sense bits per own row (ACTIVE, LOWER, IMMUTABLE, SOFT)
     // replicated in the group
@@ -92,6 +92,10 @@ struct TW {
     double fval, soft, dual_tol, sing_tol, pivot_tol, rho_soft;
     const DAQPSettings *stp;
     int *trace; int trace_cap, trace_len;
+    // cycle probes (daqp_batch_enable_profile): per-wave sums by phase, wave-uniform
+#ifdef DAQP_TINY_PROF
+    bool prof; long long pt[12]; long long pt0;
+#endif
 };
 #define TWT template <int G, int TRI, bool FM>
 #define TWR TW<G, TRI, FM> &
@@ -137,8 +141,28 @@ TWT __device__ __forceinline__ void tsense_set(TWR w, int id, int set_bits, int 
         w.rs = (w.rs | ((unsigned long long)set_bits << sh)) & ~((unsigned long long)clear_bits << sh);
     }
 }
+#ifdef DAQP_TINY_PROF
+#define TPROF(w, slot) do { if ((w).prof) { const long long t1_ = (long long)__builtin_readcyclecounter(); (w).pt[slot] += t1_ - (w).pt0; (w).pt0 = t1_; } } while (0)
+#else
+#define TPROF(w, slot) do { } while (0)
+#endif
 #define TLAM(w) (kTV + ((w).lamsw ? TV_LB : TV_LA))
 #define TLAMS(w) (kTV + ((w).lamsw ? TV_LA : TV_LB))
+
+// wave-wide maximum as a wave-uniform value (call only where every lane is active)
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    int o = dpp_i<0xB1>(v); v = o > v ? o : v;
+    o = dpp_i<0x4E>(v); v = o > v ? o : v;
+    o = dpp_i<0x141>(v); v = o > v ? o : v;
+    o = dpp_i<0x140>(v); v = o > v ? o : v;
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+// a value the optimizer cannot see through: compares derived from it are recomputed where they are used instead of being
+// kept as SGPR-pair masks across the whole pass (the first version of this kernel spilled 500 SGPRs that way)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // ---- forward substitution: x_i = rhs_i - sum_{j<i} L[i][j] x_j for rows i = from .. na-1, one row per trip, j ascending
 // (auxiliary.c:316-339).  rhs_off: LDS vector the right-hand sides are read from (TV_RHS for the CSP; TV_XL itself for
@@ -146,7 +170,8 @@ TWT __device__ __forceinline__ void tsense_set(TWR w, int id, int set_bits, int 
 TWT __device__ __forceinline__ void tforward(TWR w, int from, int rhs_off)
 {
     constexpr int Q = TW<G, TRI, FM>::Q;
-    for (int i = from; i < w.na; ++i) {     // (after an add: one trip)
+    const int na = opaque(w.na);
+    for (int i = from; i < na; ++i) {     // (after an add: one trip)
         double sum = w.sm[(kTV + rhs_off + i) * Q];
         const double *Lr = w.sm + (kTL + tlidx(i, 0)) * Q;
         double Lv[TCAP - 1], xv[TCAP - 1];
@@ -160,31 +185,20 @@ TWT __device__ __forceinline__ void tforward(TWR w, int from, int rhs_off)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
-// b <- L' \ b over the leading cnt positions, column-oriented: row j of L updates b_i, i < j, for j = cnt-1 .. 1; every b_i
-// receives its subtractions in descending j, product b_j * L[j][i] (auxiliary.c:344-352).  b_i must be 0 for i >= cnt.
-TWT __device__ __forceinline__ void tbackward(TWR w, double (&b)[TCAP], int cnt)
+// b <- L' \ b over the leading positions, column-oriented: row j of L updates b_i, i < j, for j = cnt-1 .. 1; every b_i receives
+// its subtractions in descending j, product b_j * L[j][i] (auxiliary.c:344-352).  b_j must be 0 beyond the problem's own count
+// (those steps then subtract 0 * finite); cmax >= every problem's count is wave-uniform: rows beyond it are skipped by a scalar branch.
+TWT __device__ __forceinline__ void tbackward(TWR w, double (&b)[TCAP], int cmax)
 {
     constexpr int Q = TW<G, TRI, FM>::Q;
     static_for<TCAP - 1>([&](auto jj) __attribute__((always_inline)) {
         constexpr int j = TCAP - 1 - jj;                    // 12 .. 1
-        if (j < cnt) {
+        if (j < cmax) {
             double Lv[j];
             static_for<j>([&](auto i) __attribute__((always_inline)) { Lv[i] = w.sm[(kTL + tlidx(j, i)) * Q]; });
             static_for<j>([&](auto i) __attribute__((always_inline)) { b[i] = msub<FM>(b[i], b[j], Lv[i]); });
         }
     });
-}
-// constrained stationary point (auxiliary.c:314-354): lam* in b[] and in the LDS vector
-TWT __device__ __forceinline__ void tcsp(TWR w, double (&b)[TCAP])
-{
-    constexpr int Q = TW<G, TRI, FM>::Q;
-    tforward(w, w.reuse, TV_RHS);
-    static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
-        const double z = w.sm[(kTV + TV_ZL + i) * Q];
-        b[i] = (i < w.na) ? z : 0.0;
-    });
-    tbackward(w, b, w.na);
-    w.reuse = w.na;
 }
 TWT __device__ __forceinline__ void tstore_lams(TWR w, const double (&b)[TCAP])
 {
@@ -193,29 +207,12 @@ TWT __device__ __forceinline__ void tstore_lams(TWR w, const double (&b)[TCAP])
     if (w.sub == 0) static_for<TCAP>([&](auto i) __attribute__((always_inline)) { ls[i * Q] = b[i]; });
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
-// auxiliary.c:357-376: the direction along which the singular system is unbounded, in b[] (and the lam* vector)
-TWT __device__ __forceinline__ void tsingular_direction(TWR w, double (&b)[TCAP])
-{
-    constexpr int Q = TW<G, TRI, FM>::Q;
-    const int s = w.sing;
-    const double *Ls = w.sm + (kTL + tlidx(s, 0)) * Q;
-    static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
-        const double l = (i < TCAP - 1) ? Ls[(i < TCAP - 1 ? i : 0) * Q] : 0.0;
-        b[i] = (i < s) ? -l : 0.0;
-    });
-    tbackward(w, b, s);
-    const bool flip = (tws_flag(w, s) & DAQP_LOWER) != 0;
-    static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
-        const double v = (i == s) ? 1.0 : b[i];
-        b[i] = (i <= s) ? (flip ? -v : v) : 0.0;
-    });
-}
 // ratio test of auxiliary.c:277-311 (SOFT_WEIGHTS off) on lam* = b[]: returns the position to drop (or -1) after stepping
 // lam towards lam*
 TWT __device__ __forceinline__ int tblocking(TWR w, const double (&b)[TCAP])
 {
     constexpr int Q = TW<G, TRI, FM>::Q;
-    const int na = w.na;
+    const int na = opaque(w.na);
     const bool regular = (w.sing == kEmpty);
     double *lm = w.sm + TLAM(w) * Q;
     unsigned blk = 0;
@@ -229,32 +226,35 @@ TWT __device__ __forceinline__ int tblocking(TWR w, const double (&b)[TCAP])
     if (blk == 0) return -1;
     double alpha = DAQP_INF;
     int rm = -1;
-    double lv[TCAP];
-    static_for<TCAP>([&](auto i) __attribute__((always_inline)) { lv[i] = lm[i * Q]; });
-    static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
-        if (blk & (1u << i)) {
-            const double cand = regular ? -lv[i] / (b[i] - lv[i]) : -lv[i] / b[i];
-            if (cand < alpha) { alpha = cand; rm = i; }
-        }
-    });
+    for (unsigned rest = blk; rest; rest &= rest - 1) {     // candidates in ascending position, strict `<`: the first minimum wins
+        const int i = __ffs((int)rest) - 1;
+        double bi = 0;
+        static_for<TCAP>([&](auto k) __attribute__((always_inline)) { bi = (k == i) ? b[k] : bi; });
+        const double li = lm[i * Q];
+        const double cand = regular ? -li / (bi - li) : -li / bi;
+        if (cand < alpha) { alpha = cand; rm = i; }
+    }
     if (rm < 0) return -1;
     if (w.sub == 0)
         static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
-            if (i < na) lm[i * Q] = regular ? lv[i] + alpha * (b[i] - lv[i]) : lv[i] + alpha * b[i];
+            const double li = lm[i * Q];
+            const double nv = regular ? li + alpha * (b[i] - li) : li + alpha * b[i];
+            if (i < na) lm[i * Q] = nv;
         });
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     w.sing = kEmpty;
     return rm;
 }
 // u = -M_k' lam* in working-set order (auxiliary.c:46-88): lane s forms the components s, s+G, ... from the cached rows, then
-// every lane of the group receives all of them
-TWT __device__ __forceinline__ void tprimal(TWR w, const double (&b)[TCAP])
+// every lane of the group receives all of them.  lam*_i = 0 beyond the problem's working set (0 * a cached row: exact no-op);
+// namax is wave-uniform.
+TWT __device__ __forceinline__ void tprimal(TWR w, const double (&b)[TCAP], int namax)
 {
     constexpr int Q = TW<G, TRI, FM>::Q, CP = TNC / G;
     double uu[CP];
     static_for<CP>([&](auto t) __attribute__((always_inline)) { uu[t] = 0.0; });
     static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
-        if (i < w.na) {
+        if (i < namax) {
             const double *row = w.sm + (kTR + (int)((w.slw >> (4 * i)) & 15) * TNC + w.sub) * Q;
             double rv[CP];
             static_for<CP>([&](auto t) __attribute__((always_inline)) { rv[t] = row[t * G * Q]; });
@@ -283,11 +283,12 @@ TWT __device__ __forceinline__ int tscan(TWR w, int &upper, double &bound, int &
     }
     double bv = 0.0, bb = 0.0;
     int bi = kRowNone;      // row | side << 8 | sense << 12
+    const int m = opaque(w.m);
     static_for<RPL / KG>([&](auto gg) __attribute__((always_inline)) {
         double mu[KG], du[KG], dl[KG], sc[KG];
         static_for<KG>([&](auto kk) __attribute__((always_inline)) {
             constexpr int k = KG * gg + kk;
-            const int r = w.sub + G * k, rr = r < w.m ? r : 0;
+            const int r = w.sub + G * k, rr = r < m ? r : 0;
             du[kk] = w.gdu[rr]; dl[kk] = w.gdl[rr]; sc[kk] = w.gsc[rr];
             mu[kk] = 0.0;
         });
@@ -301,7 +302,7 @@ TWT __device__ __forceinline__ int tscan(TWR w, int &upper, double &bound, int &
             constexpr int k = KG * gg + kk;
             const int r = w.sub + G * k;
             const int sn = (int)((w.rs >> (4 * k)) & 15);
-            const bool open = r < w.m && !(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE));
+            const bool open = r < m && !(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE));
             const double cu = du[kk] - mu[kk], cl = mu[kk] - dl[kk], bt = w.ep * sc[kk];
             const bool up = open && cu < bv && cu < bt;
             const bool lo = open && !up && cl < bv && cl < bt;
@@ -324,23 +325,23 @@ TWT __device__ __forceinline__ int tscan(TWR w, int &upper, double &bound, int &
 }
 
 // ---- LDL' row append (factorization.c:21-111): returns the new pivot D[na].  The row itself goes from its owner's registers
-// into cache slot `slot`; sn = sense bits of the row.
-TWT __device__ __forceinline__ double tappend(TWR w, int id, int slot, int sn)
+// into cache slot `slot`; sn = sense bits of the row; namax >= na of every appending problem is wave-uniform.
+TWT __device__ __forceinline__ double tappend(TWR w, int id, int slot, int sn, int namax)
 {
     constexpr int Q = TW<G, TRI, FM>::Q, RPL = TW<G, TRI, FM>::RPL;
-    const int na = w.na, n = w.n;
+    const int na = opaque(w.na), n = w.n;
     {   // the owning lane stores its registers
         double *dst = w.sm + (kTR + slot * TNC) * Q;
-        const bool owner = w.sub == (id & (G - 1));
-        const int kq = id / G;
+        const int kq = (w.sub == (id & (G - 1))) ? id / G : -1;
         static_for<RPL>([&](auto k) __attribute__((always_inline)) {
-            if (owner && kq == k)
+            if (opaque(kq) == k)     // (opaque: twelve separate guarded blocks -- merged into "store M[kq][j]" they send M to scratch memory)
                 static_for<TNC>([&](auto j) __attribute__((always_inline)) {
                     if constexpr (k < TRI && j < G * k) dst[j * Q] = 0.0; else dst[j * Q] = w.M[k][j];
                 });
         });
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    TPROF(w, 7);
     w.sing = kEmpty;
     const int c0 = id < w.ms ? id : 0;
     // Gram column: g_k = M_{WS[k]} . M_id with the reference's four partial sums -- one per lane -- over the columns from
@@ -365,28 +366,31 @@ TWT __device__ __forceinline__ double tappend(TWR w, int id, int slot, int sn)
         return gsum_pairs<G>(s);
     };
     double g[TCAP];
-    static_for<TCAP>([&](auto k) __attribute__((always_inline)) {
+    static_for<TCAP - 1>([&](auto k) __attribute__((always_inline)) {
         g[k] = 0.0;
-        if (k < na) {
+        if (k < namax) {      // (positions beyond the problem's own working set: slot 0 of the cache, a finite row; the value is never used)
             const int idk = (int)(k < 8 ? (w.id0 >> (6 * k)) & 63 : (w.id1 >> (6 * (k - 8))) & 63);
             const int j = (idk < w.ms) ? (c0 > idk ? c0 : idk) : c0;
             g[k] = dotrow((int)((w.slw >> (4 * k)) & 15), j);
         }
     });
+    g[TCAP - 1] = 0.0;
     double dnew = dotrow(slot, c0);
     int ns_act = 0;
     if (w.has_soft) {
         static_for<TCAP>([&](auto k) __attribute__((always_inline)) { if (k < na && (tws_flag(w, k) & DAQP_SOFT)) ns_act++; });
         if (sn & DAQP_SOFT) { ns_act++; dnew += w.rho_soft; }
     }
+    TPROF(w, 10);
     if (na == 0) return dnew;
     // l <- L \ g, column by column (every g_i receives its subtractions in ascending j: factorization.c:81-88); rows beyond
     // na carry unused values
     static_for<TCAP - 2>([&](auto j) __attribute__((always_inline)) {
-        if (j < na - 1) {
-            double Lv[TCAP - 1 - j];
-            static_for<TCAP - 1 - j>([&](auto ii) __attribute__((always_inline)) { Lv[ii] = w.sm[(kTL + tlidx(j + 1 + ii, j)) * Q]; });
-            static_for<TCAP - 1 - j>([&](auto ii) __attribute__((always_inline)) { g[j + 1 + ii] = msub<FM>(g[j + 1 + ii], Lv[ii], g[j]); });
+        if (j < namax - 1) {
+            constexpr int jc = j;
+            double Lv[TCAP - 1 - jc];
+            static_for<TCAP - 1 - jc>([&](auto ii) __attribute__((always_inline)) { Lv[ii] = w.sm[(kTL + tlidx(jc + 1 + ii, jc)) * Q]; });
+            static_for<TCAP - 1 - jc>([&](auto ii) __attribute__((always_inline)) { g[jc + 1 + ii] = msub<FM>(g[jc + 1 + ii], Lv[ii], g[jc]); });
         }
     });
     // l_k /= D_k, d_new -= sum_k l_k^2 D_k in k order (factorization.c:93-103): lane s divides for k = s, s+G, ...
@@ -417,14 +421,14 @@ TWT __device__ __forceinline__ double tappend(TWR w, int id, int slot, int sn)
 }
 
 // auxiliary.c:27-40: append constraint id (sense bits sn, multiplier lamv, CSP right-hand side rhs = -bound)
-TWT __device__ __forceinline__ void tpush(TWR w, int id, int sn, double lamv, double rhs)
+TWT __device__ __forceinline__ void tpush(TWR w, int id, int sn, double lamv, double rhs, int namax)
 {
     constexpr int Q = TW<G, TRI, FM>::Q;
     ttrace(w, id + 1);
     tsense_set(w, id, DAQP_ACTIVE, 0);
     const int slot = __ffs((int)~w.slotmask) - 1;
     w.slotmask |= 1u << slot;
-    const double dnew = tappend(w, id, slot, sn | DAQP_ACTIVE);
+    const double dnew = tappend(w, id, slot, sn | DAQP_ACTIVE, namax);
     tws_set(w, w.na, id, slot, sn);
     if (w.sub == 0) {
         w.sm[(TLAM(w) + w.na) * Q] = lamv;
@@ -435,20 +439,21 @@ TWT __device__ __forceinline__ void tpush(TWR w, int id, int sn, double lamv, do
     w.na++;
 }
 
-// ---- LDL' row delete (factorization.c:112-151) + the bookkeeping of auxiliary.c:3-22; returns 1 if the factor became singular
-TWT __device__ __forceinline__ int tdrop(TWR w, int r)
+// ---- LDL' row delete (factorization.c:112-151) + the bookkeeping of auxiliary.c:3-22; returns 1 if the factor became singular.
+// numax >= na - r - 1 of every dropping problem is wave-uniform.
+TWT __device__ __forceinline__ int tdrop(TWR w, int r, int numax)
 {
     constexpr int Q = TW<G, TRI, FM>::Q;
-    const int na = w.na;
+    const int na = opaque(w.na);
     const int idr = tws_id(w, r);
     ttrace(w, -(idr + 1));
     tsense_set(w, idr, 0, DAQP_ACTIVE);
     w.slotmask &= ~(1u << tws_slot(w, r));
     const int nupd = na - r - 1;
     double *lm = w.sm + TLAM(w) * Q;
-    if (nupd > 0) {
+    if (numax > 0) {
         constexpr int WP = (TCAP - 1 + G - 1) / G;
-        // column r below the diagonal: lane s keeps w_t for t = s, s+G, ...
+        // column r below the diagonal: lane s keeps w_t for t = s, s+G, ... (0 beyond the problem's own rows)
         double wv[WP];
         static_for<WP>([&](auto c) __attribute__((always_inline)) {
             const int t = w.sub + G * c;
@@ -474,12 +479,14 @@ TWT __device__ __forceinline__ int tdrop(TWR w, int r)
             }
         });
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // Gill-Golub-Murray-Saunders C1 rank-one update of the trailing block, pivot by pivot
+        // Gill-Golub-Murray-Saunders C1 rank-one update of the trailing block, pivot by pivot.  Problems whose own update is
+        // shorter run the remaining steps with p = 0 and store nothing.
         double alpha = w.sm[(kTV + TV_D + r) * Q];
         static_for<TCAP - 1>([&](auto j) __attribute__((always_inline)) {
-            if (j < nupd) {
+            if (j < numax) {
+                const bool mine = j < nupd;
                 const double p = gbcast<G, j % G>(wv[j / G]);
-                const double Di = w.sm[(kTV + TV_D + r + 1 + j) * Q];
+                const double Di = w.sm[(kTV + TV_D + (mine ? r + 1 + j : 0)) * Q];
                 const double dbar = Di + alpha * p * p;
                 // beta = p*alpha/dbar and alpha' = D_i*alpha/dbar: two divisions by the same number, one in the even and one
                 // in the odd lanes
@@ -487,7 +494,7 @@ TWT __device__ __forceinline__ int tdrop(TWR w, int r)
                 const double quo = num / dbar;
                 const double beta = gbcast<G, 0>(quo);
                 alpha = gbcast<G, 1>(quo);
-                if (w.sub == 0) w.sm[(kTV + TV_D + r + j) * Q] = dbar;
+                if (mine && w.sub == 0) w.sm[(kTV + TV_D + r + j) * Q] = dbar;
                 static_for<WP>([&](auto c) __attribute__((always_inline)) {
                     if constexpr (G * c + G - 1 > j) {
                         const int t = w.sub + G * c;
@@ -532,62 +539,7 @@ TWT __device__ __forceinline__ int tdrop(TWR w, int r)
     return 0;
 }
 
-// one step of iterative refinement on the active rows (auxiliary.c:498-593); lam* in b[] on entry and on return
-TWT __device__ __forceinline__ void trefine(TWR w)
-{
-    constexpr int Q = TW<G, TRI, FM>::Q;
-    const int na = w.na;
-    w.reuse = 0;
-    double b[TCAP];
-    {
-        const double *ls = w.sm + TLAMS(w) * Q;
-        static_for<TCAP>([&](auto i) __attribute__((always_inline)) { b[i] = ls[i * Q]; });
-    }
-    for (int i = 0; i < na; ++i) {
-        const int id = tws_id(w, i), fl = tws_flag(w, i);
-        const double *row = w.sm + (kTR + tws_slot(w, i) * TNC) * Q;
-        const int j0 = id < w.ms ? id : 0;
-        double mu = 0;
-        static_for<TNC>([&](auto j) __attribute__((always_inline)) {
-            const double t = mu + row[j * Q] * w.u[j];
-            mu = (j >= j0 && j < w.n) ? t : mu;
-        });
-        double li = 0;
-        static_for<TCAP>([&](auto k) __attribute__((always_inline)) { li = (k == i) ? b[k] : li; });
-        double res = mu - (-w.sm[(kTV + TV_RHS + i) * Q]);      // d = -rhs exactly
-        if (fl & DAQP_SOFT) res -= w.rho_soft * li;
-        if (w.sub == 0) w.sm[(kTV + TV_XL + i) * Q] = res;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    tforward(w, 0, TV_XL);
-    double dl[TCAP];
-    static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
-        const double z = w.sm[(kTV + TV_ZL + i) * Q];
-        dl[i] = (i < na) ? z : 0.0;
-    });
-    tbackward(w, dl, na);
-    static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
-        if (i < na) { if (w.sub == 0) w.sm[(kTV + TV_XL + i) * Q] = dl[i]; b[i] += dl[i]; }
-    });
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int i = 0; i < na; ++i) {
-        const int id = tws_id(w, i);
-        const double *row = w.sm + (kTR + tws_slot(w, i) * TNC) * Q;
-        const int j0 = id < w.ms ? id : 0;
-        double di = 0;
-        static_for<TCAP>([&](auto k) __attribute__((always_inline)) { di = (k == i) ? dl[k] : di; });
-        static_for<TNC>([&](auto j) __attribute__((always_inline)) {
-            const double t = w.u[j] - row[j * Q] * di;
-            w.u[j] = (j >= j0 && j < w.n) ? t : w.u[j];
-        });
-    }
-    double fv = w.soft;
-    static_for<TNC>([&](auto j) __attribute__((always_inline)) { fv += w.u[j] * w.u[j]; });
-    w.fval = fv;
-    tstore_lams(w, b);
-}
-
-// bound (on the side its LOWER bit says) and sense bits of constraint id, from the owning lane's registers
+// sense bits of constraint id (from the owning lane) and its bound on the side the LOWER bit says
 TWT __device__ __forceinline__ void trow_lookup(TWR w, int id, double &bound, int &sn)
 {
     const bool owner = w.sub == (id & (G - 1));
@@ -598,230 +550,329 @@ TWT __device__ __forceinline__ void trow_lookup(TWR w, int id, double &bound, in
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // daqp_ldp (daqp.c:6-108) + daqp_activate_constraints (auxiliary.c:399-479) + daqp_pivot_last (auxiliary.c:379-396) for the
-// problems of a wave, in lockstep phases.  Per problem: st = what it does next; an edit request (add / drop) with its
-// continuation; an activation cursor.  mode 1: only rebuild the working set from the ACTIVE bits.
+// problems of a wave, in lockstep passes.  Per problem (TCtl): st = what it does next; an edit request (add / drop) with its
+// continuation; an activation cursor.  Every primitive has ONE call site (the triangular solves serve the CSP, the singular
+// direction and refine_active alike: `kind` says which), so a pass is one straight walk through the code.  The wave is
+// persistent: a problem that finishes is retired and its four lanes take the next problem off the batch's counter
+// (tiny_kernel.hip.h), so the passes of a wave are not bounded by the slowest of sixteen problems.
 // ---------------------------------------------------------------------------------------------------------------------------
-enum : int { TST_ACT, TST_ITER, TST_EDIT, TST_DONE };
+enum : int { TST_ACT, TST_ITER, TST_EDIT, TST_DONE, TST_EMPTY };
+enum : int { TK_CSP, TK_SING, TK_REFINE, TK_ACTSING };    // what the solve phase of a TST_ITER problem computes
 enum : int { TAFTER_NEXT_ITER, TAFTER_CYCLE_GUARD, TAFTER_ACT_POST };
 enum : int { TACT_THEN_DONE, TACT_THEN_LOOP, TACT_THEN_NEXT_ITER, TACT_THEN_CYCLE_RESET };
 
-struct TinyOut { int flag, iterations; };
+struct TCtl {
+    int st, kind, it, flag, repaired, stall, tl_skip;
+    int depth, req_add, req_id, req_r, req_sn, after;
+    int act_then, act_i, act_next, act_flag;
+    double best, req_lam, req_rhs;
+};
+// wave-uniform loop invariants (settings)
+struct TSet {
+    double fbound, progress_tol, time_limit, refactor_tol, primal_tol, tick_s;
+    int iter_limit, cycle_tol, mode;
+    unsigned long long *tstart;
+    double *pend;       // [N][13][3]
+};
 
-TWT __device__ __forceinline__ TinyOut trun(TWR w, int mode, bool alive, bool need_activate, double *pend, unsigned long long t_start, double tick_s)
+#define TBEGIN_ITER(w, c, S) do { (c).st = ((c).it < (S).iter_limit) ? TST_ITER : TST_DONE; (c).kind = ((w).sing != kEmpty) ? TK_SING : TK_CSP; (c).tl_skip = 0; } while (0)
+
+// a fresh problem in these lanes (mode 1: only rebuild the working set from the ACTIVE bits)
+TWT __device__ __forceinline__ void tstart(TWR w, TCtl &c, const TSet &S, bool need_activate)
+{
+    c.flag = DAQP_EXIT_ITERLIMIT; c.it = 1; c.repaired = 0; c.stall = 0; c.best = -1; c.tl_skip = 0;
+    c.depth = 0; c.req_add = 1; c.req_id = 0; c.req_r = 0; c.req_sn = 0; c.after = TAFTER_NEXT_ITER; c.req_lam = 0; c.req_rhs = 0;
+    c.act_then = TACT_THEN_DONE; c.act_i = 0; c.act_next = 0; c.act_flag = 1; c.kind = TK_CSP;
+    if (S.mode == 1 || need_activate) {
+        w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0;
+        c.act_then = (S.mode == 1) ? TACT_THEN_DONE : TACT_THEN_LOOP;
+        c.st = TST_ACT;
+    } else TBEGIN_ITER(w, c, S);
+}
+
+// one lockstep pass: every live problem of the wave advances by one step of its state machine
+TWT __device__ __forceinline__ void tpass(TWR w, TCtl &c, const TSet &S, int q)
 {
     constexpr int Q = TW<G, TRI, FM>::Q, RPL = TW<G, TRI, FM>::RPL;
-    int flag = DAQP_EXIT_ITERLIMIT, it = 1, repaired = 0, stall = 0;
-    double best = -1;
-    const double fbound = 2 * w.stp->fval_bound;
-    const int iter_limit = w.stp->iter_limit;
-    const double progress_tol = w.stp->progress_tol;
-    const int cycle_tol = w.stp->cycle_tol;
-    const double time_limit = w.stp->time_limit;
-    const bool tl_armed = time_limit > 0.0;
-    int tl_skip = 0;
-#define TTL_CHECK() (tl_armed && !tl_skip && (it & 31) == 0 && time_is_up(t_start, time_limit, tick_s))
-    int depth = 0, req_add = 1, req_id = 0, req_r = 0, req_sn = 0, after = TAFTER_NEXT_ITER;
-    double req_lam = 0, req_rhs = 0;
-    int act_then = TACT_THEN_DONE, act_i = 0, act_next = 0, act_flag = 1;
-    int st;
-    if (!alive) st = TST_DONE;
-    else if (mode == 1 || need_activate) {
-        w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0;
-        act_then = (mode == 1) ? TACT_THEN_DONE : TACT_THEN_LOOP;
-        st = TST_ACT;
-    } else st = (it < iter_limit) ? TST_ITER : TST_DONE;
-
-    while (__any(st != TST_DONE)) {
-        // ---- activation cursor: the next ACTIVE-marked row in index order (auxiliary.c:399-479)
-        if (st == TST_ACT) {
-            int cand = kRowNone;
-            static_for<RPL>([&](auto kk) __attribute__((always_inline)) {
-                constexpr int k = RPL - 1 - kk;
-                const int r = w.sub + G * k;
-                if (r >= act_next && r < w.m && ((w.rs >> (4 * k)) & DAQP_ACTIVE)) cand = r;
-            });
-            cand = gmin_i<G>(cand);
-            if (cand == kRowNone) {
-                if (act_then == TACT_THEN_DONE) st = TST_DONE;
-                else if (act_then == TACT_THEN_LOOP) {
-                    if (act_flag < 0) { flag = act_flag; st = TST_DONE; }
-                    else { it = 1; st = (it < iter_limit) ? TST_ITER : TST_DONE; }
-                } else {
-                    if (act_then == TACT_THEN_CYCLE_RESET) { stall = 0; best = -1; }
-                    if (TTL_CHECK()) { flag = DAQP_EXIT_TIMELIMIT; st = TST_DONE; }
-                    else { ++it; st = (it < iter_limit) ? TST_ITER : TST_DONE; }
-                }
+#define TTL_CHECK() (S.tstart != nullptr && !c.tl_skip && (c.it & 31) == 0 && time_is_up(S.tstart[q], S.time_limit, S.tick_s))
+    const bool live = c.st != TST_DONE && c.st != TST_EMPTY;
+    // wave-uniform bounds of this pass's position loops
+    const int namax = wave_max_i(live ? w.na : 0);
+#ifdef DAQP_TINY_PROF
+    if (w.prof) { w.pt0 = (long long)__builtin_readcyclecounter(); w.pt[11] += 1; }
+#endif
+    // ---- activation cursor: the next ACTIVE-marked row in index order (auxiliary.c:399-479)
+    if (c.st == TST_ACT) {
+        int cand = kRowNone;
+        static_for<RPL>([&](auto kk) __attribute__((always_inline)) {
+            constexpr int k = RPL - 1 - kk;
+            const int r = w.sub + G * k;
+            if (r >= c.act_next && r < w.m && ((w.rs >> (4 * k)) & DAQP_ACTIVE)) cand = r;
+        });
+        cand = gmin_i<G>(cand);
+        if (cand == kRowNone) {
+            if (c.act_then == TACT_THEN_DONE) c.st = TST_DONE;
+            else if (c.act_then == TACT_THEN_LOOP) {
+                if (c.act_flag < 0) { c.flag = c.act_flag; c.st = TST_DONE; }
+                else { c.it = 1; TBEGIN_ITER(w, c, S); }
             } else {
-                double bd; int sn;
-                trow_lookup(w, cand, bd, sn);
-                act_i = cand;
-                req_add = 1; req_id = cand; req_sn = sn; req_lam = (sn & DAQP_LOWER) ? -1.0 : 1.0; req_rhs = -bd;
-                depth = 0; after = TAFTER_ACT_POST; st = TST_EDIT;
+                if (c.act_then == TACT_THEN_CYCLE_RESET) { c.stall = 0; c.best = -1; }
+                if (TTL_CHECK()) { c.flag = DAQP_EXIT_TIMELIMIT; c.st = TST_DONE; }
+                else { ++c.it; TBEGIN_ITER(w, c, S); }
             }
+        } else {
+            double bd; int sn;
+            trow_lookup(w, cand, bd, sn);
+            c.act_i = cand;
+            c.req_add = 1; c.req_id = cand; c.req_sn = sn; c.req_lam = (sn & DAQP_LOWER) ? -1.0 : 1.0; c.req_rhs = -bd;
+            c.depth = 0; c.after = TAFTER_ACT_POST; c.st = TST_EDIT;
         }
-        // ---- one iteration of daqp_ldp up to its working-set edit (daqp.c:12-64, 86-93)
-        if (st == TST_ITER) {
-            tl_skip = 0;
-            const bool was_singular = (w.sing != kEmpty);
-            double b[TCAP];
-            if (!was_singular) tcsp(w, b); else { ttrace(w, kTraceSingular); tsingular_direction(w, b); }
+    }
+    TPROF(w, 0);
+    // ---- the solve phase of an iteration (daqp.c:12-21, 86-93): CSP (auxiliary.c:314-354) or singular direction
+    // (auxiliary.c:357-376), or the solves of refine_active (auxiliary.c:498-593), through the same two substitutions
+    double b[TCAP];
+    bool go_primal = false, go_scan = false;
+    if (c.st == TST_ITER) {
+        const int kind = c.kind;
+        const bool dir = kind == TK_SING || kind == TK_ACTSING;
+        if (kind == TK_SING) ttrace(w, kTraceSingular);
+        if (kind == TK_REFINE) {    // residuals of the active rows into xldl (auxiliary.c:505-541)
+            w.reuse = 0;
+            const double *ls = w.sm + TLAMS(w) * Q;
+            for (int i = 0; i < w.na; ++i) {
+                const int id = tws_id(w, i), fl = tws_flag(w, i);
+                const double *row = w.sm + (kTR + tws_slot(w, i) * TNC) * Q;
+                const int j0 = id < w.ms ? id : 0;
+                double mu = 0;
+                static_for<TNC>([&](auto j) __attribute__((always_inline)) {
+                    const double t = mu + row[j * Q] * w.u[j];
+                    mu = (j >= j0 && j < w.n) ? t : mu;
+                });
+                double res = mu - (-w.sm[(kTV + TV_RHS + i) * Q]);      // d = -rhs exactly
+                if (fl & DAQP_SOFT) res -= w.rho_soft * ls[i * Q];
+                if (w.sub == 0) w.sm[(kTV + TV_XL + i) * Q] = res;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        if (!dir) tforward(w, kind == TK_REFINE ? 0 : w.reuse, kind == TK_REFINE ? TV_XL : TV_RHS);
+        TPROF(w, 1);
+        if (dir) {
+            const int s = w.sing;
+            const double *Ls = w.sm + (kTL + tlidx(s, 0)) * Q;
+            static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
+                const double l = Ls[(i < TCAP - 1 ? i : 0) * Q];
+                b[i] = (i < s) ? -l : 0.0;
+            });
+        } else {
+            const int na = opaque(w.na);
+            static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
+                const double z = w.sm[(kTV + TV_ZL + i) * Q];
+                b[i] = (i < na) ? z : 0.0;
+            });
+        }
+        tbackward(w, b, namax);
+        TPROF(w, 2);
+        if (dir) {
+            const int s = w.sing;
+            const bool flip = (tws_flag(w, s) & DAQP_LOWER) != 0;
+            static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
+                const double v = (i == s) ? 1.0 : b[i];
+                b[i] = (i <= s) ? (flip ? -v : v) : 0.0;
+            });
+        }
+        if (kind == TK_REFINE) {    // auxiliary.c:568-592: lam* += delta, u -= M' delta, fval
+            const int na = w.na;
+            const double *ls = w.sm + TLAMS(w) * Q;
+            for (int i = 0; i < na; ++i) {
+                const int id = tws_id(w, i);
+                const double *row = w.sm + (kTR + tws_slot(w, i) * TNC) * Q;
+                const int j0 = id < w.ms ? id : 0;
+                double di = 0;
+                static_for<TCAP>([&](auto k) __attribute__((always_inline)) { di = (k == i) ? b[k] : di; });
+                static_for<TNC>([&](auto j) __attribute__((always_inline)) {
+                    const double t = w.u[j] - row[j * Q] * di;
+                    w.u[j] = (j >= j0 && j < w.n) ? t : w.u[j];
+                });
+            }
+            static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
+                if (i < na) {
+                    if (w.sub == 0) w.sm[(kTV + TV_XL + i) * Q] = b[i];
+                    b[i] = ls[i * Q] + b[i];
+                }
+            });
+            double fv = w.soft;
+            static_for<TNC>([&](auto j) __attribute__((always_inline)) { fv += w.u[j] * w.u[j]; });
+            w.fval = fv;
             tstore_lams(w, b);
-            const int blk = tblocking(w, b);
-            if (blk >= 0) { req_add = 0; req_r = blk; depth = 0; after = TAFTER_NEXT_ITER; st = TST_EDIT; }
-            else if (was_singular) { flag = DAQP_EXIT_INFEASIBLE; st = TST_DONE; }
-            else {
-                tprimal(w, b);
-                int upper = 0, sn = 0, pick = kRowNone, pass = 0;
-                double bd = 0;
-                bool settled = false;
-                for (;;) {      // (a second trip only after refine_active)
-                    pick = tscan(w, upper, bd, sn, pass == 0);
-                    if (pass == 0 && w.fval > fbound) { flag = DAQP_EXIT_INFEASIBLE; st = TST_DONE; settled = true; break; }
-                    if (pick != kRowNone || pass == 1) break;
-                    double dmin = DAQP_INF;
-                    static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
-                        const double d = w.sm[(kTV + TV_D + i) * Q];
-                        dmin = (i < w.na && d < dmin) ? d : dmin;
-                    });
-                    if (w.na > 2 && repaired != 1 && dmin < w.stp->refactor_tol) {     // daqp.c:33-46
-                        repaired = 1; tl_skip = 1;
-                        ttrace(w, kTraceRefactor);
-                        const double *lm = w.sm + TLAM(w) * Q;
-                        for (int i = 0; i < w.na; ++i) {
-                            const int id = tws_id(w, i);
-                            if (lm[i * Q] >= 0) tsense_set(w, id, 0, DAQP_LOWER); else tsense_set(w, id, DAQP_LOWER, 0);
-                        }
-                        w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0;
-                        act_then = TACT_THEN_NEXT_ITER; act_next = 0; act_flag = 1; st = TST_ACT;
-                        settled = true;
-                        break;
+            go_scan = true;
+        } else {
+            if (kind == TK_CSP) w.reuse = w.na;
+            tstore_lams(w, b);
+            if (kind == TK_ACTSING) {   // auxiliary.c:424-459: a new equality depends on the active ones: consistent => ignore it
+                const int last = tws_id(w, w.na - 1);
+                double resid = 0.0, scale = 1.0;
+                static_for<TCAP>([&](auto j) __attribute__((always_inline)) {
+                    if (j < w.na) {
+                        const double t = b[j] * (-w.sm[(kTV + TV_RHS + j) * Q]);
+                        resid += t;
+                        scale += t < 0 ? -t : t;
                     }
-                    if (w.na > 0 && dmin < w.pivot_tol) {                                 // daqp.c:52-56
-                        ttrace(w, kTraceRefine);
-                        trefine(w);
-                        pass = 1; tl_skip = 1;
-                        continue;
-                    }
-                    break;
-                }
-                if (!settled) {
-                    if (pick == kRowNone) {
-                        flag = (w.soft > w.stp->primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
-                        st = TST_DONE;
-                    } else {
-                        // auxiliary.c:152-166: fix the side, lam <-> lam*, then add with multiplier +-1
-                        if (upper) tsense_set(w, pick, 0, DAQP_LOWER); else tsense_set(w, pick, DAQP_LOWER, 0);
-                        w.lamsw ^= 1;
-                        req_add = 1; req_id = pick; req_sn = upper ? (sn & ~DAQP_LOWER) : (sn | DAQP_LOWER);
-                        req_lam = upper ? 1.0 : -1.0; req_rhs = -bd;
-                        depth = 0; after = pass ? TAFTER_NEXT_ITER : TAFTER_CYCLE_GUARD; st = TST_EDIT;
-                    }
-                }
-            }
-        }
-        // ---- the edit: remove_constraint / add_constraint (auxiliary.c:3-44), one per problem and pass
-        bool edited = false, sing_after_drop = false;
-        if (st == TST_EDIT && !req_add) { sing_after_drop = tdrop(w, req_r) != 0; edited = true; }
-        if (st == TST_EDIT && req_add && !edited) { tpush(w, req_id, req_sn, req_lam, req_rhs); edited = true; }
-        // ---- daqp_pivot_last (auxiliary.c:379-396) as a stack of pending re-insertions, then the requester's continuation
-        if (edited) {
-            bool more = false;
-            if (!sing_after_drop) {
-                const int r = w.na - 2;
-                bool piv = false;
-                if (w.na > 1) {
-                    const double dr = w.sm[(kTV + TV_D + r) * Q], dlast = w.sm[(kTV + TV_D + w.na - 1) * Q];
-                    piv = dr < w.pivot_tol && dr < dlast;
-                }
-                if (piv) {
-                    ttrace(w, kTracePivot);
-                    if (w.sub == 0) {
-                        pend[3 * depth] = __hiloint2double(tws_flag(w, r), tws_id(w, r));
-                        pend[3 * depth + 1] = w.sm[(TLAM(w) + r) * Q];
-                        pend[3 * depth + 2] = w.sm[(kTV + TV_RHS + r) * Q];
-                    }
-                    depth++;
-                    req_add = 0; req_r = r; more = true;
-                } else if (depth > 0 && w.sing == kEmpty) {
-                    depth--;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    const double key = gpick<G>(w.sub == 0 ? pend[3 * depth] : 0.0, w.sub == 0);
-                    req_id = __double2loint(key); req_sn = __double2hiint(key);
-                    req_lam = gpick<G>(w.sub == 0 ? pend[3 * depth + 1] : 0.0, w.sub == 0);
-                    req_rhs = gpick<G>(w.sub == 0 ? pend[3 * depth + 2] : 0.0, w.sub == 0);
-                    req_add = 1; more = true;
-                }
-            }
-            if (!more) {
-                bool next_iter = false;
-                if (after == TAFTER_ACT_POST) {
-                    if (w.sing == kEmpty) { act_next = act_i + 1; st = TST_ACT; }
-                    else {
-                        const int last = tws_id(w, w.na - 1), lastflag = tws_flag(w, w.na - 1);
-                        if (lastflag & DAQP_IMMUTABLE) {   // a new equality depends on the active ones: consistent => ignore it
-                            double b[TCAP];
-                            tsingular_direction(w, b);
-                            tstore_lams(w, b);
-                            double resid = 0.0, scale = 1.0;
-                            static_for<TCAP>([&](auto j) __attribute__((always_inline)) {
-                                if (j < w.na) {
-                                    const double t = b[j] * (-w.sm[(kTV + TV_RHS + j) * Q]);
-                                    resid += t;
-                                    scale += t < 0 ? -t : t;
-                                }
-                            });
-                            tsense_set(w, last, 0, DAQP_ACTIVE);
-                            w.slotmask &= ~(1u << tws_slot(w, w.na - 1));
-                            w.na--;
-                            w.sing = kEmpty;
-                            if (w.reuse > w.na) w.reuse = w.na;
-                            if (resid <= w.stp->primal_tol * scale && resid >= -w.stp->primal_tol * scale) act_next = act_i + 1;
-                            else { act_flag = DAQP_EXIT_OVERDETERMINED_INITIAL; act_next = kRowNone; }
-                        } else {
-                            int bad = 0;
-                            static_for<RPL>([&](auto k) __attribute__((always_inline)) {   // rows >= act_i: unactivated equalities are an error, the rest are cleaned
-                                const int rr = w.sub + G * k;
-                                const int sn = (int)((w.rs >> (4 * k)) & 15);
-                                const bool later = rr >= act_i && rr < w.m && (sn & DAQP_ACTIVE);
-                                if (later && (sn & DAQP_IMMUTABLE)) bad = 1;
-                                if (later && !(sn & DAQP_IMMUTABLE)) w.rs &= ~((unsigned long long)DAQP_ACTIVE << (4 * k));
-                            });
-                            bad = gor<G>(bad);
-                            w.slotmask &= ~(1u << tws_slot(w, w.na - 1));
-                            w.na--;
-                            w.sing = kEmpty;
-                            act_flag = bad ? DAQP_EXIT_OVERDETERMINED_INITIAL : 1;
-                            act_next = kRowNone;
-                        }
-                        st = TST_ACT;
-                    }
-                } else if (after == TAFTER_CYCLE_GUARD) {   // daqp.c:66-85
-                    next_iter = true;
-                    if (w.fval - best < progress_tol) {
-                        if (stall++ > cycle_tol) {
-                            if (repaired == 1) { flag = DAQP_EXIT_CYCLE; st = TST_DONE; next_iter = false; }
-                            else {
-                                repaired = 1;
-                                ttrace(w, kTraceCycleReset);
-                                w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0;
-                                act_then = TACT_THEN_CYCLE_RESET; act_next = 0; act_flag = 1; st = TST_ACT;
-                                next_iter = false;
-                            }
-                        }
-                    } else { best = w.fval; stall = 0; }
-                } else next_iter = true;
-                if (next_iter) {
-                    if (TTL_CHECK()) { flag = DAQP_EXIT_TIMELIMIT; st = TST_DONE; }
-                    else { ++it; st = (it < iter_limit) ? TST_ITER : TST_DONE; }
-                }
+                });
+                tsense_set(w, last, 0, DAQP_ACTIVE);
+                w.slotmask &= ~(1u << tws_slot(w, w.na - 1));
+                w.na--;
+                w.sing = kEmpty;
+                if (w.reuse > w.na) w.reuse = w.na;
+                if (resid <= S.primal_tol * scale && resid >= -S.primal_tol * scale) c.act_next = c.act_i + 1;
+                else { c.act_flag = DAQP_EXIT_OVERDETERMINED_INITIAL; c.act_next = kRowNone; }
+                c.st = TST_ACT;
+            } else {
+                const int blk = tblocking(w, b);
+                if (blk >= 0) { c.req_add = 0; c.req_r = blk; c.depth = 0; c.after = TAFTER_NEXT_ITER; c.st = TST_EDIT; }
+                else if (kind == TK_SING) { c.flag = DAQP_EXIT_INFEASIBLE; c.st = TST_DONE; }
+                else go_primal = true;
             }
         }
     }
+    TPROF(w, 3);
+    // ---- primal step, feasibility scan and what follows from it (daqp.c:22-64)
+    if (go_primal || go_scan) {
+        if (go_primal) tprimal(w, b, namax);
+        TPROF(w, 4);
+        int upper = 0, sn = 0;
+        double bd = 0;
+        const int pick = tscan(w, upper, bd, sn, go_primal);
+        TPROF(w, 5);
+        if (go_primal && w.fval > S.fbound) { c.flag = DAQP_EXIT_INFEASIBLE; c.st = TST_DONE; }
+        else if (pick == kRowNone) {
+            bool fin = true;
+            if (go_primal) {
+                double dmin = DAQP_INF;
+                const int na = opaque(w.na);
+                static_for<TCAP>([&](auto i) __attribute__((always_inline)) {
+                    const double d = w.sm[(kTV + TV_D + i) * Q];
+                    dmin = (i < na && d < dmin) ? d : dmin;
+                });
+                if (w.na > 2 && c.repaired != 1 && dmin < S.refactor_tol) {     // daqp.c:33-46
+                    c.repaired = 1; c.tl_skip = 1;
+                    ttrace(w, kTraceRefactor);
+                    const double *lm = w.sm + TLAM(w) * Q;
+                    for (int i = 0; i < w.na; ++i) {
+                        const int id = tws_id(w, i);
+                        if (lm[i * Q] >= 0) tsense_set(w, id, 0, DAQP_LOWER); else tsense_set(w, id, DAQP_LOWER, 0);
+                    }
+                    w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0;
+                    c.act_then = TACT_THEN_NEXT_ITER; c.act_next = 0; c.act_flag = 1; c.st = TST_ACT;
+                    fin = false;
+                } else if (w.na > 0 && dmin < w.pivot_tol) {                         // daqp.c:52-56: refine, then scan again
+                    ttrace(w, kTraceRefine);
+                    c.kind = TK_REFINE; c.tl_skip = 1;
+                    fin = false;
+                }
+            }
+            if (fin) {
+                c.flag = (w.soft > S.primal_tol) ? DAQP_EXIT_SOFT_OPTIMAL : DAQP_EXIT_OPTIMAL;
+                c.st = TST_DONE;
+            }
+        } else {
+            // auxiliary.c:152-166: fix the side, lam <-> lam*, then add with multiplier +-1
+            if (upper) tsense_set(w, pick, 0, DAQP_LOWER); else tsense_set(w, pick, DAQP_LOWER, 0);
+            w.lamsw ^= 1;
+            c.req_add = 1; c.req_id = pick; c.req_sn = upper ? (sn & ~DAQP_LOWER) : (sn | DAQP_LOWER);
+            c.req_lam = upper ? 1.0 : -1.0; c.req_rhs = -bd;
+            c.depth = 0; c.after = go_scan ? TAFTER_NEXT_ITER : TAFTER_CYCLE_GUARD; c.st = TST_EDIT;
+        }
+    }
+    TPROF(w, 6);
+    // ---- the edit: remove_constraint / add_constraint (auxiliary.c:3-44), one per problem and pass
+    const bool dropping = c.st == TST_EDIT && !c.req_add, pushing = c.st == TST_EDIT && c.req_add;
+    bool edited = false, sing_after_drop = false;
+    if (__any(dropping)) {
+        const int numax = wave_max_i(dropping ? w.na - c.req_r - 1 : 0);
+        if (dropping) { sing_after_drop = tdrop(w, c.req_r, numax) != 0; edited = true; }
+    }
+    TPROF(w, 7);
+    if (__any(pushing)) {
+        const int pmax = wave_max_i(pushing ? w.na : 0);
+        if (pushing) { tpush(w, c.req_id, c.req_sn, c.req_lam, c.req_rhs, pmax); edited = true; }
+    }
+    TPROF(w, 8);
+    // ---- daqp_pivot_last (auxiliary.c:379-396) as a stack of pending re-insertions, then the requester's continuation
+    if (edited) {
+        bool more = false;
+        if (!sing_after_drop) {
+            const int r = w.na - 2;
+            bool piv = false;
+            if (w.na > 1) {
+                const double dr = w.sm[(kTV + TV_D + r) * Q], dlast = w.sm[(kTV + TV_D + w.na - 1) * Q];
+                piv = dr < w.pivot_tol && dr < dlast;
+            }
+            if (piv) {
+                ttrace(w, kTracePivot);
+                double *pend = S.pend + (size_t)q * 3 * TCAP;
+                if (w.sub == 0) {
+                    pend[3 * c.depth] = __hiloint2double(tws_flag(w, r), tws_id(w, r));
+                    pend[3 * c.depth + 1] = w.sm[(TLAM(w) + r) * Q];
+                    pend[3 * c.depth + 2] = w.sm[(kTV + TV_RHS + r) * Q];
+                }
+                c.depth++;
+                c.req_add = 0; c.req_r = r; more = true;
+            } else if (c.depth > 0 && w.sing == kEmpty) {
+                c.depth--;
+                const double *pend = S.pend + (size_t)q * 3 * TCAP;
+                const double key = gpick<G>(w.sub == 0 ? pend[3 * c.depth] : 0.0, w.sub == 0);
+                c.req_id = __double2loint(key); c.req_sn = __double2hiint(key);
+                c.req_lam = gpick<G>(w.sub == 0 ? pend[3 * c.depth + 1] : 0.0, w.sub == 0);
+                c.req_rhs = gpick<G>(w.sub == 0 ? pend[3 * c.depth + 2] : 0.0, w.sub == 0);
+                c.req_add = 1; more = true;
+            }
+        }
+        if (!more) {
+            bool next_iter = false;
+            if (c.after == TAFTER_ACT_POST) {
+                if (w.sing == kEmpty) { c.act_next = c.act_i + 1; c.st = TST_ACT; }
+                else if (tws_flag(w, w.na - 1) & DAQP_IMMUTABLE) { c.st = TST_ITER; c.kind = TK_ACTSING; }
+                else {
+                    int bad = 0;
+                    static_for<RPL>([&](auto k) __attribute__((always_inline)) {   // rows >= act_i: unactivated equalities are an error, the rest are cleaned
+                        const int rr = w.sub + G * k;
+                        const int sn = (int)((w.rs >> (4 * k)) & 15);
+                        const bool later = rr >= c.act_i && rr < w.m && (sn & DAQP_ACTIVE);
+                        if (later && (sn & DAQP_IMMUTABLE)) bad = 1;
+                        if (later && !(sn & DAQP_IMMUTABLE)) w.rs &= ~((unsigned long long)DAQP_ACTIVE << (4 * k));
+                    });
+                    bad = gor<G>(bad);
+                    w.slotmask &= ~(1u << tws_slot(w, w.na - 1));
+                    w.na--;
+                    w.sing = kEmpty;
+                    c.act_flag = bad ? DAQP_EXIT_OVERDETERMINED_INITIAL : 1;
+                    c.act_next = kRowNone;
+                    c.st = TST_ACT;
+                }
+            } else if (c.after == TAFTER_CYCLE_GUARD) {   // daqp.c:66-85
+                next_iter = true;
+                if (w.fval - c.best < S.progress_tol) {
+                    if (c.stall++ > S.cycle_tol) {
+                        if (c.repaired == 1) { c.flag = DAQP_EXIT_CYCLE; c.st = TST_DONE; next_iter = false; }
+                        else {
+                            c.repaired = 1;
+                            ttrace(w, kTraceCycleReset);
+                            w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0;
+                            c.act_then = TACT_THEN_CYCLE_RESET; c.act_next = 0; c.act_flag = 1; c.st = TST_ACT;
+                            next_iter = false;
+                        }
+                    }
+                } else { c.best = w.fval; c.stall = 0; }
+            } else next_iter = true;
+            if (next_iter) {
+                if (TTL_CHECK()) { c.flag = DAQP_EXIT_TIMELIMIT; c.st = TST_DONE; }
+                else { ++c.it; TBEGIN_ITER(w, c, S); }
+            }
+        }
+    }
+    TPROF(w, 9);
 #undef TTL_CHECK
-    TinyOut o;
-    o.flag = (mode == 1) ? act_flag : flag;
-    o.iterations = it;
-    return o;
 }
 
 #undef TWT

@@ -173,7 +173,8 @@ def lib():
         return _lib
     if not os.path.exists(LIBPATH):
         build()
-    L = C.CDLL(LIBPATH)
+    # DAQP_AMD_LIBRARY: another build of the library (tools/variants.sh links tuning variants side by side)
+    L = C.CDLL(os.environ.get("DAQP_AMD_LIBRARY") or LIBPATH)
     vp, ci = C.c_void_p, C.c_int
     L.daqp_amd_last_error.restype = C.c_char_p
     L.daqp_amd_version.restype = C.c_char_p

@@ -437,7 +437,7 @@ bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && 
 std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
-                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY"};
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_TINY", "DAQP_AMD_TINY_GRID"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -531,7 +531,9 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     const int lds_limit = env ? atoi(env) : 80 * 1024;
     b->spill = ldp_lds(n, m, cap, false).total_bytes > lds_limit;
     if (getenv("DAQP_AMD_FORCE_SPILL")) b->spill = true;
-    b->tiny = !b->spill && tiny_shape_ok(n, m, cap) && !getenv("DAQP_AMD_STREAM_M") && !getenv("DAQP_AMD_NO_TINY");
+    // opt-in (DAQP_AMD_TINY=1): on config C3 the 16-problems-per-wave kernel needs 2.16 ms per 125 000 solves against 1.87 ms of
+    // the one-wave-per-problem register kernel (DESIGN.md section 4.6 has the measurements and why)
+    { const char *te = getenv("DAQP_AMD_TINY"); b->tiny = te && atoi(te) != 0 && !b->spill && tiny_shape_ok(n, m, cap) && !getenv("DAQP_AMD_STREAM_M"); }
     b->tiny_tri = (b->tiny && ms >= 12) ? 3 : 0;
     if (!b->tiny && !b->spill && cap <= 64 && !getenv("DAQP_AMD_STREAM_M"))
         for (const RegShape &rs : kRegShapes)

@@ -128,7 +128,7 @@ def main():
     # the two branches of daqp_ldp that ordinary data never reaches, forced through settings (tests/test_gpu_branches.py):
     # refactor repair (daqp.c:33-46) and cycle guard (daqp.c:66-85, exit flag -2)
     forced = {"refactor": dict(refactor_tol=10.0), "cycle": dict(progress_tol=1e30, cycle_tol=0)}
-    for (n, m, ms, na), N in (((20, 40, 0, 8), 20), ((12, 48, 12, 6), 40), ((24, 60, 6, 8), 8), ((50, 150, 0, 20), 6), ((70, 160, 5, 25), 8)):
+    for (n, m, ms, na), N in (((20, 40, 0, 8), 20), ((12, 48, 12, 6), 40), ((9, 30, 4, 4), 24), ((24, 60, 6, 8), 8), ((50, 150, 0, 20), 6), ((70, 160, 5, 25), 8)):
         qs = O.generate_batch(N, n, m, ms, na, 4242 + n, start=100)
         for name, kw in forced.items():
             flags = set()

@@ -6,7 +6,7 @@
     rebuild of the factor, then exit flag -2.
 
 Each runs in the register kernel (k_ldp_reg), the generic one-wave kernel (DAQP_AMD_STREAM_M=1: k_ldp), the workgroup
-kernel (n >= 65: k_ldp_wg) and the 16-problems-per-wave kernel of tiny shapes (k_ldp_tiny), in both arithmetic modes.  Bar: exit flag,
+kernel (n >= 65: k_ldp_wg) and the 16-problems-per-wave kernel of tiny shapes (DAQP_AMD_TINY=1: k_ldp_tiny), in both arithmetic modes.  Bar: exit flag,
 iteration count and the add / remove / branch-marker trace equal to the oracle's (itself pinned on these settings against the
 reference library: oracle/pin_oracle.py), x and lam bit-identical in the exact mode and within 1e-9 in the default one,
 and the marker of the branch present in every problem's trace.
@@ -25,8 +25,9 @@ XTOL = 1e-9
 FAMILIES = {   # name -> (environment, (n, m, ms, n_active), problems)
     "register": ({}, (20, 40, 0, 8), 20),
     "register_c2": ({}, (50, 150, 0, 20), 6),
-    "tiny": ({}, (12, 48, 12, 6), 40),
-    "tiny_off": ({"DAQP_AMD_NO_TINY": "1"}, (12, 48, 12, 6), 20),
+    "tiny": ({"DAQP_AMD_TINY": "1"}, (12, 48, 12, 6), 40),
+    "tiny_generic_rows": ({"DAQP_AMD_TINY": "1"}, (9, 30, 4, 4), 24),
+    "register_c3": ({}, (12, 48, 12, 6), 20),
     "generic": ({"DAQP_AMD_STREAM_M": "1"}, (20, 40, 0, 8), 20),
     "generic_spill": ({"DAQP_AMD_STREAM_M": "1", "DAQP_AMD_FORCE_SPILL": "1"}, (24, 60, 6, 8), 8),
     "workgroup": ({}, (70, 160, 5, 25), 8),

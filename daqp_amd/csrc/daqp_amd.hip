@@ -19,6 +19,7 @@
 #include "prox.hip.h"
 #include "wg_layout.hip.h"
 #include "tiny_kernel.hip.h"
+#include "tiny_setup.hip.h"
 // the workgroup-per-problem solve kernel lives in its own translation unit (wg_kernel.hip): a change to it does not rebuild
 // everything else
 namespace daqp_amd {
@@ -39,6 +40,7 @@ extern template __global__ void k_ldp_tiny<4, 0, false>(const BatchDev *__restri
 extern template __global__ void k_ldp_tiny<4, 0, true>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_tiny<4, 3, false>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_tiny<4, 3, true>(const BatchDev *__restrict__, int);
+extern template __global__ void k_setup_tiny<4>(BatchDev, int);
 template <int C> __global__ void k_ldp_wg(BatchDev b, int mode);
 extern template __global__ void k_ldp_wg<2>(BatchDev, int);
 extern template __global__ void k_ldp_wg<4>(BatchDev, int);
@@ -102,6 +104,7 @@ struct DAQPBatch {
     bool tiny = false;    // tiny shape (n <= 12, m <= 48, <= 13 working-set rows): 16 problems per wavefront (tiny_kernel.hip.h)
     int tiny_tri = 0;     // its row slots that hold simple bounds only (zero prefix not stored: ms >= 12 -> 3)
     int tiny_grid = 1024; // persistent waves of that kernel: 4 per CU
+    bool tiny_setup = false;   // n <= 12, m <= 48: the 16-problems-per-wave setup kernel (tiny_setup.hip.h)
     bool fast_setup = false, setup_spill = false;
     // workgroup-per-problem solve kernel (wg_kernel.hip.h): shapes without a register variant and more than 64 working-set rows
     bool in_prox_loop = false;      // launches of the proximal outer loop (solve_with_prox)
@@ -437,7 +440,7 @@ bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && 
 std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
-                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_TINY", "DAQP_AMD_TINY_GRID"};
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_TINY", "DAQP_AMD_TINY_GRID", "DAQP_AMD_NO_TINY_SETUP"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -561,6 +564,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         }
     }
     b->fast_setup = (n <= 64) && !getenv("DAQP_AMD_SLOW_SETUP");
+    b->tiny_setup = b->fast_setup && n <= TNC && m <= TMR && !getenv("DAQP_AMD_NO_TINY_SETUP");
     {   // DAQP_AMD_EXACT=1: keep the reference's summation order in M = A R^-1 (bit-exact LDP); default: MFMA
         const char *ex = getenv("DAQP_AMD_EXACT");
         d.exact_setup = (ex && atoi(ex) != 0) ? 1 : 0;
@@ -853,7 +857,10 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
-    if (!lp) {
+    if (!lp && b->tiny_setup) {     // sixteen problems per wavefront; singular Hessians leave flagged for the regularising re-run below
+        hipLaunchKernelGGL(k_setup_tiny<4>, dim3((d.N + 15) / 16), dim3(64), 0, b->stream, d, mask);
+        HIPCHK(hipGetLastError());
+    } else if (!lp) {
         hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask);
         HIPCHK(hipGetLastError());
     } else HIPCHK(hipMemsetAsync(d.qs, 0, (size_t)d.N * sizeof(QState), b->stream));   // fresh records: the LP pass below fills them

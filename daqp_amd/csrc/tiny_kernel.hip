@@ -3,10 +3,12 @@
 // arithmetic (FM = false) and with fused multiply-adds (FM = true, the default mode)
 #include <hip/hip_runtime.h>
 #include "tiny_kernel.hip.h"
+#include "tiny_setup.hip.h"
 
 namespace daqp_amd {
 template __global__ void k_ldp_tiny<4, 0, false>(const BatchDev *__restrict__, int);
 template __global__ void k_ldp_tiny<4, 0, true>(const BatchDev *__restrict__, int);
 template __global__ void k_ldp_tiny<4, 3, false>(const BatchDev *__restrict__, int);
 template __global__ void k_ldp_tiny<4, 3, true>(const BatchDev *__restrict__, int);
+template __global__ void k_setup_tiny<4>(BatchDev, int);
 }

@@ -43,6 +43,15 @@ METRIC = {
 }
 
 
+ARITH = {   # what "dtype: f64" means per configuration in the library's DEFAULT mode (the `exact` entry of each line is the other mode)
+    "C2": "f64 throughout; fused multiply-adds in the iteration, M = A R^-1 on the f64 matrix cores (v_mfma_f64_16x16x4)",
+    "C3": "f64 throughout; fused multiply-adds in the iteration; setup in the reference's operation order (16 problems per wavefront, no matrix cores at n = 12)",
+    "C4": "f64 results; the feasibility scan is SCREENED in f32 under a rigorous error bound (the f64 scan decides whenever the f32 one is not certain: ~1 % of the scans), "
+          "inverse factor W = L^-1 with tree sums, M = A R^-1 on the f64 matrix cores",
+    "C5": "f64 throughout; fused multiply-adds in the iteration (factors set up once on the f64 matrix cores)",
+}
+
+
 def algorithmic_bytes(n, m, ms, iters, warm=False):
     """per-QP  B = B_io + it * 8 (m-ms) n; a warm step (C5) reads only the new f."""
     mA = m - ms
@@ -225,7 +234,7 @@ class Runner:
             parts.append({k: v[mine] for k, v in g.items()})
         return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
 
-    def run(self, cfg, steps, warmup, batch=None, strong=False, cpu_sample=-1, thread_options=None):
+    def run(self, cfg, steps, warmup, batch=None, strong=False, cpu_sample=-1, thread_options=None, exact_steps=0):
         import daqp_amd
         from daqp_amd.parallel import max_over_ranks
         torch = self.torch
@@ -281,7 +290,33 @@ class Runner:
         self.sync()
         elapsed = time.perf_counter() - t0
         elapsed = max_over_ranks(elapsed, device=self.red_device)
-        return q, res, bm, dict(N=N, N_total=N_total, elapsed=elapsed, setup_ms=setup_ms, solve_ms=solve_ms, T=T if warm else 1, fs=fs)
+        exact = None
+        if exact_steps > 0 and not warm and self.world == 1:
+            # the same steps in the library's EXACT arithmetic (DAQP_AMD_EXACT=1: the reference's operation order throughout,
+            # bit-identical results) on a second batch of workspaces -- reported next to the default mode's `value`
+            os.environ["DAQP_AMD_EXACT"] = "1"
+            try:
+                bx = daqp_amd.BatchModel(N, n, m, ms, device=self.local_rank)
+            finally:
+                os.environ.pop("DAQP_AMD_EXACT", None)
+            def xstep():
+                bx.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=mask)
+                return bx.solve(out="torch")
+            rx = xstep()
+            self.sync()
+            tx = time.perf_counter()
+            for _ in range(exact_steps):
+                rx = xstep()
+            self.sync()
+            dtx = time.perf_counter() - tx
+            a, b_ = bx.kernel_ms()
+            exact = dict(value=N * exact_steps / dtx, unit="QPs/s", steps=exact_steps, ms_per_step=dtx / exact_steps * 1e3, setup_ms=a, solve_ms=b_,
+                         same_iterations_as_default=bool((rx["iter"] == res["iter"]).all().item()),
+                         max_abs_dx_vs_default=float((rx["x"] - res["x"]).abs().max().item()),
+                         what="DAQP_AMD_EXACT=1: every sum in the reference's operation order (no fused multiply-adds, no matrix cores, no fp32 screening, no inverse factor): results bit-identical to the reference")
+            bx.close()
+            del bx, rx
+        return q, res, bm, dict(N=N, N_total=N_total, elapsed=elapsed, setup_ms=setup_ms, solve_ms=solve_ms, T=T if warm else 1, fs=fs, exact=exact)
 
     def report(self, cfg, q, res, info, steps, cpu_sample, headline):
         """rank 0: the JSON fields of one configuration"""
@@ -303,7 +338,8 @@ class Runner:
             "metric": METRIC[cfg], "value": units / info["elapsed"], "unit": "warm solves/s" if warm else "QPs/s",
             "ms_per_step": info["elapsed"] / steps * 1e3, "steps": steps,
             "workload": f"{cfg}: {N} {c['what']} per GPU" + (f" (ONE batch of {info['N_total']}, QP k on rank k mod {self.world})" if info["N_total"] else "")
-                        + f", n={n} m={m} ms={ms}, {c['na']} active at the optimum, kappa=100 (reference generate_test_QP), "
+                        + f", n={n} m={m} ms={ms}, {c['na']} active at the optimum, kappa=100 (reference generate_test_QP restated in torch on the GPU, "
+                        + "daqp_amd/synthetic.py: same family as SURVEY 8d's numpy default_rng([seed, k]) stream, not the same draws), "
                         + ("setup_daqp + cold solve untimed, then per step T=10 x {daqp_update_ldp(UPDATE_v) + daqp_solve}" if warm else
                            "daqp_quadprog semantics: setup + solve per step") + ", inputs and outputs resident in HBM",
             "batch_per_gpu": N, "mean_iterations": float(iters.mean()),
@@ -313,16 +349,25 @@ class Runner:
                          # the same time against B_io alone (inputs + outputs of the step): what is left if M stays on chip
                          "floor_frac": io_bytes / max(t_ldp + t_setup, 1e-12) / 1e9 / HBM_PEAK_GBS},
             "checks": {"all_optimal": flags_ok},
+            "arith": ARITH[cfg],
         }
+        if info.get("exact"):
+            out["exact"] = info["exact"]
         if not warm:
             out["roofline"]["pipeline"] = {"achieved": all_bytes / (t_ldp + t_setup) / 1e9, "frac": all_bytes / (t_ldp + t_setup) / 1e9 / HBM_PEAK_GBS,
                                            "setup_ms": t_setup * 1e3, "solve_ms": t_ldp * 1e3, "algorithmic_bytes_per_step": all_bytes}
             out["checks"]["max_abs_x_minus_analytic_optimum"] = float((res["x"] - q["xref"]).abs().max().item())
+        out["roofline"]["frac_is"] = ("EFFECTIVE rate: SURVEY 8(d)'s algorithmic bytes (M streamed once per iteration) over the launch time -- M is "
+                                      "held on chip, so this says how fast the nominal traffic is served, not how much of the HBM roof is used "
+                                      "(that is traffic_frac); the roof that binds the launch is instruction issue (roofline.issue)")
         prof = committed_counters(cfg, N, n, m)
         if prof:
             out["roofline"].update(prof)
             if prof.get("traffic"):     # what the launch really moves through the memory side, against the peak: the honest HBM utilisation
                 out["roofline"]["traffic_frac"] = prof["traffic"] / max(t_ldp, 1e-12) / 1e9 / HBM_PEAK_GBS
+            if prof.get("issue"):       # achieved / attainable on the issue roof, with the launch time measured in THIS run
+                out["roofline"]["issue"]["achieved_ms"] = t_ldp * 1e3
+                out["roofline"]["issue"]["frac"] = prof["issue"]["attainable_ms"] / max(t_ldp * 1e3, 1e-12)
         elif headline:
             out["roofline"]["traffic"] = None
         if cpu_sample > 0 and self.world == 1:
@@ -357,6 +402,8 @@ def committed_counters(cfg, N, n, m):
     out = {"traffic": d.get("traffic_bytes_per_launch"), "traffic_source": "profiles/" + os.path.basename(files[-1])}
     if "binding" in d:
         out["binding"] = d["binding"]
+    if "issue" in d:
+        out["issue"] = dict(d["issue"])
     return out
 
 
@@ -372,6 +419,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="QPs for the CPU baseline (-1: auto, 0: skip)")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (multi-rank smoke test on a 1-GPU box; use --backend gloo)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--no-exact", action="store_true", help="skip the extra steps in the library's exact arithmetic mode (reported under \"exact\")")
     args = ap.parse_args()
 
     R = Runner(args)
@@ -379,7 +427,10 @@ def main():
     auto_sample = {"C2": 65536, "C3": 262144, "C4": 1024, "C5": 8192}   # ~10-25 CPU-seconds each on one core-group
     sample = lambda cfg: 0 if (args.cpu_sample == 0 or R.world > 1) else (auto_sample[cfg] if args.cpu_sample < 0 else args.cpu_sample)
 
-    q, res, bm, info = R.run(args.config, args.steps, args.warmup, batch=args.batch or None, strong=args.strong)
+    exact_steps = {"C2": 3, "C3": 5, "C4": 1, "C5": 0}
+    want_exact = (not args.no_exact) and R.world == 1
+    q, res, bm, info = R.run(args.config, args.steps, args.warmup, batch=args.batch or None, strong=args.strong,
+                             exact_steps=exact_steps[args.config] if want_exact else 0)
     line = None
     if R.rank == 0:
         h = R.report(args.config, q, res, info, args.steps, sample(args.config), headline=True)
@@ -390,8 +441,10 @@ def main():
             "config": {"workload": h["workload"], "batch_per_gpu": h["batch_per_gpu"], "mean_iterations": h["mean_iterations"],
                        "parallelism": f"independent shards x{R.world}, no collective in the data path"
                                       + (f"; barrier + MAX(elapsed) over {R.comm}" if R.comm else "")},
-            "roofline": h["roofline"], "checks": h["checks"],
+            "roofline": h["roofline"], "checks": h["checks"], "arith": h["arith"],
         }
+        if "exact" in h:
+            line["exact"] = h["exact"]
         for k in ("cpu_baseline", "parity_vs_cpu"):
             if k in h:
                 line[k] = h[k]
@@ -407,11 +460,11 @@ def main():
         cfgs = {}
         for cfg in [s for s in side.split(",") if s and s != args.config]:
             st, wu = side_steps[cfg]
-            q, res, bm, info = R.run(cfg, st, wu)
+            q, res, bm, info = R.run(cfg, st, wu, exact_steps=exact_steps[cfg] if want_exact else 0)
             if R.rank == 0:
                 r = R.report(cfg, q, res, info, st, sample(cfg), headline=False)
                 cfgs[cfg] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "workload", "batch_per_gpu", "mean_iterations",
-                                               "roofline", "checks", "cpu_baseline", "parity_vs_cpu") if k in r}
+                                               "roofline", "checks", "arith", "exact", "cpu_baseline", "parity_vs_cpu") if k in r}
             bm.close()
             del q, res, bm
             R.torch.cuda.empty_cache()

@@ -62,7 +62,7 @@ EXPORTS = [
     "allocate_daqp_settings", "free_daqp_workspace", "free_daqp_ldp", "daqp_primal_init_active",
     "daqp_dual_init_active", "daqp_set_primal_start", "daqp_minrep", "allocate_daqp_workspace", "allocate_daqp_ldp", "daqp_first_violating", "daqp_batch_create", "daqp_batch_free", "daqp_amd_release_pool", "daqp_batch_set_stream",
     "daqp_batch_set_settings", "daqp_batch_set_exact", "daqp_batch_setup", "daqp_batch_setup_shared", "daqp_batch_update", "daqp_batch_solve",
-    "daqp_batch_setup_flags", "daqp_batch_working_sets", "daqp_batch_set_primal_start", "daqp_batch_prox_info", "daqp_quadprog_batch", "daqp_batch_kernel_ms",
+    "daqp_batch_setup_flags", "daqp_batch_working_sets", "daqp_batch_set_primal_start", "daqp_batch_prox_info", "daqp_quadprog_batch", "daqp_quadprog_batch_multi", "daqp_batch_kernel_ms",
     "daqp_batch_device_bytes", "daqp_amd_last_error", "daqp_amd_device_count", "daqp_amd_version",
     "setup_daqp_ldp", "daqp_ldp", "ldp2qp_solution", "daqp_extract_result",
     "daqp_batch_enable_trace", "daqp_batch_read_trace", "daqp_batch_enable_profile", "daqp_batch_read_profile", "daqp_batch_read_ldp",
@@ -198,6 +198,7 @@ def lib():
     L.daqp_batch_set_primal_start.argtypes = [vp, C.c_void_p, ci]
     L.daqp_batch_prox_info.argtypes = [vp, c_int_p, c_int_p, C.c_void_p]
     L.daqp_quadprog_batch.argtypes = [C.POINTER(DAQPBatchResult), C.POINTER(DAQPBatchProblem), C.POINTER(DAQPSettings)]
+    L.daqp_quadprog_batch_multi.argtypes = [C.POINTER(DAQPBatchResult), C.POINTER(DAQPBatchProblem), C.POINTER(DAQPSettings), c_int_p, ci]
     L.daqp_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.daqp_batch_device_bytes.argtypes = [vp]
     L.daqp_batch_device_bytes.restype = C.c_ulonglong

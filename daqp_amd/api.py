@@ -377,3 +377,29 @@ def solve_batch(H, f, A, bupper, blower=None, sense=None, ms=None, out="numpy", 
     finally:
         bm.close()
     return res
+
+
+def solve_batch_multi(H, f, A, bupper, blower=None, sense=None, ms=None, devices=None, **settings):
+    """solve_batch over several GPUs of this host: problem k on devices[k mod len(devices)] (daqp_quadprog_batch_multi: one host
+    thread, stream and set of workspaces per shard, no exchange step).  numpy arrays in, numpy arrays out; devices=None: every
+    visible device.  Returns dict(x, lam, fval, exitflag, iter, soft_slack)."""
+    N, n = f.shape[0], f.shape[1]
+    m = bupper.shape[1]
+    mA = A.shape[1] if A is not None and A.ndim == 3 else 0
+    ms = m - mA if ms is None else ms
+    if blower is None:
+        blower = np.full(bupper.shape, -INF)
+    keep = []
+    ptrs = [_ptr(a, dt, keep)[0] for a, dt in ((H, np.float64), (f, np.float64), (A if mA else None, np.float64), (bupper, np.float64),
+                                                (blower, np.float64), (sense, np.int32))]
+    p = DAQPBatchProblem(N, n, m, ms, *ptrs, MEM_HOST)
+    o = dict(x=np.empty((N, n)), lam=np.empty((N, m)), fval=np.empty(N), soft_slack=np.empty(N),
+             exitflag=np.empty(N, np.int32), iter=np.empty(N, np.int32))
+    r = DAQPBatchResult(o["x"].ctypes.data, o["lam"].ctypes.data, o["fval"].ctypes.data, o["soft_slack"].ctypes.data,
+                        o["exitflag"].ctypes.data, o["iter"].ctypes.data, MEM_HOST, 0, 0)
+    st = default_settings(**settings)
+    dev = None if devices is None else np.ascontiguousarray(devices, np.int32)
+    rc = lib().daqp_quadprog_batch_multi(C.byref(r), C.byref(p), C.byref(st), _ip(dev), 0 if dev is None else dev.size)
+    if rc != 0:
+        raise RuntimeError(f"daqp_quadprog_batch_multi failed ({rc}): {_lib.last_error()}")
+    return o

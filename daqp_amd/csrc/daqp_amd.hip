@@ -122,6 +122,13 @@ struct DAQPBatch {
     ProxDev px{};
     bool prox_ready = false;
     int counter_host[4] = {0, 0, 0, 0};   // read-back of px.counter
+    // "is any Hessian singular?" after a setup: counted on the device, copied to pinned memory without waiting.  The next solve
+    // goes out FIRST (flagged problems sit it out), then the host looks at the count: no gap between the setup and the solve
+    // launch on the device.  Anything else that needs the final setup flags resolves the question first (resolve_setup).
+    int *pin_count = nullptr;
+    hipEvent_t ev_count = nullptr;
+    bool reg_pending = false;
+    int reg_mask = 0;
     int n_prox_qps = 0;            // problems of the current setup that go through the outer loop
     int prox_outer = 0;            // outer iterations of the last solve (the longest loop of the batch)
     double *ident = nullptr;       // LP batches (H == NULL): the one n x n identity the setup pass reads as H
@@ -138,6 +145,7 @@ struct DAQPBatch {
     std::vector<double> one_lam;
     double one_fval = 0, one_soft = 0;
     int one_flag = 0, one_iter = 0;
+    bool one_valid = false;   // one_* belong to the workspace's current LDP (cleared by setup / update / a failed solve)
 };
 
 namespace {
@@ -310,13 +318,30 @@ int prox_buffers(DAQPBatch *b)
 }
 // After the first setup pass: problems whose Hessian Cholesky found singular (or all of them when eps_prox > 0) are set up
 // again from H + eps*I, eps doubling while the shifted factor is still ill-conditioned (utils.c:354-377).
-int regularise(DAQPBatch *b, int mask, bool lp)
+// the count of problems that the first setup pass flagged as singular: launched here, looked at later (resolve_setup)
+int count_flagged_async(DAQPBatch *b, int mask)
+{
+    BatchDev &d = b->d;
+    const int tpb = 128, nb = (d.N + tpb - 1) / tpb;
+    b->n_prox_qps = 0;
+    b->px.lp = 0;
+    HIPCHK(hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream));
+    hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 2);
+    HIPCHK(hipGetLastError());
+    if (!b->pin_count) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&b->pin_count), 4 * sizeof(int), hipHostMallocDefault));
+    if (!b->ev_count) HIPCHK(hipEventCreateWithFlags(&b->ev_count, hipEventDisableTiming));
+    HIPCHK(hipMemcpyAsync(b->pin_count, b->px.counter, 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipEventRecord(b->ev_count, b->stream));
+    b->reg_pending = true; b->reg_mask = mask;
+    return 0;
+}
+int regularise(DAQPBatch *b, int mask, bool lp, bool counted = false)
 {
     BatchDev &d = b->d;
     const int tpb = 128, nb = (d.N + tpb - 1) / tpb;
     b->n_prox_qps = 0;
     b->px.lp = lp ? 1 : 0;
-    if (!lp) {
+    if (!lp && !counted) {
         HIPCHK(hipMemsetAsync(b->px.counter, 0, 4 * sizeof(int), b->stream));
         hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 2);
         HIPCHK(hipGetLastError());
@@ -369,13 +394,15 @@ int launch_update_solve(DAQPBatch *b, int mask, bool descriptor_changed)
 }
 // daqp_solve for a batch that holds proximal problems: the ordinary ones are solved by one launch as usual, then the
 // outer iterations of daqp_prox.c:60-198 run for the others until each has stopped.
-int solve_with_prox(DAQPBatch *b, int mode)
+// ordinary_done: the ordinary problems have been solved already (the solve launch that went out before the host knew of any
+// singular Hessian: resolve_setup)
+int solve_with_prox(DAQPBatch *b, int mode, bool ordinary_done = false)
 {
     BatchDev &d = b->d;
     const int tpb = 128, nb = (d.N + tpb - 1) / tpb;
     hipLaunchKernelGGL(k_prox_mark, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 0);
     HIPCHK(hipGetLastError());
-    if (b->n_prox_qps < d.N) { if (launch_ldp(b, mode)) return DAQP_EXIT_UNSUPPORTED; }
+    if (!ordinary_done && b->n_prox_qps < d.N) { if (launch_ldp(b, mode)) return DAQP_EXIT_UNSUPPORTED; }
     hipLaunchKernelGGL(k_prox_mark, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, 1);
     HIPCHK(hipGetLastError());
     // the inner launches report into scratch; a problem's outputs are written when its loop ends
@@ -416,6 +443,19 @@ int solve_with_prox(DAQPBatch *b, int mode)
     return 0;
 }
 
+// The count started by the last daqp_batch_setup is looked at now; if the first pass flagged singular Hessians, their regularising
+// setup passes and their activation pass run here (utils.c:354-377).  Every entry point that needs final setup flags comes through.
+int resolve_setup(DAQPBatch *b)
+{
+    if (!b->reg_pending) return 0;
+    b->reg_pending = false;
+    HIPCHK(hipEventSynchronize(b->ev_count));
+    if (b->pin_count[0] == 0) return 0;
+    const int rc = regularise(b, b->reg_mask, false, true);
+    if (rc) return rc;
+    return launch_ldp(b, 1);
+}
+
 int check_problem(const DAQPBatch *b, const DAQPBatchProblem *p)
 {
     if (!b || !p) { set_err("null batch or problem"); return DAQP_EXIT_UNSUPPORTED; }
@@ -454,6 +494,8 @@ void destroy_batch(DAQPBatch *b)
     if (b->pin_out) (void)hipHostFree(b->pin_out);
     if (b->pin_mir) (void)hipHostFree(b->pin_mir);
     if (b->ev_in) (void)hipEventDestroy(b->ev_in);
+    if (b->ev_count) (void)hipEventDestroy(b->ev_count);
+    if (b->pin_count) (void)hipHostFree(b->pin_count);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }
@@ -678,9 +720,10 @@ void daqp_batch_free(DAQPBatch *b)
         (void)hipSetDevice(b->device);
         (void)hipStreamSynchronize(b->stream);
         b->stream = nullptr;
-        b->d.trace = nullptr; b->d.trace_cap = 0; b->d.prof = nullptr;
+        if (b->d.trace || b->d.prof) { destroy_batch(b); return; }     // (debug buffers were attached: not worth keeping, and not kept)
+        b->one_lam.clear(); b->one_valid = false;
         b->d.shared = 0; b->d.prox_pass = 0;
-        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->is_setup = false;
+        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->is_setup = false; b->reg_pending = false;
         b->timed_setup = b->timed_solve = false; b->n_prox_qps = 0; b->prox_outer = 0;
         b->one_fval = b->one_soft = 0; b->one_flag = b->one_iter = 0;
         DAQPBatch *evict = nullptr;
@@ -762,6 +805,7 @@ int daqp_batch_read_ldp(DAQPBatch *b, int q, double *M, double *R, double *v, do
 {
     if (!b || q < 0 || q >= b->d.N) return DAQP_EXIT_UNSUPPORTED;
     (void)hipSetDevice(b->device);
+    if (resolve_setup(b)) return DAQP_EXIT_UNSUPPORTED;
     if (flush_update(b)) return DAQP_EXIT_UNSUPPORTED;
     const BatchDev &d = b->d;
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -866,7 +910,8 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
     } else HIPCHK(hipMemsetAsync(d.qs, 0, (size_t)d.N * sizeof(QState), b->stream));   // fresh records: the LP pass below fills them
     // numerically singular Hessians: shifted re-runs for those problems (one tiny counting kernel when there are none);
     // an LP batch: its one setup pass
-    rc = regularise(b, mask, lp);
+    b->reg_pending = false;
+    rc = lp ? regularise(b, mask, true) : count_flagged_async(b, mask);
     if (rc) return rc;
     // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
     if (p->sense != nullptr || true) { rc = launch_ldp(b, 1); if (rc) return rc; }
@@ -892,6 +937,7 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     (void)init_mask;   // the unconstrained shortcut / elimination are per-problem decisions of daqp_quadprog: not taken here
     b->pending_mask = 0;
     b->n_prox_qps = 0;   // (a shared singular Hessian is reported as unsupported: the outer loop is per problem)
+    b->reg_pending = false;
     HIPCHK(hipSetDevice(b->device));
     BatchDev &d = b->d;
     const size_t N = d.N;
@@ -952,6 +998,8 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
     int rc = check_problem(b, p);
     if (rc) return rc;
     if (!b->is_setup) { set_err("daqp_batch_update before daqp_batch_setup"); return DAQP_EXIT_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(b->device));
+    if (resolve_setup(b)) return DAQP_EXIT_UNSUPPORTED;
     const int full = DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
     if ((mask & full) == full) {
         DAQPBatchProblem pp = *p;   // unchanged arrays may be omitted: reuse what the batch already has
@@ -1032,7 +1080,14 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
     HIPCHK(hipEventRecord(b->ev[2], b->stream));
     const int mode = b->pending_mask ? (2 | (b->pending_mask << 4)) : 0;
     b->pending_mask = 0;
-    int rc = b->n_prox_qps > 0 ? solve_with_prox(b, mode) : launch_ldp(b, mode);
+    int rc;
+    if (b->reg_pending) {
+        // straight after a setup: the solve launch goes out before the host knows whether any Hessian was singular (such
+        // problems sit it out with their internal flag); only then is the count read.  No gap on the device in the common case.
+        rc = launch_ldp(b, mode);
+        if (!rc) rc = resolve_setup(b);
+        if (!rc && b->n_prox_qps > 0) rc = solve_with_prox(b, mode, true);
+    } else rc = b->n_prox_qps > 0 ? solve_with_prox(b, mode) : launch_ldp(b, mode);
     if (rc) return rc;
     HIPCHK(hipEventRecord(b->ev[3], b->stream));
     b->timed_solve = true;
@@ -1068,6 +1123,7 @@ int daqp_batch_set_primal_start(DAQPBatch *b, const c_float *x, int memory)
 {
     if (!b || !x) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipSetDevice(b->device));
+    if (resolve_setup(b)) return DAQP_EXIT_UNSUPPORTED;
     if (!b->prox_ready) return 0;   // no singular Hessian seen: nothing would read it
     HIPCHK(hipMemcpyAsync(b->px.center, x, (size_t)b->d.N * b->d.n * sizeof(double),
                           memory == DAQP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->stream));
@@ -1082,6 +1138,7 @@ int daqp_batch_prox_info(DAQPBatch *b, int *n_prox_host, int *outer_host, c_floa
 {
     if (!b) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipSetDevice(b->device));
+    if (resolve_setup(b)) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipStreamSynchronize(b->stream));
     const int N = b->d.N;
     if (n_prox_host) {
@@ -1108,6 +1165,7 @@ int daqp_batch_setup_flags(DAQPBatch *b, int *flags_host)
 {
     if (!b || !flags_host) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipSetDevice(b->device));
+    if (resolve_setup(b)) return DAQP_EXIT_UNSUPPORTED;
     if (flush_update(b)) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipStreamSynchronize(b->stream));
     std::vector<QState> qs(b->d.N);
@@ -1121,6 +1179,7 @@ int daqp_batch_working_sets(DAQPBatch *b, int *n_active_host, int *ws_host)
 {
     if (!b) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipSetDevice(b->device));
+    if (resolve_setup(b)) return DAQP_EXIT_UNSUPPORTED;
     if (flush_update(b)) return DAQP_EXIT_UNSUPPORTED;
     HIPCHK(hipStreamSynchronize(b->stream));
     if (n_active_host) {
@@ -1173,6 +1232,10 @@ int daqp_quadprog_batch(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQ
     daqp_batch_free(b);
     return rc;
 }
+
+} // extern "C"
+#include "multi.hip.h"
+extern "C" {
 
 // ------------------------------------------------------------------------------------
 // single-problem drop-in entry points: a batch of one behind the reference's workspace struct
@@ -1321,6 +1384,7 @@ int daqp_update_ldp(const int mask, DAQPWorkspace *work, DAQPProblem *qp)
     work->qp = qp;
     DAQPBatchProblem p = one_problem(qp);
     int m = mask & ~(DAQP_UPDATE_hierarchy);
+    b->one_valid = false;
     int rc = daqp_batch_update(b, m, &p);
     if (rc < 0) return rc;
     int flag = 1;
@@ -1342,22 +1406,42 @@ int daqp_ldp(DAQPWorkspace *work)
     b->one_lam.resize(work->m > 0 ? work->m : 1);
     r.x = work->x; r.lam = b->one_lam.data(); r.fval = &b->one_fval; r.soft_slack = &b->one_soft; r.exitflag = &b->one_flag; r.iter = &b->one_iter;
     r.memory = DAQP_MEM_HOST;
+    b->one_valid = false;
     const int rc = daqp_batch_solve(b, &r);
     if (rc < 0) { b->one_flag = rc; return rc; }
     refresh_mirrors(work);
     work->iterations = b->one_iter;
+    b->one_valid = true;
     return b->one_flag;
 }
 void ldp2qp_solution(DAQPWorkspace *work) { (void)work; }   // daqp.h:13: done on the device by daqp_ldp (work->x already holds x)
 
 // api.c:455-495: package the last daqp_ldp / daqp_solve of this workspace
+// Everything comes from the workspace's own fields, as in the reference: x, the multipliers scattered from WS / lam_star /
+// n_active, fval = 1/2 (work->fval - |v|^2), iterations, soft_slack -- the host mirrors that daqp_ldp refreshed.  (A proximal
+// workspace reports the objective its outer loop formed on the device; an LP f'x.)
 void daqp_extract_result(DAQPResult *res, DAQPWorkspace *work)
 {
     DAQPBatch *b = ws_batch(work);
     if (!b || !res) return;
     if (res->x && work->x) for (int i = 0; i < work->n; ++i) res->x[i] = work->x[i];
-    if (res->lam) for (int i = 0; i < work->m; ++i) res->lam[i] = i < (int)b->one_lam.size() ? b->one_lam[i] : 0.0;
-    res->fval = b->one_fval; res->soft_slack = b->one_soft; res->iter = b->one_iter;
+    if (res->lam) {
+        for (int i = 0; i < work->m; ++i) res->lam[i] = 0;
+        if (work->WS && work->lam_star)
+            for (int i = 0; i < work->n_active; ++i)
+                if (work->WS[i] >= 0 && work->WS[i] < work->m) res->lam[work->WS[i]] = work->lam_star[i];
+    }
+    if (work->n_prox > 0 && b->one_valid) res->fval = b->one_fval;
+    else if (work->v != nullptr && (work->Rinv != nullptr || work->RinvD != nullptr)) {
+        c_float fv = work->fval;
+        for (int i = 0; i < work->n; ++i) fv -= work->v[i] * work->v[i];
+        res->fval = fv * 0.5;
+    } else if (work->qp != nullptr && work->qp->f != nullptr && work->x != nullptr) {
+        c_float fv = 0;
+        for (int i = 0; i < work->n; ++i) fv += work->qp->f[i] * work->x[i];
+        res->fval = fv;
+    }
+    res->soft_slack = work->soft_slack; res->iter = work->iterations;
     res->nodes = b->n_prox_qps > 0 ? b->prox_outer : 1;   // api.c:488: work->nh, the outer iterations of daqp_prox (daqp_prox.c:34,129)
 }
 

@@ -144,7 +144,7 @@ int setup_daqp_main(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time, i
 int daqp_update_ldp(const int mask, DAQPWorkspace *work, DAQPProblem *qp);     /* utils.c:58-221 */
 void daqp_default_settings(DAQPSettings *settings);                            /* api.c:505-527 */
 void allocate_daqp_settings(DAQPWorkspace *work);                              /* api.c:277-282 */
-void free_daqp_workspace(DAQPWorkspace *work);                                 /* api.c:393-420 */
+void free_daqp_workspace(DAQPWorkspace *work);                                 /* api.c:393-420 (the device side of a freed workspace is PARKED for the next one of its shape, up to 8: daqp_amd_release_pool() really frees, DAQP_AMD_NO_POOL=1 never parks) */
 void free_daqp_ldp(DAQPWorkspace *work);                                       /* api.c:243-275 */
 void daqp_primal_init_active(DAQPProblem *qp, c_float *x);                     /* api.c:579-616 */
 void daqp_dual_init_active(DAQPProblem *qp, c_float *lam);                     /* api.c:620-633 */
@@ -156,7 +156,7 @@ void daqp_minrep(int *is_redundant, c_float *A, c_float *b, int n, int m, int ms
 int setup_daqp_ldp(DAQPWorkspace *work, DAQPProblem *qp, const int init_mask);      /* api.c:161-209 (api.h:35) */
 int daqp_ldp(DAQPWorkspace *work);                                                  /* daqp.c:6-108 (daqp.h:12): iterate from the workspace's state; returns the exit flag */
 void ldp2qp_solution(DAQPWorkspace *work);                                          /* daqp.c:111-139 (daqp.h:13): done on the device by daqp_ldp -- a no-op kept for callers of the pair */
-void daqp_extract_result(DAQPResult *res, DAQPWorkspace *work);                     /* api.c:455-495 (api.h:54): x, lam, fval, iter of the workspace's last daqp_ldp / daqp_solve */
+void daqp_extract_result(DAQPResult *res, DAQPWorkspace *work);                     /* api.c:455-495 (api.h:54): x, lam (from WS / lam_star / n_active), fval, iter, soft_slack from the workspace's fields */
 
 /* ------------------------------------------------------------------ */
 /* (2) batch entry points (additive; not in the reference)             */
@@ -238,6 +238,15 @@ int daqp_batch_setup_flags(DAQPBatch *b, int *flags_host);
 int daqp_batch_working_sets(DAQPBatch *b, int *n_active_host, int *ws_host);
 /* one-shot: create + setup(DAQP_UPDATE_unconstrained) + solve + free == N x daqp_quadprog */
 int daqp_quadprog_batch(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQPSettings *settings);
+
+/* The same, over several GPUs of this host (independent problems, no exchange step): problem k is solved on
+ * devices[k mod n_devices] -- interleaved, so that the spread of iteration counts averages out -- by one host thread, one HIP
+ * stream and one set of device-resident workspaces per shard; results land in the caller's arrays at their own indices.  Problems
+ * and results must be host-resident (each shard stages its part).  devices == NULL: 0 .. n_devices-1; n_devices <= 0: every
+ * visible device.  The same device may be listed more than once (its shards then share it).  setup_time / solve_time: the
+ * slowest shard's. */
+int daqp_quadprog_batch_multi(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQPSettings *settings,
+                              const int *devices, int n_devices);
 
 /* device-side timing of the last setup / solve launches (HIP events on the batch's stream), ms */
 int daqp_batch_kernel_ms(DAQPBatch *b, float *setup_ms, float *solve_ms);

@@ -450,3 +450,23 @@ def test_quadprog_one_shot_reuses_parked_workspaces(oracle, gpu_lib, monkeypatch
     x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], np.zeros(25, np.int32))
     ref = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], np.zeros(25, np.int32))
     assert flag == ref[3] and bits_equal(x, ref[0])
+
+
+@pytest.mark.parametrize("cfg,N", [("C3", 1001), ("C2", 257)])
+def test_multi_device_entry_shards_on_one_gpu(oracle, gpu_lib, monkeypatch, cfg, N):
+    """daqp_quadprog_batch_multi (one host thread + one stream per device, problem k on devices[k mod G]) with the
+    box's one GPU listed two and three times: concurrent shards on one device, results scattered back to their own indices,
+    bit-identical to the unsharded daqp_quadprog_batch; a device that does not exist is refused"""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, na, seed, _ = O.CONFIGS[cfg]
+    q = O.generate_batch(N, n, m, ms, na, seed, start=7000)
+    one = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    for devs in ([0, 0], [0, 0, 0]):
+        g = daqp_amd.solve_batch_multi(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms, devices=devs)
+        assert np.array_equal(g["exitflag"], one["exitflag"]) and np.array_equal(g["iter"], one["iter"]), devs
+        assert bits_equal(g["x"], one["x"]) and bits_equal(g["lam"], one["lam"]) and bits_equal(g["fval"], one["fval"]), devs
+    ref = oracle.quadprog_batch(q["H"][:64], q["f"][:64], q["A"][:64], q["bupper"][:64], q["blower"][:64], None, ms=ms)
+    assert bits_equal(one["x"][:64], ref[0])
+    with pytest.raises(RuntimeError):
+        daqp_amd.solve_batch_multi(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms, devices=[0, 99])

@@ -8,8 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import CONFIGS
 
 out = sys.argv[1]
-SOLVE = {"C2": r"k_ldp_reg<3, 25", "C3": r"k_ldp_reg<1, 8", "C4": r"k_ldp_wg<4>", "C5": r"k_ldp_reg<3, 25"}
-SETUP = {"C2": r"k_setup_fast<56", "C3": r"k_setup_fast<16", "C4": r"k_setup<true>", "C5": r"k_setup_fast<56"}
+SOLVE = {"C2": r"k_ldp_reg<3, 25", "C3": r"k_ldp_reg<1, 8|k_ldp_tiny", "C4": r"k_ldp_wg<4>", "C5": r"k_ldp_reg<3, 25"}
+SETUP = {"C2": r"k_setup_fast<56", "C3": r"k_setup_tiny|k_setup_fast<16", "C4": r"k_setup<true>", "C5": r"k_setup_fast<56"}
+N_SIMD, F_CLK = 1024, 2.4e9        # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak (MI355X_MICROARCH.md); SQ_* cycle counters tick every 4 cycles
 
 
 def pick(raw, pat):
@@ -50,6 +51,12 @@ for path in sys.argv[2:]:
     if "issue" in s:
         i = s["issue"]
         insts = sum(s["instructions"].values())
+        # the roof that binds these kernels: instruction issue.  busy = cycles in which a wave had an instruction issuing; if every
+        # SIMD issued back to back with this instruction mix the launch would take busy / (SIMDs x clock)
+        busy = 4.0 * cs.get("SQ_ACTIVE_INST_ANY", 0.0)
+        entry["issue"] = {"wave_instructions": insts, "cycles_per_instruction": busy / insts if insts else None,
+                          "attainable_ms": busy / (N_SIMD * F_CLK) * 1e3,
+                          "note": "attainable = 4 x SQ_ACTIVE_INST_ANY / (1024 SIMDs x 2.4 GHz): every SIMD issuing back to back at the measured cycles per instruction"}
         entry["binding"] = {"resource": "instruction issue + dependent-operation latency (one wave per SIMD holds the iterate in registers)" if cfg != "C4"
                             else "per-CU memory pipeline (scan / row-cache reads at ~30 B/clk/CU) + the master wave's substitution chains",
                             "frac": i["active_inst_any_over_wave_cycles"], "frac_is": "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of the solve launch",

@@ -189,7 +189,7 @@ ldp_kernel_t pick_ldp(const DAQPBatch *b)
     const bool spill = b->spill;
 #ifdef DAQP_AMD_FEW_VARIANTS
     if (!spill) return k_ldp<4, false, 0, 0>;
-    return k_ldp<4, true, 0, 0>;
+    return C == 8 ? k_ldp<8, true, 0, 0> : k_ldp<4, true, 0, 0>;
 #else
     if (!spill) {
         if (C == 1) return k_ldp<1, false, 0, 0>;
@@ -198,6 +198,7 @@ ldp_kernel_t pick_ldp(const DAQPBatch *b)
     }
     if (C == 1) return k_ldp<1, true, 0, 0>;
     if (C == 2) return k_ldp<2, true, 0, 0>;
+    if (C == 8) return k_ldp<8, true, 0, 0>;
     return k_ldp<4, true, 0, 0>;
 #endif
 }
@@ -355,7 +356,7 @@ int regularise(DAQPBatch *b, int mask, bool lp, bool counted = false)
     // the shifted passes keep M in the reference's operation order whatever the arithmetic mode of the batch (their
     // problems are then bit-identical to the reference in both modes); an LP's one pass is the generic kernel's diagonal path
     const bool gs = b->setup_spill;
-    setup_kernel_t ks = gs ? k_setup<true> : k_setup<false>;
+    setup_kernel_t ks = gs ? (d.n > 256 ? k_setup<true, 8> : k_setup<true>) : k_setup<false>;
     size_t lds = (size_t)setup_lds(d.n, d.m, gs).total_bytes;
     if (b->fast_setup && !lp) {
         ks = (d.n <= 16) ? k_setup_fast<16, true> : (d.n <= 32 ? k_setup_fast<32, true> : (d.n <= 56 ? k_setup_fast<56, true> : k_setup_fast<64, true>));
@@ -412,10 +413,9 @@ int solve_with_prox(DAQPBatch *b, int mode, bool ordinary_done = false)
     d.f = b->px.feff; d.fval = b->px.t_fval; d.soft = b->px.t_soft; d.exitflag = b->px.t_flag; d.iter = b->px.t_iter;
     const ProxOut po = {f_user, d.lam, o_fval, o_soft, o_flag, o_iter};
     const size_t lds_grad = (size_t)ldp_lds(d.n, d.m, d.cap, b->spill).total_bytes;
-    if (b->px.lp) {
-        if (b->spill) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_gradient<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grad));
-        else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_gradient<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grad));
-    }
+    typedef void (*grad_kernel_t)(BatchDev, ProxDev, double *, ProxOut);
+    const grad_kernel_t kgrad = b->C == 8 ? k_lp_gradient<8, true> : (b->spill ? k_lp_gradient<4, true> : k_lp_gradient<4, false>);
+    if (b->px.lp) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grad));
     int rc = 0, outer = 0;
     b->in_prox_loop = true;
     hipLaunchKernelGGL(k_prox_pre, dim3(d.N), dim3(64), 0, b->stream, d, b->px, f_user);
@@ -429,8 +429,7 @@ int solve_with_prox(DAQPBatch *b, int mode, bool ordinary_done = false)
         if (read_counters(b)) { rc = 1; break; }
         if (b->counter_host[2] == 0) break;
         if (b->counter_host[3] > 0) {   // LP iterates off a vertex walk to the next constraint
-            if (b->spill) hipLaunchKernelGGL((k_lp_gradient<4, true>), dim3(d.N), dim3(64), lds_grad, b->stream, d, b->px, d.x, po);
-            else hipLaunchKernelGGL((k_lp_gradient<4, false>), dim3(d.N), dim3(64), lds_grad, b->stream, d, b->px, d.x, po);
+            hipLaunchKernelGGL(kgrad, dim3(d.N), dim3(64), lds_grad, b->stream, d, b->px, d.x, po);
             if (hipGetLastError() != hipSuccess) { rc = 1; break; }
         }
     }
@@ -526,7 +525,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         return DAQP_EXIT_UNSUPPORTED;
     }
     const int cap = n + ns_max + 1;
-    if (cap > 256 || n > 255) { set_err("n + ns + 1 = %d exceeds the 256-row working-set limit of this build", cap); return DAQP_EXIT_UNSUPPORTED; }
+    if (cap > 512 || n > 511) { set_err("n + ns + 1 = %d exceeds the 512-row working-set limit of this build", cap); return DAQP_EXIT_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         set_err("no HIP device: libdaqp_amd has no CPU path");
@@ -568,14 +567,14 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     d.npair = (n + 1) / 2; d.nblk = (m + 63) / 64; d.ldr = n | 1; d.nquad = (d.npair + 1) / 2;
     d.ltri = round_up(cap * (cap + 1) / 2, 2); d.rtri = n * (n + 1) / 2;   // even stride: 16-byte aligned rows for the direct HBM->LDS copy
     if (settings) d.st = *settings; else default_settings(&d.st);
-    b->C = cap <= 64 ? 1 : (cap <= 128 ? 2 : 4);
+    b->C = cap <= 64 ? 1 : (cap <= 128 ? 2 : (cap <= 256 ? 4 : 8));
 #ifdef DAQP_AMD_FEW_VARIANTS
-    b->C = 4;
+    if (b->C < 4) b->C = 4;
 #endif
     const char *env = getenv("DAQP_AMD_LDS_LIMIT");
     const int lds_limit = env ? atoi(env) : 80 * 1024;
     b->spill = ldp_lds(n, m, cap, false).total_bytes > lds_limit;
-    if (getenv("DAQP_AMD_FORCE_SPILL")) b->spill = true;
+    if (getenv("DAQP_AMD_FORCE_SPILL") || cap > 256) b->spill = true;
     // opt-in (DAQP_AMD_TINY=1): on config C3 the 16-problems-per-wave kernel needs 2.16 ms per 125 000 solves against 1.87 ms of
     // the one-wave-per-problem register kernel (DESIGN.md section 4.6 has the measurements and why)
     { const char *te = getenv("DAQP_AMD_TINY"); b->tiny = te && atoi(te) != 0 && !b->spill && tiny_shape_ok(n, m, cap) && !getenv("DAQP_AMD_STREAM_M"); }
@@ -590,7 +589,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.ldrc = l;
     }
     b->lds_ldp = b->NB > 0 ? (size_t)reg_lds_bytes(b->NB, n, m, cap, d.ldrc) : (size_t)ldp_lds(n, m, cap, b->spill, d.ldrc).total_bytes;
-    if (b->NB == 0 && cap > 64 && !getenv("DAQP_AMD_NO_WG")) {
+    if (b->NB == 0 && cap > 64 && cap <= 256 && !getenv("DAQP_AMD_NO_WG")) {     // (beyond 256 rows: the one-wave kernel with eight chunks, everything large in HBM scratch)
         int W = d.nblk < 4 ? 4 : (d.nblk > kWgMaxWaves ? kWgMaxWaves : d.nblk);
         if (const char *we = getenv("DAQP_AMD_WG_WAVES")) { const int v = atoi(we); if (v >= 4 && v <= kWgMaxWaves) W = v; }
         const int lds_max = 160 * 1024 - 256;          // (the kernel's few static words come on top of the dynamic allocation)
@@ -611,7 +610,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         const char *ex = getenv("DAQP_AMD_EXACT");
         d.exact_setup = (ex && atoi(ex) != 0) ? 1 : 0;
     }
-    b->setup_spill = !b->fast_setup && (setup_lds(n, m).total_bytes > 150 * 1024 || getenv("DAQP_AMD_FORCE_SPILL"));
+    b->setup_spill = !b->fast_setup && (setup_lds(n, m).total_bytes > 150 * 1024 || getenv("DAQP_AMD_FORCE_SPILL") || n > 256);
     b->lds_setup = b->fast_setup ? (size_t)fast_lds(n, m, 1, m - ms).total_bytes : (size_t)setup_lds(n, m, b->setup_spill).total_bytes;
     b->lds_update = (size_t)round_up(n, 2) * 16;
     if (b->lds_ldp > 160 * 1024 || b->lds_setup > 160 * 1024) {
@@ -893,7 +892,7 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
     // flag and active set, x and lam equal to ~1e-13, only the iteration count may differ (tests/test_gpu_reference_cases.py).
     const int mask = (init_mask & ~DAQP_UPDATE_eliminate) | DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
     typedef void (*setup_kernel_t)(BatchDev, int);
-    setup_kernel_t ks = b->setup_spill ? k_setup<true> : k_setup<false>;
+    setup_kernel_t ks = b->setup_spill ? (d.n > 256 ? k_setup<true, 8> : k_setup<true>) : k_setup<false>;
     size_t lds_setup = b->lds_setup;
     if (b->fast_setup) {
         ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : (d.n <= 56 ? k_setup_fast<56> : k_setup_fast<64>));
@@ -961,7 +960,7 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     t.N = 1; t.shared = 0; t.bu = b->wide_u; t.bl = b->wide_l; t.sense_in = nullptr;
     const int mask = DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
     typedef void (*setup_kernel_t)(BatchDev, int);
-    setup_kernel_t ks = b->setup_spill ? k_setup<true> : k_setup<false>;
+    setup_kernel_t ks = b->setup_spill ? (d.n > 256 ? k_setup<true, 8> : k_setup<true>) : k_setup<false>;
     size_t lds_setup = b->lds_setup;
     if (b->fast_setup) {
         ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : (d.n <= 56 ? k_setup_fast<56> : k_setup_fast<64>));
@@ -1217,7 +1216,7 @@ int daqp_quadprog_batch(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQ
             for (int i = 0; i < p->m; ++i) c += (p->sense[(size_t)q * p->m + i] & DAQP_SOFT) ? 1 : 0;
             if (c > ns) ns = c;
         }
-    } else if (p->sense) ns = p->m < 256 - p->n - 1 ? p->m : 256 - p->n - 1; // device-resident sense: size for the worst case
+    } else if (p->sense) ns = p->m < 512 - p->n - 1 ? p->m : 512 - p->n - 1; // device-resident sense: size for the worst case
     DAQPBatch *b = nullptr;
     int rc = daqp_batch_create(&b, p->N, p->n, p->m, p->ms, ns, settings, -1);
     if (rc) return rc;

@@ -72,7 +72,10 @@ __host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill, int
 // ------------------------------------------------------------------------------------
 // GS = true: the packed Cholesky factor and R^-1 live in per-QP HBM scratch (b.setup_g)
 // instead of LDS -- the n = 200 class of problems, where 2 x 160 KB of factors cannot be staged.
-template <bool GS>
+// NBK = 64-column blocks a lane covers (one entry per block and lane): 4 for n <= 256; 8 (n <= 512: the reference's own "large"
+// benchmark ladder goes to n = 500, interfaces/daqp-julia/test/benchmark.jl:38) with half as many rows per group, so that
+// the register footprint of the Cholesky / inverse sweeps stays the same.
+template <bool GS, int NBK = 4>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_setup(BatchDev b, int mask)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // then the rows of the group finish one after the other, each updating the later ones from registers.  Every entry
         // receives its subtractions in ascending k (utils.c:335-352).
         {
-            constexpr int KR = 8, NBK = 4;
+            constexpr int KR = 32 / NBK;
             for (int i0 = 0; i0 < n && flag > 0; i0 += KR) {
                 const int b0 = i0 >> 6;
                 double acc[KR][NBK];
@@ -248,9 +251,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     if (i < n && flag > 0) {
                         const int bi = i >> 6, li = i & 63;
                         double dsel = acc[r][0];
-                        if (bi == 1) dsel = acc[r][1];
-                        if (bi == 2) dsel = acc[r][2];
-                        if (bi == 3) dsel = acc[r][3];
+                        static_for<NBK - 1>([&](auto bq) __attribute__((always_inline)) { if (bi == bq + 1) dsel = acc[r][bq + 1]; });
                         const double dg = rl(dsel, li);
                         if (dg <= st.zero_tol) flag = shift_code;
                         else {
@@ -276,9 +277,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                     if (i2 < n) {
                                         const int b2 = i2 >> 6, l2 = i2 & 63;
                                         double ssel = acc[r][0];
-                                        if (b2 == 1) ssel = acc[r][1];
-                                        if (b2 == 2) ssel = acc[r][2];
-                                        if (b2 == 3) ssel = acc[r][3];
+                                        static_for<NBK - 1>([&](auto bq) __attribute__((always_inline)) { if (b2 == bq + 1) ssel = acc[r][bq + 1]; });
                                         const double sv = rl(ssel, l2);
                                         static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
                                             constexpr int jb = jj;
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // ascending i, as in the reference.
     if (flag > 0) {
       if (!diag) {
-        constexpr int KR = 8, NBK = 4;
+        constexpr int KR = 32 / NBK;
         for (int k0 = 0; k0 < n; k0 += KR) {
             double x[KR][NBK];
 #pragma unroll

@@ -107,3 +107,25 @@ def test_reference_known_answer_100_500(oracle, gpu_lib, monkeypatch, exact):
         assert bits_equal(g["x"][:24], ref[0]) and bits_equal(g["lam"][:24], ref[1])
     else:
         assert np.abs(g["x"][:24] - ref[0]).max() < XTOL * max(1.0, np.abs(ref[0]).max())
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "default"])
+@pytest.mark.parametrize("shape,N", [((500, 2500, 250, 400), 8), ((300, 700, 20, 120), 6), ((257, 520, 0, 90), 4)])
+def test_beyond_256_rows(oracle, gpu_lib, monkeypatch, shape, N, exact):
+    """working sets of more than 256 rows -- the top of the reference's own benchmark ladder, (n, m, ms, nAct) = (500, 2500, 250, 400)
+    (interfaces/daqp-julia/test/benchmark.jl:38): generic setup kernel with eight 64-column blocks per lane, one-wave solve
+    kernel with eight 64-row chunks, factors and active-row cache in HBM scratch.  Parity, not speed."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
+    n, m, ms, na = shape
+    q = O.generate_batch(N, n, m, ms, na, 3100 + n)
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert (ref[3] == 1).all()
+    assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4]), (g["exitflag"], ref[3], g["iter"], ref[4])
+    assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1]))
+    assert np.abs(g["x"] - q["xref"]).max() < 1e-4
+    if exact:
+        assert bits_equal(g["x"], ref[0]) and bits_equal(g["lam"], ref[1])
+    else:
+        assert np.abs(g["x"] - ref[0]).max() < XTOL * max(1.0, np.abs(ref[0]).max())

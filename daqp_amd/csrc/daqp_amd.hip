@@ -336,9 +336,9 @@ int count_flagged_async(DAQPBatch *b, int mask)
     b->reg_pending = true; b->reg_mask = mask;
     return 0;
 }
-int regularise(DAQPBatch *b, int mask, bool lp, bool counted = false)
+// `d`: the batch's own descriptor, or the one-problem descriptor of a shared factorisation (daqp_batch_setup_shared)
+int regularise(DAQPBatch *b, BatchDev &d, int mask, bool lp, bool counted = false)
 {
-    BatchDev &d = b->d;
     const int tpb = 128, nb = (d.N + tpb - 1) / tpb;
     b->n_prox_qps = 0;
     b->px.lp = lp ? 1 : 0;
@@ -350,6 +350,7 @@ int regularise(DAQPBatch *b, int mask, bool lp, bool counted = false)
         if (b->counter_host[0] == 0) return 0;
     }
     if (prox_buffers(b)) return DAQP_EXIT_UNSUPPORTED;
+    d.hshift = b->d.hshift; d.prox_mask = b->d.prox_mask;
     hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, lp ? 3 : 0);
     HIPCHK(hipGetLastError());
     typedef void (*setup_kernel_t)(BatchDev, int);
@@ -450,7 +451,7 @@ int resolve_setup(DAQPBatch *b)
     b->reg_pending = false;
     HIPCHK(hipEventSynchronize(b->ev_count));
     if (b->pin_count[0] == 0) return 0;
-    const int rc = regularise(b, b->reg_mask, false, true);
+    const int rc = regularise(b, b->d, b->reg_mask, false, true);
     if (rc) return rc;
     return launch_ldp(b, 1);
 }
@@ -910,7 +911,7 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
     // numerically singular Hessians: shifted re-runs for those problems (one tiny counting kernel when there are none);
     // an LP batch: its one setup pass
     b->reg_pending = false;
-    rc = lp ? regularise(b, mask, true) : count_flagged_async(b, mask);
+    rc = lp ? regularise(b, d, mask, true) : count_flagged_async(b, mask);
     if (rc) return rc;
     // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
     if (p->sense != nullptr || true) { rc = launch_ldp(b, 1); if (rc) return rc; }
@@ -935,9 +936,10 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     }
     (void)init_mask;   // the unconstrained shortcut / elimination are per-problem decisions of daqp_quadprog: not taken here
     b->pending_mask = 0;
-    b->n_prox_qps = 0;   // (a shared singular Hessian is reported as unsupported: the outer loop is per problem)
+    b->n_prox_qps = 0;
     b->reg_pending = false;
     HIPCHK(hipSetDevice(b->device));
+    if (b->prox_ready) HIPCHK(hipMemsetAsync(b->px.center, 0, (size_t)b->d.N * b->d.n * sizeof(double), b->stream));   // api.c:318
     BatchDev &d = b->d;
     const size_t N = d.N;
     rc |= stage(b, p->H, p->memory, (size_t)d.n * d.n, &b->sH, &b->nH, &d.H);
@@ -949,7 +951,7 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     if (rc) return DAQP_EXIT_UNSUPPORTED;
     b->was_shared = true;
     if (!b->wide_u) {
-        if (dev_alloc(b, &b->wide_u, d.m) || dev_alloc(b, &b->wide_l, d.m) || dev_alloc(b, &b->structural, d.m) || dev_alloc(b, &b->shared_flag, 2))
+        if (dev_alloc(b, &b->wide_u, d.m) || dev_alloc(b, &b->wide_l, d.m) || dev_alloc(b, &b->structural, d.m) || dev_alloc(b, &b->shared_flag, 4))
             return DAQP_EXIT_UNSUPPORTED;
         std::vector<double> hu(d.m, 1e30), hl(d.m, -1e30);
         HIPCHK(hipMemcpy(b->wide_u, hu.data(), d.m * sizeof(double), hipMemcpyHostToDevice));
@@ -970,13 +972,25 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
     hipLaunchKernelGGL(ks, dim3(1), dim3(64), lds_setup, b->stream, t, mask);
     HIPCHK(hipGetLastError());
+    // a numerically singular (or forcibly shifted) shared Hessian: the regularising passes of utils.c:354-377 on the one
+    // factorisation (this is a setup that happens once per plant: the host looks at the count right away); every problem of the
+    // batch then runs the proximal outer loop on the one shifted factor, each with its own centre (daqp_prox.c:21-221)
+    rc = regularise(b, t, mask, false);
+    if (rc) return rc;
+    const bool all_prox = b->n_prox_qps > 0;
+    b->n_prox_qps = all_prox ? d.N : 0;
     HIPCHK(hipMemcpyAsync(b->structural, d.sense, d.m * sizeof(int), hipMemcpyDeviceToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->shared_flag, &d.qs[0].setup_flag, sizeof(int), hipMemcpyDeviceToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->shared_flag + 1, &d.qs[0].diag_h, sizeof(int), hipMemcpyDeviceToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->shared_flag + 2, &d.qs[0].n_prox, sizeof(int), hipMemcpyDeviceToDevice, b->stream));
     // ---- per-problem state, then v and d of every problem through the update path
     d.shared = 1;
     hipLaunchKernelGGL(k_init_shared, dim3(d.N), dim3(64), 0, b->stream, d, (const int *)b->structural, (const int *)b->shared_flag);
     HIPCHK(hipGetLastError());
+    if (all_prox) {
+        hipLaunchKernelGGL(k_prox_share, dim3((d.N + 127) / 128), dim3(128), 0, b->stream, d, b->px);
+        HIPCHK(hipGetLastError());
+    }
     b->is_setup = true;
     const int upd = DAQP_UPDATE_v | DAQP_UPDATE_d;
     const bool lazy = b->NB > 0 && !getenv("DAQP_AMD_EAGER_UPDATE") && p->sense == nullptr;

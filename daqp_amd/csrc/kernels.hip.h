@@ -251,7 +251,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     if (i < n && flag > 0) {
                         const int bi = i >> 6, li = i & 63;
                         double dsel = acc[r][0];
-                        static_for<NBK - 1>([&](auto bq) __attribute__((always_inline)) { if (bi == bq + 1) dsel = acc[r][bq + 1]; });
+                        if (bi == 1) dsel = acc[r][1];
+                        if (bi == 2) dsel = acc[r][2];
+                        if (bi == 3) dsel = acc[r][3];
+                        if constexpr (NBK == 8) {   // (plain selects: through a lambda the array was not promoted to registers -- 260 bytes of scratch, C4 setup 47 -> 119 ms)
+                            if (bi == 4) dsel = acc[r][4];
+                            if (bi == 5) dsel = acc[r][5];
+                            if (bi == 6) dsel = acc[r][6];
+                            if (bi == 7) dsel = acc[r][7];
+                        }
                         const double dg = rl(dsel, li);
                         if (dg <= st.zero_tol) flag = shift_code;
                         else {
@@ -277,7 +285,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                     if (i2 < n) {
                                         const int b2 = i2 >> 6, l2 = i2 & 63;
                                         double ssel = acc[r][0];
-                                        static_for<NBK - 1>([&](auto bq) __attribute__((always_inline)) { if (b2 == bq + 1) ssel = acc[r][bq + 1]; });
+                                        if (b2 == 1) ssel = acc[r][1];
+                                        if (b2 == 2) ssel = acc[r][2];
+                                        if (b2 == 3) ssel = acc[r][3];
+                                        if constexpr (NBK == 8) {
+                                            if (b2 == 4) ssel = acc[r][4];
+                                            if (b2 == 5) ssel = acc[r][5];
+                                            if (b2 == 6) ssel = acc[r][6];
+                                            if (b2 == 7) ssel = acc[r][7];
+                                        }
                                         const double sv = rl(ssel, l2);
                                         static_for<NBK>([&](auto jj) __attribute__((always_inline)) {
                                             constexpr int jb = jj;
@@ -762,12 +778,11 @@ __global__ __launch_bounds__(256) void k_mirror(BatchDev b, double *slab, int ld
 // ------------------------------------------------------------------------------------
 // daqp_batch_setup_shared: per-problem state after the ONE factorisation (done with wide-open bounds, so the sense it
 // left holds only the structural bits: rows of A R^-1 that vanish, utils.c:586-613).  One wave per problem.
-__global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *structural, const int *shared_flag /* [setup_flag, diag_h] */)
+__global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *structural, const int *shared_flag /* [setup_flag, diag_h, n_prox] */)
 {
     const int q = blockIdx.x, lane = lane_id(), m = b.m;
     const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
     int flag = *shared_flag, bad = 0;
-    if (flag == DAQP_NEEDS_SHIFT) flag = DAQP_EXIT_UNSUPPORTED;   // a shared singular Hessian: the proximal driver is per-problem only
     for (int i = lane; i < m; i += 64) {
         int s = b.sense_in ? b.sense_in[(size_t)q * m + i] : 0;
         if (s & DAQP_BINARY) bad |= 2;
@@ -784,7 +799,7 @@ __global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *struc
         QState *qs = b.qs + q;
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = kEmpty; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0 && b.sense_in) ? 1 : 0;
-        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = shared_flag[1]; qs->n_prox = 0;
+        qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = shared_flag[1]; qs->n_prox = shared_flag[2];
         qs->upd_flag = 0;
     }
 }

@@ -94,6 +94,14 @@ __global__ void k_prox_final(BatchDev b, ProxDev p)
     p.eps[q] = eps;
 }
 
+// A shared factorisation that needed the shift (daqp_batch_setup_shared): every problem of the batch iterates with the one eps
+__global__ void k_prox_share(BatchDev b, ProxDev p)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= b.N || q == 0) return;
+    p.eps[q] = p.eps[0];
+}
+
 // One thread per problem: who takes part in the next launches.
 //  which 0 (before the ordinary problems are solved): proximal problems start their loop (daqp_prox.c:24-36) and sit out
 //  which 1 (before the outer iterations): proximal problems come back, the ordinary ones sit out
@@ -134,7 +142,7 @@ __device__ inline void prox_next_input(const BatchDev &b, const ProxDev &p, cons
         return;
     }
     const double eps = p.eps[q];
-    const int *mask = b.prox_mask + (size_t)q * n;
+    const int *mask = b.prox_mask + qf(b, q) * n;
     for (int i = lane; i < n; i += 64) {
         const double x = p.center[(size_t)q * n + i];
         p.feff[(size_t)q * n + i] = f[(size_t)q * n + i] - (mask[i] ? eps : 0.0) * x;
@@ -166,7 +174,7 @@ __device__ inline void prox_finish(const BatchDev &b, const ProxDev &p, const Pr
             fv = 0;
             for (int i = 0; i < n; ++i) fv += f[i] * x[i];
         } else {      // fval += eps * ||P x||^2, then 1/2 (fval - ||v||^2), summed in index order (daqp_prox.c:208-218, api.c:471-477)
-            const int *mask = b.prox_mask + (size_t)q * n;
+            const int *mask = b.prox_mask + qf(b, q) * n;
             const double *v = b.v + (size_t)q * n;
             double pn = 0.0;
             for (int i = 0; i < n; ++i) if (mask[i]) pn += x[i] * x[i];

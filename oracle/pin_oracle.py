@@ -270,6 +270,27 @@ def main():
             bad += 1
             print(f"MISMATCH primal_start[{k}] {a[3]}/{a[4]} vs {b[3]}/{b[4]}")
         rm.close()
+    # the MPC usage with a semidefinite plant Hessian (tests/test_gpu_prox.py::test_shared_singular_hessian): setup_daqp with
+    # open bounds, daqp_update_ldp(UPDATE_v|UPDATE_d) with the problem's own f / bounds, daqp_solve (the proximal loop), a warm re-solve
+    for k in range(max(8, args.n_per_config // 5)):
+        rng = np.random.default_rng([801, k])
+        n = int(rng.integers(4, 40)); m = int(rng.integers(n + 2, 3 * n + 3)); ms = 0 if k % 2 else min(4, n)
+        q = O.generate_singular_qp(n, m, ms, rank=max(1, n // 2), rng=[802, k], kind="diag" if k % 3 == 1 else "dense")
+        om, rm = ora.model(n, m, ms), strict.model(n, m, ms)
+        wide_u, wide_l = np.full(m, 1e30), np.full(m, -1e30)
+        assert om.setup(q["H"], q["f"], q["A"], wide_u, wide_l, None) == rm.setup(q["H"], q["f"], q["A"], wide_u, wide_l, None)
+        f = q["f"] + 0.2 * rng.standard_normal(n)
+        kw = dict(f=f, bupper=q["bupper"], blower=q["blower"])
+        assert om.update(O.UPDATE_v | O.UPDATE_d, **kw) == rm.update(O.UPDATE_v | O.UPDATE_d, **kw) == 0
+        for t in range(2):
+            a, b = om.solve(), rm.solve()
+            total += 1
+            if not (a[3] == b[3] and a[4] == b[4] and (a[3] < 0 or (same(a[0], b[0]) and same(a[1], b[1]) and same(a[2], b[2])))):
+                bad += 1
+                print(f"MISMATCH shared_singular[{k}][{t}] {a[3]}/{a[4]} vs {b[3]}/{b[4]}")
+            f = f + 0.05 * rng.standard_normal(n)
+            assert om.update(O.UPDATE_v, f=f) == rm.update(O.UPDATE_v, f=f) == 0
+        rm.close()
     print(f"pin result: {total - bad}/{total} bit-identical to the strict reference build")
     return 1 if bad else 0
 

@@ -217,3 +217,30 @@ def test_first_violating_host_helper():
     for x, want in (([0, 0, 0], 5), ([2, 0, 0], 0), ([0.5, -1.5, 0], 1), ([1, 1, 1.5], 3), ([1, 0.2, 0.2], 4)):
         xv = np.array(x, float)
         assert L.daqp_first_violating(dp(xv), dp(A), dp(bu), dp(bl), n, m, ms, 1e-9) == want, (x, want)
+
+
+def test_kernel_resource_budgets():
+    """The code generator's own per-kernel report of the last build (daqp_amd/_lib.py keeps it next to the objects): the hot
+    kernels stay within the scratch and occupancy they were tuned at.  An innocent-looking edit that sends a register array to
+    scratch does not fail any parity test -- it cost the generic setup kernel 2.5x in round 3 (47 -> 119 ms on config C4)."""
+    import pytest
+    from daqp_amd import _lib
+    _lib.build()
+    res = _lib.kernel_resources()
+    if not res:
+        pytest.skip("no resource report next to the objects (prebuilt library)")
+    budgets = {   # kernel: (scratch bytes per lane at most, waves per SIMD at least)
+        "k_setup<true, 4>": (128, 2), "k_setup<false, 4>": (128, 2), "k_setup<true, 8>": (128, 2),
+        "k_setup_fast<16, false>": (0, 4), "k_setup_fast<32, false>": (0, 2), "k_setup_fast<56, false>": (256, 2), "k_setup_fast<64, false>": (400, 2),
+        "k_setup_tiny<4>": (64, 1),
+        "k_ldp_reg<3, 25, true>": (0, 1), "k_ldp_reg<3, 25, false>": (0, 1), "k_ldp_reg<2, 32, true>": (0, 1),
+        "k_ldp_reg<1, 8, true>": (0, 3), "k_ldp_reg<1, 8, false>": (0, 3), "k_ldp_reg<1, 16, true>": (0, 2), "k_ldp_reg<2, 16, true>": (0, 2),
+        "k_ldp<1, false, 0, 0>": (0, 2), "k_ldp<2, false, 0, 0>": (0, 2), "k_ldp<4, true, 0, 0>": (128, 2),
+        "k_ldp_wg<2>": (256, 2), "k_ldp_wg<4>": (700, 2),
+        "k_ldp_tiny<4, 3, true>": (256, 1), "k_ldp_tiny<4, 0, true>": (512, 1),
+        "k_update": (0, 8),
+    }
+    for name, (scratch, occ) in budgets.items():
+        assert name in res, (name, sorted(res)[:8])
+        r = res[name]
+        assert r["scratch"] <= scratch and r["occupancy"] >= occ, (name, r)

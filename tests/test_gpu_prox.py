@@ -418,3 +418,47 @@ def test_concurrent_host_threads_proximal(oracle, gpu_lib, monkeypatch):
             assert out[t]["exitflag"][k] == flag and out[t]["iter"][k] == it, (t, k)
             if flag > 0:
                 assert same(out[t]["x"][k], x) and same(out[t]["lam"][k], lam), (t, k)
+
+
+@pytest.mark.parametrize("exact", ["1", "0"])
+@pytest.mark.parametrize("n,m,ms,kind", [(12, 30, 4, "dense"), (20, 60, 0, "diag"), (50, 150, 0, "dense"), (70, 150, 6, "dense")])
+def test_shared_singular_hessian(oracle, gpu_lib, monkeypatch, n, m, ms, kind, exact):
+    """ONE positive semi-definite H and ONE A for the whole batch (daqp_batch_setup_shared): the regularising passes run on the
+    one factorisation (utils.c:354-377), then every problem iterates the proximal loop (daqp_prox.c:21-221) on the shared shifted
+    factor with its own centre -- the reference's MPC usage (setup_daqp with open bounds, daqp_update_ldp(UPDATE_v|UPDATE_d),
+    daqp_solve) per problem, bit for bit, through a warm re-solve as well."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", exact)
+    N = 24
+    q0 = O.generate_singular_qp(n, m, ms, rank=max(1, n // 2), rng=[91, n], kind=kind)
+    rng = np.random.default_rng([92, n])
+    f = q0["f"][None, :] + 0.2 * rng.standard_normal((N, n))
+    shift = 0.03 * rng.standard_normal((N, m))
+    bu, bl = q0["bupper"][None, :] + shift, q0["blower"][None, :] + shift
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup_shared(q0["H"], f, q0["A"], bu, bl, None)
+    info = bm.prox_info()
+    assert (info["n_prox"] > 0).all() and (info["eps"] > 0).all() and len(set(info["eps"].tolist())) == 1
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        assert om.setup(q0["H"], f[k], q0["A"], np.full(m, 1e30), np.full(m, -1e30), None) >= 0
+        assert om.update(O.UPDATE_v | O.UPDATE_d, f=f[k], bupper=bu[k], blower=bl[k]) == 0
+        models.append(om)
+    good, outer = 0, 0
+    for t in range(2):
+        if t > 0:
+            f = f + 0.05 * rng.standard_normal((N, n))
+            bm.update(f=f)
+            for k in range(N):
+                assert models[k].update(O.UPDATE_v, f=f[k]) == 0
+        g = bm.solve()
+        outer = max(outer, int(bm.prox_info()["outer"].max()))
+        for k in range(N):
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (t, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            if r[3] > 0:
+                good += 1
+                assert same(g["x"][k], r[0]) and same(g["lam"][k], r[1]) and same(g["fval"][k], r[2]), (t, k)
+    assert good > N and outer >= 2, (good, outer)
+    bm.close()

@@ -51,12 +51,17 @@ for path in sys.argv[2:]:
     if "issue" in s:
         i = s["issue"]
         insts = sum(s["instructions"].values())
-        # the roof that binds these kernels: instruction issue.  busy = cycles in which a wave had an instruction issuing; if every
-        # SIMD issued back to back with this instruction mix the launch would take busy / (SIMDs x clock)
+        # the roof that binds these kernels: instruction issue.  The VALU pipe is the one resource a SIMD's waves cannot share:
+        # busy_valu = cycles in which a VALU instruction was issuing, summed over waves; with every SIMD's vector pipe busy back to
+        # back on this instruction mix the launch would take busy_valu / (SIMDs x clock).  busy_any counts every instruction class
+        # (scalar, LDS, memory issue overlap with VALU only across waves): the floor of a design with ONE wave per SIMD.
         busy = 4.0 * cs.get("SQ_ACTIVE_INST_ANY", 0.0)
+        busy_valu = 4.0 * cs.get("SQ_ACTIVE_INST_VALU", 0.0)
         entry["issue"] = {"wave_instructions": insts, "cycles_per_instruction": busy / insts if insts else None,
-                          "attainable_ms": busy / (N_SIMD * F_CLK) * 1e3,
-                          "note": "attainable = 4 x SQ_ACTIVE_INST_ANY / (1024 SIMDs x 2.4 GHz): every SIMD issuing back to back at the measured cycles per instruction"}
+                          "attainable_ms": busy_valu / (N_SIMD * F_CLK) * 1e3,
+                          "one_wave_per_simd_floor_ms": busy / (N_SIMD * F_CLK) * 1e3,
+                          "note": "attainable = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x 2.4 GHz): every SIMD's vector pipe issuing back to back on the measured "
+                                  "instruction mix; one_wave_per_simd_floor = the same with SQ_ACTIVE_INST_ANY (nothing overlaps inside one wave)"}
         entry["binding"] = {"resource": "instruction issue + dependent-operation latency (one wave per SIMD holds the iterate in registers)" if cfg != "C4"
                             else "per-CU memory pipeline (scan / row-cache reads at ~30 B/clk/CU) + the master wave's substitution chains",
                             "frac": i["active_inst_any_over_wave_cycles"], "frac_is": "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of the solve launch",

@@ -76,6 +76,7 @@ UNITS = {
                      "wg_layout.hip.h", "batch_dev.hip.h", "reg_kernel.hip.h", "tiny_kernel.hip.h", "multi.hip.h"],
     "reg_kernel.hip": ["reg_kernel.hip", "reg_kernel.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
     "wg_kernel.hip": ["wg_kernel.hip", "wg_kernel.hip.h", "wg_ldp.hip.h", "wg_layout.hip.h", "batch_dev.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h"],
+    "setup_kernel.hip": ["setup_kernel.hip", "setup_fast.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
     "tiny_kernel.hip": ["tiny_kernel.hip", "tiny_kernel.hip.h", "tiny_ldp.hip.h", "tiny_setup.hip.h", "batch_dev.hip.h", "wave_ldp.hip.h"],
 }
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]

@@ -36,6 +36,15 @@ DAQP_REG_SHAPE(2, 32)
 #endif
 #undef DAQP_REG_SHAPE
 // the 16-problems-per-wave kernel of tiny shapes: tiny_kernel.hip
+#define DAQP_SETUP_SIZE(NMAX) \
+    extern template __global__ void k_setup_fast<NMAX, false, false>(BatchDev, int); \
+    extern template __global__ void k_setup_fast<NMAX, false, true>(BatchDev, int); \
+    extern template __global__ void k_setup_fast<NMAX, true, false>(BatchDev, int);
+DAQP_SETUP_SIZE(16)
+DAQP_SETUP_SIZE(32)
+DAQP_SETUP_SIZE(56)
+DAQP_SETUP_SIZE(64)
+#undef DAQP_SETUP_SIZE
 extern template __global__ void k_ldp_tiny<4, 0, false>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_tiny<4, 0, true>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_tiny<4, 3, false>(const BatchDev *__restrict__, int);
@@ -293,6 +302,13 @@ int stage(DAQPBatch *b, const T *src, int memory, size_t count, T **slot, size_t
 }
 
 // ---- singular Hessians: regularising setup passes and the proximal outer loop (prox.hip.h) -------------------------
+// the one-wave setup kernel of n <= 64 by size class; fused: the default arithmetic (fused multiply-adds in the factorisation sweep)
+typedef void (*setup_kernel_t)(BatchDev, int);
+setup_kernel_t pick_setup_fast(int n, bool fused)
+{
+    if (fused) return (n <= 16) ? k_setup_fast<16, false, true> : (n <= 32 ? k_setup_fast<32, false, true> : (n <= 56 ? k_setup_fast<56, false, true> : k_setup_fast<64, false, true>));
+    return (n <= 16) ? k_setup_fast<16> : (n <= 32 ? k_setup_fast<32> : (n <= 56 ? k_setup_fast<56> : k_setup_fast<64>));
+}
 int read_counters(DAQPBatch *b)
 {
     HIPCHK(hipMemcpyAsync(b->counter_host, b->px.counter, 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
@@ -353,7 +369,6 @@ int regularise(DAQPBatch *b, BatchDev &d, int mask, bool lp, bool counted = fals
     d.hshift = b->d.hshift; d.prox_mask = b->d.prox_mask;
     hipLaunchKernelGGL(k_prox_shift, dim3(nb), dim3(tpb), 0, b->stream, d, b->px, lp ? 3 : 0);
     HIPCHK(hipGetLastError());
-    typedef void (*setup_kernel_t)(BatchDev, int);
     // the shifted passes keep M in the reference's operation order whatever the arithmetic mode of the batch (their
     // problems are then bit-identical to the reference in both modes); an LP's one pass is the generic kernel's diagonal path
     const bool gs = b->setup_spill;
@@ -892,11 +907,10 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
     // reduction is not built; such problems are solved on the full LDP instead (what setup_daqp + daqp_solve do): same exit
     // flag and active set, x and lam equal to ~1e-13, only the iteration count may differ (tests/test_gpu_reference_cases.py).
     const int mask = (init_mask & ~DAQP_UPDATE_eliminate) | DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
-    typedef void (*setup_kernel_t)(BatchDev, int);
     setup_kernel_t ks = b->setup_spill ? (d.n > 256 ? k_setup<true, 8> : k_setup<true>) : k_setup<false>;
     size_t lds_setup = b->lds_setup;
     if (b->fast_setup) {
-        ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : (d.n <= 56 ? k_setup_fast<56> : k_setup_fast<64>));
+        ks = pick_setup_fast(d.n, d.exact_setup == 0);
         lds_setup = (size_t)fast_lds(d.n, d.m, d.exact_setup, d.mA).total_bytes;   // the MFMA path overlays the A tile on R^-1
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
@@ -961,11 +975,10 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     BatchDev t = d;
     t.N = 1; t.shared = 0; t.bu = b->wide_u; t.bl = b->wide_l; t.sense_in = nullptr;
     const int mask = DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
-    typedef void (*setup_kernel_t)(BatchDev, int);
     setup_kernel_t ks = b->setup_spill ? (d.n > 256 ? k_setup<true, 8> : k_setup<true>) : k_setup<false>;
     size_t lds_setup = b->lds_setup;
     if (b->fast_setup) {
-        ks = (d.n <= 16) ? k_setup_fast<16> : (d.n <= 32 ? k_setup_fast<32> : (d.n <= 56 ? k_setup_fast<56> : k_setup_fast<64>));
+        ks = pick_setup_fast(d.n, d.exact_setup == 0);
         lds_setup = (size_t)fast_lds(d.n, d.m, d.exact_setup, d.mA).total_bytes;
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));

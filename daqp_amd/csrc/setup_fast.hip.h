@@ -89,7 +89,10 @@ __host__ __device__ inline FastLds fast_lds(int n, int m, int exact, int mA = -1
 // PROX = true: the regularising re-run of the problems flagged DAQP_NEEDS_SHIFT (utils.c:354-377, see k_setup): the same
 // code with H + hshift[q] on the diagonal (a diagonal H: in its singular coordinates only), the stricter pivot ratio and
 // the list of shifted coordinates written out.  A separate instantiation, so that the ordinary pass keeps its code.
-template <int NMAX, bool PROX = false>
+// FM = true (default arithmetic; never together with PROX): the updates of the fused Cholesky / inverse sweep as fused
+// multiply-adds -- five instead of seven instructions per updated pair, results equal to ~1e-16 relative like the rest of the
+// default mode's setup (M comes off the matrix cores there anyway).
+template <int NMAX, bool PROX = false, bool FM = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ? 2 : 1, NMAX >= 56 ? 2 : 8))) void k_setup_fast(BatchDev b, int mask)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -240,9 +243,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ?
                     constexpr int i = ii;
                     if constexpr (i + 1 < NMAX) {
                         const double s = rl(rot, i);                               // r_{k,k+1+i}, wave-uniform
-                        c[i] = c[i + 1] - s * rk;
                         const double ap = __hiloint2double(__double2hiint(a[i + 1]) | sgn, __double2loint(a[i + 1]));
-                        a[i] = ap - s * col;
+                        if constexpr (FM) { c[i] = __builtin_fma(-s, rk, c[i + 1]); a[i] = __builtin_fma(-s, col, ap); }
+                        else { c[i] = c[i + 1] - s * rk; a[i] = ap - s * col; }
                     }
                 });
             }

@@ -1,0 +1,17 @@
+// setup_kernel.hip -- translation unit of the one-wave QP -> LDP kernel for n <= 64 (setup_fast.hip.h): every size class in the
+// reference's arithmetic, with fused multiply-adds in the Cholesky / inverse sweep (the default mode), and as the regularising
+// re-run of flagged problems (PROX: always the reference's arithmetic)
+#include <hip/hip_runtime.h>
+#include "setup_fast.hip.h"
+
+namespace daqp_amd {
+#define DAQP_SETUP_SIZE(NMAX) \
+    template __global__ void k_setup_fast<NMAX, false, false>(BatchDev, int); \
+    template __global__ void k_setup_fast<NMAX, false, true>(BatchDev, int); \
+    template __global__ void k_setup_fast<NMAX, true, false>(BatchDev, int);
+DAQP_SETUP_SIZE(16)
+DAQP_SETUP_SIZE(32)
+DAQP_SETUP_SIZE(56)
+DAQP_SETUP_SIZE(64)
+#undef DAQP_SETUP_SIZE
+}

@@ -60,7 +60,8 @@ def test_fast_mode_workgroup_kernel_shapes(oracle, gpu_lib, shape):
 
 
 def test_fast_mode_ldp_close(oracle, gpu_lib):
-    """the MFMA-formed M matches the reference's to rounding; everything upstream of it stays bit-identical"""
+    """the default mode's LDP (fused multiply-adds in the Cholesky / inverse sweep, M off the matrix cores) matches the reference's
+    to rounding"""
     import daqp_amd
     n, m, ms, na, seed, _ = O.CONFIGS["C2"]
     q = O.generate_batch(4, n, m, ms, na, seed)
@@ -71,7 +72,7 @@ def test_fast_mode_ldp_close(oracle, gpu_lib):
         om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
         M, R, v, du, dl, sc = bm.read_ldp(k)
         Mo, Ro, vo, duo, dlo, sco = om.ldp()
-        assert np.array_equal(R.view(np.uint64), Ro.view(np.uint64)) and np.array_equal(v.view(np.uint64), vo.view(np.uint64))
+        assert np.abs(R - Ro).max() < 1e-13 * np.abs(Ro).max() and np.abs(v - vo).max() < 1e-13 * np.abs(vo).max()
         assert np.abs(M - Mo).max() < 1e-14 and np.abs(sc - sco).max() < 1e-13 * np.abs(sco).max()
         assert np.abs(du - duo).max() < 1e-12 and np.abs(dl - dlo).max() < 1e-12
     bm.close()

@@ -228,6 +228,56 @@ __device__ __forceinline__ double wave_sum(double v)
     v += dpp_f64<0x140>(v);
     return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
 }
+// inclusive prefix sum over the lanes (default arithmetic mode only): DPP row_shr steps inside each row of 16, then the three row
+// totals by readlane
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_or0(double v)       // lanes without a source receive +0.0
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_old(double old, double v)       // lanes without a source receive `old`
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// inclusive scan of the affine maps s -> a_j s + b_j, composed in lane order (lane j: the map of lanes 0..j): the linear recurrence
+// s_{j+1} = a_j s_j + b_j for all j at once.  rows: 16-lane rows that hold anything but identities (1, 0).
+__device__ __forceinline__ void wave_scan_affine(double &a, double &b, int rows)
+{
+#define DAQP_AFF_STEP(CTRL) { const double as_ = dpp_f64_old<CTRL>(1.0, a), bs_ = dpp_f64_old<CTRL>(0.0, b); b = __builtin_fma(a, bs_, b); a = a * as_; }
+    DAQP_AFF_STEP(0x111) DAQP_AFF_STEP(0x112) DAQP_AFF_STEP(0x114) DAQP_AFF_STEP(0x118)
+#undef DAQP_AFF_STEP
+    if (rows > 1) {
+        const int row = lane_id() >> 4;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            if (k < rows) {
+                const double at = rl(a, 16 * k - 1), bt = rl(b, 16 * k - 1);
+                const bool in = row == k;
+                b = __builtin_fma(a, in ? bt : 0.0, b);
+                a = a * (in ? at : 1.0);
+            }
+        }
+    }
+}
+__device__ __forceinline__ double wave_scan_incl(double v)
+{
+    v += dpp_f64_or0<0x111>(v);   // row_shr:1
+    v += dpp_f64_or0<0x112>(v);   // row_shr:2
+    v += dpp_f64_or0<0x114>(v);   // row_shr:4
+    v += dpp_f64_or0<0x118>(v);   // row_shr:8
+    const int lane = lane_id();
+    const double s0 = rl(v, 15), s1 = rl(v, 31), s2 = rl(v, 47);
+    double carry = (lane >= 16) ? s0 : 0.0;
+    carry += (lane >= 32) ? s1 : 0.0;
+    carry += (lane >= 48) ? s2 : 0.0;
+    return v + carry;
+}
 // ordered sum: acc - p_0 - p_1 - ... - p_{cnt-1} (p must be 0 in lanes >= cnt)
 __device__ __forceinline__ double ordered_sub(double acc, double p, int cnt)
 {
@@ -420,6 +470,83 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM> &w, int r)
     double sx = 0, Xn = w.xl;
     const int pl = lane < nupd ? lane : -1;
     double *Lr = w.L + tri(r + lane_now()) + r;
+    // (the smallest register shape keeps the chain: its updates are a handful of pivots, where the scans' fixed cost does not
+    //  pay -- C3 1.90 ms with the chain, 1.96 ms with the two passes)
+    if constexpr (FM && NP > 8) {
+        // Default arithmetic: the same update with no scalar work per pivot.  With t = 1/alpha the recurrence alpha' = alpha D / dbar
+        // becomes the running sum t' = t + p^2 / D, and the p_j themselves do not depend on alpha or beta at all (w_i -= p_j L_ij
+        // uses the OLD column): pass A is that chain alone -- afterwards lane j holds p_j --, then ONE prefix sum and four
+        // lane-parallel divisions serve every pivot at once (alpha_j = 1 / t_j, dbar_j = D_j + alpha_j p_j^2, beta_j = p_j alpha_j /
+        // dbar_j), the CSP's x rides along as ONE scan of affine maps, and pass B applies w_i -= p_j L_ij; L_ij += beta_j w_i with
+        // both scalars ready: two broadcasts and two fused multiply-adds per pivot, no guard inside.
+        // (Measured on C2: the pass B below alone, with the x recurrence and the guards of the chain still inside, cost what the whole
+        // chain had cost -- ~180 cycles per pivot are ~25 issued instructions, not division latency; with x as a scan and no guards
+        // the removal's update went from 6.6 k to 5.2 k cycles.  Keeping BOTH forms in the kernel cost more than either: 31.2 ms.)
+        // A singular factor has its zero pivot in the LAST position only: its 1/D = inf reaches t of lanes that nothing reads, and
+        // beta, dbar are formed from dbar itself (beta = p alpha / dbar, dbar = D + alpha p^2: finite there, as in the chain).
+        {
+            double wa = wv;
+            chunks_up(nupd, [&](auto c) __attribute__((always_inline)) {
+                if (8 * c < nupd) {
+                    double La[8];
+                    static_for<8>([&](auto q) __attribute__((always_inline)) {
+                        constexpr int j = 8 * c + q;
+                        La[q] = (pl > j) ? Lr[j] : 0.0;
+                    });
+                    static_for<8>([&](auto q) __attribute__((always_inline)) {
+                        constexpr int j = 8 * c + q;
+                        wa = __builtin_fma(-rl(wa, j), La[q], wa);      // (lanes <= j and lanes beyond the range: La == 0)
+                    });
+                }
+            });
+            const double rD = 1.0 / ((lane < nupd) ? Drot : 1.0);
+            const double pp = (lane < nupd) ? wa * wa : 0.0;
+            const double tv = 1.0 / alpha + wave_scan_incl(pp * rD);     // lane j: t_{j+1}
+            const double rtv = 1.0 / tv;
+            double rtp;                                                    // lane j: alpha_j = 1 / t_j (lane 0: alpha itself)
+            {
+                const int lo = __builtin_amdgcn_update_dpp(__double2loint(alpha), __double2loint(rtv), 0x138, 0xF, 0xF, false);   // wave_shr:1
+                const int hi = __builtin_amdgcn_update_dpp(__double2hiint(alpha), __double2hiint(rtv), 0x138, 0xF, 0xF, false);
+                rtp = __hiloint2double(hi, lo);
+            }
+            double betav;
+            {   // the new pivots, back in working-set numbering (before pass B: nothing of this stays live across it)
+                const double dbarv = __builtin_fma(pp, rtp, Drot);
+                betav = (lane < nupd) ? wa * rtp / dbarv : 0.0;
+                const double dsh = __shfl(dbarv, (lane - r) & 63);
+                if (lane >= r && lane < r + nupd) Dn = dsh;
+            }
+            {   // the CSP's x through the update: s_{j+1} = s_j + beta_j (X_j + p_j (x_r - s_j)) is the affine recurrence
+                // s -> (1 - beta_j p_j) s + beta_j (X_j + p_j x_r): one scan instead of three dependent operations per pivot
+                const bool in = lane < nupd;
+                double a = in ? __builtin_fma(-betav, wa, 1.0) : 1.0;
+                double bb = in ? betav * __builtin_fma(wa, xr, Xrot) : 0.0;
+                wave_scan_affine(a, bb, (nupd + 15) >> 4);
+                const double sj = dpp_f64_old<0x138>(0.0, bb);                       // wave_shr:1 -- lane j: s_j
+                const double xtv = __builtin_fma(wa, xr - sj, Xrot);
+                const double xsh = __shfl(xtv, (lane - r) & 63);
+                if (lane >= r && lane < r + nupd) Xn = xsh;
+            }
+            chunks_up(nupd, [&](auto c) __attribute__((always_inline)) {
+                if (8 * c < nupd) {
+                    double Lc[8];
+                    static_for<8>([&](auto q) __attribute__((always_inline)) {
+                        constexpr int j = 8 * c + q;
+                        Lc[q] = (pl > j) ? Lr[j] : 0.0;
+                    });
+                    static_for<8>([&](auto q) __attribute__((always_inline)) {   // (no guards inside: lanes <= j and pivots beyond the
+                        constexpr int j = 8 * c + q;                             //  range see zeros -- p, beta, their L entries)
+                        wv = __builtin_fma(-rl(wa, j), Lc[q], wv);
+                        Lc[q] = __builtin_fma(rl(betav, j), wv, Lc[q]);
+                    });
+                    static_for<8>([&](auto q) __attribute__((always_inline)) {
+                        constexpr int j = 8 * c + q;
+                        if (pl > j) Lr[j] = Lc[q];
+                    });
+                }
+            });
+        }
+    } else {
     chunks_up(nupd, [&](auto c) __attribute__((always_inline)) {
         if (8 * c < nupd) {
             double Lc[8];
@@ -453,6 +580,7 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM> &w, int r)
             });
         }
     });
+    }
     w.D = Dn;
     if constexpr (FM) {
         if (w.reuse >= na) {          // x was complete: keep it so (rdrop_core sets reuse to the new na)

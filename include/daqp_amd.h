@@ -137,6 +137,9 @@ typedef struct DAQPWorkspace {
 /* ------------------------------------------------------------------ */
 /* (1) single-problem drop-in entry points                             */
 /* ------------------------------------------------------------------ */
+/* LATENCY: each of these is a batch of ONE on the GPU -- a few launches and small copies, 0.2-0.4 ms per daqp_quadprog call where
+   the reference needs ~0.02 ms on one core for a small problem.  They exist so that bindings written against the reference's api.h
+   link and behave; a caller that loops over many QPs of one shape should hand them over at once: section (2), daqp_quadprog_batch. */
 void daqp_quadprog(DAQPResult *res, DAQPProblem *qp, DAQPSettings *settings); /* api.c:62-79 */
 void daqp_solve(DAQPResult *res, DAQPWorkspace *work);                         /* api.c:8-59 */
 int setup_daqp(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time);     /* api.c:88-90 */

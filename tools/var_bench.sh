@@ -1,0 +1,11 @@
+for t in "" t0 t4 t12 t16 t99; do
+  if [ -n "$t" ]; then export DAQP_AMD_LIBRARY=$GRAFT_REPO_ROOT/daqp_amd/lib/variants/libdaqp_amd_$t.so; else unset DAQP_AMD_LIBRARY; fi
+  echo "variant ${t:-default8}"
+  python bench.py --steps 20 --warmup 2 --side-configs C3,C5 --no-exact --cpu-sample 0 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+def sh(t,c):
+    r=c['roofline']; print('  ',t, round(c['value']), r.get('pipeline',{}).get('setup_ms'), round(r['avg_launch_ms'],3))
+sh('C2',d)
+for k,c in d['configs'].items(): sh(k,c)"
+done

@@ -520,9 +520,9 @@ extern "C" {
 
 const char *daqp_amd_last_error(void) { return g_err; }
 #ifdef DAQP_AMD_FEW_VARIANTS
-const char *daqp_amd_version(void) { return "daqp_amd 0.2 (gfx950, fp64: one wavefront per QP, one workgroup per QP beyond 64 working-set rows) [dev build: few template instantiations]"; }
+const char *daqp_amd_version(void) { return "daqp_amd 0.3 (gfx950, fp64: one wavefront per QP, one workgroup per QP beyond 64 working-set rows, up to 512 rows) [dev build: few template instantiations]"; }
 #else
-const char *daqp_amd_version(void) { return "daqp_amd 0.2 (gfx950, fp64: one wavefront per QP, one workgroup per QP beyond 64 working-set rows)"; }
+const char *daqp_amd_version(void) { return "daqp_amd 0.3 (gfx950, fp64: one wavefront per QP, one workgroup per QP beyond 64 working-set rows, up to 512 rows)"; }
 #endif
 int daqp_amd_device_count(void)
 {

@@ -171,21 +171,46 @@ __device__ __forceinline__ double dot4_pipelined(const double *a, const double *
 
 // The chains below run over eight static chunks of eight lanes, each behind its own "is this chunk live" branch (~18 cycles
 // whether taken or not).  Working sets of up to 16 rows pay for the upper six chunks with ONE branch, those of up to 32 rows for the upper four.
-template <class F> __device__ __forceinline__ void chunks_up(int live, F &&f)
+// The smallest register shape (n <= 16: working sets of a handful of rows) runs chunks of FOUR steps instead: at three waves per
+// SIMD that kernel is bound by instruction issue, and a chain over 3 rows then executes 4 steps, not 8 (C3: -9 % instructions).
+template <int NP> constexpr int chain_g() { return NP <= 8 ? 4 : 8; }
+template <int G = 8, class F> __device__ __forceinline__ void chunks_up(int live, F &&f)
 {
-    static_for<2>([&](auto c) __attribute__((always_inline)) { f(c); });
-    if (live > 16) {
-        static_for<2>([&](auto c) __attribute__((always_inline)) { f(std::integral_constant<int, c + 2>{}); });
-        if (live > 32) static_for<4>([&](auto c) __attribute__((always_inline)) { f(std::integral_constant<int, c + 4>{}); });
+    if constexpr (G == 8) {
+        static_for<2>([&](auto c) __attribute__((always_inline)) { f(c); });
+        if (live > 16) {
+            static_for<2>([&](auto c) __attribute__((always_inline)) { f(std::integral_constant<int, c + 2>{}); });
+            if (live > 32) static_for<4>([&](auto c) __attribute__((always_inline)) { f(std::integral_constant<int, c + 4>{}); });
+        }
+    } else {
+        static_for<2>([&](auto c) __attribute__((always_inline)) { f(c); });
+        if (live > 8) {
+            static_for<2>([&](auto c) __attribute__((always_inline)) { f(std::integral_constant<int, c + 2>{}); });
+            if (live > 16) {
+                static_for<4>([&](auto c) __attribute__((always_inline)) { f(std::integral_constant<int, c + 4>{}); });
+                if (live > 32) static_for<8>([&](auto c) __attribute__((always_inline)) { f(std::integral_constant<int, c + 8>{}); });
+            }
+        }
     }
 }
-template <class F> __device__ __forceinline__ void chunks_down(int live, F &&f)   // f(cc), chunk 7 - cc: top chunks first
+template <int G = 8, class F> __device__ __forceinline__ void chunks_down(int live, F &&f)   // f(cc), chunk 64/G - 1 - cc: top chunks first
 {
-    if (live > 16) {
-        if (live > 32) static_for<4>([&](auto cc) __attribute__((always_inline)) { f(cc); });
-        static_for<2>([&](auto cc) __attribute__((always_inline)) { f(std::integral_constant<int, cc + 4>{}); });
+    if constexpr (G == 8) {
+        if (live > 16) {
+            if (live > 32) static_for<4>([&](auto cc) __attribute__((always_inline)) { f(cc); });
+            static_for<2>([&](auto cc) __attribute__((always_inline)) { f(std::integral_constant<int, cc + 4>{}); });
+        }
+        static_for<2>([&](auto cc) __attribute__((always_inline)) { f(std::integral_constant<int, cc + 6>{}); });
+    } else {
+        if (live > 8) {
+            if (live > 16) {
+                if (live > 32) static_for<8>([&](auto cc) __attribute__((always_inline)) { f(cc); });
+                static_for<4>([&](auto cc) __attribute__((always_inline)) { f(std::integral_constant<int, cc + 8>{}); });
+            }
+            static_for<2>([&](auto cc) __attribute__((always_inline)) { f(std::integral_constant<int, cc + 12>{}); });
+        }
+        static_for<2>([&](auto cc) __attribute__((always_inline)) { f(std::integral_constant<int, cc + 14>{}); });
     }
-    static_for<2>([&](auto cc) __attribute__((always_inline)) { f(std::integral_constant<int, cc + 6>{}); });
 }
 // b <- L' \ b over the leading cnt positions (column-oriented; product order b_j * L[j][i]).
 // Lanes >= cnt must hold b == 0.
@@ -199,16 +224,17 @@ __device__ __forceinline__ double rbackward(RWave<NB, NP, FM> &w, double b, int 
     // spilled SGPR pairs).  Lanes >= cnt may pick up unused values; nothing reads them.
     const unsigned room = (unsigned)(cnt - 1 - lane);
     const int nlane = -1 - lane;
-    chunks_down(cnt, [&](auto cc) __attribute__((always_inline)) {
-        constexpr int c = 7 - cc;
-        if (8 * c < cnt && cnt > 1) {
-            double Lb[8];
-            static_for<8>([&](auto q) __attribute__((always_inline)) {   // unconditional loads (any address inside the LDS allocation is fine)
-                constexpr int j = 8 * c + 7 - q;
+    constexpr int G = chain_g<NP>();
+    chunks_down<G>(cnt, [&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = 64 / G - 1 - cc;
+        if (G * c < cnt && cnt > 1) {
+            double Lb[G];
+            static_for<G>([&](auto q) __attribute__((always_inline)) {   // unconditional loads (any address inside the LDS allocation is fine)
+                constexpr int j = G * c + G - 1 - q;
                 Lb[q] = Ll[tri(j)];
             });
-            static_for<8>([&](auto q) __attribute__((always_inline)) {
-                constexpr int j = 8 * c + 7 - q;
+            static_for<G>([&](auto q) __attribute__((always_inline)) {
+                constexpr int j = G * c + G - 1 - q;
                 if constexpr (j >= 1) {
                     const double bj = rl(b, j);
                     const double t = msub<FM>(b, bj, Lb[q]);
@@ -279,10 +305,11 @@ __device__ __forceinline__ double wave_scan_incl(double v)
     return v + carry;
 }
 // ordered sum: acc - p_0 - p_1 - ... - p_{cnt-1} (p must be 0 in lanes >= cnt)
+template <int G = 8>
 __device__ __forceinline__ double ordered_sub(double acc, double p, int cnt)
 {
-    chunks_up(cnt, [&](auto c) __attribute__((always_inline)) {
-        if (8 * c < cnt) static_for<8>([&](auto q) __attribute__((always_inline)) { acc -= rl(p, 8 * c + q); });
+    chunks_up<G>(cnt, [&](auto c) __attribute__((always_inline)) {
+        if (G * c < cnt) static_for<G>([&](auto q) __attribute__((always_inline)) { acc -= rl(p, G * c + q); });
     });
     return acc;
 }
@@ -300,17 +327,18 @@ __device__ __forceinline__ double rforward(RWave<NB, NP, FM> &w, double x, doubl
         // the usual case after an add: only the last row is open.  Its products in parallel, then the j-ordered
         // chain of subtractions on broadcast operands -- the same operations as the sweep below for that row
         const double p = (lane < na - 1) ? w.L[tri(na - 1) + lane_now()] * x : 0.0;
-        const double last = FM ? rl(rhs, na - 1) - wave_sum(p) : ordered_sub(rl(rhs, na - 1), p, na - 1);   // (default mode: a tree instead of the k-ordered chain)
+        const double last = FM ? rl(rhs, na - 1) - wave_sum(p) : ordered_sub<chain_g<NP>()>(rl(rhs, na - 1), p, na - 1);   // (default mode: a tree instead of the k-ordered chain)
         return (lane == na - 1) ? last : x;
     }
     const int pl = pending ? lane : -1;
     const double *Lr = w.L + tri(lane_now());
-    chunks_up(na - 1, [&](auto c) __attribute__((always_inline)) {
-        if (8 * c < na - 1) {
-            double Lk[8];
-            static_for<8>([&](auto q) __attribute__((always_inline)) { Lk[q] = Lr[8 * c + q]; });
-            static_for<8>([&](auto q) __attribute__((always_inline)) {
-                constexpr int j = 8 * c + q;
+    constexpr int G = chain_g<NP>();
+    chunks_up<G>(na - 1, [&](auto c) __attribute__((always_inline)) {
+        if (G * c < na - 1) {
+            double Lk[G];
+            static_for<G>([&](auto q) __attribute__((always_inline)) { Lk[q] = Lr[G * c + q]; });
+            static_for<G>([&](auto q) __attribute__((always_inline)) {
+                constexpr int j = G * c + q;
                 const double xj = rl(x, j);
                 const double t = msub<FM>(x, Lk[q], xj);
                 x = (pl > j) ? t : x;     // rows > j that are still open; steps j >= na-1 select nothing (pl < na)
@@ -392,12 +420,13 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP, FM> &w, int id, int 
     {
         const int pl = lane < na ? lane : -1;
         const double *Lr = w.L + tri(lane_now());
-        chunks_up(na - 1, [&](auto c) __attribute__((always_inline)) {
-            if (8 * c < na - 1) {
-                double Lk[8];
-                static_for<8>([&](auto q) __attribute__((always_inline)) { Lk[q] = Lr[8 * c + q]; });
-                static_for<8>([&](auto q) __attribute__((always_inline)) {
-                    constexpr int j = 8 * c + q;
+        constexpr int G = chain_g<NP>();
+        chunks_up<G>(na - 1, [&](auto c) __attribute__((always_inline)) {
+            if (G * c < na - 1) {
+                double Lk[G];
+                static_for<G>([&](auto q) __attribute__((always_inline)) { Lk[q] = Lr[G * c + q]; });
+                static_for<G>([&](auto q) __attribute__((always_inline)) {
+                    constexpr int j = G * c + q;
                     const double lj = rl(g, j);
                     const double t = msub<FM>(g, Lk[q], lj);
                     g = (pl > j) ? t : g;
@@ -412,7 +441,7 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP, FM> &w, int id, int 
         w.L[base + lane_now()] = lk;
         p = t * lk;
     }
-    double acc = FM ? dnew - wave_sum(p) : ordered_sub(dnew, p, na);
+    double acc = FM ? dnew - wave_sum(p) : ordered_sub<chain_g<NP>()>(dnew, p, na);
     if (acc < w.sing_tol || na >= n + ns_act) { w.sing = na; acc = 0; }
     WSYNC();
     return acc;
@@ -547,15 +576,16 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM> &w, int r)
             });
         }
     } else {
-    chunks_up(nupd, [&](auto c) __attribute__((always_inline)) {
-        if (8 * c < nupd) {
-            double Lc[8];
-            static_for<8>([&](auto q) __attribute__((always_inline)) {
-                constexpr int j = 8 * c + q;
+    constexpr int G = chain_g<NP>();
+    chunks_up<G>(nupd, [&](auto c) __attribute__((always_inline)) {
+        if (G * c < nupd) {
+            double Lc[G];
+            static_for<G>([&](auto q) __attribute__((always_inline)) {
+                constexpr int j = G * c + q;
                 Lc[q] = (pl > j) ? Lr[j] : 0.0;
             });
-            static_for<8>([&](auto q) __attribute__((always_inline)) {
-                constexpr int j = 8 * c + q;
+            static_for<G>([&](auto q) __attribute__((always_inline)) {
+                constexpr int j = G * c + q;
                 if (j < nupd) {
                     const double p = rl(wv, j);
                     const double Di = rl(Drot, j);
@@ -574,8 +604,8 @@ __device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM> &w, int r)
                     }
                 }
             });
-            static_for<8>([&](auto q) __attribute__((always_inline)) {
-                constexpr int j = 8 * c + q;
+            static_for<G>([&](auto q) __attribute__((always_inline)) {
+                constexpr int j = G * c + q;
                 if (pl > j) Lr[j] = Lc[q];
             });
         }
@@ -717,15 +747,16 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP, FM> &w)
     const int soff = (lane < na) ? w.slot * w.ldr : 0;
     const double lz = (lane < na) ? w.lams : 0.0;
     const double *rc = w.rowc + lane_now();
-    chunks_up(na, [&](auto c) __attribute__((always_inline)) {
-        if (8 * c < na) {
-            double rv[8], li[8];
-            static_for<8>([&](auto q) __attribute__((always_inline)) {
-                constexpr int i = 8 * c + q;
+    constexpr int G = chain_g<NP>();
+    chunks_up<G>(na, [&](auto c) __attribute__((always_inline)) {
+        if (G * c < na) {
+            double rv[G], li[G];
+            static_for<G>([&](auto q) __attribute__((always_inline)) {
+                constexpr int i = G * c + q;
                 li[q] = rl(lz, i);
                 rv[q] = rc[rli(soff, i)];
             });
-            static_for<8>([&](auto q) __attribute__((always_inline)) { uu = msub<FM>(uu, rv[q], li[q]); });
+            static_for<G>([&](auto q) __attribute__((always_inline)) { uu = msub<FM>(uu, rv[q], li[q]); });
         }
     });
     WSYNC();

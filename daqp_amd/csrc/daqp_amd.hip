@@ -742,6 +742,11 @@ void daqp_batch_free(DAQPBatch *b)
         b->timed_setup = b->timed_solve = false; b->n_prox_qps = 0; b->prox_outer = 0;
         b->one_fval = b->one_soft = 0; b->one_flag = b->one_iter = 0;
         DAQPBatch *evict = nullptr;
+        {   // parked workspaces are released when the process exits (registered at the first parking: runs before the HIP
+            // runtime's own teardown, which was registered at load time)
+            static std::once_flag once;
+            std::call_once(once, [] { std::atexit(daqp_amd_release_pool); });
+        }
         {
             std::lock_guard<std::mutex> lk(g_pool_mu);
             g_pool.push_back(b);

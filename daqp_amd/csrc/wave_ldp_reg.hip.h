@@ -173,7 +173,10 @@ __device__ __forceinline__ double dot4_pipelined(const double *a, const double *
 // whether taken or not).  Working sets of up to 16 rows pay for the upper six chunks with ONE branch, those of up to 32 rows for the upper four.
 // The smallest register shape (n <= 16: working sets of a handful of rows) runs chunks of FOUR steps instead: at three waves per
 // SIMD that kernel is bound by instruction issue, and a chain over 3 rows then executes 4 steps, not 8 (C3: -9 % instructions).
-template <int NP> constexpr int chain_g() { return NP <= 8 ? 4 : 8; }
+#ifndef DAQP_AMD_CHAIN4_UP_TO
+#define DAQP_AMD_CHAIN4_UP_TO 8     // register shapes with NP up to this run chunks of four (measured: C2's shape is slower with them)
+#endif
+template <int NP> constexpr int chain_g() { return NP <= DAQP_AMD_CHAIN4_UP_TO ? 4 : 8; }
 template <int G = 8, class F> __device__ __forceinline__ void chunks_up(int live, F &&f)
 {
     if constexpr (G == 8) {

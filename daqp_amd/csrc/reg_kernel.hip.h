@@ -51,71 +51,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     const int q = blockIdx.x, lane = lane_id();
     const int n = b.n, m = b.m, cap = b.cap;
     QState *qs = b.qs + q;
-    // everything read from the per-QP record is wave-uniform; say so, or every loop bounded by
-    // n_active becomes a divergent (exec-masked) loop with readfirstlane waterfalls around v_readlane
-    const int sflag = __builtin_amdgcn_readfirstlane(qs->setup_flag);
-    int q_need_act = __builtin_amdgcn_readfirstlane(qs->need_activate);
-    const int qdiag = __builtin_amdgcn_readfirstlane(qs->diag_h);
-    if (mode == 1) { if (sflag < 0 || !q_need_act) return; }
-    if (sflag < 0) {
-        if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
-        return;
-    }
-    if (mode == 0 && !upd) {   // the last update failed its bound check: report that, keep the state (see k_update)
-        const int uflag = __builtin_amdgcn_readfirstlane(qs->upd_flag);
-        if (uflag < 0) {
-            if (lane == 0) { b.exitflag[q] = uflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
-            return;
-        }
+    if (mode == 1) {   // an activation launch looks at the record first: almost every problem leaves here, without touching M
+        if (__builtin_amdgcn_readfirstlane(qs->setup_flag) < 0 || !__builtin_amdgcn_readfirstlane(qs->need_activate)) return;
     }
     typedef RegLds<NB> o;
-    {   // time_limit stamp and seconds per tick (rrun reads them from u[66], u[67])
-        const unsigned long long ts = solve_stamp(b.tstart, q);
-        if (lane == 0) { reinterpret_cast<unsigned long long *>(smem + o::u)[66] = ts; smem[o::u + 67] = b.tick_s; }
-    }
-    const int rowc_size = reg_lds_rowc_size(n, m, cap, b.ldrc);
-    RWave<NB, NP, FM> w;
-    // phase counters live in the (otherwise unused) D/xl slots of the LDS carve-up
-    w.prof = (kProfile && (b.prof != nullptr) && mode == 0) ? reinterpret_cast<long long *>(smem + o::prof) : nullptr;
-    if (kProfile && w.prof && lane < 32) w.prof[lane] = 0;
-    w.n = n; w.m = m; w.ms = b.ms; w.ldr = b.ldrc;
-    w.L = smem + o::L; w.rowc = smem + reg_lds_rowc(NB, cap); w.u = smem + o::u; w.pend_lam = smem + o::pend_lam;
-    w.rowv = smem + o::rowv;
-    w.pend_id = reinterpret_cast<int *>(smem + o::pend_id);
-    w.stp = b.st_dev;
-    w.dual_tol = b.st.dual_tol; w.sing_tol = b.st.sing_tol; w.pivot_tol = b.st.pivot_tol; w.rho_soft = b.st.rho_soft;
-    w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
-    w.trace_cap = b.trace_cap; w.trace_len = 0;
-    w.na = __builtin_amdgcn_readfirstlane(qs->n_active);
-    w.reuse = __builtin_amdgcn_readfirstlane(qs->reuse_ind);
-    w.sing = __builtin_amdgcn_readfirstlane(qs->sing_ind);
-    w.fval = rl(qs->fval, 0); w.soft = rl(qs->soft_slack, 0);
-    const int swapped = __builtin_amdgcn_readfirstlane(qs->lam_swapped);
+    // ---- ONE batch of loads.  Everything whose address does not depend on the per-problem record goes out before the first
+    // wait: the rows of M, the row view, the new bounds / f / R^-1 of a pending update, the working-set ids and vectors of a
+    // warm start -- and the record itself (before: the record, then the ids, then M -- three dependent trips).  Measured on the
+    // warm path (tools/c5_phases.py): issuing this batch takes 11.6 k cycles -- the 76.8 KB of M at what one CU's miss path
+    // delivers to four waves -- and the record is there when the last load has been issued; prologue 35.2 k -> 34.1 k of a warm
+    // solve's 141 k cycles (then: active rows + L 3.5 k, v = R^-T f 5.6 k, d 2.5 k).
     const size_t qfac = qf(b, q);
     const double *gdu = b.dupper + (size_t)q * m, *gdl = b.dlower + (size_t)q * m, *gsc = b.scaling + qfac * m;
     int *gsense = b.sense + (size_t)q * m;
     double *gv = b.vecs + (size_t)q * 5 * cap;
     int *gws = b.WS + (size_t)q * cap;
-
-    if (w.sing == DAQP_UNCONSTRAINED_OPTIMAL && mode == 0 && !upd) {   // api.c:40-45 (an update resets sing_ind first)
-        const double *xu = b.xunc + (size_t)q * n, *vq = b.v + (size_t)q * n;
-        if (b.x) for (int i = lane; i < n; i += 64) b.x[(size_t)q * n + i] = xu[i];
-        if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = 0;
-        double fv = 0;
-        for (int i = 0; i < n; ++i) { const double vi = vq[i]; fv -= vi * vi; }
-        fv *= 0.5;
-        if (lane == 0) {
-            b.exitflag[q] = DAQP_EXIT_OPTIMAL; b.iter[q] = 1;
-            if (b.fval) b.fval[q] = fv;
-            if (b.soft) b.soft[q] = 0;
-            qs->iterations = 1; qs->fval = 0; qs->soft_slack = 0; qs->exitflag = DAQP_EXIT_OPTIMAL;
-        }
-        return;
-    }
+    const int rowc_size = reg_lds_rowc_size(n, m, cap, b.ldrc);
+    RWave<NB, NP, FM> w;
+    w.rowc = smem + reg_lds_rowc(NB, cap);
     // a pending UPDATE_v needs R^-1 and f: their loads go out first and arrive together with the rows of M
     const int rinv0 = rowc_size - round_up(b.rtri, 2) - 2;
     double *Rl0 = w.rowc + rinv0;
-    double f_in = 0;
+    double f_raw = 0, f_sc = 1;
     if (upd & DAQP_UPDATE_v) {
         const double *Rq = b.Rinv + qfac * b.rtri, *f = b.f + (size_t)q * n;
         const int odd8 = (int)(((size_t)Rq >> 3) & 1);
@@ -124,10 +81,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         const int body = (b.rtri - odd8) & ~1;
         copy_async(Rl0 + odd8, Rq + odd8, body);
         if (odd8 + body < b.rtri) copy_async_dwords(Rl0 + odd8 + body, Rq + odd8 + body, 1);
-        if (lane < n) f_in = (lane < b.ms && !qdiag) ? f[lane] / gsc[lane] : f[lane];
+        if (lane < n) { f_raw = f[lane]; if (lane < b.ms) f_sc = gsc[lane]; }
     }
     // ---- row view: bounds, tolerance, sense and the rows of M themselves -> registers
-    const double ep = -w.stp->primal_tol;
     double scr[NB];
     int softbits = 0;
     w.rs = 0;
@@ -155,24 +111,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
             blr[bb] = (r < m) ? nbl[r] : 0.0;
         });
     }
-    // the warm-start state rides in the same early batch: working-set ids / vectors into registers, packed L and (as
-    // soon as the ids are there) the active rows straight into LDS -- all of it in flight together with the rows of M
-    const bool act = lane < w.na;
-    const int wsid_r = act ? gws[lane] : 0;
+    // the warm-start state: working-set ids / vectors into registers (masked by n_active once the record is here)
+    const int wsid_raw = (lane < cap) ? gws[lane] : 0;
     const double D_r = (lane < cap) ? gv[lane] : 0.0, xl_r = (lane < cap) ? gv[cap + lane] : 0.0, zl_r = (lane < cap) ? gv[2 * cap + lane] : 0.0;
     const double la_r = (lane < cap) ? gv[3 * cap + lane] : 0.0, lb_r = (lane < cap) ? gv[4 * cap + lane] : 0.0;
-    copy_async(w.L, b.L + (size_t)q * b.ltri, round_up(tri(w.na), 2));
-    auto fetch_active_rows = [&]() __attribute__((always_inline)) {
-        for (int i = 0; i < w.na; ++i) {
-            const int id = rli(wsid_r, i);
-            const double2 *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63) + (size_t)lane * 64;
-            if (lane < b.npair)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(w.rowc + (size_t)i * w.ldr), 16, 0, 0);
-        }
-    };
-    const bool rows_early = !(upd & DAQP_UPDATE_v) || w.na * w.ldr <= rinv0;   // R^-1 is staged in the top of the row cache
-    if (rows_early) fetch_active_rows();
+    // the record (wave-uniform: readfirstlane'd below, after everything else has been issued)
+    const int rec_sflag = qs->setup_flag, rec_need = qs->need_activate, rec_diag = qs->diag_h, rec_uflag = qs->upd_flag;
+    const int rec_na = qs->n_active, rec_reuse = qs->reuse_ind, rec_sing = qs->sing_ind, rec_swapped = qs->lam_swapped;
+    const double rec_fval = qs->fval, rec_soft = qs->soft_slack;
     __builtin_amdgcn_sched_barrier(0);
     if (nblk_u == NB && npair_u == NP) {
         // the shape fills the template exactly (the benchmark's case): NB*NP unconditional loads in ONE basic block, each
@@ -194,6 +140,77 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
             });
         });
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the record.  Everything read from it is wave-uniform; say so, or every loop bounded by n_active becomes a
+    // divergent (exec-masked) loop with readfirstlane waterfalls around v_readlane
+    const int sflag = __builtin_amdgcn_readfirstlane(rec_sflag);
+    int q_need_act = __builtin_amdgcn_readfirstlane(rec_need);
+    const int qdiag = __builtin_amdgcn_readfirstlane(rec_diag);
+    if (sflag < 0) {
+        if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
+        copy_wait();   // nothing may still be landing in LDS when the workgroup ends
+        return;
+    }
+    if (mode == 0 && !upd) {   // the last update failed its bound check: report that, keep the state (see k_update)
+        const int uflag = __builtin_amdgcn_readfirstlane(rec_uflag);
+        if (uflag < 0) {
+            if (lane == 0) { b.exitflag[q] = uflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
+            return;
+        }
+    }
+    {   // time_limit stamp and seconds per tick (rrun reads them from u[66], u[67])
+        const unsigned long long ts = solve_stamp(b.tstart, q);
+        if (lane == 0) { reinterpret_cast<unsigned long long *>(smem + o::u)[66] = ts; smem[o::u + 67] = b.tick_s; }
+    }
+    // phase counters live in the (otherwise unused) D/xl slots of the LDS carve-up
+    w.prof = (kProfile && (b.prof != nullptr) && mode == 0) ? reinterpret_cast<long long *>(smem + o::prof) : nullptr;
+    if (kProfile && w.prof && lane < 32) w.prof[lane] = 0;
+    w.n = n; w.m = m; w.ms = b.ms; w.ldr = b.ldrc;
+    w.L = smem + o::L; w.u = smem + o::u; w.pend_lam = smem + o::pend_lam;
+    w.rowv = smem + o::rowv;
+    w.pend_id = reinterpret_cast<int *>(smem + o::pend_id);
+    w.stp = b.st_dev;
+    w.dual_tol = b.st.dual_tol; w.sing_tol = b.st.sing_tol; w.pivot_tol = b.st.pivot_tol; w.rho_soft = b.st.rho_soft;
+    w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
+    w.trace_cap = b.trace_cap; w.trace_len = 0;
+    w.na = __builtin_amdgcn_readfirstlane(rec_na);
+    w.reuse = __builtin_amdgcn_readfirstlane(rec_reuse);
+    w.sing = __builtin_amdgcn_readfirstlane(rec_sing);
+    w.fval = rl(rec_fval, 0); w.soft = rl(rec_soft, 0);
+    const int swapped = __builtin_amdgcn_readfirstlane(rec_swapped);
+
+    if (w.sing == DAQP_UNCONSTRAINED_OPTIMAL && mode == 0 && !upd) {   // api.c:40-45 (an update resets sing_ind first)
+        const double *xu = b.xunc + (size_t)q * n, *vq = b.v + (size_t)q * n;
+        if (b.x) for (int i = lane; i < n; i += 64) b.x[(size_t)q * n + i] = xu[i];
+        if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = 0;
+        double fv = 0;
+        for (int i = 0; i < n; ++i) { const double vi = vq[i]; fv -= vi * vi; }
+        fv *= 0.5;
+        if (lane == 0) {
+            b.exitflag[q] = DAQP_EXIT_OPTIMAL; b.iter[q] = 1;
+            if (b.fval) b.fval[q] = fv;
+            if (b.soft) b.soft[q] = 0;
+            qs->iterations = 1; qs->fval = 0; qs->soft_slack = 0; qs->exitflag = DAQP_EXIT_OPTIMAL;
+        }
+        return;
+    }
+    const double f_in = (lane < b.ms && !qdiag) ? f_raw / f_sc : f_raw;
+    const double ep = -w.stp->primal_tol;
+    // packed L and (the ids are here now) the active rows straight into LDS -- one more trip, overlapped with the update's arithmetic
+    const bool act = lane < w.na;
+    const int wsid_r = act ? wsid_raw : 0;
+    copy_async(w.L, b.L + (size_t)q * b.ltri, round_up(tri(w.na), 2));
+    auto fetch_active_rows = [&]() __attribute__((always_inline)) {
+        for (int i = 0; i < w.na; ++i) {
+            const int id = rli(wsid_r, i);
+            const double2 *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63) + (size_t)lane * 64;
+            if (lane < b.npair)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(w.rowc + (size_t)i * w.ldr), 16, 0, 0);
+        }
+    };
+    const bool rows_early = !(upd & DAQP_UPDATE_v) || w.na * w.ldr <= rinv0;   // R^-1 is staged in the top of the row cache
+    if (rows_early) fetch_active_rows();
     static_for<NB>([&](auto bb) __attribute__((always_inline)) {
         const int r = bb * 64 + lane;
         w.rowv[r] = dur[bb];

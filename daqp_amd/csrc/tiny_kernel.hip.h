@@ -140,7 +140,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     for (int i = sub; i < cap; i += G) {
                         const bool in = i < TCAP;
                         const int ii = in ? i : 0;
-                        const double d0 = vq[(TV_D + ii) * Q], d1 = vq[(TV_XL + ii) * Q], d2 = vq[(TV_ZL + ii) * Q], d3 = vq[(la + ii) * Q], d4 = vq[(lb + ii) * Q];
+                        const double d0 = vq[(TV_D + ii) * Q], d1 = vq[(TV_XL + ii) * Q], d2 = vq[(TV_ZL + ii) * Q], d3 = vq[(la + ii) * Q];
+                        double d4 = vq[(lb + ii) * Q];
+                        // ldp2qp_solution scales lam* in place (daqp.c:136-138): the stored iterate -- what daqp_extract_result and
+                        // the host mirror of work->lam_star read -- holds the scaled multipliers, as the other kernels leave them
+                        if (mode != 1 && flag > 0 && i < w.na) d4 *= gsc[tws_id(w, ii)];
                         gv[i] = in ? d0 : 0.0; gv[cap + i] = in ? d1 : 0.0; gv[2 * cap + i] = in ? d2 : 0.0;
                         gv[3 * cap + i] = in ? d3 : 0.0; gv[4 * cap + i] = in ? d4 : 0.0;
                         gws[i] = (i < w.na) ? tws_id(w, i) : -1;

@@ -197,3 +197,25 @@ def test_same_results_as_the_register_kernel(oracle, gpu_lib, monkeypatch):
         res[first] = g0
         bm.close()
     assert bits_equal(res["1"]["x"], res["0"]["x"]) and np.array_equal(res["1"]["iter"], res["0"]["iter"])
+
+
+def test_single_problem_entry_points_and_proximal_loop(oracle, gpu_lib):
+    """with the kernel opted in process-wide, the single-problem drop-in path (host mirrors of work->lam_star, daqp_extract_result)
+    and the proximal loop around tiny shapes still return the reference's bits: the stored iterate holds lam* scaled by
+    ldp2qp_solution (daqp.c:136-138), as the other kernels leave it.  (The whole GPU suite passes under DAQP_AMD_TINY=1.)"""
+    import daqp_amd
+    n, m, ms = 9, 20, 3
+    q = O.generate_qp(n, m, ms, 4, rng=[661, 1])
+    x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+    r = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+    assert flag == r[3] and info["iterations"] == r[4] and bits_equal(x, r[0]) and bits_equal(info["lam"], r[1])
+    qs = O.generate_singular_qp(n, m, ms, rank=4, rng=[662, 2])
+    x, fval, flag, info = daqp_amd.solve(qs["H"], qs["f"], qs["A"], qs["bupper"], qs["blower"], qs["sense"])
+    r = oracle.quadprog(qs["H"], qs["f"], qs["A"], qs["bupper"], qs["blower"], qs["sense"])
+    assert flag == r[3] and info["iterations"] == r[4] and bits_equal(x, r[0]) and bits_equal(info["lam"], r[1]) and fval == r[2]
+    lp = O.generate_lp(n, m, ms, [663, 3])
+    x, fval, flag, info = daqp_amd.solve(None, lp["f"], lp["A"], lp["bupper"], lp["blower"], lp["sense"])
+    r = oracle.quadprog(None, lp["f"], lp["A"], lp["bupper"], lp["blower"], lp["sense"])
+    assert flag == r[3] and info["iterations"] == r[4]
+    if r[3] > 0:
+        assert bits_equal(x, r[0]) and bits_equal(info["lam"], r[1])

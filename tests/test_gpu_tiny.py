@@ -199,11 +199,12 @@ def test_same_results_as_the_register_kernel(oracle, gpu_lib, monkeypatch):
     assert bits_equal(res["1"]["x"], res["0"]["x"]) and np.array_equal(res["1"]["iter"], res["0"]["iter"])
 
 
-def test_single_problem_entry_points_and_proximal_loop(oracle, gpu_lib):
+def test_single_problem_entry_points_and_proximal_loop(oracle, gpu_lib, monkeypatch):
     """with the kernel opted in process-wide, the single-problem drop-in path (host mirrors of work->lam_star, daqp_extract_result)
     and the proximal loop around tiny shapes still return the reference's bits: the stored iterate holds lam* scaled by
     ldp2qp_solution (daqp.c:136-138), as the other kernels leave it.  (The whole GPU suite passes under DAQP_AMD_TINY=1.)"""
     import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
     n, m, ms = 9, 20, 3
     q = O.generate_qp(n, m, ms, 4, rng=[661, 1])
     x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])

@@ -167,6 +167,46 @@ def test_degenerate_cases_fast_mode(oracle, gpu_lib, monkeypatch):
     assert len(differing) <= 2 and same >= total - 2, (same, total, differing)
 
 
+def _nasty_wide(trial):
+    rng = np.random.default_rng([199, trial])
+    eps = 10.0 ** rng.uniform(-13, -2)
+    n = int(rng.integers(17, 49)); m = int(rng.integers(n + 4, min(3 * n, 150))); ms = int(rng.integers(0, min(n, m // 3) + 1))
+    na = int(rng.integers(2, min(n, m - ms)))
+    return O.generate_nasty(n, m, ms, na, eps, rng, n_dup=int(rng.integers(0, 6)), n_eq=int(rng.integers(0, 3)),
+                            n_soft=int(rng.integers(0, 3)), dep_eq=bool(rng.integers(0, 2)))
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "default"])
+def test_degenerate_cases_wider_register_shapes(oracle, gpu_lib, monkeypatch, exact):
+    """the degenerate family at n = 17..48: the register shapes <1,16>, <2,16>, <2,32>, <3,25>, whose default mode runs a
+    removal's rank-one update in two passes with lane-parallel divisions (wave_ldp_reg.hip.h) -- singular factors (a zero
+    last pivot), pivot_last and the singular direction included.  Exact mode: bit-identical; default mode: the bar of
+    test_degenerate_cases_fast_mode (every optimum along the reference's path; an infeasibility certificate may come one
+    iteration apart in a few problems)."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
+    total, differing, flags = 0, [], set()
+    for trial in range(240):
+        q = _nasty_wide(trial)
+        x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        r = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+        assert (flag > 0) == (r[3] > 0), (trial, flag, r[3])
+        total += 1
+        flags.add(int(r[3]))
+        if exact:
+            assert flag == r[3] and info["iterations"] == r[4], (trial, flag, r[3], info["iterations"], r[4])
+            if flag > 0:
+                assert bits_equal(x, r[0]) and bits_equal(info["lam"], r[1]) and fval == r[2], trial
+            continue
+        same = flag == r[3] and info["iterations"] == r[4] and (flag < 0 or (
+            np.array_equal(np.sign(info["lam"]), np.sign(r[1])) and np.abs(x - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max())))
+        if not same:
+            differing.append((trial, int(flag), int(r[3]), int(info["iterations"]), int(r[4])))
+            assert flag == r[3] and flag < 0 and abs(info["iterations"] - r[4]) <= 1, differing[-1]
+    assert 1 in flags and len(flags) >= 2, flags       # (this family at these sizes: optimal, soft-optimal, over-determined starts)
+    assert len(differing) <= max(2, total // 50), differing
+
+
 def test_degenerate_branches_are_taken_on_the_gpu(oracle, gpu_lib, monkeypatch):
     """the degenerate set drives the GPU state machines through pivot_last (auxiliary.c:379-396), the singular direction
     (auxiliary.c:357-376) and refine_active (auxiliary.c:498-593) -- counted through the branch markers of the event trace,

@@ -27,6 +27,7 @@ namespace daqp_amd {
 #define DAQP_REG_SHAPE(NB, NP) \
     extern template __global__ void k_ldp_reg<NB, NP, false>(const BatchDev *__restrict__, int); \
     extern template __global__ void k_ldp_reg<NB, NP, true>(const BatchDev *__restrict__, int);
+DAQP_REG_SHAPE(1, 6)
 DAQP_REG_SHAPE(1, 8)
 DAQP_REG_SHAPE(3, 25)
 #ifndef DAQP_AMD_FEW_VARIANTS
@@ -174,14 +175,15 @@ typedef void (*ldp_reg_kernel_t)(const BatchDev *, int);
 // register-resident variants: (row blocks, k-pairs) held per lane; needs cap <= 64 and L/rows in LDS
 struct RegShape { int nb, np; };
 #ifdef DAQP_AMD_FEW_VARIANTS   // development builds: fewer instantiations, faster compile
-const RegShape kRegShapes[] = {{1, 8}, {3, 25}};
+const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {3, 25}};
 #else
-const RegShape kRegShapes[] = {{1, 8}, {1, 16}, {2, 16}, {3, 25}, {2, 32}};
+const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {1, 16}, {2, 16}, {3, 25}, {2, 32}};
 #endif
 // exact: the reference's arithmetic (two roundings per multiply-add); otherwise fused multiply-adds (default mode)
 ldp_reg_kernel_t pick_ldp_reg(const DAQPBatch *b, bool exact)
 {
 #define DAQP_REG_PICK(nb, np) if (b->NB == nb && b->NP == np) return exact ? k_ldp_reg<nb, np, false> : k_ldp_reg<nb, np, true>;
+    DAQP_REG_PICK(1, 6)
     DAQP_REG_PICK(1, 8)
     DAQP_REG_PICK(3, 25)
 #ifndef DAQP_AMD_FEW_VARIANTS

@@ -7,6 +7,7 @@ namespace daqp_amd {
 #define DAQP_REG_SHAPE(NB, NP) \
     template __global__ void k_ldp_reg<NB, NP, false>(const BatchDev *__restrict__, int); \
     template __global__ void k_ldp_reg<NB, NP, true>(const BatchDev *__restrict__, int);
+DAQP_REG_SHAPE(1, 6)
 DAQP_REG_SHAPE(1, 8)
 DAQP_REG_SHAPE(3, 25)
 #ifndef DAQP_AMD_FEW_VARIANTS

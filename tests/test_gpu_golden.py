@@ -510,3 +510,38 @@ def test_multi_device_entry_shards_on_one_gpu(oracle, gpu_lib, monkeypatch, cfg,
     assert bits_equal(one["x"][:64], ref[0])
     with pytest.raises(RuntimeError):
         daqp_amd.solve_batch_multi(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms, devices=[0, 99])
+
+
+def test_multi_device_entry_mixed_outcomes(oracle, gpu_lib, monkeypatch):
+    """the multi-device entry on a batch with a sense array (equalities, soft rows), infeasible problems (crossed bounds) and
+    singular Hessians (the proximal loop inside a shard) mixed: every problem comes back at its own index with the unsharded
+    call's bits, whichever shard solved it"""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, na = 10, 28, 3, 4
+    N = 101                                    # (not a multiple of the shard count)
+    q = O.generate_batch(N, n, m, ms, na, 7311)
+    H, f, A, bu, bl = (q[k].copy() for k in ("H", "f", "A", "bupper", "blower"))
+    sense = np.zeros((N, m), np.int32)
+    rng = np.random.default_rng(7312)
+    for k in range(N):
+        if k % 7 == 3:                         # infeasible: a crossed pair of bounds
+            bl[k, 5] = bu[k, 5] + 1.0
+        if k % 5 == 1:                         # an equality and a soft row
+            e, s_ = rng.permutation(m)[:2]
+            sense[k, e] = 5; bl[k, e] = bu[k, e]
+            sense[k, s_] = 8
+        if k % 11 == 6:                        # a rank-deficient Hessian: the proximal loop
+            T = rng.standard_normal((4, n)); H[k] = T.T @ T
+    one = daqp_amd.solve_batch(H, f, A, bu, bl, sense, ms=ms)
+    assert {1, -1} <= set(one["exitflag"].tolist())
+    for devs in ([0, 0], [0, 0, 0]):
+        g = daqp_amd.solve_batch_multi(H, f, A, bu, bl, sense, ms=ms, devices=devs)
+        assert np.array_equal(g["exitflag"], one["exitflag"]) and np.array_equal(g["iter"], one["iter"]), devs
+        ok = one["exitflag"] > 0
+        assert bits_equal(g["x"][ok], one["x"][ok]) and bits_equal(g["lam"][ok], one["lam"][ok]) and bits_equal(g["fval"][ok], one["fval"][ok]), devs
+    for k in range(0, N, 9):
+        r = oracle.quadprog(H[k], f[k], A[k], bu[k], bl[k], sense[k])
+        assert one["exitflag"][k] == r[3] and one["iter"][k] == r[4], k
+        if r[3] > 0:
+            assert bits_equal(one["x"][k], r[0]) and bits_equal(one["lam"][k], r[1]), k

@@ -436,7 +436,8 @@ def test_shared_singular_hessian(oracle, gpu_lib, monkeypatch, n, m, ms, kind, e
     shift = 0.03 * rng.standard_normal((N, m))
     bu, bl = q0["bupper"][None, :] + shift, q0["blower"][None, :] + shift
     bm = daqp_amd.BatchModel(N, n, m, ms)
-    bm.setup_shared(q0["H"], f, q0["A"], bu, bl, None)
+    # (the second shape passes an all-zero sense array: the eager route -- update kernel and activation pass at setup)
+    bm.setup_shared(q0["H"], f, q0["A"], bu, bl, np.zeros((N, m), np.int32) if n == 20 else None)
     info = bm.prox_info()
     assert (info["n_prox"] > 0).all() and (info["eps"] > 0).all() and len(set(info["eps"].tolist())) == 1
     models = []

@@ -129,3 +129,29 @@ def test_beyond_256_rows(oracle, gpu_lib, monkeypatch, shape, N, exact):
         assert bits_equal(g["x"], ref[0]) and bits_equal(g["lam"], ref[1])
     else:
         assert np.abs(g["x"] - ref[0]).max() < XTOL * max(1.0, np.abs(ref[0]).max())
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "default"])
+def test_beyond_256_rows_with_equalities_and_soft_rows(oracle, gpu_lib, monkeypatch, exact):
+    """n = 258 with equalities (sense 5) and soft rows (sense 8): the eight-chunk one-wave kernel's activation pass (equalities
+    enter the working set at setup) and its soft-constraint branches, working-set capacity n + n_soft + 1 > 256"""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
+    n, m, ms, na = 258, 520, 6, 70
+    N = 4
+    qs = []
+    for k in range(N):
+        q = O.generate_qp(n, m, ms, na, rng=[3300, k])
+        q = {key: q[key] for key in ("H", "f", "A", "bupper", "blower", "sense")}
+        qs.append(O.add_sense_variety(q, ms, 3, 2, [3301, k]))
+    b = {key: np.stack([q[key] for q in qs]) for key in ("H", "f", "A", "bupper", "blower", "sense")}
+    g = daqp_amd.solve_batch(b["H"], b["f"], b["A"], b["bupper"], b["blower"], b["sense"], ms=ms)
+    for k in range(N):
+        r = oracle.quadprog(qs[k]["H"], qs[k]["f"], qs[k]["A"], qs[k]["bupper"], qs[k]["blower"], qs[k]["sense"])
+        assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+        if r[3] > 0:
+            assert np.array_equal(np.sign(g["lam"][k]), np.sign(r[1])), k
+            if exact:
+                assert bits_equal(g["x"][k], r[0]) and bits_equal(g["lam"][k], r[1]) and g["fval"][k] == r[2], k
+            else:
+                assert np.abs(g["x"][k] - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max()), k

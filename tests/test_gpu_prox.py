@@ -336,7 +336,7 @@ def test_shift_doubling(oracle, gpu_lib, monkeypatch):
     mdl.close()
 
 
-@pytest.mark.parametrize("n,m,ms,kind", [(120, 260, 5, "sing"), (150, 300, 0, "lp"), (200, 420, 10, "diag")])
+@pytest.mark.parametrize("n,m,ms,kind", [(120, 260, 5, "sing"), (150, 300, 0, "lp"), (200, 420, 10, "diag"), (260, 540, 4, "sing"), (258, 530, 0, "lp")])
 def test_large_shapes(oracle, gpu_lib, monkeypatch, n, m, ms, kind):
     """n > 64: the generic setup kernel (factors in LDS or HBM scratch) and the streamed / spilled solve kernels, with the
     spilled instantiation of the LP gradient step."""

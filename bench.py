@@ -27,6 +27,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+VALU_PEAK_GCYC = 1024 * 2.4  # 256 CUs x 4 SIMDs x 2.4 GHz: G SIMD-cycles/s in which a vector pipe can be issuing (same guide)
+# what binds each configuration's solve launch (counters in profiles/r*_pmc_summary.json)
+BOUND = {"C2": "issue", "C3": "issue", "C4": "cu-miss-path", "C5": "issue"}
+BOUND_IS = {
+    "issue": "instruction issue: M and the iterate are register-resident, HBM sees a few percent of the algorithmic bytes. achieved = VALU-busy "
+             "SIMD-cycles of the launch (4 x SQ_ACTIVE_INST_VALU, committed counter pass of this library build) / launch time (HIP events, this run); "
+             "peak = 1024 SIMDs x 2.4 GHz",
+    "cu-miss-path": "each CU's own miss path (~30 B/clk from L2/MALL/HBM in the scan / primal / Gram phases) plus the master wave's serial phases; "
+                    "frac is quoted on the same issue roof as the other configurations (VALU-busy SIMD-cycles / launch time / (1024 SIMDs x 2.4 GHz)), "
+                    "the HBM side's utilisation is traffic_frac",
+}
 
 # name -> (n, m, ms, active at the optimum, QPs per GPU (weak) / in total (strong), description)
 CONFIGS = {
@@ -61,10 +72,40 @@ def algorithmic_bytes(n, m, ms, iters, warm=False):
     return b_in, b_out, stream
 
 
+CPU_LEG_S = 1.2     # every timed CPU leg lasts at least about this long (the sample is swept `passes` times inside the clock)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def timed_leg(run, units):
+    """run(passes) -> (seconds, ...): one calibration call with one pass, then -- if that was shorter than CPU_LEG_S -- the
+    measured call with as many passes as fill CPU_LEG_S.  Returns (units per second, wall seconds, passes, result of the call)."""
+    r = run(1)
+    if r[0] >= CPU_LEG_S:
+        return units / r[0], r[0], 1, r
+    passes = 1
+    for _ in range(4):      # (the first, cold pass overstates the time per pass: rescale until the leg is long enough)
+        passes = int(min(1 << 16, max(passes + 1, np.ceil(1.15 * passes * CPU_LEG_S / max(r[0], 1e-6)))))
+        r = run(passes)
+        if r[0] >= 0.85 * CPU_LEG_S:
+            break
+    return units * passes / r[0], r[0], passes, r
+
+
 def cpu_baseline(q_host, ms, gpu_res, threads_options):
     """The same QPs solved one at a time by daqp_quadprog on host threads: the reference library itself (oracle/_ref, driven
-    by oracle/ref_batch.c: one pthread per contiguous slice) when it travelled with the repo, else this repo's C restatement
-    built with the reference's flags.  Reported: the best of the thread counts tried."""
+    by oracle/ref_batch.c: one pthread per contiguous slice, threads created before the clock starts) when it travelled with
+    the repo, else this repo's C restatement built with the reference's flags.  Every thread count of `threads_options` is
+    tried, each for >= CPU_LEG_S seconds of wall time; reported: the best."""
     from oracle import oracle as O
     S = q_host["f"].shape[0]
     tried = ""
@@ -73,11 +114,13 @@ def cpu_baseline(q_host, ms, gpu_res, threads_options):
     best = None
     if kind == "reference":
         for th in threads_options:
-            r = O.timed_cpu_batch(libpath, th, q_host["H"], q_host["f"], q_host["A"], q_host["bupper"], q_host["blower"], ms)
-            tried += f"{th} threads: {S / r[0]:.0f} QPs/s; "
-            if best is None or r[0] < best[1][0]:
-                best = (th, r)
-        cores, (dt, x, lam, fval, flag, it) = best[0], best[1]
+            rate, wall, passes, r = timed_leg(lambda ps: O.timed_cpu_batch(libpath, th, q_host["H"], q_host["f"], q_host["A"], q_host["bupper"],
+                                                                           q_host["blower"], ms, passes=ps), S)
+            tried += f"{th} threads: {rate:.0f} QPs/s ({passes} passes, {wall:.2f} s); "
+            if best is None or rate > best[1]:
+                best = (th, rate, wall, passes, r)
+        cores, rate, wall, passes, (_, x, lam, fval, flag, it) = best
+        dt = S / rate
     else:
         import threading
         solver = O.Oracle(fast=True)
@@ -99,6 +142,7 @@ def cpu_baseline(q_host, ms, gpu_res, threads_options):
         for t in th:
             t.join()
         dt = time.perf_counter() - t0
+        wall, passes = dt, 1
     parity = dict(
         sample=int(S),
         identical_active_set=float(np.mean(np.all(np.sign(lam) == np.sign(gpu_res["lam"]), axis=1))),
@@ -106,9 +150,9 @@ def cpu_baseline(q_host, ms, gpu_res, threads_options):
         identical_exitflag=float(np.mean(flag == gpu_res["exitflag"])),
         max_abs_dx=float(np.abs(x - gpu_res["x"]).max()),
     )
-    return dict(value=S / dt, unit="QPs/s", cores=int(cores), kind=kind,
-                sample=f"first {S} QPs of the rank-0 batch, daqp_quadprog one QP at a time on {cores} host threads "
-                       f"({S * 1.0 / dt / cores:.0f} QPs/s per thread), wall {dt:.2f} s" + (f" [best of: {tried.strip()}]" if tried else "")), parity, cores
+    return dict(value=S / dt, unit="QPs/s", cores=int(cores), kind=kind, cpu=cpu_model(), wall_s=wall, passes=passes,
+                sample=f"first {S} QPs of the rank-0 batch swept {passes}x inside the clock, daqp_quadprog one QP at a time on {cores} host threads "
+                       f"({S * 1.0 / dt / cores:.0f} QPs/s per thread), wall {wall:.2f} s" + (f" [best of: {tried.strip()}]" if tried else "")), parity, cores
 
 
 def cpu_baseline_warm(q_host, fs_host, ms, thread_options):
@@ -123,13 +167,16 @@ def cpu_baseline_warm(q_host, fs_host, ms, thread_options):
         libpath = os.path.join(O.HERE, "_ref", "libdaqp_ref.so")
         best, tried = None, ""
         for th in thread_options:
-            r = O.timed_cpu_warm(libpath, th, q_host["H"], q_host["f"], q_host["A"], q_host["bupper"], q_host["blower"], fs_host, ms)
-            tried += f"{th} threads: {S * T / r[0]:.0f}/s; "
-            if best is None or r[0] < best[1][0]:
-                best = (th, r)
-        cores, (dt, x, lam, flag, it) = best
+            rate, wall, passes, r = timed_leg(lambda ps: O.timed_cpu_warm(libpath, th, q_host["H"], q_host["f"], q_host["A"], q_host["bupper"],
+                                                                          q_host["blower"], fs_host, ms, passes=ps), S * T)
+            tried += f"{th} threads: {rate:.0f}/s ({passes} passes, {wall:.2f} s); "
+            if best is None or rate > best[1]:
+                best = (th, rate, wall, passes, r)
+        cores, rate, wall, passes, (_, x, lam, flag, it) = best
+        dt = S * T / rate
         kind = "reference"
-        how = f"C driver, {cores} pthreads, no Python in the timed loop [best of: {tried.strip()}]"
+        how = (f"C driver, {cores} pthreads created before the clock starts, no Python in the timed loop; the walk is swept {passes}x (forth and back: "
+               f"every step one increment away from the previous one) [best of: {tried.strip()}]")
     else:
         drv = O.Oracle(fast=True)
         x, lam = np.zeros((T, S, n)), np.zeros((T, S, m))
@@ -146,9 +193,10 @@ def cpu_baseline_warm(q_host, fs_host, ms, thread_options):
                 x[t, k], lam[t, k], flag[t, k], it[t, k] = r[0], r[1], r[3], r[4]
             dt += time.perf_counter() - t0
         cores, kind, how = 1, "port", "C restatement through ctypes on one thread (oracle/_ref did not travel)"
-    return dict(value=S * T / dt, unit="warm solves/s", cores=int(cores), kind=kind,
+        wall, passes = dt, 1
+    return dict(value=S * T / dt, unit="warm solves/s", cores=int(cores), kind=kind, cpu=cpu_model(), wall_s=wall, passes=passes,
                 sample=f"first {S} QPs x the first {T} warm steps of the walk of f: daqp_update_ldp(UPDATE_v) + daqp_solve per step, "
-                       f"setup_daqp + cold solve untimed; {how}; wall {dt:.2f} s"), dict(x=x, lam=lam, flag=flag, iter=it)
+                       f"setup_daqp + cold solve untimed; {how}; wall {wall:.2f} s"), dict(x=x, lam=lam, flag=flag, iter=it)
 
 
 def warm_parity(bm_factory, q, fs, S, T, cpu):
@@ -182,6 +230,7 @@ class Runner:
         self.torch, self.dist = torch, dist
         self.args = args
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        assert self.world == args.gpus, "launch_plan() lets nothing else through"
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
         if not torch.cuda.is_available():
@@ -334,6 +383,16 @@ class Runner:
         t_setup = float(np.mean(info["setup_ms"])) * 1e-3
         ach = ldp_bytes / t_ldp / 1e9
         flags_ok = bool((res["exitflag"] == 1).all().item())
+        hbm_eff = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ldp_bytes,
+                   "is": "EFFECTIVE rate: SURVEY 8(d)'s algorithmic bytes (M streamed once per iteration) over the launch time -- M is held on chip "
+                         "(C4: screened through an fp32 image), so this says how fast the nominal traffic is served and may exceed 1; it is NOT the "
+                         "fraction of a roof.  The HBM side's real utilisation is traffic_frac"}
+        roof = {"bound": BOUND[cfg], "bound_is": BOUND_IS[BOUND[cfg]],
+                "kernel": "solve launch (dual active-set iteration + back-transform" + (", fused UPDATE_v" if warm else "") + ")",
+                "achieved": None, "peak": VALU_PEAK_GCYC, "unit": "G VALU-busy SIMD-cycles/s", "frac": None,
+                "avg_launch_ms": t_ldp * 1e3, "traffic": None, "hbm_effective": hbm_eff,
+                # the step time against B_io alone (inputs + outputs of the step): what is left of an HBM bound if M stays on chip
+                "floor_frac": io_bytes / max(t_ldp + t_setup, 1e-12) / 1e9 / HBM_PEAK_GBS}
         out = {
             "metric": METRIC[cfg], "value": units / info["elapsed"], "unit": "warm solves/s" if warm else "QPs/s",
             "ms_per_step": info["elapsed"] / steps * 1e3, "steps": steps,
@@ -343,68 +402,127 @@ class Runner:
                         + ("setup_daqp + cold solve untimed, then per step T=10 x {daqp_update_ldp(UPDATE_v) + daqp_solve}" if warm else
                            "daqp_quadprog semantics: setup + solve per step") + ", inputs and outputs resident in HBM",
             "batch_per_gpu": N, "mean_iterations": float(iters.mean()),
-            "roofline": {"bound": "hbm", "kernel": "solve launch (dual active-set iteration + back-transform" + (", fused UPDATE_v" if warm else "") + ")",
-                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "avg_launch_ms": t_ldp * 1e3, "algorithmic_bytes_per_launch": ldp_bytes,
-                         # the same time against B_io alone (inputs + outputs of the step): what is left if M stays on chip
-                         "floor_frac": io_bytes / max(t_ldp + t_setup, 1e-12) / 1e9 / HBM_PEAK_GBS},
+            "roofline": roof,
             "checks": {"all_optimal": flags_ok},
             "arith": ARITH[cfg],
         }
         if info.get("exact"):
             out["exact"] = info["exact"]
         if not warm:
-            out["roofline"]["pipeline"] = {"achieved": all_bytes / (t_ldp + t_setup) / 1e9, "frac": all_bytes / (t_ldp + t_setup) / 1e9 / HBM_PEAK_GBS,
-                                           "setup_ms": t_setup * 1e3, "solve_ms": t_ldp * 1e3, "algorithmic_bytes_per_step": all_bytes}
+            roof["pipeline"] = {"hbm_effective": all_bytes / (t_ldp + t_setup) / 1e9, "hbm_effective_frac": all_bytes / (t_ldp + t_setup) / 1e9 / HBM_PEAK_GBS,
+                                "setup_ms": t_setup * 1e3, "solve_ms": t_ldp * 1e3, "algorithmic_bytes_per_step": all_bytes}
             out["checks"]["max_abs_x_minus_analytic_optimum"] = float((res["x"] - q["xref"]).abs().max().item())
-        out["roofline"]["frac_is"] = ("EFFECTIVE rate: SURVEY 8(d)'s algorithmic bytes (M streamed once per iteration) over the launch time -- M is "
-                                      "held on chip, so this says how fast the nominal traffic is served, not how much of the HBM roof is used "
-                                      "(that is traffic_frac); the roof that binds the launch is instruction issue (roofline.issue)")
-        prof = committed_counters(cfg, N, n, m)
-        if prof:
-            out["roofline"].update(prof)
-            if prof.get("traffic"):     # what the launch really moves through the memory side, against the peak: the honest HBM utilisation
-                out["roofline"]["traffic_frac"] = prof["traffic"] / max(t_ldp, 1e-12) / 1e9 / HBM_PEAK_GBS
+        prof = committed_counters(cfg, N)
+        roof["library"] = library_stamp()
+        if prof.get("stale"):
+            # no committed counter pass was taken with THIS build of the library (or with this batch size): nothing is quoted
+            roof["stale"] = True
+            roof["stale_why"] = prof["why"]
+        else:
+            roof["traffic"] = prof.get("traffic")
+            roof["traffic_source"] = prof["traffic_source"]
+            for k in ("binding", "issue"):
+                if k in prof:
+                    roof[k] = prof[k]
+            if prof.get("traffic"):     # what the launch really moves through the memory side, against the peak: the HBM side's utilisation
+                roof["traffic_frac"] = prof["traffic"] / max(t_ldp, 1e-12) / 1e9 / HBM_PEAK_GBS
             if prof.get("issue"):       # achieved / attainable on the issue roof, with the launch time measured in THIS run
-                out["roofline"]["issue"]["achieved_ms"] = t_ldp * 1e3
-                out["roofline"]["issue"]["frac"] = prof["issue"]["attainable_ms"] / max(t_ldp * 1e3, 1e-12)
-        elif headline:
-            out["roofline"]["traffic"] = None
+                att = prof["issue"]["attainable_ms"]
+                roof["issue"]["achieved_ms"] = t_ldp * 1e3
+                roof["issue"]["frac"] = att / max(t_ldp * 1e3, 1e-12)
+                # VALU-busy cycles of the launch (counter pass) / launch time (this run) against 1024 SIMDs x 2.4 GHz
+                roof["achieved"] = att * 1e-3 * VALU_PEAK_GCYC / max(t_ldp, 1e-12)
+                roof["frac"] = roof["achieved"] / VALU_PEAK_GCYC
         if cpu_sample > 0 and self.world == 1:
             S = min(N, cpu_sample)
             if warm:
                 import daqp_amd
                 qh = {k: q[k][:S].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}
-                base, cpu = cpu_baseline_warm(qh, info["fs"][:T, :S].cpu().numpy(), ms, self.side_threads)
+                base, cpu = cpu_baseline_warm(qh, info["fs"][:T, :S].cpu().numpy(), ms, self.thread_options)
                 parity = warm_parity(lambda S_: daqp_amd.BatchModel(S_, n, m, ms, device=self.local_rank), q, info["fs"], S, T, cpu)
             else:
                 qh = {k: q[k][:S].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}
                 gh = {k: res[k][:S].cpu().numpy() for k in ("x", "lam", "iter", "exitflag")}
-                base, parity, best = cpu_baseline(qh, ms, gh, self.thread_options if headline else self.side_threads)
-                if headline:
-                    self.side_threads = [best]
+                base, parity, best = cpu_baseline(qh, ms, gh, self.thread_options)
             out["cpu_baseline"] = base
             out["parity_vs_cpu"] = parity
         return out
 
 
-def committed_counters(cfg, N, n, m):
+def library_stamp():
+    """what identifies the build of the library the counters belong to: its version string and a hash of every file under
+    daqp_amd/csrc (the same function stamps profiles/r*_pmc_summary.json, tools/pmc_config_summary.py)"""
+    import glob
+    import hashlib
+    import daqp_amd
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "daqp_amd", "csrc", "*"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode() + b"\0")
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return {"version": daqp_amd.lib().daqp_amd_version().decode(), "csrc_sha16": h.hexdigest()[:16]}
+
+
+def committed_counters(cfg, N):
     """HBM bytes per solve launch and the issue-side counters from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
     and the SQ groups each in its own run, corrected as MI355X_MICROARCH.md prescribes; profiles/README.md).  Counters cannot be
-    collected from inside this process, so the figures are those measured with this same workload, and only quoted for it."""
+    collected from inside this process, so the figures are those measured with this same workload -- and they are quoted ONLY
+    from a summary stamped with the build of the library that is loaded now (library_stamp) and taken at this batch size;
+    otherwise the record says `stale` and carries no counter-derived number."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
+        return {"stale": True, "why": "no profiles/r*_pmc_summary.json"}
+    now = library_stamp()
+    why = "no committed counter summary carries this configuration"
+    for f in reversed(files):
+        doc = json.load(open(f))
+        d = doc.get(cfg)
+        if not d:
+            continue
+        if doc.get("_stamp") != now:
+            why = f"newest summary with {cfg} ({os.path.basename(f)}) was taken with library {doc.get('_stamp')}, loaded is {now}"
+            break
+        if d.get("batch") != N:
+            why = f"{os.path.basename(f)} holds {cfg} at batch {d.get('batch')}, this run uses {N}"
+            break
+        out = {"traffic": d.get("traffic_bytes_per_launch"), "traffic_source": "profiles/" + os.path.basename(f)}
+        if "binding" in d:
+            out["binding"] = d["binding"]
+        if "issue" in d:
+            out["issue"] = dict(d["issue"])
+        return out
+    return {"stale": True, "why": why}
+
+
+def launch_plan(gpus, env, argv):
+    """What `bench.py --gpus N` has to do about ranks.  Under a torch.distributed launcher (WORLD_SIZE set) the launcher's world
+    size must BE --gpus (anything else is a mis-launch and fails loudly); without one, N == 1 runs in this process (returns
+    None) and N > 1 returns the command that re-executes this script as N ranks under torch.distributed.run."""
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={ws} ranks; start as many ranks as --gpus says")
         return None
-    d = json.load(open(files[-1])).get(cfg)
-    if not d or d.get("batch") != N:
+    if gpus == 1:
         return None
-    out = {"traffic": d.get("traffic_bytes_per_launch"), "traffic_source": "profiles/" + os.path.basename(files[-1])}
-    if "binding" in d:
-        out["binding"] = d["binding"]
-    if "issue" in d:
-        out["issue"] = dict(d["issue"])
-    return out
+    import socket
+    with socket.socket() as sk:           # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(cmd, args):
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not args.single_device and have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {have} HIP device(s) are visible (one rank per GPU; --single-device puts every rank on cuda:0 for tests)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -421,9 +539,15 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--no-exact", action="store_true", help="skip the extra steps in the library's exact arithmetic mode (reported under \"exact\")")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    plan = launch_plan(args.gpus, os.environ, sys.argv[1:])
+    if plan is not None:
+        # plain `python bench.py --gpus N` (no launcher): start the N ranks here, rank r on device r, and hand back their exit
+        # code; rank 0's JSON line goes to this process's stdout through the launcher
+        sys.exit(self_launch(plan, args))
 
     R = Runner(args)
-    R.side_threads = R.thread_options[-2:-1] or R.thread_options
     auto_sample = {"C2": 65536, "C3": 262144, "C4": 1024, "C5": 8192}   # ~10-25 CPU-seconds each on one core-group
     sample = lambda cfg: 0 if (args.cpu_sample == 0 or R.world > 1) else (auto_sample[cfg] if args.cpu_sample < 0 else args.cpu_sample)
 
@@ -439,8 +563,8 @@ def main():
             "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": h["workload"], "batch_per_gpu": h["batch_per_gpu"], "mean_iterations": h["mean_iterations"],
-                       "parallelism": f"independent shards x{R.world}, no collective in the data path"
-                                      + (f"; barrier + MAX(elapsed) over {R.comm}" if R.comm else "")},
+                       "parallelism": f"{R.world} rank(s), one per GPU, independent shards (QP k -> rank k mod {R.world} with --strong), no collective in the data path"
+                                      + (f"; barrier + MAX(elapsed) over {R.comm}, {R.world} rank(s)" if R.comm else "")},
             "roofline": h["roofline"], "checks": h["checks"], "arith": h["arith"],
         }
         if "exact" in h:

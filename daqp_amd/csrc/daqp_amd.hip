@@ -462,15 +462,20 @@ int solve_with_prox(DAQPBatch *b, int mode, bool ordinary_done = false)
 
 // The count started by the last daqp_batch_setup is looked at now; if the first pass flagged singular Hessians, their regularising
 // setup passes and their activation pass run here (utils.c:354-377).  Every entry point that needs final setup flags comes through.
-int resolve_setup(DAQPBatch *b)
+// had_flagged: whether the first pass had flagged any problem (the caller's early solve launch then reported the internal code for them)
+int resolve_setup(DAQPBatch *b, bool *had_flagged = nullptr)
 {
+    if (had_flagged) *had_flagged = false;
     if (!b->reg_pending) return 0;
-    b->reg_pending = false;
     HIPCHK(hipEventSynchronize(b->ev_count));
-    if (b->pin_count[0] == 0) return 0;
-    const int rc = regularise(b, b->d, b->reg_mask, false, true);
-    if (rc) return rc;
-    return launch_ldp(b, 1);
+    if (b->pin_count[0] == 0) { b->reg_pending = false; return 0; }
+    if (had_flagged) *had_flagged = true;
+    int rc = regularise(b, b->d, b->reg_mask, false, true);
+    if (!rc) rc = launch_ldp(b, 1);
+    // a failed pass leaves problems with the internal code and nothing that would ever resolve it: the batch is not set up
+    if (rc) { b->is_setup = false; b->reg_pending = false; return rc; }
+    b->reg_pending = false;
+    return 0;
 }
 
 int check_problem(const DAQPBatch *b, const DAQPBatchProblem *p)
@@ -768,12 +773,28 @@ void daqp_amd_release_pool(void)
 }
 
 void daqp_batch_set_exact(DAQPBatch *b, int exact) { if (b) b->d.exact_setup = exact ? 1 : 0; }
-void daqp_batch_set_stream(DAQPBatch *b, void *hip_stream) { if (b) b->stream = reinterpret_cast<hipStream_t>(hip_stream); }
+void daqp_batch_set_stream(DAQPBatch *b, void *hip_stream)
+{
+    if (!b) return;
+    hipStream_t ns = reinterpret_cast<hipStream_t>(hip_stream);
+    if (ns != b->stream) {
+        // work already queued for this batch on the old stream (the reset of a pooled workspace, a setup) stays ahead of whatever
+        // the new stream is given: a non-blocking stream does not order itself against the null stream
+        hipEvent_t e = nullptr;
+        (void)hipSetDevice(b->device);
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+            if (hipEventRecord(e, b->stream) == hipSuccess) (void)hipStreamWaitEvent(ns, e, 0);
+            (void)hipEventDestroy(e);
+        }
+    }
+    b->stream = ns;
+}
 void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings)
 {
     if (!b) return;
-    if (settings) b->d.st = *settings; else default_settings(&b->d.st);
     (void)hipSetDevice(b->device);
+    (void)resolve_setup(b);    // regularising passes of the last setup still owed: they belong to the settings that setup ran with (eps_prox)
+    if (settings) b->d.st = *settings; else default_settings(&b->d.st);
     (void)hipMemcpyAsync(b->st_dev, &b->d.st, sizeof(DAQPSettings), hipMemcpyHostToDevice, b->stream);
 }
 unsigned long long daqp_batch_device_bytes(const DAQPBatch *b) { return b ? b->bytes : 0; }
@@ -1117,9 +1138,16 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
     if (b->reg_pending) {
         // straight after a setup: the solve launch goes out before the host knows whether any Hessian was singular (such
         // problems sit it out with their internal flag); only then is the count read.  No gap on the device in the common case.
+        bool had_flagged = false;
         rc = launch_ldp(b, mode);
-        if (!rc) rc = resolve_setup(b);
+        if (!rc) rc = resolve_setup(b, &had_flagged);
         if (!rc && b->n_prox_qps > 0) rc = solve_with_prox(b, mode, true);
+        // the early launch wrote the internal "needs the shift" code for the flagged problems; those whose regularising passes
+        // failed (-5 after the doublings, -1 for a zero row) report that now; the others were rewritten by their outer loop
+        if (!rc && had_flagged) {
+            hipLaunchKernelGGL(k_report_failed_setups, dim3((d.N + 127) / 128), dim3(128), 0, b->stream, d);
+            HIPCHK(hipGetLastError());
+        }
     } else rc = b->n_prox_qps > 0 ? solve_with_prox(b, mode) : launch_ldp(b, mode);
     if (rc) return rc;
     HIPCHK(hipEventRecord(b->ev[3], b->stream));

@@ -102,6 +102,21 @@ __global__ void k_prox_share(BatchDev b, ProxDev p)
     p.eps[q] = p.eps[0];
 }
 
+// One thread per problem: a solve launch that went out BEFORE the host knew of the singular Hessians (daqp_batch_solve straight after
+// a setup) reported the internal "needs the shift" code for them.  Once the regularising passes have run, every problem whose setup
+// ended in a failure reports its FINAL flag (-5 after the doublings, -1 for a zero row of the shifted pass: utils.c:354-377) exactly as
+// a solve launch after the passes would have (api.c:70-78: x / lam untouched, no iterations).
+__global__ void k_report_failed_setups(BatchDev b)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= b.N) return;
+    const int sflag = b.qs[q].setup_flag;
+    if (sflag >= 0 || sflag == DAQP_PROX_SKIP) return;
+    b.exitflag[q] = sflag; b.iter[q] = 0;
+    if (b.fval) b.fval[q] = 0;
+    if (b.soft) b.soft[q] = 0;
+}
+
 // One thread per problem: who takes part in the next launches.
 //  which 0 (before the ordinary problems are solved): proximal problems start their loop (daqp_prox.c:24-36) and sit out
 //  which 1 (before the outer iterations): proximal problems come back, the ordinary ones sit out

@@ -30,8 +30,9 @@ __global__ __launch_bounds__(64) void k_setup_tiny(BatchDev b, int mask)
     const int q = valid ? q_raw : b.N - 1;
     const int n = b.n, m = b.m, ms = b.ms, mA = b.mA;
     const DAQPSettings &st = b.st;
-    const double *H = b.H + (size_t)q * n * n, *f = b.f + (size_t)q * n, *A = b.A + (size_t)q * mA * n;
-    const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
+    const double *H = b.H + (size_t)q * n * n, *f = b.f + (size_t)q * n, *A = (b.A != nullptr && mA > 0) ? b.A + (size_t)q * mA * n : H;
+    // (the row slots load unconditionally and mask the result: without general rows / without constraints the loads go to the problem's own H)
+    const double *bu = m > 0 ? b.bu + (size_t)q * m : H, *bl = m > 0 ? b.bl + (size_t)q * m : H;
     double *sc = b.scaling + (size_t)q * m, *du = b.dupper + (size_t)q * m, *dl = b.dlower + (size_t)q * m;
     QState *qs = b.qs + q;
     const bool force = st.eps_prox > 0.0;

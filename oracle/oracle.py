@@ -382,39 +382,40 @@ def generate_batch(N, n, m, ms, n_active, seed, kappa=100.0, start=0):
     return out
 
 
-def timed_cpu_batch(libpath, threads, H, f, A, bupper, blower, ms=0):
-    """daqp_quadprog of `libpath` over a batch on `threads` host threads (oracle/ref_batch.c).
-    Returns (seconds, x, lam, fval, exitflag, iter)."""
+def timed_cpu_batch(libpath, threads, H, f, A, bupper, blower, ms=0, passes=1):
+    """daqp_quadprog of `libpath` over a batch on `threads` host threads (oracle/ref_batch.c), `passes` sweeps over the batch
+    inside the clock (threads are created before it starts).  Returns (seconds of all passes, x, lam, fval, exitflag, iter)."""
     build()
     L = C.CDLL(os.path.join(HERE, "librefbatch.so"))
     L.ref_batch_run.restype = C.c_double
-    L.ref_batch_run.argtypes = [C.c_char_p] + [C.c_int] * 5 + [c_double_p] * 8 + [c_int_p] * 2
+    L.ref_batch_run.argtypes = [C.c_char_p] + [C.c_int] * 6 + [c_double_p] * 8 + [c_int_p] * 2
     H, f, A, bupper, blower = _f64(H), _f64(f), _f64(A), _f64(bupper), _f64(blower)
     N, n = f.shape
     m = bupper.shape[1]
     x, lam, fval = np.zeros((N, n)), np.zeros((N, m)), np.zeros(N)
     flag, it = np.zeros(N, np.int32), np.zeros(N, np.int32)
-    dt = L.ref_batch_run(libpath.encode(), threads, N, n, m, ms, _dp(H), _dp(f), _dp(A), _dp(bupper), _dp(blower),
+    dt = L.ref_batch_run(libpath.encode(), threads, int(passes), N, n, m, ms, _dp(H), _dp(f), _dp(A), _dp(bupper), _dp(blower),
                          _dp(x), _dp(lam), _dp(fval), _ip(flag), _ip(it))
     if dt < 0:
         raise RuntimeError(f"could not load daqp_quadprog from {libpath}")
     return dt, x, lam, fval, flag, it
 
 
-def timed_cpu_warm(libpath, threads, H, f, A, bupper, blower, fs, ms=0):
+def timed_cpu_warm(libpath, threads, H, f, A, bupper, blower, fs, ms=0, passes=1):
     """config C5 on `threads` host threads, all in C (oracle/ref_batch.c::ref_warm_run): setup_daqp + cold daqp_solve per QP
     (untimed), then the T = fs.shape[0] warm steps daqp_update_ldp(UPDATE_v) + daqp_solve of every QP (timed).
+    `passes` > 1 walks the same path back and forth inside the clock (ref_batch.c); outputs are those of the first, forward pass.
     Returns (seconds of the warm phase, x [T,N,n], lam [T,N,m], exitflag [T,N], iter [T,N])."""
     build()
     L = C.CDLL(os.path.join(HERE, "librefbatch.so"))
     L.ref_warm_run.restype = C.c_double
-    L.ref_warm_run.argtypes = [C.c_char_p] + [C.c_int] * 6 + [c_double_p] * 8 + [c_int_p] * 2
+    L.ref_warm_run.argtypes = [C.c_char_p] + [C.c_int] * 7 + [c_double_p] * 8 + [c_int_p] * 2
     H, f, A, bupper, blower, fs = _f64(H), _f64(f), _f64(A), _f64(bupper), _f64(blower), _f64(fs)
     N, n = f.shape
     m, T = bupper.shape[1], fs.shape[0]
     x, lam = np.zeros((T, N, n)), np.zeros((T, N, m))
     flag, it = np.zeros((T, N), np.int32), np.zeros((T, N), np.int32)
-    dt = L.ref_warm_run(libpath.encode(), threads, N, n, m, ms, T, _dp(H), _dp(f), _dp(A), _dp(bupper), _dp(blower), _dp(fs),
+    dt = L.ref_warm_run(libpath.encode(), threads, int(passes), N, n, m, ms, T, _dp(H), _dp(f), _dp(A), _dp(bupper), _dp(blower), _dp(fs),
                         _dp(x), _dp(lam), _ip(flag), _ip(it))
     if dt < 0:
         raise RuntimeError(f"could not load the workspace API from {libpath}")

@@ -17,16 +17,19 @@ typedef void (*quadprog_fn)(DAQPResult *, DAQPProblem *, DAQPSettings *);
 
 typedef struct {
     quadprog_fn fn;
-    int lo, hi, n, m, ms;
+    int lo, hi, n, m, ms, passes;
     const double *H, *f, *A, *bu, *bl;
     double *x, *lam, *fval;
     int *flag, *iter;
+    pthread_barrier_t *bar;
 } slice_t;
 
 static void *run_slice(void *arg)
 {
     slice_t *s = (slice_t *)arg;
     const size_t n = s->n, m = s->m, mA = s->m - s->ms;
+    pthread_barrier_wait(s->bar);               /* the clock starts when every thread exists and stands here */
+    for (int pass = 0; pass < s->passes; pass++)
     for (int q = s->lo; q < s->hi; q++) {
         DAQPProblem qp;
         memset(&qp, 0, sizeof(qp));
@@ -39,11 +42,13 @@ static void *run_slice(void *arg)
         s->fn(&r, &qp, NULL);
         s->fval[q] = r.fval; s->flag[q] = r.exitflag; s->iter[q] = r.iter;
     }
+    pthread_barrier_wait(s->bar);
     return NULL;
 }
 
-/* returns wall seconds, or -1 if the library/symbol could not be loaded */
-double ref_batch_run(const char *libpath, int threads, int N, int n, int m, int ms, const double *H, const double *f,
+/* `passes` sweeps over the batch (each QP solved `passes` times: same inputs, same outputs) between two barriers: thread
+ * creation and joining are outside the clock.  Returns wall seconds of all passes, or -1 if the library/symbol could not be loaded */
+double ref_batch_run(const char *libpath, int threads, int passes, int N, int n, int m, int ms, const double *H, const double *f,
                      const double *A, const double *bu, const double *bl, double *x, double *lam, double *fval, int *flag,
                      int *iter)
 {
@@ -56,15 +61,21 @@ double ref_batch_run(const char *libpath, int threads, int N, int n, int m, int 
     pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * threads);
     slice_t *sl = (slice_t *)malloc(sizeof(slice_t) * threads);
     struct timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
+    pthread_barrier_t bar;
+    if (passes < 1) passes = 1;
+    pthread_barrier_init(&bar, NULL, threads + 1);
     for (int t = 0; t < threads; t++) {
-        slice_t s = {fn, (int)((long long)N * t / threads), (int)((long long)N * (t + 1) / threads), n, m, ms,
-                     H, f, A, bu, bl, x, lam, fval, flag, iter};
+        slice_t s = {fn, (int)((long long)N * t / threads), (int)((long long)N * (t + 1) / threads), n, m, ms, passes,
+                     H, f, A, bu, bl, x, lam, fval, flag, iter, &bar};
         sl[t] = s;
         pthread_create(&tid[t], NULL, run_slice, &sl[t]);
     }
-    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    pthread_barrier_wait(&bar);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    pthread_barrier_wait(&bar);
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    pthread_barrier_destroy(&bar);
     free(tid); free(sl);
     return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
@@ -80,7 +91,7 @@ typedef void (*freews_fn)(DAQPWorkspace *);
 
 typedef struct {
     setup_fn setup; solve_fn solve; update_fn update; freews_fn free_ws, free_ldp;
-    int lo, hi, N, n, m, ms, T;
+    int lo, hi, N, n, m, ms, T, passes;
     const double *H, *f, *A, *bu, *bl, *fs;
     double *x, *lam;
     int *flag, *iter;
@@ -111,16 +122,24 @@ static void *run_warm_slice(void *arg)
     pthread_barrier_wait(s->bar);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    /* pass 0 walks f forward through fs[0..T-1] and records every step's result; further passes (to make the timed phase long
+     * enough to be a measurement) walk the same path back -- fs[T-2], ..., fs[0], the original f -- and forth again: every step is
+     * still ONE increment of the random walk away from the previous one, the workload per warm solve is the same; their results
+     * go to scratch. */
+    for (int pass = 0; pass < s->passes; pass++)
     for (int k = 0; k < cnt; k++) {
         const size_t q = s->lo + k;
-        for (int t = 0; t < s->T; t++) {
-            qps[k].f = (double *)s->fs + ((size_t)t * N + q) * n;
+        for (int j = 0; j < s->T; j++) {
+            const int back = pass & 1;
+            const int t = back ? s->T - 2 - j : j;             /* t == -1: the original f */
+            qps[k].f = t < 0 ? (double *)s->f + q * n : (double *)s->fs + ((size_t)t * N + q) * n;
             s->update(DAQP_UPDATE_v, &ws[k], &qps[k]);
             DAQPResult r;
             memset(&r, 0, sizeof(r));
-            r.x = s->x + ((size_t)t * N + q) * n; r.lam = s->lam + ((size_t)t * N + q) * m;
+            if (pass == 0) { r.x = s->x + ((size_t)t * N + q) * n; r.lam = s->lam + ((size_t)t * N + q) * m; }
+            else { r.x = x0; r.lam = l0; }
             s->solve(&r, &ws[k]);
-            s->flag[(size_t)t * N + q] = r.exitflag; s->iter[(size_t)t * N + q] = r.iter;
+            if (pass == 0) { s->flag[(size_t)t * N + q] = r.exitflag; s->iter[(size_t)t * N + q] = r.iter; }
         }
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -132,7 +151,7 @@ static void *run_warm_slice(void *arg)
 }
 
 /* returns the wall seconds of the warm phase (first thread in to last thread out), or -1 */
-double ref_warm_run(const char *libpath, int threads, int N, int n, int m, int ms, int T, const double *H, const double *f,
+double ref_warm_run(const char *libpath, int threads, int passes, int N, int n, int m, int ms, int T, const double *H, const double *f,
                     const double *A, const double *bu, const double *bl, const double *fs, double *x, double *lam, int *flag,
                     int *iter)
 {
@@ -150,7 +169,7 @@ double ref_warm_run(const char *libpath, int threads, int N, int n, int m, int m
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, NULL, threads + 1);
     for (int t = 0; t < threads; t++) {
-        warm_slice_t s = {su, so, up, fw, fl, (int)((long long)N * t / threads), (int)((long long)N * (t + 1) / threads), N, n, m, ms, T,
+        warm_slice_t s = {su, so, up, fw, fl, (int)((long long)N * t / threads), (int)((long long)N * (t + 1) / threads), N, n, m, ms, T, passes < 1 ? 1 : passes,
                           H, f, A, bu, bl, fs, x, lam, flag, iter, &bar, 0.0};
         sl[t] = s;
         pthread_create(&tid[t], NULL, run_warm_slice, &sl[t]);

@@ -245,3 +245,41 @@ def test_kernel_resource_budgets():
         assert name in res, (name, sorted(res)[:8])
         r = res[name]
         assert r["scratch"] <= scratch and r["occupancy"] >= occ, (name, r)
+
+
+def test_bench_gpus_flag_decides_the_ranks():
+    """bench.py --gpus N: N > 1 without a launcher re-executes as N ranks under torch.distributed.run on the loopback interface;
+    under a launcher the world size must be N; N == 1 stays in-process (tests/test_gpu_bench_contract.py runs all of it on the GPU)"""
+    import pytest
+    import bench
+    assert bench.launch_plan(1, {}, ["--gpus", "1"]) is None
+    assert bench.launch_plan(4, {"WORLD_SIZE": "4", "RANK": "2"}, []) is None
+    cmd = bench.launch_plan(8, {}, ["--gpus", "8", "--config", "C3", "--strong"])
+    i = cmd.index("torch.distributed.run")
+    assert cmd[i + 1:i + 6] == ["--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1"] and cmd[i + 6] == "--master-port"
+    assert 1024 < int(cmd[i + 7]) < 65536 and cmd[i + 8] == os.path.join(ROOT, "bench.py") and cmd[i + 9:] == ["--gpus", "8", "--config", "C3", "--strong"]
+    for gpus, ws in ((8, "1"), (1, "2"), (2, "8")):
+        with pytest.raises(SystemExit, match=f"--gpus {gpus} but the launcher started WORLD_SIZE={ws}"):
+            bench.launch_plan(gpus, {"WORLD_SIZE": ws}, [])
+
+
+def test_bench_quotes_counters_only_for_the_loaded_library(tmp_path, monkeypatch):
+    """roofline numbers derived from rocprofv3 counters come from committed passes; bench.py quotes a summary only when its stamp
+    (library version + hash of daqp_amd/csrc) is that of the library it runs, and the batch size is the one profiled"""
+    import json
+    import bench
+    now = bench.library_stamp()
+    assert len(now["csrc_sha16"]) == 16 and now["version"].startswith("daqp_amd")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "library_stamp", lambda: now)
+    assert bench.committed_counters("C2", 100000)["stale"]
+    entry = {"batch": 100000, "traffic_bytes_per_launch": 1.0e10, "issue": {"attainable_ms": 9.0}, "binding": {"resource": "x"}}
+    (prof / "r09a_pmc_summary.json").write_text(json.dumps({"_stamp": {"version": now["version"], "csrc_sha16": "0" * 16}, "C2": entry}))
+    r = bench.committed_counters("C2", 100000)
+    assert r["stale"] and "was taken with library" in r["why"]
+    (prof / "r09b_pmc_summary.json").write_text(json.dumps({"_stamp": now, "C2": entry}))
+    r = bench.committed_counters("C2", 100000)
+    assert "stale" not in r and r["traffic"] == 1.0e10 and r["issue"]["attainable_ms"] == 9.0 and r["traffic_source"] == "profiles/r09b_pmc_summary.json"
+    assert bench.committed_counters("C2", 4096)["stale"] and bench.committed_counters("C4", 10000)["stale"]

@@ -336,6 +336,50 @@ def test_shift_doubling(oracle, gpu_lib, monkeypatch):
     mdl.close()
 
 
+@pytest.mark.parametrize("exact", ["1", "0"])
+@pytest.mark.parametrize("shape", [(9, 22, 2), (50, 150, 0), (12, 40, 12), (70, 150, 3)])
+def test_failed_shifts_report_their_flag_in_a_one_shot_batch(oracle, gpu_lib, monkeypatch, shape, exact):
+    """solve_batch straight after the setup, nothing in between that would resolve the setup flags (the solve launch goes out before the
+    host knows of the singular Hessians): problems whose regularising passes fail -- indefinite H: -5 after the doublings; a zero row
+    of A whose bounds exclude 0 in a problem that needed the shift: -1 -- report THAT, never the internal "needs the shift" code;
+    definite, semidefinite and infeasible problems of the same batch as usual."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", exact)
+    n, m, ms = shape
+    N = 21
+    qs = []
+    for k in range(N):
+        if k % 3 == 0:
+            q = O.generate_qp(n, m, ms, max(1, n // 3), rng=[97, n, k])
+            q["sense"] = np.zeros(m, np.int32)
+        else:
+            q = O.generate_singular_qp(n, m, ms, rank=1 + (k * 5) % (n - 1), rng=[97, n, k])
+            if k % 3 == 2:
+                q["H"] = q["H"] - [0.7, 40.0, 1e5][(k // 3) % 3] * np.eye(n)        # indefinite: no shift is enough
+            elif k % 6 == 1 and m > ms:
+                q["A"] = q["A"].copy(); q["A"][0] = 0.0                                  # zero row, 0 outside its bounds
+                q["bupper"] = q["bupper"].copy(); q["blower"] = q["blower"].copy()
+                q["blower"][ms] = 1.0; q["bupper"][ms] = 2.0
+        qs.append(q)
+    ref = oracle_each(oracle, qs)
+    assert {r[3] for r in ref} >= {1, -5, -1}
+    b = stack(qs)
+    r = daqp_amd.solve_batch(b["H"], b["f"], b["A"], b["bupper"], b["blower"], b["sense"], ms=ms)
+    mdl = daqp_amd.BatchModel(N, n, m, ms)
+    mdl.setup(b["H"], b["f"], b["A"], b["bupper"], b["blower"], b["sense"], init_mask=64)
+    r2 = mdl.solve()                                             # no setup_flags() / prox_info() before the first solve
+    for k in range(N):
+        x, lam, fval, flag, it = ref[k]
+        for got in (r, r2):
+            assert got["exitflag"][k] == flag, (k, got["exitflag"][k], flag)
+            if flag > 0 and (exact == "1" or k % 3 != 0):      # (shifted problems are bit-identical in both modes)
+                assert got["iter"][k] == it and same(got["x"][k], x) and same(got["lam"][k], lam), k
+            elif flag > 0:
+                assert got["iter"][k] == it and np.abs(got["x"][k] - x).max() < 1e-9
+    assert (mdl.setup_flags() < 0).sum() == sum(1 for rr in ref if rr[3] in (-5,)) + sum(1 for k, rr in enumerate(ref) if rr[3] == -1 and k % 6 == 1)
+    mdl.close()
+
+
 @pytest.mark.parametrize("n,m,ms,kind", [(120, 260, 5, "sing"), (150, 300, 0, "lp"), (200, 420, 10, "diag"), (260, 540, 4, "sing"), (258, 530, 0, "lp")])
 def test_large_shapes(oracle, gpu_lib, monkeypatch, n, m, ms, kind):
     """n > 64: the generic setup kernel (factors in LDS or HBM scratch) and the streamed / spilled solve kernels, with the

@@ -5,7 +5,7 @@ MI355X_MICROARCH.md prescribes, + WRITE_SIZE) and the issue-side counters that s
 the setup launch.  bench.py quotes `traffic_bytes_per_launch` and `binding` of the newest summary."""
 import json, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import CONFIGS
+from bench import CONFIGS, library_stamp
 
 out = sys.argv[1]
 SOLVE = {"C2": r"k_ldp_reg<3, 25", "C3": r"k_ldp_reg<1, [68]|k_ldp_tiny", "C4": r"k_ldp_wg<4>", "C5": r"k_ldp_reg<3, 25"}
@@ -38,7 +38,8 @@ def describe(c):
     return d
 
 
-res = {}
+# the build of the library these counters were taken with: bench.py quotes a summary only when the loaded library carries the same stamp
+res = {"_stamp": library_stamp()}
 for path in sys.argv[2:]:
     cfg = re.search(r"(C\d)", os.path.basename(path)).group(1)
     raw = json.load(open(path))

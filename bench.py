@@ -365,7 +365,8 @@ class Runner:
                          what="DAQP_AMD_EXACT=1: every sum in the reference's operation order (no fused multiply-adds, no matrix cores, no fp32 screening, no inverse factor): results bit-identical to the reference")
             bx.close()
             del bx, rx
-        return q, res, bm, dict(N=N, N_total=N_total, elapsed=elapsed, setup_ms=setup_ms, solve_ms=solve_ms, T=T if warm else 1, fs=fs, exact=exact)
+        rechecked = int(bm.rechecked())   # problems of the last step whose INFEASIBLE verdict took the second pass in the reference's arithmetic: none here
+        return q, res, bm, dict(N=N, N_total=N_total, rechecked=rechecked, elapsed=elapsed, setup_ms=setup_ms, solve_ms=solve_ms, T=T if warm else 1, fs=fs, exact=exact)
 
     def report(self, cfg, q, res, info, steps, cpu_sample, headline):
         """rank 0: the JSON fields of one configuration"""
@@ -403,7 +404,7 @@ class Runner:
                            "daqp_quadprog semantics: setup + solve per step") + ", inputs and outputs resident in HBM",
             "batch_per_gpu": N, "mean_iterations": float(iters.mean()),
             "roofline": roof,
-            "checks": {"all_optimal": flags_ok},
+            "checks": {"all_optimal": flags_ok, "rechecked_in_exact_arithmetic": info["rechecked"]},
             "arith": ARITH[cfg],
         }
         if info.get("exact"):

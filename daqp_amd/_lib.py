@@ -63,7 +63,9 @@ EXPORTS = [
     "daqp_dual_init_active", "daqp_set_primal_start", "daqp_minrep", "allocate_daqp_workspace", "allocate_daqp_ldp", "daqp_first_violating", "daqp_batch_create", "daqp_batch_free", "daqp_amd_release_pool", "daqp_batch_set_stream",
     "daqp_batch_set_settings", "daqp_batch_set_exact", "daqp_batch_setup", "daqp_batch_setup_shared", "daqp_batch_update", "daqp_batch_solve",
     "daqp_batch_setup_flags", "daqp_batch_working_sets", "daqp_batch_set_primal_start", "daqp_batch_prox_info", "daqp_quadprog_batch", "daqp_quadprog_batch_multi", "daqp_batch_kernel_ms",
-    "daqp_batch_device_bytes", "daqp_amd_last_error", "daqp_amd_device_count", "daqp_amd_version",
+    "daqp_batch_create_multi", "daqp_batch_free_multi", "daqp_batch_multi_shards", "daqp_batch_multi_shard", "daqp_batch_setup_multi", "daqp_batch_update_multi",
+    "daqp_batch_solve_multi", "daqp_batch_setup_multi_shards", "daqp_batch_update_multi_shards", "daqp_batch_solve_multi_shards",
+    "daqp_batch_device_bytes", "daqp_batch_rechecked", "daqp_amd_last_error", "daqp_amd_device_count", "daqp_amd_version", "daqp_amd_has_tiny",
     "setup_daqp_ldp", "daqp_ldp", "ldp2qp_solution", "daqp_extract_result",
     "daqp_batch_enable_trace", "daqp_batch_read_trace", "daqp_batch_enable_profile", "daqp_batch_read_profile", "daqp_batch_read_ldp",
 ]
@@ -73,15 +75,21 @@ EXPORTS = [
 # object was compiled with other flags)
 UNITS = {
     "daqp_amd.hip": ["daqp_amd.hip", "kernels.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h", "setup_fast.hip.h", "prox.hip.h",
-                     "wg_layout.hip.h", "batch_dev.hip.h", "reg_kernel.hip.h", "tiny_kernel.hip.h", "tiny_ldp.hip.h", "tiny_setup.hip.h", "multi.hip.h"],
+                     "wg_layout.hip.h", "batch_dev.hip.h", "recheck.hip.h", "reg_kernel.hip.h", "tiny_kernel.hip.h", "tiny_ldp.hip.h", "tiny_setup.hip.h", "multi.hip.h"],
     "reg_kernel.hip": ["reg_kernel.hip", "reg_kernel.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
     "wg_kernel.hip": ["wg_kernel.hip", "wg_kernel.hip.h", "wg_ldp.hip.h", "wg_layout.hip.h", "batch_dev.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h"],
-    "setup_kernel.hip": ["setup_kernel.hip", "setup_fast.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
+    "setup_kernel.hip": ["setup_kernel.hip", "setup_fast.hip.h", "tiny_setup.hip.h", "tiny_ldp.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
     "tiny_kernel.hip": ["tiny_kernel.hip", "tiny_kernel.hip.h", "tiny_ldp.hip.h", "tiny_setup.hip.h", "batch_dev.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h"],
 }
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 OBJDIR = os.path.join(LIBDIR, "obj")
 UNITS = {u: d for u, d in UNITS.items() if os.path.exists(os.path.join(CSRC, u))}
+WITH_TINY = "-DDAQP_AMD_WITH_TINY"   # the 16-problems-per-wave solve kernel: its own unit, only in builds that ask for it (tools/tinybuild.sh)
+
+
+def units(extra_flags=()):
+    """translation units of a build with these flags"""
+    return [u for u in UNITS if u != "tiny_kernel.hip" or WITH_TINY in extra_flags]
 
 
 def _flag_key(extra_flags=()):
@@ -106,15 +114,16 @@ def _unit_stale(unit, extra_flags=()):
 def _stale(extra_flags=()):
     if not os.path.exists(LIBPATH):
         return True
-    if any(_unit_stale(u, extra_flags) or os.path.getmtime(os.path.join(OBJDIR, u + ".o")) > os.path.getmtime(LIBPATH) for u in UNITS):
+    if any(_unit_stale(u, extra_flags) or os.path.getmtime(os.path.join(OBJDIR, u + ".o")) > os.path.getmtime(LIBPATH) for u in units(extra_flags)):
         return True
     if extra_flags:
         return False
     try:   # a development build (tools/devbuild.sh: fewer kernel variants) is never what build() should leave behind
-        v = C.CDLL(LIBPATH).daqp_amd_version
+        L = C.CDLL(LIBPATH)
+        v = L.daqp_amd_version
         v.restype = C.c_char_p
-        return b"dev build" in v()
-    except OSError:
+        return b"dev build" in v() or bool(L.daqp_amd_has_tiny())    # (nor is a build that carries the opt-in tiny solve kernel)
+    except (OSError, AttributeError):
         return True
 
 
@@ -139,7 +148,7 @@ def build(force=False, verbose=False, extra_flags=()):
             if not force and not _stale(extra_flags):      # another process built it while this one waited
                 return LIBPATH
             procs = []
-            for unit in UNITS:
+            for unit in units(extra_flags):
                 if force or _unit_stale(unit, extra_flags):
                     obj = os.path.join(OBJDIR, unit + ".o")
                     # the code generator's per-kernel register / scratch / LDS report is kept next to the object
@@ -163,7 +172,7 @@ def build(force=False, verbose=False, extra_flags=()):
                 with open(obj + ".flags", "w") as fh:
                     fh.write(_flag_key(extra_flags))
             tmp = LIBPATH + ".tmp.%d" % os.getpid()
-            cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *[os.path.join(OBJDIR, u + ".o") for u in UNITS], "-o", tmp]
+            cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *[os.path.join(OBJDIR, u + ".o") for u in units(extra_flags)], "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
@@ -181,7 +190,7 @@ def kernel_resources():
             "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
             "LDS Size [bytes/block]": "lds"}
     out = {}
-    for unit in UNITS:
+    for unit in units():
         path = os.path.join(OBJDIR, unit + ".o.resources.txt")
         if not os.path.exists(path):
             continue
@@ -239,7 +248,20 @@ def lib():
     L.daqp_batch_prox_info.argtypes = [vp, c_int_p, c_int_p, C.c_void_p]
     L.daqp_quadprog_batch.argtypes = [C.POINTER(DAQPBatchResult), C.POINTER(DAQPBatchProblem), C.POINTER(DAQPSettings)]
     L.daqp_quadprog_batch_multi.argtypes = [C.POINTER(DAQPBatchResult), C.POINTER(DAQPBatchProblem), C.POINTER(DAQPSettings), c_int_p, ci]
+    L.daqp_batch_create_multi.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci, C.POINTER(DAQPSettings), c_int_p, ci]
+    L.daqp_batch_free_multi.argtypes = [vp]
+    L.daqp_batch_free_multi.restype = None
+    L.daqp_batch_multi_shards.argtypes = [vp]
+    L.daqp_batch_multi_shard.argtypes = [vp, ci, c_int_p, c_int_p]
+    L.daqp_batch_multi_shard.restype = vp
+    L.daqp_batch_setup_multi.argtypes = [vp, C.POINTER(DAQPBatchProblem), ci]
+    L.daqp_batch_update_multi.argtypes = [vp, ci, C.POINTER(DAQPBatchProblem)]
+    L.daqp_batch_solve_multi.argtypes = [vp, C.POINTER(DAQPBatchResult)]
+    L.daqp_batch_setup_multi_shards.argtypes = [vp, C.POINTER(DAQPBatchProblem), ci]
+    L.daqp_batch_update_multi_shards.argtypes = [vp, ci, C.POINTER(DAQPBatchProblem)]
+    L.daqp_batch_solve_multi_shards.argtypes = [vp, C.POINTER(DAQPBatchResult)]
     L.daqp_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.daqp_batch_rechecked.argtypes = [vp]
     L.daqp_batch_device_bytes.argtypes = [vp]
     L.daqp_batch_device_bytes.restype = C.c_ulonglong
     L.daqp_batch_enable_trace.argtypes = [vp, ci]

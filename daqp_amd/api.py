@@ -317,6 +317,11 @@ class BatchModel:
     def device_bytes(self):
         return int(lib().daqp_batch_device_bytes(self._h))
 
+    def rechecked(self):
+        """problems of the last solve whose INFEASIBLE verdict was re-derived in the reference's arithmetic (default mode, first
+        solve after a setup: include/daqp_amd.h, daqp_batch_rechecked)"""
+        return int(lib().daqp_batch_rechecked(self._h))
+
     # test hooks
     def enable_trace(self, cap=4096):
         lib().daqp_batch_enable_trace(self._h, cap)
@@ -403,3 +408,72 @@ def solve_batch_multi(H, f, A, bupper, blower=None, sense=None, ms=None, devices
     if rc != 0:
         raise RuntimeError(f"daqp_quadprog_batch_multi failed ({rc}): {_lib.last_error()}")
     return o
+
+
+class MultiBatchModel:
+    """N QPs of one shape held on several GPUs of this host between calls (include/daqp_amd.h, DAQPMultiBatch): problem k lives on
+    devices[k mod G].  setup -> solve -> {update(f, bounds) -> solve}* with ONE host-resident batch in the caller's order, numpy in,
+    numpy out -- BatchModel's sequence, sharded.  devices=None: every visible device; a device may be listed more than once."""
+
+    def __init__(self, N, n, m, ms=0, ns_max=0, devices=None, **settings):
+        self.N, self.n, self.m, self.ms = N, n, m, ms
+        self._settings = default_settings(**settings)
+        dev = None if devices is None else np.ascontiguousarray(devices, np.int32)
+        h = C.c_void_p()
+        rc = lib().daqp_batch_create_multi(C.byref(h), N, n, m, ms, ns_max, C.byref(self._settings), _ip(dev), 0 if dev is None else dev.size)
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_create_multi failed ({rc}): {_lib.last_error()}")
+        self._h = h
+        self.shards = int(lib().daqp_batch_multi_shards(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().daqp_batch_free_multi(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _problem(self, keep, H=None, f=None, A=None, bupper=None, blower=None, sense=None):
+        mA = self.m - self.ms
+        ptrs = [_ptr(a, dt, keep)[0] for a, dt in ((H, np.float64), (f, np.float64), (A if mA else None, np.float64), (bupper, np.float64),
+                                                    (blower, np.float64), (sense, np.int32))]
+        return DAQPBatchProblem(self.N, self.n, self.m, self.ms, *ptrs, MEM_HOST)
+
+    def setup(self, H, f, A, bupper, blower=None, sense=None, init_mask=0):
+        if blower is None:
+            blower = np.full(np.shape(bupper), -INF)
+        keep = []
+        p = self._problem(keep, H, f, A, bupper, blower, sense)
+        rc = lib().daqp_batch_setup_multi(self._h, C.byref(p), init_mask)
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_setup_multi failed ({rc}): {_lib.last_error()}")
+
+    def update(self, f=None, bupper=None, blower=None):
+        mask = (UPDATE_v if f is not None else 0) | (UPDATE_d if (bupper is not None or blower is not None) else 0)
+        keep = []
+        p = self._problem(keep, None, f, None, bupper, blower, None)
+        rc = lib().daqp_batch_update_multi(self._h, mask, C.byref(p))
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_update_multi failed ({rc}): {_lib.last_error()}")
+
+    def solve(self):
+        N, n, m = self.N, self.n, self.m
+        o = dict(x=np.empty((N, n)), lam=np.empty((N, m)), fval=np.empty(N), soft_slack=np.empty(N),
+                 exitflag=np.empty(N, np.int32), iter=np.empty(N, np.int32))
+        r = DAQPBatchResult(o["x"].ctypes.data, o["lam"].ctypes.data, o["fval"].ctypes.data, o["soft_slack"].ctypes.data,
+                            o["exitflag"].ctypes.data, o["iter"].ctypes.data, MEM_HOST, 0, 0)
+        rc = lib().daqp_batch_solve_multi(self._h, C.byref(r))
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_solve_multi failed ({rc}): {_lib.last_error()}")
+        o["solve_time"] = r.solve_time
+        return o
+
+    def shard(self, g):
+        """(DAQPBatch handle, problems on it, device) of shard g -- for the single-device inspection calls"""
+        sn, dev = C.c_int(0), C.c_int(0)
+        h = lib().daqp_batch_multi_shard(self._h, g, C.byref(sn), C.byref(dev))
+        return h, sn.value, dev.value

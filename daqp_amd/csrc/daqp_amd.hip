@@ -17,8 +17,11 @@
 #include "reg_kernel.hip.h"
 #include "setup_fast.hip.h"
 #include "prox.hip.h"
+#include "recheck.hip.h"
 #include "wg_layout.hip.h"
+#ifdef DAQP_AMD_WITH_TINY
 #include "tiny_kernel.hip.h"
+#endif
 #include "tiny_setup.hip.h"
 // the workgroup-per-problem solve kernel lives in its own translation unit (wg_kernel.hip): a change to it does not rebuild
 // everything else
@@ -46,11 +49,15 @@ DAQP_SETUP_SIZE(32)
 DAQP_SETUP_SIZE(56)
 DAQP_SETUP_SIZE(64)
 #undef DAQP_SETUP_SIZE
+// the 16-problems-per-wave SOLVE kernel of tiny shapes is not part of the default build (measured slower than the register kernel on
+// config C3): -DDAQP_AMD_WITH_TINY compiles tiny_kernel.hip in (tools/tinybuild.sh), DAQP_AMD_TINY=1 then selects it
+#ifdef DAQP_AMD_WITH_TINY
 extern template __global__ void k_ldp_tiny<4, 0, false>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_tiny<4, 0, true>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_tiny<4, 3, false>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_tiny<4, 3, true>(const BatchDev *__restrict__, int);
-extern template __global__ void k_setup_tiny<4>(BatchDev, int);
+#endif
+extern template __global__ void k_setup_tiny<4>(BatchDev, int);   // (the 16-per-wave SETUP kernel is the default for these shapes: setup_kernel.hip)
 template <int C> __global__ void k_ldp_wg(BatchDev b, int mode);
 extern template __global__ void k_ldp_wg<2>(BatchDev, int);
 extern template __global__ void k_ldp_wg<4>(BatchDev, int);
@@ -156,6 +163,13 @@ struct DAQPBatch {
     double one_fval = 0, one_soft = 0;
     int one_flag = 0, one_iter = 0;
     bool one_valid = false;   // one_* belong to the workspace's current LDP (cleared by setup / update / a failed solve)
+    // default arithmetic: INFEASIBLE verdicts of a solve straight after a setup are re-derived in the reference's arithmetic (recheck.hip.h)
+    bool fresh = false;        // the state is that of the last daqp_batch_setup (own H / A per problem, not an LP): nothing solved or updated since
+    int fresh_mask = 0;        // its init_mask
+    bool recheck = true;       // DAQP_AMD_NO_RECHECK=1 switches the second pass off
+    DAQPBatch *redo = nullptr; // companion batch in the exact mode (created with the first infeasible verdict, grown on demand)
+    int *redo_list = nullptr, *redo_count = nullptr, *pin_redo = nullptr;
+    int rechecked = 0;         // problems the last solve sent through the second pass
 };
 
 namespace {
@@ -233,6 +247,7 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         HIPCHK(hipGetLastError());
         return 0;
     }
+#ifdef DAQP_AMD_WITH_TINY
     if (b->tiny) {
         const bool exact = b->d.exact_setup != 0 || b->in_prox_loop;
         ldp_reg_kernel_t kt = b->tiny_tri == 3 ? (exact ? k_ldp_tiny<4, 3, false> : k_ldp_tiny<4, 3, true>)
@@ -246,6 +261,7 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         HIPCHK(hipGetLastError());
         return 0;
     }
+#endif
     if (b->NB > 0) {
         // problems that run the proximal outer loop keep the reference's arithmetic in both modes (their setup passes do as well)
         ldp_reg_kernel_t kr = pick_ldp_reg(b, b->d.exact_setup != 0 || b->in_prox_loop);
@@ -478,6 +494,85 @@ int resolve_setup(DAQPBatch *b, bool *had_flagged = nullptr)
     return 0;
 }
 
+// recheck.hip.h: after the solve launches of a default-mode solve that directly follows a setup.  One 4-byte read-back; nothing
+// else happens unless some problem was declared infeasible.
+int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fresh);
+void destroy_batch(DAQPBatch *b);
+int recheck_infeasible(DAQPBatch *b)
+{
+    BatchDev &d = b->d;
+    b->rechecked = 0;
+    if (!b->redo_list) {
+        if (dev_alloc(b, &b->redo_list, (size_t)d.N) || dev_alloc(b, &b->redo_count, 1)) return DAQP_EXIT_UNSUPPORTED;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&b->pin_redo), sizeof(int), hipHostMallocDefault));
+    }
+    HIPCHK(hipMemsetAsync(b->redo_count, 0, sizeof(int), b->stream));
+    hipLaunchKernelGGL(k_mark_infeasible, dim3((d.N + 127) / 128), dim3(128), 0, b->stream, d, b->redo_list, b->redo_count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(b->pin_redo, b->redo_count, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    const int count = *b->pin_redo;
+    if (count == 0) return 0;
+    if (d.N == 1) {
+        // one problem (daqp_quadprog): the same workspace again, in the exact mode; its inputs are still in the device slab
+        DAQPBatchProblem pp;
+        pp.N = 1; pp.n = d.n; pp.m = d.m; pp.ms = d.ms;
+        pp.H = const_cast<double *>(d.H); pp.f = const_cast<double *>(d.f); pp.A = const_cast<double *>(d.A);
+        pp.bupper = const_cast<double *>(d.bu); pp.blower = const_cast<double *>(d.bl); pp.sense = const_cast<int *>(d.sense_in);
+        pp.memory = DAQP_MEM_DEVICE;
+        d.exact_setup = 1;
+        int rc = batch_setup(b, &pp, b->fresh_mask, false);
+        if (!rc) rc = launch_ldp(b, 0);
+        if (!rc && b->reg_pending) rc = resolve_setup(b);      // (the count of singular Hessians of this pass: none, the first pass had none)
+        d.exact_setup = 0;
+        b->rechecked = 1;
+        return rc;
+    }
+    int cap = 2;
+    while (cap < count) cap *= 2;
+    if (cap > d.N) cap = d.N;
+    if (b->redo && b->redo->d.N < cap) { b->redo->stream = nullptr; destroy_batch(b->redo); b->redo = nullptr; }
+    if (!b->redo) {
+        DAQPBatch *rb = nullptr;
+        if (daqp_batch_create(&rb, cap < 2 ? 2 : cap, d.n, d.m, d.ms, b->ns_max, &d.st, b->device)) return DAQP_EXIT_UNSUPPORTED;
+        rb->recheck = false;
+        b->redo = rb;
+    }
+    DAQPBatch *rb = b->redo;
+    BatchDev &rd = rb->d;
+    rb->stream = b->stream;
+    rd.exact_setup = 1;
+    rd.st = d.st;
+    HIPCHK(hipMemcpyAsync(rb->st_dev, &rd.st, sizeof(DAQPSettings), hipMemcpyHostToDevice, rb->stream));
+    if (d.trace && (!rd.trace || rd.trace_cap != d.trace_cap)) { if (daqp_batch_enable_trace(rb, d.trace_cap)) return DAQP_EXIT_UNSUPPORTED; }
+    if (!d.trace) { rd.trace = nullptr; rd.trace_cap = 0; }
+    const size_t R = rd.N, n = d.n, m = d.m;
+    int rc = 0;
+    rc |= slot_reserve(rb, &rb->sH, &rb->nH, R * n * n); rc |= slot_reserve(rb, &rb->sf, &rb->nf, R * n);
+    rc |= slot_reserve(rb, &rb->sA, &rb->nA, R * d.mA * n); rc |= slot_reserve(rb, &rb->sbu, &rb->nbu, R * m);
+    rc |= slot_reserve(rb, &rb->sbl, &rb->nbl, R * m);
+    if (d.sense_in) rc |= slot_reserve(rb, &rb->ssense, &rb->nsense, R * m);
+    if (rc) return DAQP_EXIT_UNSUPPORTED;
+    hipLaunchKernelGGL(k_gather_problems, dim3(rd.N), dim3(256), 0, b->stream, d, (const int *)b->redo_list, (const int *)b->redo_count,
+                       rb->sH, rb->sf, rb->sA, rb->sbu, rb->sbl, d.sense_in ? rb->ssense : (int *)nullptr);
+    HIPCHK(hipGetLastError());
+    DAQPBatchProblem pp;
+    pp.N = rd.N; pp.n = d.n; pp.m = d.m; pp.ms = d.ms;
+    pp.H = rb->sH; pp.f = rb->sf; pp.A = rb->sA; pp.bupper = rb->sbu; pp.blower = rb->sbl; pp.sense = d.sense_in ? rb->ssense : nullptr;
+    pp.memory = DAQP_MEM_DEVICE;
+    rc = daqp_batch_setup(rb, &pp, b->fresh_mask);
+    if (rc) return rc;
+    DAQPBatchResult rr;
+    memset(&rr, 0, sizeof(rr));
+    rr.memory = DAQP_MEM_DEVICE;
+    rc = daqp_batch_solve(rb, &rr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scatter_problems, dim3(count), dim3(256), 0, b->stream, d, rd, (const int *)b->redo_list, (const int *)b->redo_count);
+    HIPCHK(hipGetLastError());
+    b->rechecked = count;
+    return 0;
+}
+
 int check_problem(const DAQPBatch *b, const DAQPBatchProblem *p)
 {
     if (!b || !p) { set_err("null batch or problem"); return DAQP_EXIT_UNSUPPORTED; }
@@ -502,7 +597,7 @@ bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && 
 std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
-                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_TINY", "DAQP_AMD_TINY_GRID", "DAQP_AMD_NO_TINY_SETUP"};
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_TINY", "DAQP_AMD_TINY_GRID", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -511,6 +606,8 @@ void destroy_batch(DAQPBatch *b)
 {
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
+    if (b->redo) { b->redo->stream = nullptr; destroy_batch(b->redo); b->redo = nullptr; }
+    if (b->pin_redo) (void)hipHostFree(b->pin_redo);
     for (void *p : b->owned) (void)hipFree(p);
     if (b->pin_in) (void)hipHostFree(b->pin_in);
     if (b->pin_out) (void)hipHostFree(b->pin_out);
@@ -527,10 +624,18 @@ extern "C" {
 
 const char *daqp_amd_last_error(void) { return g_err; }
 #ifdef DAQP_AMD_FEW_VARIANTS
-const char *daqp_amd_version(void) { return "daqp_amd 0.3 (gfx950, fp64: one wavefront per QP, one workgroup per QP beyond 64 working-set rows, up to 512 rows) [dev build: few template instantiations]"; }
+const char *daqp_amd_version(void) { return "daqp_amd 0.4 (gfx950, fp64: one wavefront per QP, one workgroup per QP beyond 64 working-set rows, up to 512 rows) [dev build: few template instantiations]"; }
 #else
-const char *daqp_amd_version(void) { return "daqp_amd 0.3 (gfx950, fp64: one wavefront per QP, one workgroup per QP beyond 64 working-set rows, up to 512 rows)"; }
+const char *daqp_amd_version(void) { return "daqp_amd 0.4 (gfx950, fp64: one wavefront per QP, one workgroup per QP beyond 64 working-set rows, up to 512 rows)"; }
 #endif
+int daqp_amd_has_tiny(void)
+{
+#ifdef DAQP_AMD_WITH_TINY
+    return 1;
+#else
+    return 0;
+#endif
+}
 int daqp_amd_device_count(void)
 {
     int c = 0;
@@ -584,6 +689,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     DAQPBatch *b = new DAQPBatch();
     b->device = device;
     b->env_key = env_key; b->ns_max = ns_max;
+    { const char *nr = getenv("DAQP_AMD_NO_RECHECK"); b->recheck = !(nr && atoi(nr) != 0); }
     if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); delete b; return DAQP_EXIT_UNSUPPORTED; }
     BatchDev &d = b->d;
     d.N = N; d.n = n; d.m = m; d.ms = ms; d.cap = cap; d.mA = m - ms;
@@ -600,7 +706,11 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     if (getenv("DAQP_AMD_FORCE_SPILL") || cap > 256) b->spill = true;
     // opt-in (DAQP_AMD_TINY=1): on config C3 the 16-problems-per-wave kernel needs 2.16 ms per 125 000 solves against 1.87 ms of
     // the one-wave-per-problem register kernel (DESIGN.md section 4.6 has the measurements and why)
+#ifdef DAQP_AMD_WITH_TINY
     { const char *te = getenv("DAQP_AMD_TINY"); b->tiny = te && atoi(te) != 0 && !b->spill && tiny_shape_ok(n, m, cap) && !getenv("DAQP_AMD_STREAM_M"); }
+#else
+    b->tiny = false;   // (DAQP_AMD_TINY=1 needs a library built with -DDAQP_AMD_WITH_TINY: daqp_amd_has_tiny())
+#endif
     b->tiny_tri = (b->tiny && ms >= 12) ? 3 : 0;
     if (!b->tiny && !b->spill && cap <= 64 && !getenv("DAQP_AMD_STREAM_M"))
         for (const RegShape &rs : kRegShapes)
@@ -714,7 +824,11 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         if (const char *ge = getenv("DAQP_AMD_WG_GRID")) { const long long v = atoll(ge); if (v >= 1) g = v; }   // tuning: problems in flight
         b->wg_grid = (int)(g < N ? g : N);
         rc |= dev_alloc(b, &d.wg_counter, 1);
-        rc |= dev_alloc(b, &d.wg_rowc, (size_t)b->wg_grid * cap * d.ldr);
+        {   // row-major active rows per workgroup in flight, whole 32-column chunks per row; the pad columns are zero and stay zero
+            const size_t cnt = (size_t)b->wg_grid * cap * wg_row_stride(n);
+            rc |= dev_alloc(b, &d.wg_rowc, cnt);
+            if (!rc && hipMemset(d.wg_rowc, 0, cnt * sizeof(double)) != hipSuccess) rc = 1;
+        }
         rc |= dev_alloc(b, &d.wg_rowcT, (size_t)b->wg_grid * n * d.wg_capT);
         rc |= dev_alloc(b, &d.fallback, Nn);
         if (!rc && hipMemset(d.fallback, 0, Nn * sizeof(int)) != hipSuccess) rc = 1;
@@ -745,7 +859,7 @@ void daqp_batch_free(DAQPBatch *b)
         if (b->d.trace || b->d.prof) { destroy_batch(b); return; }     // (debug buffers were attached: not worth keeping, and not kept)
         b->one_lam.clear(); b->one_valid = false;
         b->d.shared = 0; b->d.prox_pass = 0;
-        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->is_setup = false; b->reg_pending = false;
+        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->is_setup = false; b->reg_pending = false; b->fresh = false; b->rechecked = 0;
         b->timed_setup = b->timed_solve = false; b->n_prox_qps = 0; b->prox_outer = 0;
         b->one_fval = b->one_soft = 0; b->one_flag = b->one_iter = 0;
         DAQPBatch *evict = nullptr;
@@ -797,7 +911,8 @@ void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings)
     if (settings) b->d.st = *settings; else default_settings(&b->d.st);
     (void)hipMemcpyAsync(b->st_dev, &b->d.st, sizeof(DAQPSettings), hipMemcpyHostToDevice, b->stream);
 }
-unsigned long long daqp_batch_device_bytes(const DAQPBatch *b) { return b ? b->bytes : 0; }
+unsigned long long daqp_batch_device_bytes(const DAQPBatch *b) { return b ? b->bytes + (b->redo ? b->redo->bytes : 0) : 0; }
+int daqp_batch_rechecked(const DAQPBatch *b) { return b ? b->rechecked : 0; }
 
 // debugging aid used by the parity tests: per-problem add/remove event trace (cap ints each;
 // the last slot receives the event count).  Pass cap 0 to switch it off.
@@ -868,10 +983,11 @@ int daqp_batch_read_ldp(DAQPBatch *b, int q, double *M, double *R, double *v, do
     return 0;
 }
 
-static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fresh);
 // setup_daqp_main on fresh workspaces (api.c:93-151): the iterate of the proximal loop starts at the origin again (api.c:318)
 int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask) { return batch_setup(b, p, init_mask, true); }
-static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fresh)
+} // extern "C"
+namespace {
+int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fresh)
 {
     int rc = check_problem(b, p);
     if (rc) return rc;
@@ -956,12 +1072,16 @@ static int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, b
     rc = lp ? regularise(b, d, mask, true) : count_flagged_async(b, mask);
     if (rc) return rc;
     // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
-    if (p->sense != nullptr || true) { rc = launch_ldp(b, 1); if (rc) return rc; }
+    rc = launch_ldp(b, 1);
+    if (rc) return rc;
     HIPCHK(hipEventRecord(b->ev[1], b->stream));
     b->timed_setup = true;
     b->is_setup = true;
+    b->fresh = !lp; b->fresh_mask = init_mask;
     return 0;
 }
+} // namespace
+extern "C" {
 
 // N problems that share H and A (condensed MPC: one plant, many states): p->H is ONE n x n matrix, p->A ONE (m-ms) x n
 // matrix; f, bupper, blower (and sense, if given) are per problem as usual.  Semantics: the reference's MPC usage -- one
@@ -992,6 +1112,7 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &b->nsense, &d.sense_in);
     if (rc) return DAQP_EXIT_UNSUPPORTED;
     b->was_shared = true;
+    b->fresh = false;
     if (!b->wide_u) {
         if (dev_alloc(b, &b->wide_u, d.m) || dev_alloc(b, &b->wide_l, d.m) || dev_alloc(b, &b->structural, d.m) || dev_alloc(b, &b->shared_flag, 4))
             return DAQP_EXIT_UNSUPPORTED;
@@ -1054,6 +1175,7 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
     if (!b->is_setup) { set_err("daqp_batch_update before daqp_batch_setup"); return DAQP_EXIT_UNSUPPORTED; }
     HIPCHK(hipSetDevice(b->device));
     if (resolve_setup(b)) return DAQP_EXIT_UNSUPPORTED;
+    b->fresh = false;
     const int full = DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
     if ((mask & full) == full) {
         DAQPBatchProblem pp = *p;   // unchanged arrays may be omitted: reuse what the batch already has
@@ -1150,6 +1272,10 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
         }
     } else rc = b->n_prox_qps > 0 ? solve_with_prox(b, mode) : launch_ldp(b, mode);
     if (rc) return rc;
+    // default arithmetic, first solve after a setup: INFEASIBLE verdicts are re-derived in the reference's arithmetic (recheck.hip.h)
+    if (b->fresh && b->recheck && d.exact_setup == 0 && !b->was_shared) { rc = recheck_infeasible(b); if (rc) return rc; }
+    else b->rechecked = 0;
+    b->fresh = false;
     HIPCHK(hipEventRecord(b->ev[3], b->stream));
     b->timed_solve = true;
     if (!dev && d.N == 1 && b->pin_out != nullptr) {   // one problem: the result slab in one copy

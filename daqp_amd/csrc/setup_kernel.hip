@@ -3,6 +3,7 @@
 // re-run of flagged problems (PROX: always the reference's arithmetic)
 #include <hip/hip_runtime.h>
 #include "setup_fast.hip.h"
+#include "tiny_setup.hip.h"
 
 namespace daqp_amd {
 #define DAQP_SETUP_SIZE(NMAX) \
@@ -14,4 +15,6 @@ DAQP_SETUP_SIZE(32)
 DAQP_SETUP_SIZE(56)
 DAQP_SETUP_SIZE(64)
 #undef DAQP_SETUP_SIZE
+// tiny shapes (n <= 12, m <= 48): sixteen problems per wavefront (tiny_setup.hip.h), the default setup for them
+template __global__ void k_setup_tiny<4>(BatchDev, int);
 }

@@ -19,10 +19,10 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = wg_wave();   // (wave-uniform by construction: say so, or the master's whole body sits in a "divergent" branch)
     const int n = b.n, m = b.m, cap = b.cap, W = (int)(blockDim.x >> 6);
     WgCtx c;
-    c.n = n; c.m = m; c.ms = b.ms; c.cap = cap; c.capL = b.wg_capL; c.npair = b.npair; c.nblk = b.nblk; c.ldr = b.ldr; c.capT = b.wg_capT;
+    c.n = n; c.m = m; c.ms = b.ms; c.cap = cap; c.capL = b.wg_capL; c.npair = b.npair; c.nblk = b.nblk; c.ldr = wg_row_stride(n); c.capT = b.wg_capT;
     c.W = W; c.exact = b.exact_setup;
     c.oL = wg_lds_L(C, m); c.lmax = wg_round_up(b.wg_capL * (b.wg_capL + 1) / 2, 2) - 1;
-    c.rowc = b.wg_rowc + (size_t)blockIdx.x * cap * b.ldr;
+    c.rowc = b.wg_rowc + (size_t)blockIdx.x * cap * wg_row_stride(n);
     c.rowcT = b.wg_rowcT + (size_t)blockIdx.x * n * b.wg_capT;
     const int T = (int)blockDim.x;
 
@@ -90,18 +90,13 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
         }
         for (int e = tid; e < wg_round_up(n, 2) + 2; e += T) SD(c, u)[e] = 0;
         __syncthreads();
-        for (int i = wv; i < na0; i += W) {         // rebuild the active-row scratch (both orientations), a row per wave and trip
+        for (int i = wv; i < na0; i += W) {         // rebuild the active-row scratch, a row per wave and trip
             const int id = SI(c, ws)[i];
             if (lane == 0) SI(c, slot_id)[i] = id;
             const double2 *src = reinterpret_cast<const double2 *>(c.Mblk) + ((size_t)(id >> 6) * c.npair) * 64 + (id & 63);
             for (int t = lane; t < c.npair; t += 64) {
                 const double2 v = src[(size_t)t * 64];
-                const bool two = 2 * t + 1 < n;
-                double *rw = c.rowc + (size_t)i * c.ldr + 2 * t;
-                rw[0] = v.x;
-                if (two) rw[1] = v.y;
-                c.rowcT[(size_t)(2 * t) * c.capT + i] = v.x;
-                if (two) c.rowcT[(size_t)(2 * t + 1) * c.capT + i] = v.y;
+                wg_store_row_pair(c, i, t, v, 2 * t + 1 < n);
             }
         }
         __syncthreads();

@@ -33,7 +33,7 @@ struct WgL {
     static constexpr int CAP = 64 * C;
     // doubles
     static constexpr int D = 0, xl = CAP, zl = 2 * CAP, lamA = 3 * CAP, lamB = 4 * CAP, pend_lam = 5 * CAP, gram = 6 * CAP, rhs = 7 * CAP, u = 8 * CAP,
-                         mnew = u + 258, red = mnew + 258, cand = red + 64 * kWgMaxWaves, prof = cand + 8 * kWgMaxWaves, dend = prof + 20;
+                         mnew = u + 258, red = mnew + 258, cand = red + 128 * kWgMaxWaves, prof = cand + 8 * kWgMaxWaves, dend = prof + 20;
     // ints, counted from double offset dend
     static constexpr int ws = 0, slot = CAP, slot_id = 2 * CAP, freestk = 3 * CAP, pend_id = 4 * CAP, cmd = 5 * CAP, sense = 5 * CAP + 16;
 };
@@ -104,7 +104,20 @@ __device__ __forceinline__ void wtrace(WgWave<C> &w, int ev)
 // the parallel phases: executed by EVERY wave of the workgroup with the same arguments (barriers inside are workgroup-wide)
 // ---------------------------------------------------------------------------------------------------------------------
 
-// row `id` of the LDP constraint matrix -> LDS (mnew) and both orientations of the scratch at `slot`
+// one column pair of an active row into the scratch: row-major [slot][ldr] (ldr: a multiple of 32 doubles, 16-byte stores, the pad
+// columns n .. ldr-1 are zero from the allocation on and stay zero); the transposed copy [n][capT] is kept in the exact mode only --
+// its Gram column follows the reference's dot_row per slot (lane <-> slot); the default mode reads the row-major copy alone
+__device__ __forceinline__ void wg_store_row_pair(const WgCtx &c, int slot, int t, double2 v, bool two)
+{
+    if (!two) v.y = 0.0;
+    *reinterpret_cast<double2 *>(c.rowc + (size_t)slot * c.ldr + 2 * t) = v;
+    if (c.exact) {
+        c.rowcT[(size_t)(2 * t) * c.capT + slot] = v.x;
+        if (two) c.rowcT[(size_t)(2 * t + 1) * c.capT + slot] = v.y;
+    }
+}
+
+// row `id` of the LDP constraint matrix -> LDS (mnew) and the scratch at `slot`
 template <int C>
 __device__ __forceinline__ void wg_fetch_row(const WgCtx &c, int id, int slot, bool to_lds)
 {
@@ -114,12 +127,9 @@ __device__ __forceinline__ void wg_fetch_row(const WgCtx &c, int id, int slot, b
         const double2 v = src[(size_t)t * 64];
         const bool two = 2 * t + 1 < c.n;
         if (to_lds) { SD(c, mnew)[2 * t] = v.x; SD(c, mnew)[2 * t + 1] = two ? v.y : 0.0; }
-        double *rw = c.rowc + (size_t)slot * c.ldr + 2 * t;
-        rw[0] = v.x;
-        if (two) rw[1] = v.y;
-        c.rowcT[(size_t)(2 * t) * c.capT + slot] = v.x;
-        if (two) c.rowcT[(size_t)(2 * t + 1) * c.capT + slot] = v.y;
+        wg_store_row_pair(c, slot, t, v, two);
     }
+    if (to_lds && t >= c.npair && 2 * t < 258) { SD(c, mnew)[2 * t] = 0.0; if (2 * t + 1 < 258) SD(c, mnew)[2 * t + 1] = 0.0; }   // the Gram pass reads whole 32-column chunks
 }
 
 // u = -sum_i lam*_i row(ws[i])  (auxiliary.c:46-88): lane <-> column, rows in working-set order.  Exact mode: one sweep per
@@ -129,41 +139,66 @@ template <int C>
 __device__ __forceinline__ void wg_primal(const WgCtx &c, int na, const double *lams)
 {
     const int wv = wg_wave(), lane = wg_lane();
+    if (!c.exact) {
+        // default mode: lane <-> column PAIR (16-byte loads: twice the bytes in flight per lane -- these passes run at
+        // bytes in flight / latency, and the latency is set by the whole chip streaming at once), the working set cut into
+        // W / (column blocks) segments, partial sums added in segment order
+        const int hp = c.ldr >> 1;                      // pairs per row, pad included (pad columns are zero)
+        const int CB = (c.npair + 63) >> 6;
+        int segs = c.W / CB;
+        if (segs < 1) segs = 1;
+        const int cb = wv % CB, seg = wv / CB;
+        const int per = (na + segs - 1) / segs;
+        const int i0 = seg * per, i1 = (i0 + per < na) ? i0 + per : na;
+        const int pj = cb * 64 + lane;
+        const int pp = pj < hp ? pj : 0;
+        double ax = 0, ay = 0;
+        if (seg < segs) {
+            constexpr int PB = 24;     // rows in flight per lane
+            for (int i = i0; i < i1; i += PB) {
+                double2 rv[PB];
+                double li[PB];
+#pragma unroll
+                for (int q = 0; q < PB; ++q) {
+                    const int ii = (i + q < i1) ? i + q : i1 - 1;
+                    rv[q] = reinterpret_cast<const double2 *>(c.rowc + (size_t)SI(c, slot)[ii] * c.ldr)[pp];
+                    li[q] = (i + q < i1) ? lams[ii] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < PB; ++q) { ax = __builtin_fma(-rv[q].x, li[q], ax); ay = __builtin_fma(-rv[q].y, li[q], ay); }
+            }
+        }
+        double2 *red2 = reinterpret_cast<double2 *>(SD(c, red));
+        if (seg < segs) { double2 a; a.x = ax; a.y = ay; red2[seg * 64 * CB + cb * 64 + lane] = a; }    // segs * CB <= W waves of 64 lanes, 16 bytes each
+        __syncthreads();
+        const int t = wg_tid();
+        if (t < c.npair) {
+            double2 sacc = red2[t];
+            for (int g = 1; g < segs; ++g) { const double2 o = red2[g * 64 * CB + t]; sacc.x += o.x; sacc.y += o.y; }
+            SD(c, u)[2 * t] = sacc.x;
+            if (2 * t + 1 < c.n) SD(c, u)[2 * t + 1] = sacc.y;
+        }
+        return;
+    }
     const int CB = (c.n + 63) >> 6;
-    int segs = c.exact ? 1 : c.W / CB;
-    if (segs < 1) segs = 1;
-    if (segs > 4) segs = 4;
-    const int cb = wv % CB, seg = wv / CB;
-    const int per = (na + segs - 1) / segs;
-    const int i0 = seg * per, i1 = (i0 + per < na) ? i0 + per : na;
+    const int cb = wv % CB;
     const int j = cb * 64 + lane;
     const int jj = j < c.n ? j : 0;
     double acc = 0;
-    if (seg < segs) {
-        constexpr int PB = 24;     // rows in flight per lane: the scratch rows come from L2 / HBM, a batch costs one round trip
-        for (int i = i0; i < i1; i += PB) {
+    if (wv < CB) {     // exact mode: one sweep per column block, rows in working-set order (auxiliary.c:46-88)
+        constexpr int PB = 24;
+        for (int i = 0; i < na; i += PB) {
             double rv[PB], li[PB];
 #pragma unroll
             for (int q = 0; q < PB; ++q) {
-                const int ii = (i + q < i1) ? i + q : i1 - 1;
+                const int ii = (i + q < na) ? i + q : na - 1;
                 rv[q] = c.rowc[(size_t)SI(c, slot)[ii] * c.ldr + jj];
-                li[q] = (i + q < i1) ? lams[ii] : 0.0;
+                li[q] = (i + q < na) ? lams[ii] : 0.0;
             }
 #pragma unroll
-            for (int q = 0; q < PB; ++q) if (i + q < i1) acc -= rv[q] * li[q];
+            for (int q = 0; q < PB; ++q) if (i + q < na) acc -= rv[q] * li[q];
         }
-    }
-    if (segs == 1) {
-        if (wv < CB && j < c.n) SD(c, u)[j] = acc;
-    } else {
-        if (seg < segs) SD(c, red)[seg * 64 * CB + cb * 64 + lane] = acc;    // segs * CB <= W waves of 64 lanes
-        __syncthreads();
-        const int t = wg_tid();
-        if (t < c.n) {
-            double s = SD(c, red)[t];
-            for (int g = 1; g < segs; ++g) s += SD(c, red)[g * 64 * CB + t];
-            SD(c, u)[t] = s;
-        }
+        if (j < c.n) SD(c, u)[j] = acc;
     }
 }
 
@@ -255,43 +290,47 @@ __device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol)
 {
     const int wv = wg_wave(), lane = wg_lane(), n = c.n;
     float *u32 = reinterpret_cast<float *>(SD(c, red));     // the reduction area is idle during a scan
+    constexpr int DEPTH = 32;   // 16-byte loads in flight per lane
+    const int blk0 = (wv + c.W - 1) % c.W;                  // (wave 0, the master, takes its blocks last)
+    float4 mm[DEPTH];
+    // the image does not depend on u: the first batch of this wave's first block goes out BEFORE u is converted and published --
+    // its trip to memory overlaps the conversion and the barrier instead of following them
+    auto load_batch = [&](const float4 *src, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q) { const int tt = (t + q < c.nquad) ? t + q : c.nquad - 1; mm[q] = src[(size_t)tt * 64]; }
+    };
+    if (blk0 < c.nblk) load_batch(reinterpret_cast<const float4 *>(c.M32) + ((size_t)blk0 * c.nquad) * 64 + lane, 0);
     for (int j = wg_tid(); j < 4 * c.nquad; j += 64 * c.W) u32[j] = (j < n) ? (float)SD(c, u)[j] : 0.0f;
     __syncthreads();
     const double ep = -primal_tol;
     double s1 = DAQP_INF, s2 = DAQP_INF, minq = DAQP_INF, q1 = DAQP_INF, gap1 = 0.0;
     int i1 = kBig, up1 = 0, bad = 0;
     const float4 *u4 = reinterpret_cast<const float4 *>(u32);
-    constexpr int DEPTH = 32;   // 16-byte loads in flight per lane
-    for (int blk = (wv + c.W - 1) % c.W; blk < c.nblk; blk += c.W) {
+    for (int blk = blk0; blk < c.nblk; blk += c.W) {
         const int r = blk * 64 + lane;
         const bool own = r < c.m;
         const int rr = own ? r : 0;
         const float4 *src = reinterpret_cast<const float4 *>(c.M32) + ((size_t)blk * c.nquad) * 64 + lane;
         const double du = c.dupper[rr], dl = c.dlower[rr], sc = c.scaling[rr];
         float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int t = 0;
-        for (; t + DEPTH <= c.nquad; t += DEPTH) {
-            float4 mm[DEPTH];
+        for (int t = 0; t < c.nquad; t += DEPTH) {
+            if (blk != blk0 || t != 0) load_batch(src, t);
+            if (t + DEPTH <= c.nquad) {
 #pragma unroll
-            for (int q = 0; q < DEPTH; ++q) mm[q] = src[(size_t)(t + q) * 64];
+                for (int q = 0; q < DEPTH; ++q) {
+                    const float4 uk = u4[t + q];
+                    a0 = __builtin_fmaf(mm[q].x, uk.x, a0); a1 = __builtin_fmaf(mm[q].y, uk.y, a1);
+                    a2 = __builtin_fmaf(mm[q].z, uk.z, a2); a3 = __builtin_fmaf(mm[q].w, uk.w, a3);
+                }
+            } else {
 #pragma unroll
-            for (int q = 0; q < DEPTH; ++q) {
-                const float4 uk = u4[t + q];
-                a0 = __builtin_fmaf(mm[q].x, uk.x, a0); a1 = __builtin_fmaf(mm[q].y, uk.y, a1);
-                a2 = __builtin_fmaf(mm[q].z, uk.z, a2); a3 = __builtin_fmaf(mm[q].w, uk.w, a3);
-            }
-        }
-        if (t < c.nquad) {
-            float4 mm[DEPTH];
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) { const int tt = (t + q < c.nquad) ? t + q : c.nquad - 1; mm[q] = src[(size_t)tt * 64]; }
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) {
-                const bool in = t + q < c.nquad;
-                const float4 uk = u4[in ? t + q : 0];
-                const float z = in ? 1.0f : 0.0f;       // (a repeated last load counts zero times)
-                a0 = __builtin_fmaf(mm[q].x * z, uk.x, a0); a1 = __builtin_fmaf(mm[q].y * z, uk.y, a1);
-                a2 = __builtin_fmaf(mm[q].z * z, uk.z, a2); a3 = __builtin_fmaf(mm[q].w * z, uk.w, a3);
+                for (int q = 0; q < DEPTH; ++q) {
+                    const bool in = t + q < c.nquad;
+                    const float4 uk = u4[in ? t + q : 0];
+                    const float z = in ? 1.0f : 0.0f;       // (a repeated last load counts zero times)
+                    a0 = __builtin_fmaf(mm[q].x * z, uk.x, a0); a1 = __builtin_fmaf(mm[q].y * z, uk.y, a1);
+                    a2 = __builtin_fmaf(mm[q].z * z, uk.z, a2); a3 = __builtin_fmaf(mm[q].w * z, uk.w, a3);
+                }
             }
         }
         const double mu = (double)((a0 + a1) + (a2 + a3));
@@ -366,29 +405,57 @@ __device__ __forceinline__ void wg_gram(const WgCtx &c, int id, int hi)
         }
         return;
     }
-    const int per = ((n + segs - 1) / segs + 7) & ~7;
-    const int ja = seg * per, jb_ = (ja + per < n) ? ja + per : n;
-    double acc = 0;
-    if (seg < segs) {
-        constexpr int GB = 24;     // columns in flight per lane
-        for (int j = ja; j < jb_; j += GB) {
-            double rv[GB], mv[GB];
+}
+
+// The append's row fetch + Gram column in the default arithmetic, as ONE phase: FOUR slots per wave-load from the row-major scratch --
+// 16 lanes x 16 bytes = 256 contiguous bytes of one row each --, a row in ldr / 32 such loads, three groups of four slots in flight
+// per lane; every wave works, every lane of it (the lane <-> slot pass over the transposed copy kept 6 of 8 waves and 2/3 of their
+// lanes busy with 8-byte loads: 29 k cycles per append for ~200 KB).  The sixteen partial sums of a slot meet in four DPP steps inside
+// their row of lanes.  The rows already in the scratch do not depend on the new one: the first batch of their loads is issued
+// BEFORE the new row is fetched (one trip to memory for both instead of two in a row); the new row's own entry |m_new|^2 is
+// formed from its LDS copy.
+template <int C>
+__device__ __forceinline__ void wg_fetch_gram_fast(const WgCtx &c, int id, int newslot, int hi)
+{
+    const int wv = wg_wave(), lane = wg_lane();
+    const int l16 = lane & 15, sub = lane >> 4;
+    const int nch = c.ldr >> 5;                           // 32-column chunks per row (<= 8: n <= 255)
+    const int NG = (hi + 3) >> 2;
+    constexpr int GP = 3;
+    double2 rv[GP][8];
+    auto load_groups = [&](int g0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < GB; ++q) { const int jj = (j + q < jb_) ? j + q : jb_ - 1; rv[q] = col[(size_t)jj * c.capT]; mv[q] = SD(c, mnew)[jj]; }
+        for (int k = 0; k < GP; ++k) {
+            const int g = g0 + k * c.W;
+            const int sl = 4 * (g < NG ? g : g0) + sub;          // (a group beyond the end re-reads the first: the value is discarded)
+            const double2 *row = reinterpret_cast<const double2 *>(c.rowc + (size_t)(sl < c.cap ? sl : 0) * c.ldr) + l16;
 #pragma unroll
-            for (int q = 0; q < GB; ++q) if (j + q < jb_) acc += rv[q] * mv[q];
+            for (int i = 0; i < 8; ++i) if (i < nch) rv[k][i] = row[16 * i];
         }
-    }
-    if (segs == 1) {
-        if (wv < RG && s < hi) SD(c, gram)[s] = acc;
-    } else {
-        if (seg < segs) SD(c, red)[seg * 64 * RG + rg * 64 + lane] = acc;     // segs * RG <= W
-        __syncthreads();
-        const int t = wg_tid();
-        if (t < hi) {
-            double g = SD(c, red)[t];
-            for (int q = 1; q < segs; ++q) g += SD(c, red)[q * 64 * RG + t];
-            SD(c, gram)[t] = g;
+    };
+    if (wv < NG) load_groups(wv);
+    wg_fetch_row<C>(c, id, newslot, true);
+    __syncthreads();
+    double2 mv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mv[i] = reinterpret_cast<const double2 *>(SD(c, mnew))[(i < nch ? 16 * i : 0) + l16];
+    for (int g0 = wv; g0 < NG; g0 += GP * c.W) {
+        if (g0 != wv) load_groups(g0);
+#pragma unroll
+        for (int k = 0; k < GP; ++k) {
+            const int g = g0 + k * c.W, sl = 4 * g + sub;
+            const bool self = sl == newslot;                     // (its row in the scratch may not have landed when the load went out)
+            double a = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (i < nch) {
+                const double rx = self ? mv[i].x : rv[k][i].x, ry = self ? mv[i].y : rv[k][i].y;
+                a = __builtin_fma(rx, mv[i].x, a); a = __builtin_fma(ry, mv[i].y, a);
+            }
+            a += dpp_f64<0xB1>(a);
+            a += dpp_f64<0x4E>(a);
+            a += dpp_f64<0x141>(a);
+            a += dpp_f64<0x140>(a);
+            if (g < NG && l16 == 0 && sl < hi) SD(c, gram)[sl] = a;
         }
     }
 }
@@ -672,15 +739,15 @@ __device__ __forceinline__ void wg_do(const WgCtx &c, int code, double primal_to
     else if (code == WG_SCAN) wg_scan<C>(c, primal_tol);
     else if (code == WG_SCAN32) wg_scan32<C>(c, primal_tol);
     else if (code == WG_FETCH_GRAM) {
-        wg_fetch_row<C>(c, a0, a1, true);
-        __syncthreads();
-        wg_gram<C>(c, a0, hi);
+        if (c.exact) {
+            wg_fetch_row<C>(c, a0, a1, true);
+            __syncthreads();
+            wg_gram<C>(c, a0, hi);
+        } else wg_fetch_gram_fast<C>(c, a0, a1, hi);
     } else if (code == WG_COMPACT) wg_compact<C>(c, a0, na);
     else if (code == WG_WCSP) wg_wcsp<C>(c, a0, na, const_cast<double *>(lams));
-    else if (code == WG_WAPPEND) {
-        wg_fetch_row<C>(c, a0, a1, true);
-        __syncthreads();
-        wg_gram<C>(c, a0, hi);
+    else if (code == WG_WAPPEND) {          // (the inverse factor exists in the default arithmetic only)
+        wg_fetch_gram_fast<C>(c, a0, a1, hi);
         __syncthreads();
         wg_wappend<C>(c, na);
     } else if (code == WG_WDELETE) wg_wdelete<C>(c, a0, na, a1 != 0);

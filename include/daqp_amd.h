@@ -242,17 +242,46 @@ int daqp_batch_working_sets(DAQPBatch *b, int *n_active_host, int *ws_host);
 /* one-shot: create + setup(DAQP_UPDATE_unconstrained) + solve + free == N x daqp_quadprog */
 int daqp_quadprog_batch(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQPSettings *settings);
 
-/* The same, over several GPUs of this host (independent problems, no exchange step): problem k is solved on
- * devices[k mod n_devices] -- interleaved, so that the spread of iteration counts averages out -- by one host thread, one HIP
- * stream and one set of device-resident workspaces per shard; results land in the caller's arrays at their own indices.  Problems
- * and results must be host-resident (each shard stages its part).  devices == NULL: 0 .. n_devices-1; n_devices <= 0: every
- * visible device.  The same device may be listed more than once (its shards then share it).  setup_time / solve_time: the
- * slowest shard's. */
+/* ---- several GPUs of this host (independent problems, no exchange step) -------------------------------------------
+ * A DAQPMultiBatch is G device-resident shards -- each an ordinary DAQPBatch on its own device and HIP stream, driven by its own
+ * persistent host thread -- over which ONE batch of N problems is dealt: problem k lives on shard k mod G (interleaved, so that the
+ * spread of iteration counts averages out).  Factors, working sets and iterates stay on the devices between calls, so the
+ * reference's setup_daqp -> daqp_solve -> {daqp_update_ldp -> daqp_solve}* sequence runs over G devices from one C process.
+ * devices == NULL: 0 .. n_devices-1; n_devices <= 0: every visible device (a list, if passed, is then ignored).  A device may be
+ * listed more than once (its shards share it).  G = min(n_devices, N).
+ *   daqp_batch_setup_multi / update_multi / solve_multi take ONE host-resident batch in the caller's order (memory must be
+ *     DAQP_MEM_HOST): every shard gathers its problems through pinned buffers, chunk by chunk, two deep, into its own device slots;
+ *     results come back the same way, each to its own index.  update_multi: mask within DAQP_UPDATE_v|DAQP_UPDATE_d (f / bupper /
+ *     blower as given) or a full re-setup (every array).
+ *   daqp_batch_*_multi_shards take G descriptors, ps[g] / rs[g] = shard g's problems / results back to back (N = that shard's
+ *     size: daqp_batch_multi_shard), host-resident or resident ON THAT SHARD'S DEVICE (used in place); the shards run side by side.
+ *   daqp_batch_multi_shard hands out shard g's DAQPBatch (for the inspection calls above: setup flags, working sets, kernel times).
+ * Every call returns when all shards have finished it. */
+typedef struct DAQPMultiBatch DAQPMultiBatch;
+int daqp_batch_create_multi(DAQPMultiBatch **out, int N, int n, int m, int ms, int ns_max, const DAQPSettings *settings,
+                            const int *devices, int n_devices);
+void daqp_batch_free_multi(DAQPMultiBatch *mb);
+int daqp_batch_multi_shards(const DAQPMultiBatch *mb);                                           /* G */
+DAQPBatch *daqp_batch_multi_shard(DAQPMultiBatch *mb, int g, int *shard_N, int *device);        /* shard g; either out-pointer may be NULL */
+int daqp_batch_setup_multi(DAQPMultiBatch *mb, const DAQPBatchProblem *p, int init_mask);
+int daqp_batch_update_multi(DAQPMultiBatch *mb, int mask, const DAQPBatchProblem *p);
+int daqp_batch_solve_multi(DAQPMultiBatch *mb, DAQPBatchResult *r);
+int daqp_batch_setup_multi_shards(DAQPMultiBatch *mb, const DAQPBatchProblem *ps /* [G] */, int init_mask);
+int daqp_batch_update_multi_shards(DAQPMultiBatch *mb, int mask, const DAQPBatchProblem *ps /* [G] */);
+int daqp_batch_solve_multi_shards(DAQPMultiBatch *mb, DAQPBatchResult *rs /* [G] */);
+/* one-shot on top of it: create + setup(DAQP_UPDATE_unconstrained) + solve + free == N x daqp_quadprog over the listed devices;
+ * problems and results host-resident; setup_time / solve_time: the slowest shard's */
 int daqp_quadprog_batch_multi(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQPSettings *settings,
                               const int *devices, int n_devices);
 
 /* device-side timing of the last setup / solve launches (HIP events on the batch's stream), ms */
 int daqp_batch_kernel_ms(DAQPBatch *b, float *setup_ms, float *solve_ms);
+/* Default arithmetic only: problems that the FIRST solve after a daqp_batch_setup declares infeasible are set up and solved again in
+   the reference's own arithmetic, and that result (exit flag, iter, lam, stored iterate) is the one reported -- "infeasible" is decided
+   by comparing rounding noise with dual_tol (auxiliary.c:284-287) and only the reference's arithmetic reproduces the reference's noise.
+   This needs the inputs of that setup (device-resident arrays are used in place) to stay valid until the solve has run.
+   Returns how many problems of the last daqp_batch_solve took the second pass.  DAQP_AMD_NO_RECHECK=1 switches it off. */
+int daqp_batch_rechecked(const DAQPBatch *b);
 /* bytes of device memory held by the batch */
 unsigned long long daqp_batch_device_bytes(const DAQPBatch *b);
 
@@ -270,6 +299,9 @@ int daqp_batch_read_ldp(DAQPBatch *b, int q, c_float *M, c_float *R, c_float *v,
 const char *daqp_amd_last_error(void);
 int daqp_amd_device_count(void);
 const char *daqp_amd_version(void);
+/* 1 if this build carries the opt-in 16-problems-per-wavefront solve kernel of tiny shapes (-DDAQP_AMD_WITH_TINY, tools/tinybuild.sh;
+   selected at run time with DAQP_AMD_TINY=1); the default build does not: the kernel is slower than the default one */
+int daqp_amd_has_tiny(void);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,38 @@ def test_oracle_golden_warm_sequence(oracle):
         assert np.array_equal(x.view(np.uint64), g["x"][t].view(np.uint64))
 
 
+def _c4_fixture():
+    """tests/golden/golden_c4.npz: inputs (stored as float32: the problems were rounded to fp32-representable values before the
+    reference solved them) and the reference's outputs of 4 QPs of config C4 (tests/golden/make_golden_configs.py)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_c4.npz"), allow_pickle=False)
+    assert (int(g["n"]), int(g["m"]), int(g["ms"])) == (200, 600, 0)
+    qs = [{kk: g[f"{k}/{kk}"].astype(np.float64) for kk in ("H", "f", "A", "bupper", "blower")} for k in range(4)]
+    return g, qs
+
+
+def test_oracle_golden_c4(oracle):
+    g, qs = _c4_fixture()
+    for k, q in enumerate(qs):
+        x, lam, fval, flag, it = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None)
+        assert flag == int(g[f"{k}/exitflag"]) == 1 and it == int(g[f"{k}/iter"]) and fval == float(g[f"{k}/fval"])
+        assert np.array_equal(x.view(np.uint64), g[f"{k}/x"].view(np.uint64)) and np.array_equal(lam.view(np.uint64), g[f"{k}/lam"].view(np.uint64))
+
+
+def test_oracle_golden_warm_sequence_c2(oracle):
+    """config C5's shape: 10 warm steps on C2-sized QPs, the reference's own outputs at every step"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_warm_c2.npz"), allow_pickle=False)
+    n, m, ms, T = int(g["n"]), int(g["m"]), int(g["ms"]), int(g["T"])
+    for k in range(2):
+        om = oracle.model(n, m, ms)
+        assert om.setup(g[f"{k}/H"], g[f"{k}/fs"][0], g[f"{k}/A"], g[f"{k}/bupper"], g[f"{k}/blower"], None) == 1
+        for t in range(T + 1):
+            if t > 0:
+                assert om.update(O.UPDATE_v, f=g[f"{k}/fs"][t]) == 0
+            x, lam, fval, flag, it = om.solve()
+            assert flag == int(g[f"{k}/exitflag"][t]) and it == int(g[f"{k}/iter"][t]) and fval == float(g[f"{k}/fval"][t]), (k, t)
+            assert np.array_equal(x.view(np.uint64), g[f"{k}/x"][t].view(np.uint64)) and np.array_equal(lam.view(np.uint64), g[f"{k}/lam"][t].view(np.uint64))
+
+
 def test_oracle_golden_proximal(oracle):
     """singular / forcibly shifted Hessians and LPs through the proximal outer loop: fixtures from the REFERENCE (strict build)"""
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_prox.npz"), allow_pickle=False)
@@ -237,8 +269,7 @@ def test_kernel_resource_budgets():
         "k_ldp_reg<3, 25, true>": (0, 1), "k_ldp_reg<3, 25, false>": (0, 1), "k_ldp_reg<2, 32, true>": (0, 1),
         "k_ldp_reg<1, 6, true>": (0, 3), "k_ldp_reg<1, 6, false>": (0, 3), "k_ldp_reg<1, 8, true>": (0, 3), "k_ldp_reg<1, 8, false>": (0, 3), "k_ldp_reg<1, 16, true>": (0, 2), "k_ldp_reg<2, 16, true>": (16, 2),
         "k_ldp<1, false, 0, 0>": (0, 2), "k_ldp<2, false, 0, 0>": (0, 2), "k_ldp<4, true, 0, 0>": (128, 2),
-        "k_ldp_wg<2>": (256, 2), "k_ldp_wg<4>": (700, 2),
-        "k_ldp_tiny<4, 3, true>": (256, 1), "k_ldp_tiny<4, 0, true>": (512, 1),
+        "k_ldp_wg<2>": (400, 2), "k_ldp_wg<4>": (700, 2),
         "k_update": (0, 8),
     }
     for name, (scratch, occ) in budgets.items():

@@ -49,6 +49,7 @@ def test_bench_json_line(gpu_lib):
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert d["metric"].endswith("n=50 m=150") and d["config"]["workload"].startswith("C2: 4096 ")
     assert d["value"] > 0 and d["ms_per_step"] > 0 and "traffic" in d["roofline"]
+    assert d["checks"]["all_optimal"] and d["checks"]["rechecked_in_exact_arithmetic"] == 0      # the default-mode kernels' own verdicts
     check_roofline(d["roofline"], "C2")
     assert d["roofline"].get("stale") is True      # batch 4096: no committed counter pass at that size
     c = d["cpu_baseline"]
@@ -61,7 +62,7 @@ def test_bench_json_line(gpu_lib):
     for name, s in d["configs"].items():
         for k in ("metric", "value", "unit", "ms_per_step", "workload", "roofline", "cpu_baseline", "parity_vs_cpu", "checks"):
             assert k in s, (name, k)
-        assert s["workload"].startswith(name + ": ") and s["value"] > 0 and s["checks"]["all_optimal"]
+        assert s["workload"].startswith(name + ": ") and s["value"] > 0 and s["checks"]["all_optimal"] and s["checks"]["rechecked_in_exact_arithmetic"] == 0
         check_roofline(s["roofline"], name)
         assert s["cpu_baseline"]["kind"] == "port" or s["cpu_baseline"]["wall_s"] >= 1.0
     assert "n=12 m=48" in d["configs"]["C3"]["metric"] and d["configs"]["C3"]["parity_vs_cpu"]["identical_iter"] == 1.0

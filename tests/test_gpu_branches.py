@@ -55,6 +55,9 @@ def test_forced_branch(oracle, gpu_lib, monkeypatch, family, branch, exact):
     kw, marker_name, want_flag = FORCED[branch]
     marker = getattr(api, marker_name)
     monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
+    monkeypatch.setenv("DAQP_AMD_NO_RECHECK", "1")     # (no problem here is infeasible: the default-mode kernels are judged unassisted)
+    if "DAQP_AMD_TINY" in env and not gpu_lib.daqp_amd_has_tiny():
+        pytest.skip("library built without -DDAQP_AMD_WITH_TINY (tools/tinybuild.sh): the opt-in 16-per-wave solve kernel is not in the default build")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     q = O.generate_batch(N, n, m, ms, na, 4242 + n, start=100)

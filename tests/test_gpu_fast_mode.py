@@ -13,6 +13,10 @@ XTOL = 1e-9
 @pytest.fixture(autouse=True)
 def fast_mode(monkeypatch):
     monkeypatch.delenv("DAQP_AMD_EXACT", raising=False)
+    # every problem of this file has an optimum: the default-mode kernels are judged on their own, without the second pass in the
+    # reference's arithmetic that an INFEASIBLE verdict gets (csrc/recheck.hip.h) -- a kernel that wrongly reported -1 would
+    # otherwise come back corrected, and green
+    monkeypatch.setenv("DAQP_AMD_NO_RECHECK", "1")
 
 
 @pytest.mark.parametrize("cfg,N", [("C1", 256), ("C2", 2048), ("C3", 4096), ("C4", 48)])

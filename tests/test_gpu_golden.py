@@ -74,6 +74,69 @@ def test_golden_warm_sequence(gpu_lib, monkeypatch, exact):
             assert np.abs(x - g["x"][t]).max() < XTOL, t
 
 
+@pytest.mark.parametrize("exact", [True, False])
+def test_golden_c4(gpu_lib, monkeypatch, exact):
+    """config C4 (n=200, m=600: the workgroup kernel, the generic setup) against outputs written by the REFERENCE library: 4 QPs with 87
+    to 399 iterations, as one batch and one at a time (tests/golden/golden_c4.npz; inputs regenerated and checked by hash)"""
+    import daqp_amd
+    from test_cpu import _c4_fixture
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
+    g, qs = _c4_fixture()
+    b = {k: np.stack([q[k] for q in qs]) for k in ("H", "f", "A", "bupper", "blower")}
+    r = daqp_amd.solve_batch(b["H"], b["f"], b["A"], b["bupper"], b["blower"], None, ms=0)
+    one = daqp_amd.solve(qs[1]["H"], qs[1]["f"], qs[1]["A"], qs[1]["bupper"], qs[1]["blower"], None)
+    for k in range(4):
+        gx, gl = g[f"{k}/x"], g[f"{k}/lam"]
+        got = [(r["x"][k], r["lam"][k], r["fval"][k], r["exitflag"][k], r["iter"][k])]
+        if k == 1:
+            got.append((one[0], one[3]["lam"], one[1], one[2], one[3]["iterations"]))
+        for x, lam, fval, flag, it in got:
+            assert flag == int(g[f"{k}/exitflag"]) and it == int(g[f"{k}/iter"]), (k, flag, it, int(g[f"{k}/iter"]))
+            if exact:
+                assert bits_equal(x, gx) and bits_equal(lam, gl) and fval == float(g[f"{k}/fval"]), k
+            else:
+                assert np.array_equal(np.sign(lam), np.sign(gl)) and np.abs(x - gx).max() < XTOL, k
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_golden_warm_sequence_c2(gpu_lib, monkeypatch, exact):
+    """config C5's shape against the REFERENCE's own sequence: setup_daqp -> daqp_solve -> 10 x {daqp_update_ldp(UPDATE_v) -> daqp_solve}
+    on C2-sized QPs (tests/golden/golden_warm_c2.npz) -- through the single-problem workspace API and, both QPs together, through
+    BatchModel (the fused update + solve launch of the register kernel)"""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_warm_c2.npz"), allow_pickle=False)
+    n, m, ms, T = int(g["n"]), int(g["m"]), int(g["ms"]), int(g["T"])
+
+    def check(t, k, x, lam, fval, flag, it):
+        assert flag == int(g[f"{k}/exitflag"][t]) and it == int(g[f"{k}/iter"][t]), (k, t, it, int(g[f"{k}/iter"][t]))
+        if exact:
+            assert bits_equal(x, g[f"{k}/x"][t]) and bits_equal(lam, g[f"{k}/lam"][t]) and fval == float(g[f"{k}/fval"][t]), (k, t)
+        else:
+            assert np.array_equal(np.sign(lam), np.sign(g[f"{k}/lam"][t])) and np.abs(x - g[f"{k}/x"][t]).max() < XTOL, (k, t)
+
+    for k in range(2):
+        d = daqp_amd.Model()
+        flag, _ = d.setup(g[f"{k}/H"], g[f"{k}/fs"][0], g[f"{k}/A"], g[f"{k}/bupper"], g[f"{k}/blower"], None)
+        assert flag == 1
+        for t in range(T + 1):
+            if t > 0:
+                assert d.update(f=g[f"{k}/fs"][t]) == 0
+            x, fval, ef, info = d.solve()
+            check(t, k, x, info["lam"], fval, ef, info["iterations"])
+    st = lambda key: np.stack([g[f"{k}/{key}"] for k in range(2)])
+    bm = daqp_amd.BatchModel(2, n, m, ms)
+    fs = st("fs")                                          # (2, T+1, n)
+    bm.setup(st("H"), np.ascontiguousarray(fs[:, 0]), st("A"), st("bupper"), st("blower"), None, init_mask=0)
+    for t in range(T + 1):
+        if t > 0:
+            bm.update(f=np.ascontiguousarray(fs[:, t]))
+        r = bm.solve()
+        for k in range(2):
+            check(t, k, r["x"][k], r["lam"][k], r["fval"][k], r["exitflag"][k], r["iter"][k])
+    bm.close()
+
+
 def _problem_struct(q, sense):
     import ctypes as C
     from daqp_amd._lib import DAQPProblem, c_double_p, c_int_p
@@ -127,10 +190,12 @@ def _nasty(trial):
 def test_degenerate_cases_fast_mode(oracle, gpu_lib, monkeypatch):
     """the 400 near-degenerate problems of test_gpu_parity (duplicate rows at 1e-13..1e-2, dependent equalities, soft rows)
     in the DEFAULT arithmetic mode.  These problems sit on the solver's thresholds on purpose; the bar: exit flag, iteration
-    count, active set (index and side) identical and x within 1e-9 relative for every problem that has an optimum, and for
-    every infeasible one but those whose certificate comes one iteration apart (see the assertion below).  The count and every
-    differing trial (flags, iterations, fval of both) are written to gpurun_out/degenerate_fast_mode.json; with the decision
-    that flipped (tools/degenerate_report.py) they are committed as profiles/r03_degenerate_fast_mode.json."""
+    count, active set (index and side) identical and x within 1e-9 relative for EVERY problem -- 400 of 400.  Round 3 stood at 398:
+    two infeasible problems whose certificate came one iteration apart, because "infeasible" is decided by comparing rounding
+    noise of a singular direction with dual_tol (auxiliary.c:284-287; profiles/r03_degenerate_fast_mode.json).  Since round 4 an
+    INFEASIBLE verdict of the first solve after a setup is re-derived in the reference's arithmetic (csrc/recheck.hip.h), so those
+    problems report the reference's iteration count and multipliers bit for bit.  The count and every differing trial are written
+    to gpurun_out/degenerate_fast_mode.json (tools/degenerate_report.py explains a difference decision by decision)."""
     import json
     import daqp_amd
     monkeypatch.setenv("DAQP_AMD_EXACT", "0")
@@ -158,13 +223,7 @@ def test_degenerate_cases_fast_mode(oracle, gpu_lib, monkeypatch):
     with open(os.path.join(out, "degenerate_fast_mode.json"), "w") as fh:
         json.dump(dict(same=same, total=total, differing=differing), fh, indent=1)
     print(f"degenerate set, default arithmetic: {same}/{total} identical; differing trials: {[d['trial'] for d in differing]}")
-    # Every optimum must be found along the reference's path.  The only accepted difference (profiles/r03_degenerate_fast_mode.json,
-    # tools/degenerate_report.py): an INFEASIBLE problem whose certificate is reached one iteration apart, because a component of
-    # a singular direction that is 0 in exact arithmetic (rounding noise ~1e-9 behind a pivot of ~1e-7) is compared with
-    # dual_tol = 1e-12 (auxiliary.c:284-287) -- trials 113 and 183 of this family.
-    for d in differing:
-        assert d["flag"] == d["ref_flag"] == -1 and abs(d["iter"] - d["ref_iter"]) <= 1, d
-    assert len(differing) <= 2 and same >= total - 2, (same, total, differing)
+    assert not differing and same == total == 400, (same, total, differing)
 
 
 def _nasty_wide(trial):
@@ -181,8 +240,7 @@ def test_degenerate_cases_wider_register_shapes(oracle, gpu_lib, monkeypatch, ex
     """the degenerate family at n = 17..48: the register shapes <1,16>, <2,16>, <2,32>, <3,25>, whose default mode runs a
     removal's rank-one update in two passes with lane-parallel divisions (wave_ldp_reg.hip.h) -- singular factors (a zero
     last pivot), pivot_last and the singular direction included.  Exact mode: bit-identical; default mode: the bar of
-    test_degenerate_cases_fast_mode (every optimum along the reference's path; an infeasibility certificate may come one
-    iteration apart in a few problems)."""
+    test_degenerate_cases_fast_mode (every problem along the reference's path, infeasible ones included)."""
     import daqp_amd
     monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
     total, differing, flags = 0, [], set()
@@ -202,9 +260,61 @@ def test_degenerate_cases_wider_register_shapes(oracle, gpu_lib, monkeypatch, ex
             np.array_equal(np.sign(info["lam"]), np.sign(r[1])) and np.abs(x - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max())))
         if not same:
             differing.append((trial, int(flag), int(r[3]), int(info["iterations"]), int(r[4])))
-            assert flag == r[3] and flag < 0 and abs(info["iterations"] - r[4]) <= 1, differing[-1]
     assert 1 in flags and len(flags) >= 2, flags       # (this family at these sizes: optimal, soft-optimal, over-determined starts)
-    assert len(differing) <= max(2, total // 50), differing
+    assert not differing, differing
+
+
+def test_infeasible_verdicts_are_rechecked_in_a_batch(oracle, gpu_lib, monkeypatch):
+    """default arithmetic, batches: the problems a first solve declares infeasible take the second pass in the reference's arithmetic
+    (csrc/recheck.hip.h) -- through the one-shot entry and through BatchModel, in the register, generic and workgroup kernel families;
+    what comes back for them is bit-identical to the oracle (flag, iter, lam untouched / zero as the reference leaves it), the count is
+    reported, everything else in the batch is untouched by the pass; and with DAQP_AMD_NO_RECHECK=1 nothing is re-solved."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "0")
+    for (n, m, ms, na), env in (((10, 30, 3, 4), {}), ((24, 70, 0, 9), {}), ((24, 70, 4, 9), {"DAQP_AMD_STREAM_M": "1"}), ((70, 160, 5, 20), {})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        N = 37
+        q = O.generate_batch(N, n, m, ms, na, 777 + n)
+        bad = [1, 5, 6, 20, 36]
+        for j, k in enumerate(bad):      # infeasible in different ways: crossed pairs of general rows that only the iteration finds
+            r0 = ms + (3 * j) % (m - ms - 1)
+            q["A"][k, r0 + 1 - ms] = q["A"][k, r0 - ms]
+            q["bupper"][k, r0] = -1.0 - j; q["blower"][k, r0] = -1e30
+            q["blower"][k, r0 + 1] = 1.0 + j; q["bupper"][k, r0 + 1] = 1e30
+        ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+        assert (ref[3][bad] == -1).all() and (np.delete(ref[3], bad) == 1).all()
+        g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+        mdl = daqp_amd.BatchModel(N, n, m, ms)
+        mdl.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=64 + 128)
+        g2 = mdl.solve()
+        assert mdl.rechecked() == len(bad)
+        for got in (g, g2):
+            assert np.array_equal(got["exitflag"], ref[3]) and np.array_equal(got["iter"], ref[4])
+            ok = ref[3] > 0
+            assert np.array_equal(np.sign(got["lam"][ok]), np.sign(ref[1][ok])) and np.abs(got["x"] - ref[0])[ok].max() < XTOL
+        na_, ws = mdl.working_sets()                    # the stored iterate of a re-solved problem is the exact run's
+        g3 = mdl.solve()                                # a second solve (warm, nothing changed): no second pass, same verdicts
+        assert mdl.rechecked() == 0 and np.array_equal(g3["exitflag"], ref[3])
+        mdl.close()
+        monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+        xm = daqp_amd.BatchModel(N, n, m, ms)
+        monkeypatch.setenv("DAQP_AMD_EXACT", "0")
+        xm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=64 + 128)
+        gx = xm.solve()
+        nx, wx = xm.working_sets()
+        assert xm.rechecked() == 0 and np.array_equal(na_[bad], nx[bad]) and np.array_equal(ws[bad], wx[bad])
+        assert bits_equal(g2["lam"][bad], gx["lam"][bad]) and np.array_equal(gx["iter"], ref[4])
+        xm.close()
+        monkeypatch.setenv("DAQP_AMD_NO_RECHECK", "1")
+        mdl = daqp_amd.BatchModel(N, n, m, ms)
+        mdl.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=64 + 128)
+        g4 = mdl.solve()
+        assert mdl.rechecked() == 0 and np.array_equal(g4["exitflag"], ref[3])
+        mdl.close()
+        monkeypatch.delenv("DAQP_AMD_NO_RECHECK")
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def test_degenerate_branches_are_taken_on_the_gpu(oracle, gpu_lib, monkeypatch):
@@ -545,3 +655,112 @@ def test_multi_device_entry_mixed_outcomes(oracle, gpu_lib, monkeypatch):
         assert one["exitflag"][k] == r[3] and one["iter"][k] == r[4], k
         if r[3] > 0:
             assert bits_equal(one["x"][k], r[0]) and bits_equal(one["lam"][k], r[1]), k
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "default"])
+@pytest.mark.parametrize("cfg,N,T", [("C2", 517, 10), ("C3", 20011, 3)])
+def test_persistent_multi_device_batch(oracle, gpu_lib, monkeypatch, cfg, N, T, exact):
+    """DAQPMultiBatch (include/daqp_amd.h): config C5's warm sequence -- setup_daqp, cold daqp_solve, then T x {daqp_update_ldp(UPDATE_v),
+    daqp_solve} on device-resident factors -- and a strong-scaled C3 batch, driven from ONE process over the box's one GPU listed two and
+    three times (k mod G sharding, one persistent host thread + stream per shard, pinned chunked staging of the one host batch):
+    every step bit-identical to the unsharded BatchModel; the first steps also against the oracle."""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
+    n, m, ms, na, seed, _ = O.CONFIGS[cfg]
+    q = O.generate_batch(N, n, m, ms, na, seed, start=9000)
+    rng = np.random.default_rng(4500 + N)
+    fs = [q["f"]]
+    for t in range(T):
+        fs.append(fs[-1] + 0.05 * rng.standard_normal(q["f"].shape))
+    one = daqp_amd.BatchModel(N, n, m, ms)
+    one.setup(q["H"], fs[0], q["A"], q["bupper"], q["blower"], None, init_mask=0)
+    ref = [one.solve()]
+    for t in range(1, T + 1):
+        one.update(f=fs[t])
+        ref.append(one.solve())
+    one.close()
+    om = [oracle.model(n, m, ms) for _ in range(4)]
+    for k, o in enumerate(om):
+        assert o.setup(q["H"][k], fs[0][k], q["A"][k], q["bupper"][k], q["blower"][k], None) == 1
+    for t in range(2):
+        for k, o in enumerate(om):
+            if t > 0:
+                assert o.update(O.UPDATE_v, f=fs[t][k]) == 0
+            x, lam, fval, flag, it = o.solve()
+            assert ref[t]["exitflag"][k] == flag and ref[t]["iter"][k] == it and np.abs(ref[t]["x"][k] - x).max() < XTOL
+    for devs in ([0, 0], [0, 0, 0]):
+        mb = daqp_amd.MultiBatchModel(N, n, m, ms, devices=devs)
+        assert mb.shards == len(devs) and sum(mb.shard(g)[1] for g in range(mb.shards)) == N
+        mb.setup(q["H"], fs[0], q["A"], q["bupper"], q["blower"], None, init_mask=0)
+        for t in range(T + 1):
+            if t > 0:
+                mb.update(f=fs[t])
+            g = mb.solve()
+            r = ref[t]
+            assert np.array_equal(g["exitflag"], r["exitflag"]) and np.array_equal(g["iter"], r["iter"]), (devs, t)
+            assert bits_equal(g["x"], r["x"]) and bits_equal(g["lam"], r["lam"]) and bits_equal(g["fval"], r["fval"]), (devs, t)
+        mb.close()
+
+
+def test_multi_device_batch_takes_device_arrays_per_shard(gpu_lib, monkeypatch):
+    """the per-shard face of the multi-device batch: shard g's problems handed over as device-resident arrays (torch tensors on that
+    shard's device, used in place), results left on the device -- setup, a bound update and two solves, against the unsharded run;
+    and the argument checks (a device batch through the one-host-batch call, a shape mismatch, an empty device list = all devices)"""
+    import ctypes as C
+    import torch
+    import daqp_amd
+    from daqp_amd._lib import DAQPBatchProblem, DAQPBatchResult, MEM_DEVICE, MEM_HOST, lib
+    monkeypatch.setenv("DAQP_AMD_EXACT", "1")
+    n, m, ms, na = 24, 70, 4, 9
+    N = 203
+    q = O.generate_batch(N, n, m, ms, na, 8123)
+    bu2 = q["bupper"] + 0.01
+    one = daqp_amd.BatchModel(N, n, m, ms)
+    one.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=0)
+    r0 = one.solve()
+    one.update(bupper=bu2, blower=q["blower"])
+    r1 = one.solve()
+    one.close()
+    L = lib()
+    G = 3
+    devs = np.zeros(G, np.int32)
+    h = C.c_void_p()
+    st = daqp_amd.default_settings()
+    assert L.daqp_batch_create_multi(C.byref(h), N, n, m, ms, 0, C.byref(st), devs.ctypes.data_as(C.POINTER(C.c_int)), G) == 0
+    tens, ps, rs, outs = [], [], [], []
+    for g in range(G):
+        idx = np.arange(g, N, G)
+        t = {k: torch.from_numpy(np.ascontiguousarray(v[idx])).cuda() for k, v in dict(H=q["H"], f=q["f"], A=q["A"], bu=q["bupper"], bl=q["blower"], bu2=bu2).items()}
+        o = dict(x=torch.empty((idx.size, n), dtype=torch.float64, device="cuda"), lam=torch.empty((idx.size, m), dtype=torch.float64, device="cuda"),
+                 fval=torch.empty(idx.size, dtype=torch.float64, device="cuda"), flag=torch.empty(idx.size, dtype=torch.int32, device="cuda"),
+                 it=torch.empty(idx.size, dtype=torch.int32, device="cuda"))
+        tens.append(t); outs.append(o)
+        ps.append(DAQPBatchProblem(idx.size, n, m, ms, t["H"].data_ptr(), t["f"].data_ptr(), t["A"].data_ptr(), t["bu"].data_ptr(), t["bl"].data_ptr(), None, MEM_DEVICE))
+        rs.append(DAQPBatchResult(o["x"].data_ptr(), o["lam"].data_ptr(), o["fval"].data_ptr(), None, o["flag"].data_ptr(), o["it"].data_ptr(), MEM_DEVICE, 0, 0))
+    torch.cuda.synchronize()
+    PS, RS = (DAQPBatchProblem * G)(*ps), (DAQPBatchResult * G)(*rs)
+    assert L.daqp_batch_setup_multi_shards(h, PS, 0) == 0 and L.daqp_batch_solve_multi_shards(h, RS) == 0
+
+    def gathered(key):
+        out = np.empty((N,) + tuple(outs[0][key].shape[1:]), dtype=outs[0][key].cpu().numpy().dtype)
+        for g in range(G):
+            out[np.arange(g, N, G)] = outs[g][key].cpu().numpy()
+        return out
+    assert np.array_equal(gathered("flag"), r0["exitflag"]) and np.array_equal(gathered("it"), r0["iter"]) and bits_equal(gathered("x"), r0["x"])
+    for g in range(G):
+        PS[g].bupper = tens[g]["bu2"].data_ptr(); PS[g].H = None; PS[g].A = None; PS[g].f = None
+    assert L.daqp_batch_update_multi_shards(h, daqp_amd.UPDATE_d, PS) == 0 and L.daqp_batch_solve_multi_shards(h, RS) == 0
+    assert np.array_equal(gathered("it"), r1["iter"]) and bits_equal(gathered("x"), r1["x"]) and bits_equal(gathered("lam"), r1["lam"])
+    # argument checks
+    bad = DAQPBatchProblem(N, n, m, ms, tens[0]["H"].data_ptr(), tens[0]["f"].data_ptr(), tens[0]["A"].data_ptr(), tens[0]["bu"].data_ptr(), tens[0]["bl"].data_ptr(), None, MEM_DEVICE)
+    assert L.daqp_batch_setup_multi(h, C.byref(bad), 0) < 0 and b"host-resident" in L.daqp_amd_last_error()
+    f64 = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data
+    wrong = DAQPBatchProblem(N - 1, n, m, ms, f64(q["H"]), f64(q["f"]), f64(q["A"]), f64(q["bupper"]), f64(q["blower"]), None, MEM_HOST)
+    assert L.daqp_batch_setup_multi(h, C.byref(wrong), 0) < 0 and b"does not match" in L.daqp_amd_last_error()
+    L.daqp_batch_free_multi(h)
+    h2 = C.c_void_p()
+    empty = np.zeros(1, np.int32)
+    assert L.daqp_batch_create_multi(C.byref(h2), 5, n, m, ms, 0, C.byref(st), empty.ctypes.data_as(C.POINTER(C.c_int)), 0) == 0   # n_devices <= 0: all devices, the list is not read
+    assert L.daqp_batch_multi_shards(h2) == min(L.daqp_amd_device_count(), 5)
+    L.daqp_batch_free_multi(h2)
+    assert daqp_amd.solve_batch_multi(q["H"][:5], q["f"][:5], q["A"][:5], q["bupper"][:5], q["blower"][:5], None, ms=ms, devices=[])["exitflag"].tolist() == [1] * 5

@@ -1,4 +1,4 @@
-"""k_ldp_tiny (DAQP_AMD_TINY=1): the 16-problems-per-wavefront solve kernel for tiny shapes (n <= 12, m <= 48, working sets of at most
+"""k_ldp_tiny (a build with -DDAQP_AMD_WITH_TINY -- tools/tinybuild.sh -- and DAQP_AMD_TINY=1; skipped on the default build): the 16-problems-per-wavefront solve kernel for tiny shapes (n <= 12, m <= 48, working sets of at most
 13 rows) against the oracle -- persistent waves with retire / refill of finished problems, lockstep passes, four lanes per problem.
 
 exact mode: bit-identical x, lam, fval, iteration count, exit flag and add / remove / branch trace; default mode: identical exit
@@ -17,7 +17,11 @@ XTOL = 1e-9
 
 
 @pytest.fixture(autouse=True)
-def tiny_on(monkeypatch):
+def tiny_on(monkeypatch, gpu_lib):
+    # the kernel is not part of the default build (slower than the register kernel on the shape it was written for):
+    # tools/tinybuild.sh links a library that carries it; load that one with DAQP_AMD_LIBRARY=... to run this file
+    if not gpu_lib.daqp_amd_has_tiny():
+        pytest.skip("library built without -DDAQP_AMD_WITH_TINY (tools/tinybuild.sh)")
     monkeypatch.setenv("DAQP_AMD_TINY", "1")
 
 
@@ -29,12 +33,8 @@ def bits_equal(a, b):
 def compare(g, ref, exact, tag):
     assert np.array_equal(g["exitflag"], ref[3]), (tag, np.nonzero(g["exitflag"] != ref[3])[0][:8])
     ok = ref[3] > 0
-    # (default arithmetic: an INFEASIBLE problem's certificate may come an iteration earlier or later -- rounding noise of a singular
-    #  direction against dual_tol, profiles/r03_degenerate_fast_mode.json; problems with an optimum must take the reference's path)
-    sel = slice(None) if exact else ok
-    assert np.array_equal(g["iter"][sel], ref[4][sel]), (tag, np.nonzero(g["iter"] != ref[4])[0][:8])
-    if not exact:
-        assert (np.abs(g["iter"] - ref[4])[~ok] <= 1).all(), tag
+    # (default arithmetic too: infeasible verdicts of a first solve are re-derived in the reference's arithmetic, csrc/recheck.hip.h)
+    assert np.array_equal(g["iter"], ref[4]), (tag, np.nonzero(g["iter"] != ref[4])[0][:8])
     if exact:
         assert bits_equal(g["x"][ok], ref[0][ok]) and bits_equal(g["lam"][ok], ref[1][ok]) and np.array_equal(g["fval"][ok], ref[2][ok]), tag
     else:

@@ -23,6 +23,3 @@ done
 python tools/pmc_config_summary.py $O/pmc_summary.json $O/pmc_raw_C2.json $O/pmc_raw_C3.json $O/pmc_raw_C4.json $O/pmc_raw_C5.json > $O/pmc_summary_print.txt 2>&1
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 tools/ubench4.bin > $O/ubench4.txt 2>&1
-# the opt-in 16-problems-per-wave solve kernel of tiny shapes on C3, for the record
-DAQP_AMD_TINY=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_tiny -o kt -- python bench.py --config C3 --steps 10 --warmup 2 --cpu-sample 0 --side-configs none --no-exact > $O/c3_tiny_bench.json 2> $O/c3_tiny.err
-find /tmp/kt_tiny -name "*kernel_stats.csv" -exec cp {} $O/c3_tiny_kernel_stats.csv \;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
             w.c = c;
             w.t_start = solve_stamp(b.tstart, q); w.tick_s = b.tick_s;
             w.profiling = (b.prof != nullptr) && mode == 0;
-            if (w.profiling && lane < 20) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[lane] = 0;
+            if (w.profiling && lane < 24) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[lane] = 0;
             w.stp = b.st_dev;
             w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
             w.trace_cap = b.trace_cap; w.trace_len = 0;
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
             w.lam_b = uni(qs->lam_swapped) ? 1 : 0;
             // inverse-factor representation: default arithmetic, cold start, no soft rows (wg_ldp.hip.h)
             w.use_w = (b.wg_inverse && !c.exact && mode == 0 && na0 == 0 && !need_act && !has_soft) ? 1 : 0;
+            w.fast_na = -1;
             int iters = 0;
             const int flag = wrun(w, mode, need_act != 0, iters);
             if (!w.overflow) wleave_w(w, w.na);                          // the stored iterate is always L   // (need_activate at mode 0: defensive, setup/update runs mode 1 itself)
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
                 SI(c, cmd)[0] = WG_EXIT;
                 if (w.profiling) {
                     for (int i = 0; i < 16; ++i) b.prof[(size_t)q * 32 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];
-                    for (int i = 16; i < 20; ++i) b.prof[(size_t)q * 32 + 9 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];   // [25..28]: scans, fp64 re-scans
+                    for (int i = 16; i < 23; ++i) b.prof[(size_t)q * 32 + 9 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];   // [25..28]: scans, fp64 re-scans; [29..31]: inside an append
                 }
             }
             __syncthreads();

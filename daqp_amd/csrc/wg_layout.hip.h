@@ -8,7 +8,7 @@ constexpr int kWgMaxWaves = 8;    // 512 threads: two waves per SIMD, i.e. 256 V
 
 __host__ __device__ inline int wg_round_up(int a, int b) { return (a + b - 1) / b * b; }
 // double offset of packed L, and the bytes of dynamic LDS for capL rows of it
-__host__ __device__ inline int wg_lds_L(int C, int m) { const int CAP = 64 * C; return 8 * CAP + 2 * 258 + 136 * kWgMaxWaves + 20 + wg_round_up(5 * CAP + 16 + wg_round_up(m, 4), 4) / 2; }
+__host__ __device__ inline int wg_lds_L(int C, int m) { const int CAP = 64 * C; return 8 * CAP + 2 * 258 + 136 * kWgMaxWaves + 24 + wg_round_up(5 * CAP + 16 + wg_round_up(m, 4), 4) / 2; }
 // row stride of the workgroup kernel's active-row scratch: whole 32-column chunks (the default mode's Gram pass reads a row as
 // ldr / 32 loads of 16 lanes x 16 bytes; the pad columns are zero)
 __host__ __device__ inline int wg_row_stride(int n) { return wg_round_up(n, 32); }

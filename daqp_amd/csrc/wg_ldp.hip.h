@@ -33,7 +33,7 @@ struct WgL {
     static constexpr int CAP = 64 * C;
     // doubles
     static constexpr int D = 0, xl = CAP, zl = 2 * CAP, lamA = 3 * CAP, lamB = 4 * CAP, pend_lam = 5 * CAP, gram = 6 * CAP, rhs = 7 * CAP, u = 8 * CAP,
-                         mnew = u + 258, red = mnew + 258, cand = red + 128 * kWgMaxWaves, prof = cand + 8 * kWgMaxWaves, dend = prof + 20;
+                         mnew = u + 258, red = mnew + 258, cand = red + 128 * kWgMaxWaves, prof = cand + 8 * kWgMaxWaves, dend = prof + 24;
     // ints, counted from double offset dend
     static constexpr int ws = 0, slot = CAP, slot_id = 2 * CAP, freestk = 3 * CAP, pend_id = 4 * CAP, cmd = 5 * CAP, sense = 5 * CAP + 16;
 };
@@ -52,6 +52,11 @@ __device__ __forceinline__ double *wg_sm() { extern __shared__ __attribute__((al
 // so the address must stay inside the allocation
 #define WLIDX(c, e) ((e) < (c).lmax ? (e) : (c).lmax)
 #define SI(c, name) (reinterpret_cast<int *>(wg_sm() + WgL<C>::dend) + WgL<C>::name)
+#define SI64(c) (reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof) + 23)      // probe scratch: the cycle stamp of the current command's start
+// probes inside a command (thread 0 of the workgroup; armed by cmd[6]): WGPROBE_BEGIN stamps, WGPROBE adds the time since the last stamp to a slot
+#define WGPROBE_BEGIN(c) do { if (SI(c, cmd)[6] && wg_tid() == 0) SI64(c)[0] = (long long)__builtin_readcyclecounter(); } while (0)
+#define WGPROBE(c, slot) do { if (SI(c, cmd)[6] && wg_tid() == 0) { const long long n_ = (long long)__builtin_readcyclecounter(); \
+    reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[slot] += n_ - SI64(c)[0]; SI64(c)[0] = n_; } } while (0)
 
 // Thread coordinates as values the optimizer cannot see through.  Everything below runs inside two nested loops (the
 // persistent workgroup's problem loop and the master's state machine); addresses of the form "base + f(lane)" are loop
@@ -78,6 +83,7 @@ struct WgWave {
     int lam_b;                            // 1: lam lives in buffer B and lam* in buffer A (the reference swaps the two pointers on every add)
     int na, reuse, sing, has_soft, nfree, hi_slot, overflow;
     int use_w;                            // 1: the LDS factor area holds W = L^-1 (default arithmetic, regular factor), see "inverse factor" below
+    int fast_na;                          // inverse factor: na right after a regular append (the next CSP is then an O(na) update, wdirection), else -1
     double fval, soft;
     const DAQPSettings *stp;              // device copy of the settings: scalar loads at the point of use
     int *trace; int trace_cap, trace_len;
@@ -436,6 +442,9 @@ __device__ __forceinline__ void wg_fetch_gram_fast(const WgCtx &c, int id, int n
     if (wv < NG) load_groups(wv);
     wg_fetch_row<C>(c, id, newslot, true);
     __syncthreads();
+#ifndef DAQP_WG_PROBE2
+    if (SI(c, cmd)[6] && wg_tid() == 0) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[22] += (long long)__builtin_readcyclecounter() - SI64(c)[0];   // (probe: the new row is in LDS)
+#endif
     double2 mv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) mv[i] = reinterpret_cast<const double2 *>(SD(c, mnew))[(i < nch ? 16 * i : 0) + l16];
@@ -515,33 +524,50 @@ __device__ __forceinline__ double wred_sum(double v)
     v += dpp_f64<0x140>(v);
     return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
 }
-// rows from..na-1 of (W v) + v: four rows per wave and trip (their reductions overlap), lanes <-> columns (adjacent lanes,
-// adjacent addresses)
+// rows from..na-1 of (W v) + v.  SIXTEEN rows per wave and trip, four lanes per row (lane = 4 * row + part: part p sums the columns
+// j = p (mod 4), so the four lanes of a row read four adjacent doubles per step); the four partial sums of a row meet in two
+// quad-permute steps, and whatever `out` does with a finished row -- a division, a store -- happens for sixteen rows at once.
+// (Round 3 summed a row across the whole wave, four rows per trip: 64-lane reductions with read-lanes, ~2.1 k cycles per trip and
+// 8.6 k per W g of a 130-row factor -- a single wave issuing ~200 dependent instructions per trip; the LDS traffic itself is 68 KB.)
 template <int C, class F>
 __device__ __forceinline__ void wg_w_rows(const WgCtx &c, const double *vec, int from, int na, F &&out)
 {
     const int wv = wg_wave(), lane = wg_lane();
-    double vr[C];
+    const int r = lane >> 2, p = lane & 3;
+    for (int i0 = from + 16 * wv; i0 < na; i0 += 16 * c.W) {
+        const int i = i0 + r;
+        const bool valid = i < na;
+        const int base = tri(valid ? i : na - 1);
+        const int ilast = (i0 + 15 < na) ? i0 + 15 : na - 1;
+        const int kmax = (ilast + 3) >> 2;                  // steps of four columns that the longest row of the block needs
+        const int kfull = i0 >> 2;                          // steps whose columns lie left of EVERY row's diagonal: no test inside
+        double a0 = 0, a1 = 0;
+        const double *wr_ = SDL(c) + base + p, *vp_ = vec + p;
+        int k = 0;
+        for (; k + 8 <= kfull; k += 8) {
+            double wq[8], vq[8];
 #pragma unroll
-    for (int cc = 0; cc < C; ++cc) { const int j = lane + 64 * cc; vr[cc] = (j < na) ? vec[j] : 0.0; }
-    for (int i0 = from + 4 * wv; i0 < na; i0 += 4 * c.W) {
-        double acc[4] = {0, 0, 0, 0};
+            for (int q = 0; q < 8; ++q) { wq[q] = wr_[4 * (k + q)]; vq[q] = vp_[4 * (k + q)]; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q;
-            const int base = tri(i);
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc) {
-                const int j = lane + 64 * cc;
-                if (64 * cc < i && i < na) { const double wij = SDL(c)[WLIDX(c, base + j)]; acc[q] = __builtin_fma((j < i) ? wij : 0.0, vr[cc], acc[q]); }
-            }
+            for (int q = 0; q < 8; q += 2) { a0 = __builtin_fma(wq[q], vq[q], a0); a1 = __builtin_fma(wq[q + 1], vq[q + 1], a1); }
         }
+        for (; k < kmax; k += 4) {                          // the rest, column by column against the row's own diagonal
+            double wq[4], vq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = wred_sum(acc[q]);
-        // lane q finishes row i0 + q (whatever `out` does -- a division, a store -- happens once for the four rows)
-        const double mine = (lane == 0) ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
-        const int irow = i0 + (lane & 3);
-        if (lane < 4 && irow < na) out(irow, mine + vec[irow]);
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * (k + q) + p;
+                const bool in = valid && j < i;
+                wq[q] = SDL(c)[WLIDX(c, base + (in ? j : 0))];
+                vq[q] = vec[in ? j : 0];
+                if (!in) wq[q] = 0.0;
+            }
+            a0 = __builtin_fma(wq[0], vq[0], a0); a1 = __builtin_fma(wq[1], vq[1], a1);
+            a0 = __builtin_fma(wq[2], vq[2], a0); a1 = __builtin_fma(wq[3], vq[3], a1);
+        }
+        double acc = a0 + a1;
+        acc += dpp_f64<0xB1>(acc);    // quad_perm [1,0,3,2]
+        acc += dpp_f64<0x4E>(acc);    // quad_perm [2,3,0,1]
+        if (p == 0 && valid) out(i, acc + vec[i]);
     }
 }
 // (W' v)_j = v_j + sum_{i > j} W[i][j] v_i for every column: thread <-> column (adjacent lanes, adjacent addresses), the rows cut
@@ -555,16 +581,19 @@ __device__ __forceinline__ void wg_w_cols(const WgCtx &c, const double *vec, int
     // 134 rows to sum, chunk 2 has six): waves [0,b1) serve chunk 0, [b1,b2) chunk 1, [b2,W) chunk 2 (scalars only: a
     // run-time indexed table would live in scratch memory)
     int b1 = c.W, b2 = c.W;
+    // (rounded quotients through a float reciprocal: the split only balances work, any split is correct, and every thread computes
+    //  the same one; an integer division is ~40 instructions on this hardware and there were three of them per call)
     if (chunks == 2) {
-        b1 = (na * c.W + (2 * na - 64) / 2) / (2 * na - 64);
+        b1 = (int)((float)(na * c.W) / (float)(2 * na - 64) + 0.5f);
         b1 = b1 < 1 ? 1 : (b1 > c.W - 1 ? c.W - 1 : b1);
     } else if (chunks >= 3) {
-        const int total = 3 * na - 192;
-        b1 = (na * c.W + total / 2) / total;
+        const float inv = 1.0f / (float)(3 * na - 192);
+        b1 = (int)((float)(na * c.W) * inv + 0.5f);
         b1 = b1 < 1 ? 1 : (b1 > c.W - 2 ? c.W - 2 : b1);
-        b2 = ((2 * na - 64) * c.W + total / 2) / total;
+        b2 = (int)((float)((2 * na - 64) * c.W) * inv + 0.5f);
         b2 = b2 < b1 + 1 ? b1 + 1 : (b2 > c.W - 1 ? c.W - 1 : b2);
     }
+    b1 = uni(b1); b2 = uni(b2);
     const int chunk = wv < b1 ? 0 : (wv < b2 ? 1 : 2);
     const int wfirst = chunk == 0 ? 0 : (chunk == 1 ? b1 : b2), wend = chunk == 0 ? b1 : (chunk == 1 ? b2 : c.W);
     const int nsl = wend - wfirst, slice = wv - wfirst;
@@ -572,7 +601,7 @@ __device__ __forceinline__ void wg_w_cols(const WgCtx &c, const double *vec, int
     if (chunk < chunks) {
         const int j = chunk * 64 + lane;
         const int rows0 = 64 * chunk + 1, span = na - rows0;          // rows rows0 .. na-1 concern this chunk
-        const int per = (span + nsl - 1) / (nsl > 0 ? nsl : 1);
+        const int per = uni((int)((float)(span + nsl - 1) / (float)(nsl > 0 ? nsl : 1) + 1e-3f));   // (nsl <= 8, span < 256: exact)
         int lo = rows0 + slice * per, hi = lo + per < na ? lo + per : na;
         if (lo < j + 1) lo = j + 1;
         double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -605,11 +634,20 @@ __device__ __forceinline__ void wg_w_cols(const WgCtx &c, const double *vec, int
 template <int C>
 __device__ __forceinline__ void wg_wcsp(const WgCtx &c, int from, int na, double *lams)
 {
+#ifdef DAQP_WG_PROBE2
+    WGPROBE_BEGIN(c);
+#endif
     wg_w_rows<C>(c, SD(c, rhs), from, na, [&](int i, double xi) __attribute__((always_inline)) {
         SD(c, xl)[i] = xi; SD(c, zl)[i] = xi / SD(c, D)[i];
     });
     __syncthreads();
+#ifdef DAQP_WG_PROBE2
+    WGPROBE(c, 22);
+#endif
     wg_w_cols<C>(c, SD(c, zl), na, [&](int j, double v) __attribute__((always_inline)) { lams[j] = v; });
+#ifdef DAQP_WG_PROBE2
+    WGPROBE(c, 19);
+#endif
 }
 // after the Gram column: l and the new row of W; leaves each wave's part of sum_i y_i l_i in cand[wave]
 template <int C>
@@ -619,16 +657,25 @@ __device__ __forceinline__ void wg_wappend(const WgCtx &c, int na)
     double *gp = SD(c, pend_lam), *lv = SD(c, mnew);
     if (tid < na) gp[tid] = SD(c, gram)[SI(c, slot)[tid]];
     __syncthreads();
-    double dpart = 0;                      // (lanes 0..3 of every wave each carry the rows they finished)
+#ifdef DAQP_WG_PROBE2
+    WGPROBE_BEGIN(c);
+#endif
+    double dpart = 0;                      // (the first lane of every quad carries the rows it finished)
     wg_w_rows<C>(c, gp, 0, na, [&](int i, double yi) __attribute__((always_inline)) {
         const double li = yi / SD(c, D)[i];
         dpart = __builtin_fma(yi, li, dpart);
         lv[i] = li;
     });
-    dpart = wred_sum(wg_lane() < 4 ? dpart : 0.0);
+    dpart = wred_sum((wg_lane() & 3) == 0 ? dpart : 0.0);
     if (wg_lane() == 0) SD(c, cand)[wg_wave()] = dpart;
     __syncthreads();
+#ifdef DAQP_WG_PROBE2
+    WGPROBE(c, 20);
+#endif
     wg_w_cols<C>(c, lv, na, [&](int j, double v) __attribute__((always_inline)) { SDL(c)[tri(na) + j] = -v; });
+#ifdef DAQP_WG_PROBE2
+    WGPROBE(c, 21);
+#endif
 }
 // delete row / column r (nupd = na - r - 1 >= 1 trailing rows; D[r] and the trailing D checked > 0 by the master)
 template <int C>
@@ -686,9 +733,8 @@ __device__ __forceinline__ void wg_wdelete(const WgCtx &c, int r, int na, bool x
             const double pt = pvec[t], bt = bvec[t];
             const double x = __builtin_fma(-pt, s, __builtin_fma(pt, xr, SD(c, xl)[r + 1 + t]));
             s = __builtin_fma(bt, x, s);
-            SD(c, xl)[r + t] = x;
-            SD(c, zl)[r + t] = x / SD(c, D)[r + t];
-        }
+            SD(c, xl)[r + t] = x;         // (z = x / D for these rows: by the master, lane-parallel, after the command -- a division
+        }                                 //  per step of this ONE thread's serial sweep was what a removal waited for)
     }
     if (cn < na - 1) {
         const bool shift = cn >= r;
@@ -747,9 +793,15 @@ __device__ __forceinline__ void wg_do(const WgCtx &c, int code, double primal_to
     } else if (code == WG_COMPACT) wg_compact<C>(c, a0, na);
     else if (code == WG_WCSP) wg_wcsp<C>(c, a0, na, const_cast<double *>(lams));
     else if (code == WG_WAPPEND) {          // (the inverse factor exists in the default arithmetic only)
+        const bool pr = SI(c, cmd)[6] != 0 && wg_tid() == 0;
+        if (pr) SI64(c)[0] = (long long)__builtin_readcyclecounter();
         wg_fetch_gram_fast<C>(c, a0, a1, hi);
         __syncthreads();
+        const long long t1 = pr ? (long long)__builtin_readcyclecounter() : 0;
         wg_wappend<C>(c, na);
+#ifndef DAQP_WG_PROBE2
+        if (pr) { long long *pp = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof); pp[20] += t1 - SI64(c)[0]; pp[21] += (long long)__builtin_readcyclecounter() - t1; }
+#endif
     } else if (code == WG_WDELETE) wg_wdelete<C>(c, a0, na, a1 != 0);
     else if (code == WG_W2L) wg_w2l<C>(c, a0);
 }
@@ -762,6 +814,7 @@ __device__ __forceinline__ void wg_run(WgWave<C> &w, int code, int a0 = 0, int a
     if (wg_lane() == 0) {
         SI(c, cmd)[0] = code; SI(c, cmd)[1] = a0; SI(c, cmd)[2] = a1; SI(c, cmd)[3] = w.na; SI(c, cmd)[4] = w.hi_slot + 1;
         SI(c, cmd)[5] = w.lam_b ? 0 : 1;   // which buffer holds lam*
+        SI(c, cmd)[6] = w.profiling ? 1 : 0;
     }
     __syncthreads();
     const long long tA = w.profiling ? (long long)__builtin_readcyclecounter() : 0;
@@ -771,7 +824,9 @@ __device__ __forceinline__ void wg_run(WgWave<C> &w, int code, int a0 = 0, int a
     if (w.profiling && (code == WG_SCAN32) && wg_lane() == 0) {
         const long long tC = (long long)__builtin_readcyclecounter();
         reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[18] += tB - tA;
+#ifndef DAQP_WG_PROBE2
         reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[19] += tC - tB;
+#endif
     }
 }
 // everybody else: serve commands until the master says EXIT
@@ -878,7 +933,7 @@ __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
             wleave_w(w, na + 1);
             if (lane == 0) SD(c, D)[na] = 0;
             w.sing = na;
-        } else if (lane == 0) SD(c, D)[na] = dnew;
+        } else { if (lane == 0) SD(c, D)[na] = dnew; w.fast_na = na + 1; }
         WSYNC();
         WPROF_ACC(w, 9);
         return;
@@ -988,6 +1043,14 @@ __device__ __forceinline__ void wldl_delete(WgWave<C> &w, int r)
             const int xvalid = (w.reuse >= na) ? 1 : 0;     // x = W rhs complete (the removal follows a CSP): updated by the sweep
             WPROF_T0(w);
             wg_run(w, WG_WDELETE, r, xvalid);
+            if (xvalid) {
+#pragma unroll
+                for (int cc = 0; cc < C; ++cc) {            // z = x / D over the rows whose x the sweep carried (new numbering r .. na-2)
+                    const int i = lane + 64 * cc;
+                    if (i >= r && i < na - 1) SD(c, zl)[i] = SD(c, xl)[i] / SD(c, D)[i];
+                }
+                WSYNC();
+            }
             WPROF_ACC(w, 11);
             if (xvalid) w.reuse = na;                       // (wdrop_core lowers it to na - 1 = all rows of the new factor)
             return;
@@ -1069,6 +1132,7 @@ __device__ __forceinline__ int wdrop_core(WgWave<C> &w, int r)
     w.nfree++;
     wldl_delete(w, r);
     w.na--;
+    w.fast_na = -1;
     int wsn[C], sln[C];
     double lmn[C], rhn[C];
 #pragma unroll
@@ -1228,7 +1292,34 @@ __device__ __forceinline__ void wdirection(WgWave<C> &w)
     const bool regular = (w.sing == kEmpty);
     if (w.use_w) {    // (regular by construction: a singular pivot leaves the inverse-factor representation at once)
         WPROF_T0(w);
-        wg_run(w, WG_WCSP, w.reuse);
+        if (w.fast_na == na && w.reuse == na - 1) {
+            // Right after a regular append nothing about the old rows has changed: x_i = (W rhs)_i and z_i = x_i / D_i stand, the
+            // new row of W is [-l' W, 1], so x_new = rhs_new - l . x_old, and with lam*_old = W_old' z_old still in the buffer that
+            // the add's pointer swap (auxiliary.c:159-160) turned into lam:  lam*_j = lam_j + z_new W[new][j],  lam*_new = z_new.
+            // O(na) on this wave, no pass over W and no workgroup command (the full CSP: ~2 k + ~3.9 k cycles and four barriers).
+            const int nw = na - 1;
+            const double *lv = SD(c, mnew), *lam = WLAM(w);
+            double *lams = WLAMS(w);
+            double part[C], lold[C], wn[C];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                const int i = lane + 64 * cc;
+                const bool in = i < nw;
+                part[cc] = in ? lv[i] * SD(c, xl)[i] : 0.0;
+                lold[cc] = in ? lam[i] : 0.0;
+                wn[cc] = in ? SDL(c)[WLIDX(c, tri(nw) + i)] : 0.0;
+            }
+            const double xn = und(SD(c, rhs)[nw] - wsum<C>(part));
+            const double zn = und(xn / SD(c, D)[nw]);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                const int i = lane + 64 * cc;
+                if (i < nw) lams[i] = __builtin_fma(zn, wn[cc], lold[cc]);
+            }
+            if (lane == 0) { SD(c, xl)[nw] = xn; SD(c, zl)[nw] = zn; lams[nw] = zn; }
+            WSYNC();
+        } else wg_run(w, WG_WCSP, w.reuse);
+        w.fast_na = -1;
         WPROF_ACC(w, 7);
         w.reuse = na;
         return;
@@ -1533,7 +1624,7 @@ __device__ __forceinline__ int wrun(WgWave<C> &w, int mode, bool need_activate, 
     else pc = WPC_START_LOOP;
 #define WTL_CHECK() (timed && !tl_skip && (it & 31) == 0 && time_is_up(w.t_start, w.stp->time_limit, w.tick_s))
 #define WUNIFORM() do { w.na = uni(w.na); w.reuse = uni(w.reuse); w.sing = uni(w.sing); w.nfree = uni(w.nfree); w.hi_slot = uni(w.hi_slot); \
-                        w.lam_b = uni(w.lam_b); w.overflow = uni(w.overflow); } while (0)
+                        w.lam_b = uni(w.lam_b); w.overflow = uni(w.overflow); w.fast_na = uni(w.fast_na); } while (0)
     while (pc != WPC_DONE && !w.overflow) {
         // (belt and braces: the iterate's scalars are wave-uniform by construction; saying so once per state keeps every loop
         //  bounded by them a scalar loop whatever the optimizer concluded about the joins of the previous state)

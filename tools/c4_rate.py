@@ -30,4 +30,7 @@ if len(sys.argv) > 2:
     if not os.environ.get("DAQP_AMD_NO_WG"):   # workgroup kernel: finer split (the setup kernel's counters sit at [16:22])
         n2 = ["csp forward", "csp backward", "add: fetch+gram", "add: chains", "drop: compaction", "drop: chain", "scan: |u|^2 + pick"]
         print("  of which:", ", ".join(f"{n2[k]} {pr[:, 6 + k].sum() / it:.0f}" for k in range(7)), f"| general forward sweeps per iteration {pr[:, 15].sum() / it:.3f} | backward: loads {pr[:, 13].sum() / it:.0f}, chains {pr[:, 14].sum() / it:.0f}")
+if len(sys.argv) > 2 and not os.environ.get("DAQP_AMD_NO_WG"):
+    adds = pr[:, 25].sum()
+    print("  per append (cycles): row fetch until it is in LDS %.0f, Gram column after that %.0f, W g / l / new row of W %.0f" % (pr[:, 31].sum() / adds, (pr[:, 29].sum() - pr[:, 31].sum()) / adds, pr[:, 30].sum() / adds))
 print(f"C4 N={N}: {N / dt:.0f} QPs/s, kernels setup/solve ms {bm.kernel_ms()}, mean iter {r['iter'].double().mean().item():.1f}, optimal {(r['exitflag'] == 1).all().item()}, parity(16) {ok}, max|dx| {np.abs(r['x'][:16].cpu().numpy() - ref[0]).max():.1e}")

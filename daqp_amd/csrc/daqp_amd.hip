@@ -168,7 +168,7 @@ struct DAQPBatch {
     int fresh_mask = 0;        // its init_mask
     bool recheck = true;       // DAQP_AMD_NO_RECHECK=1 switches the second pass off
     DAQPBatch *redo = nullptr; // companion batch in the exact mode (created with the first infeasible verdict, grown on demand)
-    int *redo_list = nullptr, *redo_count = nullptr, *pin_redo = nullptr;
+    int *redo_list = nullptr, *redo_count = nullptr, *pin_redo = nullptr, *pin_redo_dev = nullptr;   // pin_redo: a mapped host word the marking kernel writes
     int rechecked = 0;         // problems the last solve sent through the second pass
 };
 
@@ -503,14 +503,27 @@ int recheck_infeasible(DAQPBatch *b)
     BatchDev &d = b->d;
     b->rechecked = 0;
     if (!b->redo_list) {
-        if (dev_alloc(b, &b->redo_list, (size_t)d.N) || dev_alloc(b, &b->redo_count, 1)) return DAQP_EXIT_UNSUPPORTED;
-        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&b->pin_redo), sizeof(int), hipHostMallocDefault));
+        if (dev_alloc(b, &b->redo_list, (size_t)d.N) || dev_alloc(b, &b->redo_count, 2)) return DAQP_EXIT_UNSUPPORTED;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&b->pin_redo), sizeof(int), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->pin_redo_dev), b->pin_redo, 0));
     }
-    HIPCHK(hipMemsetAsync(b->redo_count, 0, sizeof(int), b->stream));
-    hipLaunchKernelGGL(k_mark_infeasible, dim3((d.N + 127) / 128), dim3(128), 0, b->stream, d, b->redo_list, b->redo_count);
+    HIPCHK(hipMemsetAsync(b->redo_count, 0, 2 * sizeof(int), b->stream));
+    __atomic_store_n(b->pin_redo, -1, __ATOMIC_RELEASE);
+    hipLaunchKernelGGL(k_mark_infeasible, dim3((d.N + 127) / 128), dim3(128), 0, b->stream, d, b->redo_list, b->redo_count, b->pin_redo_dev);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(b->pin_redo, b->redo_count, sizeof(int), hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    {   // poll the mapped word (written by the kernel's last block); a stream that has failed is noticed through hipStreamQuery
+        unsigned spins = 0;
+        while (__atomic_load_n(b->pin_redo, __ATOMIC_ACQUIRE) < 0) {
+            if ((++spins & 0x3fff) == 0) {
+                const hipError_t qe = hipStreamQuery(b->stream);
+                if (qe != hipSuccess && qe != hipErrorNotReady) { set_err("the solve launch failed: %s", hipGetErrorString(qe)); return DAQP_EXIT_UNSUPPORTED; }
+                if (qe == hipSuccess && __atomic_load_n(b->pin_redo, __ATOMIC_ACQUIRE) < 0) {   // (everything has run and the word never arrived)
+                    HIPCHK(hipMemcpy(b->pin_redo, b->redo_count, sizeof(int), hipMemcpyDeviceToHost));
+                    break;
+                }
+            }
+        }
+    }
     const int count = *b->pin_redo;
     if (count == 0) return 0;
     if (d.N == 1) {

@@ -8,8 +8,8 @@
 // threshold-sitting problems, profiles/r03_degenerate_fast_mode.json).  Infeasible problems are rare and end early, so they are the
 // ones worth a second, bit-identical pass: their exit flag, iteration count, multipliers and stored iterate are then the reference's.
 //
-// Mechanics (host side: recheck_infeasible in daqp_amd.hip): k_mark_infeasible compacts the indices; the host reads the count (one
-// 4-byte copy); if it is not zero the inputs of those problems are gathered into a small companion batch that runs in the exact
+// Mechanics (host side: recheck_infeasible in daqp_amd.hip): k_mark_infeasible compacts the indices and publishes the count into a
+// mapped host word that the host polls; if it is not zero the inputs of those problems are gathered into a small companion batch that runs in the exact
 // mode (k_gather_problems), set up and solved there by the ordinary kernels, and results, LDP and iterate are copied back over
 // the problem's slots (k_scatter_problems).  No kernel of the hot path knows about any of this.
 #pragma once
@@ -18,14 +18,27 @@
 namespace daqp_amd {
 
 // one thread per problem: solve-time INFEASIBLE of an ordinary problem (its setup succeeded, it is not in the proximal loop --
-// that loop already runs the reference's arithmetic in both modes)
-__global__ void k_mark_infeasible(BatchDev b, int *list, int *count)
+// that loop already runs the reference's arithmetic in both modes).  The block that finishes last publishes the count straight
+// into host memory (a mapped, pinned word the host is polling: it learns the answer a couple of microseconds after this kernel
+// ends, without a stream synchronisation -- on a 2.4 ms step of tiny problems the synchronisation cost 2 % of the throughput).
+// tick[0]: count, tick[1]: blocks done (both zeroed by the host before the launch).
+__global__ void k_mark_infeasible(BatchDev b, int *list, int *tick, int *host_count)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= b.N) return;
-    const QState *qs = b.qs + q;
-    if (b.exitflag[q] == DAQP_EXIT_INFEASIBLE && qs->setup_flag > 0 && qs->n_prox == 0 && qs->upd_flag >= 0)
-        list[atomicAdd(count, 1)] = q;
+    if (q < b.N) {
+        const QState *qs = b.qs + q;
+        if (b.exitflag[q] == DAQP_EXIT_INFEASIBLE && qs->setup_flag > 0 && qs->n_prox == 0 && qs->upd_flag >= 0)
+            list[atomicAdd(tick, 1)] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(tick + 1, 1) == (int)gridDim.x - 1) {
+            __threadfence();
+            const int cnt = __hip_atomic_load(tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_count, cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 template <typename T>

@@ -29,6 +29,8 @@ struct BatchDev {
     double *rowc_g;    // [N][cap*ldr] only when the active-row cache / L spill out of LDS
     double *setup_g;   // [N][2*rtri] only when the setup factors spill out of LDS
     double *setup_sq;  // [N][round_up(n,32)][round_up(n,16)] generic setup, default mode: R^-1 as a zero-padded square (the matrix cores' B operand)
+    int defer_m;       // 1: k_setup leaves the general rows (M = A R^-1, normalisation, d, images) to k_setup_m, launched right behind it
+    int *m_tick;       // [N] k_setup_m: per problem, workgroups done and how many of them saw what (one word, zero between setups)
     // outputs
     double *x, *lam, *fval, *soft;
     int *exitflag, *iter;

@@ -18,6 +18,7 @@
 #include "setup_fast.hip.h"
 #include "prox.hip.h"
 #include "recheck.hip.h"
+#include "setup_m.hip.h"
 #include "wg_layout.hip.h"
 #ifdef DAQP_AMD_WITH_TINY
 #include "tiny_kernel.hip.h"
@@ -418,6 +419,22 @@ int regularise(DAQPBatch *b, BatchDev &d, int mask, bool lp, bool counted = fals
     b->n_prox_qps = b->counter_host[1];
     return 0;
 }
+// the generic setup's general rows as their own launch right behind k_setup (setup_m.hip.h): default arithmetic, n <= 208, not an LP /
+// regularising pass (those keep the reference's arithmetic inside k_setup)
+bool defers_m(const DAQPBatch *b, const BatchDev &d)
+{
+    static const bool off = [] { const char *e = getenv("DAQP_AMD_NO_SETUP_M"); return e && atoi(e) != 0; }();
+    return !off && !b->fast_setup && !d.exact_setup && d.setup_sq != nullptr && d.m_tick != nullptr && d.n <= 208 && d.mA > 0 && d.prox_pass == 0;
+}
+int launch_setup_m(DAQPBatch *b, const BatchDev &d)
+{
+    const int nrb = (d.mA + kSetupMRows - 1) / kSetupMRows;
+    const size_t lds = (size_t)setup_m_lds().total_bytes;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_setup_m), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_setup_m, dim3((unsigned)((size_t)d.N * nrb)), dim3(256), lds, b->stream, d, nrb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 // daqp_update_ldp(mask within UPDATE_v|UPDATE_d) followed by daqp_solve, whichever kernels the shape uses
 int launch_update_solve(DAQPBatch *b, int mask, bool descriptor_changed)
 {
@@ -610,7 +627,7 @@ bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && 
 std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
-                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_TINY", "DAQP_AMD_TINY_GRID", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK"};
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_TINY", "DAQP_AMD_TINY_GRID", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -790,6 +807,8 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         const size_t sq = Nn * (size_t)round_up(n, 32) * (size_t)round_up(n, 16);
         rc |= dev_alloc(b, &d.setup_sq, sq);
         if (!rc) HIPCHK(hipMemset(d.setup_sq, 0, sq * sizeof(double)));
+        rc |= dev_alloc(b, &d.m_tick, Nn);
+        if (!rc) HIPCHK(hipMemset(d.m_tick, 0, Nn * sizeof(int)));
     }
     if (N == 1) {   // one slab: x[n] lam[m] fval soft | flag iter  -> one device->host copy per solve
         double *slab = nullptr;
@@ -1076,8 +1095,10 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
         hipLaunchKernelGGL(k_setup_tiny<4>, dim3((d.N + 15) / 16), dim3(64), 0, b->stream, d, mask);
         HIPCHK(hipGetLastError());
     } else if (!lp) {
+        d.defer_m = defers_m(b, d) ? 1 : 0;
         hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask);
         HIPCHK(hipGetLastError());
+        if (d.defer_m) { if (launch_setup_m(b, d)) return DAQP_EXIT_UNSUPPORTED; d.defer_m = 0; }
     } else HIPCHK(hipMemsetAsync(d.qs, 0, (size_t)d.N * sizeof(QState), b->stream));   // fresh records: the LP pass below fills them
     // numerically singular Hessians: shifted re-runs for those problems (one tiny counting kernel when there are none);
     // an LP batch: its one setup pass
@@ -1145,8 +1166,10 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
+    t.defer_m = defers_m(b, t) ? 1 : 0;
     hipLaunchKernelGGL(ks, dim3(1), dim3(64), lds_setup, b->stream, t, mask);
     HIPCHK(hipGetLastError());
+    if (t.defer_m) { if (launch_setup_m(b, t)) return DAQP_EXIT_UNSUPPORTED; t.defer_m = 0; }
     // a numerically singular (or forcibly shifted) shared Hessian: the regularising passes of utils.c:354-377 on the one
     // factorisation (this is a setup that happens once per plant: the host looks at the count right away); every problem of the
     // batch then runs the proximal outer loop on the one shifted factor, each with its own centre (daqp_prox.c:21-221)

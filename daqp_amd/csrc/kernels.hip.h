@@ -107,6 +107,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int nprox = 0;
     // default arithmetic mode: M = A R^-1 on the matrix cores (below), which read R^-1 from a zero-padded square image
     bool mfma_m = !b.exact_setup && b.setup_sq != nullptr && b.n <= 208;   // (52 k steps of A in registers)
+    // ... and, when the host follows this launch with k_setup_m (setup_m.hip.h: a workgroup per 64 rows of A, R^-1 shared through
+    // LDS), the general rows are not formed here at all: this kernel leaves what is owed in qs->pad_
     const int sq_ld = round_up(n, 16);
     double *Rsq = b.setup_sq ? b.setup_sq + (size_t)q * round_up(n, 32) * sq_ld : nullptr;
     // optional phase cycle counters -> b.prof[q][16..21]: checks, Cholesky, inverse, v/x_unc, M rows, simple bounds + write-back
@@ -454,7 +456,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // matrix instructions that consume them, column tile by column tile, only up to each tile's last row (R^-1 is upper
     // triangular).  Nothing of A is staged in LDS.  The sums are fp64 fused in a different order than the reference's: M agrees
     // to ~1e-16 relative (the exact mode keeps the chain below).
-    if (flag > 0 && mfma_m) {
+    const bool defer_m = mfma_m && b.defer_m != 0 && mA > 0;
+    if (flag > 0 && mfma_m && !defer_m) {
         typedef double v4d __attribute__((ext_vector_type(4)));
         constexpr int KB = 16, NKT = 56;          // n <= 208: 52 k steps (56: whole blocks of eight)
         double *ob = smem + o.tile;               // [16][64] one column block of results on its way to the blocked image
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (b.prof && lane == 0) for (int i = 0; i < 3; ++i) b.prof[(size_t)q * 32 + 22 + i] = mp[i];
 #undef MPROF
     }
-    if (flag > 0) {
+    if (flag > 0 && !defer_m) {
         constexpr int KB = kSetupRows;
         const int np2 = round_up(n, 2);
         double *at = smem + o.tile;               // [KB][np2] rows of A
@@ -607,7 +610,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
             }
         }
-        __threadfence();   // phase B reads the image back through other lanes
+        // phase B reads the image back through other lanes of this ONE wave: a workgroup-scope fence (a device-scope fence writes the
+        // XCD's dirty L2 back -- per problem; setup_m.hip.h has the measurement)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         GPROF(3);
         WSYNC();
         for (int tb = 0; tb < mA && flag > 0; tb += 64) {
@@ -719,7 +725,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     const int all_feasible = __all(feasible);
     int sing = kEmpty;
-    if (flag > 0 && unc && all_feasible) { sing = DAQP_UNCONSTRAINED_OPTIMAL; activate = 0; }
+    if (flag > 0 && unc && all_feasible && !defer_m) { sing = DAQP_UNCONSTRAINED_OPTIMAL; activate = 0; }
+    // general rows deferred to k_setup_m: what it has to know (the shortcut is decided there, once every row's d is known)
+    const int owed = (flag > 0 && defer_m) ? (1 | (unc ? 2 : 0) | (all_feasible ? 0 : 4)) : 0;
     // --- write back
     if (flag > 0) {
         for (int e = lane; e < b.rtri; e += 64) b.Rinv[(size_t)q * b.rtri + e] = Ro[e];
@@ -730,7 +738,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag; qs->n_prox = (flag > 0) ? nprox : 0;
-        qs->upd_flag = 0;
+        qs->upd_flag = 0; qs->pad_ = owed;
     }
     GPROF(5);
     if (b.prof && lane == 0) for (int i = 0; i < 6; ++i) b.prof[(size_t)q * 32 + 16 + i] = gpt[i];
@@ -798,7 +806,7 @@ __global__ __launch_bounds__(64) void k_init_shared(BatchDev b, const int *struc
     if (lane == 0) {
         QState *qs = b.qs + q;
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = kEmpty; qs->iterations = 0;
-        qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0 && b.sense_in) ? 1 : 0;
+        qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0 && b.sense_in) ? 1 : 0; qs->pad_ = 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = shared_flag[1]; qs->n_prox = shared_flag[2];
         qs->upd_flag = 0;
     }

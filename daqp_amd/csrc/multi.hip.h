@@ -85,12 +85,22 @@ int pin_acquire(MultiShard *s, size_t need, char **buf, int *which)
     return 0;
 }
 
-// shard s takes rows k = g, g + G, ... of a host array of N rows of `per` elements into `dst` (device, Ng rows back to back)
+// shard s takes rows k = g, g + G, ... of a host array of N rows of `per` elements into `dst` (device, Ng rows back to back).
+// One shard: the rows are contiguous, one plain copy.  Several: by default a pitched copy straight out of the caller's memory (the
+// runtime gathers the rows while it stages them; measured faster than gathering here: tools/pcie_rate.py); DAQP_AMD_MULTI_PINNED=1:
+// gathered into this shard's pinned buffers chunk by chunk, two deep (what to use when the caller's arrays are pinned already or
+// the runtime's pitched path is slow).
 template <typename T>
 int stage_rows_in(MultiShard *s, const T *src, size_t per, T *dst)
 {
     if (!src || per == 0 || s->Ng == 0) return 0;
     const size_t row = per * sizeof(T);
+    if (s->G == 1) { HIPCHK(hipMemcpyAsync(dst, src, row * (size_t)s->Ng, hipMemcpyHostToDevice, s->stream)); return 0; }
+    static const bool pinned = [] { const char *e = getenv("DAQP_AMD_MULTI_PINNED"); return e && atoi(e) != 0; }();
+    if (!pinned) {
+        HIPCHK(hipMemcpy2DAsync(dst, row, src + (size_t)s->g * per, row * (size_t)s->G, row, (size_t)s->Ng, hipMemcpyHostToDevice, s->stream));
+        return 0;
+    }
     size_t rows_per = kPinChunk / row;
     if (rows_per == 0) rows_per = 1;
     for (size_t j0 = 0; j0 < (size_t)s->Ng; j0 += rows_per) {
@@ -110,6 +120,7 @@ int stage_rows_out(MultiShard *s, const T *src_dev, size_t per, T *dst)
 {
     if (!dst || per == 0 || s->Ng == 0) return 0;
     const size_t row = per * sizeof(T);
+    if (s->G == 1) { HIPCHK(hipMemcpyAsync(dst, src_dev, row * (size_t)s->Ng, hipMemcpyDeviceToHost, s->stream)); return 0; }
     size_t rows_per = kPinChunk / row;
     if (rows_per == 0) rows_per = 1;
     // two chunks in flight: chunk c is scattered by the host while chunk c + 1 crosses the bus

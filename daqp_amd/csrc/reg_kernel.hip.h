@@ -257,7 +257,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
             if (lane < n) fl[lane] = f_in;
             copy_wait();
             WSYNC();
-            if (lane < n) {
+            if constexpr (FM) {
+                // default arithmetic: the triangle FOLDED over the lanes.  Column i has i + 1 terms -- lane n-1 would run an n-step
+                // chain while lane 0 runs one (5.6 k cycles of a warm solve at n = 50) -- so lane i takes the first LH = n/2 + 1 terms of
+                // its own column (j = i, i-1, ...) and then the tail of column n-1-i that its owner leaves over (j = n-2-i-LH .. 0 when
+                // that column is longer than LH): every lane ~n/2 terms, one exchange at the end.  Same products, one more association
+                // than the reference's single chain (the exact mode keeps utils.c:474-497's order below).
+                const int i = lane < n ? lane : 0, pc = n - 1 - i;                 // own column, partner column
+                const int LH = n / 2 + 1;
+                const int own_lo = (i + 1 > LH) ? i - LH + 1 : 0;                      // own terms: j = i .. own_lo
+                const int tail_hi = (pc + 1 > LH && pc != i) ? pc - LH : -1;           // partner's left-over: j = tail_hi .. 0
+                double acc = 0, acc2 = 0;
+                for (int j0 = i; j0 >= own_lo; j0 -= kChunk) {
+                    double rr[kChunk], ff[kChunk];
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) { const int j = (j0 - k >= own_lo) ? j0 - k : own_lo; rr[k] = Rl[roff(j, n) + i]; ff[k] = fl[j]; }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) if (j0 - k >= own_lo) acc = __builtin_fma(rr[k], ff[k], acc);
+                }
+                for (int j0 = tail_hi; j0 >= 0; j0 -= kChunk) {
+                    double rr[kChunk], ff[kChunk];
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) { const int j = (j0 - k >= 0) ? j0 - k : 0; rr[k] = Rl[roff(j, n) + pc]; ff[k] = fl[j]; }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) if (j0 - k >= 0) acc2 = __builtin_fma(rr[k], ff[k], acc2);
+                }
+                const double other = __shfl(acc2, (lane < n) ? n - 1 - lane : lane);   // the lane that worked on THIS lane's column
+                if (lane < n) {
+                    acc += other;
+                    vv[lane] = acc;
+                    b.v[(size_t)q * n + lane] = acc;
+                }
+            } else if (lane < n) {
                 const int i = lane;
                 double acc = Rl[roff(i, n) + i] * fl[i];
                 for (int j0 = i - 1; j0 >= 0; j0 -= kChunk) {
@@ -368,7 +399,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         WSYNC();
         const long long te2 = (long long)__builtin_readcyclecounter();
         if (b.lam && lane < w.na) lamq[w.wsid] = w.lams;                // ... then scatter by WS
-        if (flag > 0 && lane < n) {
+        if constexpr (FM) {
+            // x = R^-1 (u - v), default arithmetic: the triangle folded as for v above -- row i has n - i terms; lane i takes the first
+            // LH of its own row (j = i, i+1, ...) and the tail of row n-1-i that its owner leaves over (j = n-1-i+LH .. n-1)
+            if (flag > 0) {      // (wave-uniform)
+                const int i = lane < n ? lane : 0, pr = n - 1 - i;
+                const int LH = n / 2 + 1;
+                const int own_hi = (n - i > LH) ? i + LH - 1 : n - 1;                  // own terms: j = i .. own_hi
+                const int tail_lo = (n - pr > LH && pr != i) ? pr + LH : n;            // partner's left-over: j = tail_lo .. n-1
+                const double *row = Rl + roff(i, n), *prow = Rl + roff(pr, n);
+                double acc = 0, acc2 = 0;
+                for (int j0 = i; j0 <= own_hi; j0 += kChunk) {
+                    double rr[kChunk], uu[kChunk];
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) { const int j = (j0 + k <= own_hi) ? j0 + k : own_hi; rr[k] = row[j]; uu[k] = w.u[j]; }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) if (j0 + k <= own_hi) acc = __builtin_fma(rr[k], uu[k], acc);
+                }
+                for (int j0 = tail_lo; j0 < n; j0 += kChunk) {
+                    double rr[kChunk], uu[kChunk];
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) { const int j = (j0 + k < n) ? j0 + k : n - 1; rr[k] = prow[j]; uu[k] = w.u[j]; }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) if (j0 + k < n) acc2 = __builtin_fma(rr[k], uu[k], acc2);
+                }
+                const double other = __shfl(acc2, (lane < n) ? n - 1 - lane : lane);
+                if (lane < n) {
+                    xi = acc + other;
+                    if (lane < b.ms && !qdiag) xi /= sc_sb;   // daqp.c:124-134: no division in the RinvD branch
+                }
+            }
+        } else if (flag > 0 && lane < n) {
             const double *row = Rl + roff(lane, n);
             xi = w.u[lane] * row[lane];
             for (int j0 = lane + 1; j0 < n; j0 += kChunk) {

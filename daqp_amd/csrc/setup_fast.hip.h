@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ?
     SPROF(5);
     if (lane == 0) {
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
-        qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
+        qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0; qs->pad_ = 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag; qs->n_prox = (flag > 0) ? nprox : 0;
         qs->upd_flag = 0;
         if (kProfile && b.prof) for (int i = 0; i < 10; ++i) b.prof[(size_t)q * 32 + i] = pt[i];

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include "setup_fast.hip.h"
 #include "tiny_setup.hip.h"
+#define DAQP_AMD_SETUP_M_IMPL   // (k_setup_m is not a template: defined in this translation unit, declared where it is launched)
+#include "setup_m.hip.h"
 
 namespace daqp_amd {
 #define DAQP_SETUP_SIZE(NMAX) \

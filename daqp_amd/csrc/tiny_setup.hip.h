@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) void k_setup_tiny(BatchDev b, int mask)
     static_for<RPL>([&](auto k) __attribute__((always_inline)) { const int r = sub + G * k; if (r < m) b.sense[(size_t)q * m + r] = sens[k]; });
     if (sub == 0) {
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
-        qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
+        qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0; qs->pad_ = 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = (flag > 0 && isdiag) ? 1 : 0; qs->n_prox = 0;
         qs->upd_flag = 0;
     }

@@ -141,7 +141,7 @@ struct QState {   // per-problem scalars kept in HBM between launches
     int n_active, reuse_ind, sing_ind, iterations;
     int lam_swapped, setup_flag, need_activate, exitflag;
     double fval, soft_slack;
-    int upd_flag, pad_;  // upd_flag < 0: the last daqp_update_ldp(UPDATE_v|UPDATE_d) failed its bound check (utils.c:98-103): solves report it
+    int upd_flag, pad_;  // pad_: between k_setup and k_setup_m only -- what the first leaves to the second (setup_m.hip.h), else 0; upd_flag < 0: the last daqp_update_ldp(UPDATE_v|UPDATE_d) failed its bound check (utils.c:98-103): solves report it
                          // until the next update; factors and working set are kept (the reference's workspace stays usable too)
     int diag_h, n_prox; // n_prox > 0: the factor is of a shifted Hessian, solves go through the proximal outer loop (prox.hip.h)
                         // diag_h 1: H was diagonal -- the reference's RinvD branch (utils.c:245-312): rows < ms of R^-1 are kept

@@ -173,3 +173,55 @@ def test_fast_mode_shared_structure_large(oracle, gpu_lib):
             assert np.array_equal(np.sign(g["lam"][k]), np.sign(r[1])), (t, k)
             assert np.abs(g["x"][k] - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max(), np.abs(r[1]).max()), (t, k, np.abs(g["x"][k] - r[0]).max(), np.abs(r[1]).max())
     bm.close()
+
+
+@pytest.mark.parametrize("shape", [(200, 600, 0, 80), (70, 150, 6, 20), (65, 130, 65, 10), (129, 333, 10, 40), (208, 250, 3, 30), (100, 64, 0, 10), (90, 40, 9, 8)])
+def test_general_rows_as_their_own_launch(oracle, gpu_lib, monkeypatch, shape):
+    """k_setup_m (csrc/setup_m.hip.h): the generic setup's general rows -- M = A R^-1 on the matrix cores with R^-1 shared through LDS by
+    the four waves of a workgroup, normalisation, d, both images -- as a launch of their own behind k_setup.  The LDP it leaves
+    equals the reference's to rounding and the one-kernel path's (DAQP_AMD_NO_SETUP_M=1) to rounding, for row counts that are no
+    multiple of 64 or 16, simple bounds in front (image blocks that straddle workgroups), a zero row (IMMUTABLE), the setup_daqp and the
+    daqp_quadprog variants of d; the solves that follow take the reference's path."""
+    import daqp_amd
+    n, m, ms, na = shape
+    N = 5
+    q = O.generate_batch(N, n, m, ms, na, 3100 + n + m)
+    if m - ms > 3:
+        q["A"][1, 2] = 0.0                                # a zero row with 0 inside its bounds: IMMUTABLE, scaling 1
+        q["bupper"][1, ms + 2] = 1.0; q["blower"][1, ms + 2] = -1.0
+    ldps = {}
+    for env in ("0", "1"):
+        monkeypatch.setenv("DAQP_AMD_NO_SETUP_M", env)
+        for mask in (0, 64 + 128):
+            bm = daqp_amd.BatchModel(N, n, m, ms)
+            bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=mask)
+            assert (bm.setup_flags() == 1).all()
+            ldps[env, mask] = [bm.read_ldp(k) for k in range(N)]
+            g = bm.solve()
+            if mask:
+                ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+                assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4]), (env, mask)
+                assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1])) and np.abs(g["x"] - ref[0]).max() < XTOL
+            bm.close()
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        Mo, Ro, vo, duo, dlo, sco = om.ldp()
+        for env in ("0", "1"):
+            M, R, v, du, dl, sc = ldps[env, 0][k]
+            assert np.abs(M - Mo).max() < 1e-13 and np.abs(sc - sco).max() < 1e-12 * np.abs(sco).max(), (env, k)
+            assert np.abs(du - duo).max() < 1e-11 and np.abs(dl - dlo).max() < 1e-11, (env, k)
+        for mask in (0, 192):
+            a, b_ = ldps["0", mask][k], ldps["1", mask][k]
+            assert np.abs(a[0] - b_[0]).max() < 1e-13 and np.abs(a[3] - b_[3]).max() < 1e-11 and np.abs(a[5] - b_[5]).max() < 1e-12 * np.abs(b_[5]).max(), (mask, k)
+    monkeypatch.setenv("DAQP_AMD_NO_SETUP_M", "0")
+    # an infeasible zero row, and a problem whose unconstrained optimum is feasible (the shortcut: one iteration, no multipliers)
+    if m - ms > 3:
+        q2 = {kk: vv.copy() for kk, vv in q.items()}
+        q2["A"][3, 1] = 0.0; q2["bupper"][3, ms + 1] = -1.0; q2["blower"][3, ms + 1] = -2.0
+        q2["bupper"][4] = 1e6; q2["blower"][4] = -1e6
+        g = daqp_amd.solve_batch(q2["H"], q2["f"], q2["A"], q2["bupper"], q2["blower"], None, ms=ms)
+        ref = oracle.quadprog_batch(q2["H"], q2["f"], q2["A"], q2["bupper"], q2["blower"], None, ms=ms)
+        assert ref[3][3] == -1 and ref[3][4] == 1 and ref[4][4] == 1
+        assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4])
+        assert np.abs(g["x"][4] - ref[0][4]).max() < XTOL and not g["lam"][4].any()

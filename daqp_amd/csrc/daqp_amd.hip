@@ -755,7 +755,9 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     if (b->NB == 0 && cap > 64 && cap <= 256 && !getenv("DAQP_AMD_NO_WG")) {     // (beyond 256 rows: the one-wave kernel with eight chunks, everything large in HBM scratch)
         int W = d.nblk < 4 ? 4 : (d.nblk > kWgMaxWaves ? kWgMaxWaves : d.nblk);
         if (const char *we = getenv("DAQP_AMD_WG_WAVES")) { const int v = atoi(we); if (v >= 4 && v <= kWgMaxWaves) W = v; }
-        const int lds_max = 160 * 1024 - 256;          // (the kernel's few static words come on top of the dynamic allocation)
+        const int lds_max = 160 * 1024 - 512;          // (the kernel's static LDS -- 320 bytes by the code generator's report -- comes on top of the
+                                                       //  dynamic allocation: with 256 bytes of reserve a shape whose packed factor ended within 64 bytes
+                                                       //  of the limit, (n, m) = (187, 371), could not be launched at all)
         const int Cw = cap <= 128 ? 2 : 4;
         int capL = cap;
         while (capL > 16 && wg_lds_bytes(Cw, m, capL) > lds_max) --capL;
@@ -849,9 +851,14 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         wg_kernel_t kw = b->wg_C == 2 ? k_ldp_wg<2> : k_ldp_wg<4>;
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kw), 64 * b->wg_W, b->lds_wg) != hipSuccess || per_cu < 1)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg) != hipSuccess) {
+            (void)hipGetLastError();      // (not sticky: the next launch check must not report this)
+            b->use_wg = false;            // the kernel cannot be launched with this much LDS: the one-wave kernel takes the shape
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kw), 64 * b->wg_W, b->lds_wg) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
             per_cu = 1;
+        }
         long long g = (long long)cus * per_cu;
         if (const char *ge = getenv("DAQP_AMD_WG_GRID")) { const long long v = atoll(ge); if (v >= 1) g = v; }   // tuning: problems in flight
         b->wg_grid = (int)(g < N ? g : N);
@@ -1096,6 +1103,10 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
         HIPCHK(hipGetLastError());
     } else if (!lp) {
         d.defer_m = defers_m(b, d) ? 1 : 0;
+        if (d.defer_m) {    // the instantiation without the general rows (k_setup_m follows): more waves per SIMD
+            ks = b->setup_spill ? k_setup<true, 4, true> : k_setup<false, 4, true>;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
+        }
         hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask);
         HIPCHK(hipGetLastError());
         if (d.defer_m) { if (launch_setup_m(b, d)) return DAQP_EXIT_UNSUPPORTED; d.defer_m = 0; }
@@ -1167,6 +1178,10 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
     t.defer_m = defers_m(b, t) ? 1 : 0;
+    if (t.defer_m) {
+        ks = b->setup_spill ? k_setup<true, 4, true> : k_setup<false, 4, true>;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
+    }
     hipLaunchKernelGGL(ks, dim3(1), dim3(64), lds_setup, b->stream, t, mask);
     HIPCHK(hipGetLastError());
     if (t.defer_m) { if (launch_setup_m(b, t)) return DAQP_EXIT_UNSUPPORTED; t.defer_m = 0; }

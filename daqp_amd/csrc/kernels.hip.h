@@ -75,8 +75,15 @@ __host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill, int
 // NBK = 64-column blocks a lane covers (one entry per block and lane): 4 for n <= 256; 8 (n <= 512: the reference's own "large"
 // benchmark ladder goes to n = 500, interfaces/daqp-julia/test/benchmark.jl:38) with half as many rows per group, so that
 // the register footprint of the Cholesky / inverse sweeps stays the same.
-template <bool GS, int NBK = 4>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_setup(BatchDev b, int mask)
+#ifndef DAQP_AMD_SETUP_DEFER_WAVES
+#define DAQP_AMD_SETUP_DEFER_WAVES 2
+#endif
+// DEFER: the instantiation that is followed by k_setup_m (setup_m.hip.h) -- the general rows are compiled out, and with them the A
+// operand of the matrix-core phase.  What is left (Cholesky, inverse, v, simple bounds) is latency-bound per wave, but it does NOT
+// fit the register budget of a third wave per SIMD: at 168 registers the sweeps' row groups spill (125 registers, 196 bytes of
+// scratch) and the launch takes 2.3x as long (measured on config C4: 39.0 ms against 17.0 per 4 096 problems) -- two waves it is
+template <bool GS, int NBK = 4, bool DEFER = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP_AMD_SETUP_DEFER_WAVES : 2, DEFER ? DAQP_AMD_SETUP_DEFER_WAVES : 2))) void k_setup(BatchDev b, int mask)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = lane_id();
@@ -456,8 +463,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // matrix instructions that consume them, column tile by column tile, only up to each tile's last row (R^-1 is upper
     // triangular).  Nothing of A is staged in LDS.  The sums are fp64 fused in a different order than the reference's: M agrees
     // to ~1e-16 relative (the exact mode keeps the chain below).
-    const bool defer_m = mfma_m && b.defer_m != 0 && mA > 0;
-    if (flag > 0 && mfma_m && !defer_m) {
+    const bool defer_m = DEFER && mfma_m && b.defer_m != 0 && mA > 0;
+    if (!DEFER && flag > 0 && mfma_m && !defer_m) {
         typedef double v4d __attribute__((ext_vector_type(4)));
         constexpr int KB = 16, NKT = 56;          // n <= 208: 52 k steps (56: whole blocks of eight)
         double *ob = smem + o.tile;               // [16][64] one column block of results on its way to the blocked image
@@ -534,7 +541,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (b.prof && lane == 0) for (int i = 0; i < 3; ++i) b.prof[(size_t)q * 32 + 22 + i] = mp[i];
 #undef MPROF
     }
-    if (flag > 0 && !defer_m) {
+    if ((!DEFER || !defer_m) && flag > 0 && !defer_m) {
         constexpr int KB = kSetupRows;
         const int np2 = round_up(n, 2);
         double *at = smem + o.tile;               // [KB][np2] rows of A

@@ -48,7 +48,7 @@ def test_fast_mode_shapes(oracle, gpu_lib, shape):
     assert np.abs(g["x"] - ref[0]).max() < XTOL
 
 
-@pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (129, 200, 10, 30), (229, 400, 20, 60), (229, 420, 0, 205)])
+@pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (129, 200, 10, 30), (229, 400, 20, 60), (229, 420, 0, 205), (187, 371, 0, 92)])
 def test_fast_mode_workgroup_kernel_shapes(oracle, gpu_lib, shape):
     """the workgroup solve kernel in the default arithmetic: the inverse factor W = L^-1 (CSP / append / delete as matrix-vector
     products over all waves), primal step and Gram column summed in per-wave segments, fp32-screened scan.  The last shape's

@@ -25,7 +25,11 @@ def campaign(exact):
             na = int(rng.integers(5, min(n, m - ms) // 2))
             N = 6
             q = O.generate_batch(N, n, m, ms, na, 900 + s)
-        g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+        try:
+            g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+        except RuntimeError as e:
+            print("FAILED at case", s, (n, m, ms, na), "N", N, e, flush=True)
+            raise
         r = ora.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
         ok = np.array_equal(g["exitflag"], r[3]) and np.array_equal(g["iter"], r[4])
         if exact:

@@ -9,6 +9,8 @@ from oracle import oracle as O
 nC2 = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 nC3 = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 nsh = int(sys.argv[3]) if len(sys.argv) > 3 else 150
+nbig = int(sys.argv[4]) if len(sys.argv) > 4 else 40
+os.environ["DAQP_AMD_NO_RECHECK"] = "1"      # every problem here has an optimum: the default-mode kernels' own verdicts, unassisted
 ora = O.Oracle()
 
 
@@ -43,4 +45,11 @@ for s in range(nsh):
     for exact in (True, False):
         ok = run(f"shape n={n} m={m} ms={ms} na={na}", q, ms, exact)
         allok &= ok
+# shapes of the workgroup kernel / the generic setup with its own M launch (n > 64; working sets beyond 64 rows)
+for s in range(nbig):
+    n = int(rng.integers(65, 209)); m = int(rng.integers(n + 1, min(640, 3 * n + 8))); ms = int(rng.integers(0, min(n, m // 3) + 1))
+    na = int(rng.integers(2, max(3, min(n - 1, (m - ms) // 2, 150))))
+    q = O.generate_batch(6, n, m, ms, na, 9000 + s)
+    for exact in (True, False):
+        allok &= run(f"shape n={n} m={m} ms={ms} na={na}", q, ms, exact)
 print("ALL OK" if allok else "MISMATCHES FOUND")

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
     __shared__ int q_sh;
     __shared__ int m_int[8];       // master -> everybody after the iteration: flag, iterations, na, reuse, sing, lam swapped, overflow
     __shared__ double m_dbl[2];    // fval, soft
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = wg_wave();   // (wave-uniform by construction: say so, or the master's whole body sits in a "divergent" branch)
+    const int wv = wg_wave();   // (wave-uniform by construction: say so, or the master's whole body sits in a "divergent" branch)
     const int n = b.n, m = b.m, cap = b.cap, W = (int)(blockDim.x >> 6);
     WgCtx c;
     c.n = n; c.m = m; c.ms = b.ms; c.cap = cap; c.capL = b.wg_capL; c.npair = b.npair; c.nblk = b.nblk; c.ldr = wg_row_stride(n); c.capT = b.wg_capT;
@@ -27,6 +27,10 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
     const int T = (int)blockDim.x;
 
     for (;;) {
+        // (thread coordinates taken anew, behind an opaque asm, in each part of the loop body: whatever is computed from a kernel-wide
+        //  `tid` -- LDS and HBM addresses of the load / write-back loops below -- is invariant in this loop, gets hoisted out of it and
+        //  then sits in registers across the master's state machine and the workers' command loop: ~40 spilled registers of 267)
+        const int tid = wg_tid(), lane = tid & 63;
         __syncthreads();                       // the previous problem is completely done with LDS
         if (tid == 0) q_sh = atomicAdd(b.wg_counter, 1);
         __syncthreads();
@@ -136,28 +140,29 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
         __syncthreads();
 
         // ---- everybody: outputs and the persistent iterate
+        const int tide = wg_tid();             // (see the top of the loop)
         const int flag = uni(m_int[0]), iters = uni(m_int[1]), na = uni(m_int[2]);
         if (uni(m_int[6])) {            // overflow: nothing of the problem's state in HBM has been touched; the one-wave kernel redoes it
-            if (tid == 0) b.fallback[q] = 1;
+            if (tide == 0) b.fallback[q] = 1;
             continue;
         }
         double *lams = uni(m_int[5]) ? SD(c, lamA) : SD(c, lamB);
         if (mode == 1) {
-            if (tid == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
+            if (tide == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
         } else {
             // ldp2qp_solution (daqp.c:111-139) + daqp_extract_result (api.c:455-495)
             const double *Rq = b.Rinv + qfac * b.rtri, *vq = b.v + (size_t)q * n;
             double *vl = SD(c, mnew);                                    // v staged in LDS (the new-row buffer is free now)
-            for (int i = tid; i < n; i += T) vl[i] = vq[i];
+            for (int i = tide; i < n; i += T) vl[i] = vq[i];
             __syncthreads();
             if (flag > 0) {
-                for (int i = tid; i < n; i += T) SD(c, u)[i] = SD(c, u)[i] - vl[i];
-                for (int i = tid; i < na; i += T) lams[i] *= c.scaling[SI(c, ws)[i]];
+                for (int i = tide; i < n; i += T) SD(c, u)[i] = SD(c, u)[i] - vl[i];
+                for (int i = tide; i < na; i += T) lams[i] *= c.scaling[SI(c, ws)[i]];
             }
             __syncthreads();
             if (flag > 0) {
                 const int diag = qs->diag_h;
-                for (int i = tid; i < n; i += T) {
+                for (int i = tide; i < n; i += T) {
                     const double *row = Rq + roff(i, n);
                     double xi = SD(c, u)[i] * row[i];
                     for (int j = i + 1; j < n; ++j) xi += row[j] * SD(c, u)[j];
@@ -165,14 +170,14 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
                     if (b.x) b.x[(size_t)q * n + i] = xi;
                 }
             } else if (b.x) {
-                for (int i = tid; i < n; i += T) b.x[(size_t)q * n + i] = SD(c, u)[i];
+                for (int i = tide; i < n; i += T) b.x[(size_t)q * n + i] = SD(c, u)[i];
             }
             if (b.lam) {
-                for (int i = tid; i < m; i += T) b.lam[(size_t)q * m + i] = 0;
+                for (int i = tide; i < m; i += T) b.lam[(size_t)q * m + i] = 0;
                 __syncthreads();
-                for (int i = tid; i < na; i += T) b.lam[(size_t)q * m + SI(c, ws)[i]] = lams[i];
+                for (int i = tide; i < na; i += T) b.lam[(size_t)q * m + SI(c, ws)[i]] = lams[i];
             }
-            if (tid == 0) {
+            if (tide == 0) {
                 double fv = m_dbl[0];
                 for (int i = 0; i < n; ++i) { const double vi = vl[i]; fv -= vi * vi; }
                 fv *= 0.5;
@@ -182,18 +187,18 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
                 qs->iterations = iters; qs->exitflag = flag; qs->need_activate = 0;
             }
         }
-        for (int i = tid; i < cap; i += T) {
+        for (int i = tide; i < cap; i += T) {
             gv[i] = SD(c, D)[i]; gv[cap + i] = SD(c, xl)[i]; gv[2 * cap + i] = SD(c, zl)[i];
             gv[3 * cap + i] = SD(c, lamA)[i]; gv[4 * cap + i] = SD(c, lamB)[i];
             gws[i] = (i < na) ? SI(c, ws)[i] : -1;
         }
-        for (int i = tid; i < m; i += T) gsense[i] = SI(c, sense)[i];
+        for (int i = tide; i < m; i += T) gsense[i] = SI(c, sense)[i];
         {
             const int used = tri(na);
             double *gL = b.L + (size_t)q * b.ltri;
-            for (int e = tid; e < used; e += T) gL[e] = SDL(c)[e];
+            for (int e = tide; e < used; e += T) gL[e] = SDL(c)[e];
         }
-        if (tid == 0) {
+        if (tide == 0) {
             qs->n_active = na; qs->reuse_ind = m_int[3]; qs->sing_ind = m_int[4];
             qs->lam_swapped = m_int[5];
             qs->fval = m_dbl[0]; qs->soft_slack = m_dbl[1];

@@ -22,6 +22,13 @@
 
 namespace daqp_amd {
 
+// 16-byte loads in flight per lane in the feasibility scans.  16, measured on C4 (profiles/r04d_scan_depth.txt): 21.2 k cycles per scan at 32,
+// 18.2 k at 16, 19.4 k at 8 -- the stream runs at what a CU's miss path delivers either way (~30 B/clk), and 64 fewer registers in
+// flight take the spills out of the phases around it
+#ifndef DAQP_WG_SCAN_DEPTH
+#define DAQP_WG_SCAN_DEPTH 16
+#endif
+
 enum : int { WG_EXIT = 0, WG_PRIMAL = 1, WG_SCAN = 2, WG_FETCH_GRAM = 3, WG_COMPACT = 4, WG_SCAN32 = 5, WG_WCSP = 6, WG_WAPPEND = 7, WG_WDELETE = 8, WG_W2L = 9 };
 
 // LDS layout for working sets of up to 64*C rows.  Everything but the packed L sits at COMPILE-TIME offsets (vectors sized
@@ -71,6 +78,7 @@ __device__ __forceinline__ int wg_lane() { return wg_tid() & 63; }
 // substitution chains).  Anything that steers control flow or indexes a cross-lane read goes through these first.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool ub(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
+__device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ double und(double v)
 {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -221,7 +229,7 @@ __device__ __forceinline__ void wg_scan(const WgCtx &c, double primal_tol)
     const double2 *u2 = reinterpret_cast<const double2 *>(SD(c, u));
     const bool odd = (n & 1) != 0;
     const int full = odd ? c.npair - 1 : c.npair;
-    constexpr int DEPTH = 32;   // 16-byte loads in flight per lane: 32 KiB per wave (two waves per SIMD leave 256 registers)
+    constexpr int DEPTH = DAQP_WG_SCAN_DEPTH;   // 16-byte loads in flight per lane
     // candidate of row r given mu = M_r . u (auxiliary.c:126-150)
     auto consider = [&](int r, double mu, double du, double dl, double sc) __attribute__((always_inline)) {
         const int sn = SI(c, sense)[r];
@@ -291,12 +299,76 @@ __device__ __forceinline__ void wg_scan(const WgCtx &c, double primal_tol)
 // threshold by more than E, and otherwise runs the fp64 scan above.  Each wave leaves in LDS: its best value s1 (as the
 // fp64 scan's candidate value, du - mu or mu - dl), row, side, the runner-up value s2, the smallest margin to the threshold
 // over its rows, the winner's own margin and side gap, and whether anything was not finite.
+#ifndef DAQP_WG_SCAN_U_REGS
+#define DAQP_WG_SCAN_U_REGS 1
+#endif
+#if DAQP_WG_SCAN_U_REGS
+// u is read as FOUR fp32 registers per lane (column lane + 64 i; zero from n on) and a product's u operand is a scalar read out of a
+// register (v_readlane with a constant lane), not a broadcast read of LDS: no fp32 copy of u to publish, no barrier before the stream,
+// and no second set of 16-byte temporaries next to the loads in flight (the LDS reads of a batch were hoisted above its arithmetic:
+// as many registers again as the batch itself).  Every load is "uniform base + lane": the block's start and the quad's offset are
+// scalars (and told so with readfirstlane: inside the loops the addresses otherwise become sixteen per-lane pointer induction
+// variables), the lane's 16 bytes a 32-bit offset shared by all loads of the pass.
+template <int C>
+__device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol)
+{
+    const int wv = wg_wave(), lane = wg_lane(), n = c.n;
+    const unsigned lane_u = (unsigned)lane;
+    constexpr int DEPTH = 16;                               // 16-byte loads in flight per lane = the 64 columns one register of u covers
+    const int blk0 = (wv + c.W - 1) % c.W;                  // (wave 0, the master, takes its blocks last)
+    float4 mm[DEPTH];
+    const float4 *M4 = reinterpret_cast<const float4 *>(c.M32);
+    auto load_batch = [&](int blk, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q) {
+            const int tt = (t + q < c.nquad) ? t + q : c.nquad - 1;
+            const int off = uni((blk * c.nquad + tt) * 64);
+            mm[q] = (M4 + off)[lane_u];
+        }
+    };
+    // the image does not depend on u: the first batch of this wave's first block goes out BEFORE u is read
+    if (blk0 < c.nblk) load_batch(blk0, 0);
+    float U[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int j = lane + 64 * i; U[i] = (j < n) ? (float)SD(c, u)[j] : 0.0f; }
+    const double ep = -primal_tol;
+    double s1 = DAQP_INF, s2 = DAQP_INF, minq = DAQP_INF, q1 = DAQP_INF, gap1 = 0.0;
+    int i1 = kBig, up1 = 0, bad = 0;
+    for (int blk = blk0; blk < c.nblk; blk += c.W) {
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int b = 0; DEPTH * b < c.nquad; ++b) {
+            if (blk != blk0 || b != 0) load_batch(blk, DEPTH * b);
+            const float ub = (b == 0) ? U[0] : ((b == 1) ? U[1] : ((b == 2) ? U[2] : U[3]));
+            // (a quad repeated past the end of the row meets u = 0: columns >= n)
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) {
+                a0 = __builtin_fmaf(mm[q].x, rlf(ub, 4 * q), a0); a1 = __builtin_fmaf(mm[q].y, rlf(ub, 4 * q + 1), a1);
+                a2 = __builtin_fmaf(mm[q].z, rlf(ub, 4 * q + 2), a2); a3 = __builtin_fmaf(mm[q].w, rlf(ub, 4 * q + 3), a3);
+            }
+        }
+        const double mu = (double)((a0 + a1) + (a2 + a3));
+        const int r = blk * 64 + lane;
+        if (r < c.m) {                                      // (the row's bounds: after the stream, they are not what the pass waits for)
+            const int sn = SI(c, sense)[r];
+            if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
+                const double du = c.dupper[r], dl = c.dlower[r], sc = c.scaling[r];
+                if (!(mu - mu == 0.0)) bad = 1;
+                const double cu = du - mu, cl = mu - dl;
+                const bool isup = cu <= cl;
+                const double s = isup ? cu : cl, q = s - ep * sc, gap = isup ? cl - cu : cu - cl;
+                if (q < minq) minq = q;
+                if (s < s1) { s2 = s1; s1 = s; i1 = r; up1 = isup ? 1 : 0; q1 = q; gap1 = gap; }
+                else if (s < s2) s2 = s;
+            }
+        }
+    }
+#else
 template <int C>
 __device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol)
 {
     const int wv = wg_wave(), lane = wg_lane(), n = c.n;
     float *u32 = reinterpret_cast<float *>(SD(c, red));     // the reduction area is idle during a scan
-    constexpr int DEPTH = 32;   // 16-byte loads in flight per lane
+    constexpr int DEPTH = DAQP_WG_SCAN_DEPTH;   // 16-byte loads in flight per lane
     const int blk0 = (wv + c.W - 1) % c.W;                  // (wave 0, the master, takes its blocks last)
     float4 mm[DEPTH];
     // the image does not depend on u: the first batch of this wave's first block goes out BEFORE u is converted and published --
@@ -353,6 +425,7 @@ __device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol)
             }
         }
     }
+#endif
     // the wave's best, runner-up and smallest margin
     double bv = s1;
     int bi = i1, aux = lane;

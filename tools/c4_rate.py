@@ -6,6 +6,7 @@ import torch, daqp_amd
 from oracle import oracle as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 n, m, ms, na, seed, _ = O.CONFIGS["C4"]
+na = int(os.environ.get("C4_NA", na))      # (experiments: fewer rows active at the optimum -> smaller working sets)
 from daqp_amd.synthetic import generate_batch_torch
 q = generate_batch_torch(N, n, m, ms, na, seed=seed)
 qn = {k: q[k][:16].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}

@@ -326,28 +326,27 @@ __device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol)
             mm[q] = (M4 + off)[lane_u];
         }
     };
+    // Whole 64-row blocks, one per wave and round, as far as they come out even (nfull = the largest multiple of W); the blocks left
+    // over -- two of C4's ten -- are cut by 64-column batches over ALL waves (DAQP_WG_SCAN_SPLIT): a wave streams at ~6 B/clk whatever
+    // its depth, so a scan lasts as long as its busiest wave, and with two waves on a second block the other six had nothing in flight
+    // for the second half of it.  The batches' partial sums meet in LDS (red), in batch order.
+#ifndef DAQP_WG_SCAN_SPLIT
+#define DAQP_WG_SCAN_SPLIT 1
+#endif
+    const int nb = (c.nquad + DEPTH - 1) / DEPTH;           // batches per block (<= 4)
+    const int nfull = DAQP_WG_SCAN_SPLIT ? (c.nblk / c.W) * c.W : c.nblk;
+    const int nunits = (c.nblk - nfull) * nb;               // (block, batch) pieces of the left-over blocks
+    float *part = reinterpret_cast<float *>(SD(c, red));    // [unit][64]; the reduction area is idle during a scan
     // the image does not depend on u: the first batch of this wave's first block goes out BEFORE u is read
-    if (blk0 < c.nblk) load_batch(blk0, 0);
+    if (blk0 < nfull) load_batch(blk0, 0);
     float U[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int j = lane + 64 * i; U[i] = (j < n) ? (float)SD(c, u)[j] : 0.0f; }
     const double ep = -primal_tol;
     double s1 = DAQP_INF, s2 = DAQP_INF, minq = DAQP_INF, q1 = DAQP_INF, gap1 = 0.0;
     int i1 = kBig, up1 = 0, bad = 0;
-    for (int blk = blk0; blk < c.nblk; blk += c.W) {
-        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int b = 0; DEPTH * b < c.nquad; ++b) {
-            if (blk != blk0 || b != 0) load_batch(blk, DEPTH * b);
-            const float ub = (b == 0) ? U[0] : ((b == 1) ? U[1] : ((b == 2) ? U[2] : U[3]));
-            // (a quad repeated past the end of the row meets u = 0: columns >= n)
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) {
-                a0 = __builtin_fmaf(mm[q].x, rlf(ub, 4 * q), a0); a1 = __builtin_fmaf(mm[q].y, rlf(ub, 4 * q + 1), a1);
-                a2 = __builtin_fmaf(mm[q].z, rlf(ub, 4 * q + 2), a2); a3 = __builtin_fmaf(mm[q].w, rlf(ub, 4 * q + 3), a3);
-            }
-        }
-        const double mu = (double)((a0 + a1) + (a2 + a3));
-        const int r = blk * 64 + lane;
+    auto ubatch = [&](int b) __attribute__((always_inline)) { return (b == 0) ? U[0] : ((b == 1) ? U[1] : ((b == 2) ? U[2] : U[3])); };
+    auto consider = [&](int r, double mu) __attribute__((always_inline)) {
         if (r < c.m) {                                      // (the row's bounds: after the stream, they are not what the pass waits for)
             const int sn = SI(c, sense)[r];
             if (!(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE))) {
@@ -360,6 +359,40 @@ __device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol)
                 if (s < s1) { s2 = s1; s1 = s; i1 = r; up1 = isup ? 1 : 0; q1 = q; gap1 = gap; }
                 else if (s < s2) s2 = s;
             }
+        }
+    };
+    for (int blk = blk0; blk < nfull; blk += c.W) {
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int b = 0; b < nb; ++b) {
+            if (blk != blk0 || b != 0) load_batch(blk, DEPTH * b);
+            const float ub = ubatch(b);
+            // (a quad repeated past the end of the row meets u = 0: columns >= n)
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) {
+                a0 = __builtin_fmaf(mm[q].x, rlf(ub, 4 * q), a0); a1 = __builtin_fmaf(mm[q].y, rlf(ub, 4 * q + 1), a1);
+                a2 = __builtin_fmaf(mm[q].z, rlf(ub, 4 * q + 2), a2); a3 = __builtin_fmaf(mm[q].w, rlf(ub, 4 * q + 3), a3);
+            }
+        }
+        consider(blk * 64 + lane, (double)((a0 + a1) + (a2 + a3)));
+    }
+    if (nunits > 0) {
+        for (int j = wv; j < nunits; j += c.W) {
+            const int blk = nfull + j / nb, b = j % nb;
+            load_batch(blk, DEPTH * b);
+            const float ub = ubatch(b);
+            float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) {
+                a0 = __builtin_fmaf(mm[q].x, rlf(ub, 4 * q), a0); a1 = __builtin_fmaf(mm[q].y, rlf(ub, 4 * q + 1), a1);
+                a2 = __builtin_fmaf(mm[q].z, rlf(ub, 4 * q + 2), a2); a3 = __builtin_fmaf(mm[q].w, rlf(ub, 4 * q + 3), a3);
+            }
+            part[j * 64 + lane] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        for (int l = wv; l < c.nblk - nfull; l += c.W) {    // a left-over block's rows: its batches' sums in batch order
+            float mu = part[(l * nb) * 64 + lane];
+            for (int b = 1; b < nb; ++b) mu += part[(l * nb + b) * 64 + lane];
+            consider((nfull + l) * 64 + lane, (double)mu);
         }
     }
 #else

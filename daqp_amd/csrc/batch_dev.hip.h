@@ -30,6 +30,7 @@ struct BatchDev {
     double *setup_g;   // [N][2*rtri] only when the setup factors spill out of LDS
     double *setup_sq;  // [N][round_up(n,32)][round_up(n,16)] generic setup, default mode: R^-1 as a zero-padded square (the matrix cores' B operand)
     int defer_m;       // 1: k_setup leaves the general rows (M = A R^-1, normalisation, d, images) to k_setup_m, launched right behind it
+    double *fact;      // [N][4] k_fact_wg (setup_fact.hip.h) ran in front of k_setup: {1 = R^-1 is in setup_g / setup_sq already, smallest pivot, largest pivot}, or null
     int *m_tick;       // [N] k_setup_m: per problem, workgroups done and how many of them saw what (one word, zero between setups)
     // outputs
     double *x, *lam, *fval, *soft;

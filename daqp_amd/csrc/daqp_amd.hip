@@ -19,6 +19,7 @@
 #include "prox.hip.h"
 #include "recheck.hip.h"
 #include "setup_m.hip.h"
+#include "setup_fact.hip.h"
 #include "wg_layout.hip.h"
 #ifdef DAQP_AMD_WITH_TINY
 #include "tiny_kernel.hip.h"
@@ -124,6 +125,7 @@ struct DAQPBatch {
     int tiny_grid = 1024; // persistent waves of that kernel: 4 per CU
     bool tiny_setup = false;   // n <= 12, m <= 48: the 16-problems-per-wave setup kernel (tiny_setup.hip.h)
     bool fast_setup = false, setup_spill = false;
+    double *fact_buf = nullptr;     // [N][4] records of k_fact_wg (setup_fact.hip.h), allocated for the shapes it serves
     // workgroup-per-problem solve kernel (wg_kernel.hip.h): shapes without a register variant and more than 64 working-set rows
     bool in_prox_loop = false;      // launches of the proximal outer loop (solve_with_prox)
     bool use_wg = false;
@@ -810,6 +812,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         rc |= dev_alloc(b, &d.setup_sq, sq);
         if (!rc) HIPCHK(hipMemset(d.setup_sq, 0, sq * sizeof(double)));
         rc |= dev_alloc(b, &d.m_tick, Nn);
+        if (b->setup_spill && n <= kFactMaxN && !getenv("DAQP_AMD_NO_FACT_WG")) rc |= dev_alloc(b, &b->fact_buf, Nn * 4);
         if (!rc) HIPCHK(hipMemset(d.m_tick, 0, Nn * sizeof(int)));
     }
     if (N == 1) {   // one slab: x[n] lam[m] fval soft | flag iter  -> one device->host copy per solve
@@ -1106,6 +1109,17 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
         if (d.defer_m) {    // the instantiation without the general rows (k_setup_m follows): more waves per SIMD
             ks = b->setup_spill ? k_setup<true, 4, true> : k_setup<false, 4, true>;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
+        }
+        // default arithmetic, factors out of LDS (the n = 200 class): Cholesky and inverse by k_fact_wg, a workgroup per problem with
+        // the triangle in LDS and the matrix cores behind each panel (setup_fact.hip.h); k_setup takes R^-1 from the scratch
+        d.fact = nullptr;
+        if (d.defer_m && b->setup_spill && b->fact_buf && d.n <= kFactMaxN && !(d.st.eps_prox > 0.0)) {
+            const size_t lds = fact_lds_bytes(d.n);
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fact_wg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+                d.fact = b->fact_buf;
+                hipLaunchKernelGGL(k_fact_wg, dim3(d.N), dim3(512), lds, b->stream, d);
+                HIPCHK(hipGetLastError());
+            } else (void)hipGetLastError();
         }
         hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask);
         HIPCHK(hipGetLastError());

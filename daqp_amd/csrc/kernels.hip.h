@@ -151,7 +151,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
     // Row i: lane <-> column j, k-ordered subtraction chain kept in a register.
     double pmin = DAQP_INF, pmax = 0.0;
     int diag = 0;   // H diagonal: the reference's RinvD branch (utils.c:245-312), as in k_setup_fast
-    if (flag > 0) {
+    // default arithmetic, 64 < n <= 200: k_fact_wg (setup_fact.hip.h: a workgroup per problem, the triangle in LDS, matrix cores) has
+    // factored and inverted already -- R^-1 sits in the scratch and in the square image, the record carries the pivots' range
+    bool factored = false;
+    if constexpr (GS) {
+        if (b.fact != nullptr && !pp) {
+            const double *rec = b.fact + (size_t)q * 4;
+            factored = __builtin_amdgcn_readfirstlane((int)rec[0]) != 0;
+            if (factored) { pmin = rec[1]; pmax = rec[2]; }
+        }
+    }
+    if (flag > 0 && !factored) {
         int offd = 0;
         for (int e = lane; e < n * n; e += 64) {
             const int i = e / n, j = e - i * n;
@@ -193,7 +203,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
         }
     }
     GPROF(0);
-    if (flag > 0 && !diag) {
+    if (flag > 0 && factored && pmin <= st.zero_tol * pmax) flag = shift_code;   // utils.c:354-356
+    if (flag > 0 && !diag && !factored) {
         for (int e0 = lane; e0 < n * n; e0 += 64 * 8) {   // 16 loads per lane per trip (H and its transpose), then the stores
             double h1[8], h2[8];
             int ii[8], jj[8];
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
     // chains are independent: each hides the other's broadcast latency).  Every entry still receives its terms in
     // ascending i, as in the reference.
     if (flag > 0) {
-      if (!diag) {
+      if (!diag && !factored) {
         constexpr int KR = 32 / NBK;
         for (int k0 = 0; k0 < n; k0 += KR) {
             double x[KR][NBK];

@@ -6,6 +6,8 @@
 #include "tiny_setup.hip.h"
 #define DAQP_AMD_SETUP_M_IMPL   // (k_setup_m is not a template: defined in this translation unit, declared where it is launched)
 #include "setup_m.hip.h"
+#define DAQP_AMD_SETUP_FACT_IMPL   // (likewise k_fact_wg)
+#include "setup_fact.hip.h"
 
 namespace daqp_amd {
 #define DAQP_SETUP_SIZE(NMAX) \

@@ -25,7 +25,8 @@ if len(sys.argv) > 2:
     names = ["csp", "ratio test(no block)", "primal", "scan", "add (incl. guard)", "ratio test + drop", "-", "-"]
     sp = pr[:, 16:22].mean(axis=0)
     print("  setup cycles per QP: checks %.0f, Cholesky %.0f, inverse %.0f, v/x_unc + unnormalised M %.0f, normalise + d %.0f, bounds+write-back %.0f | total %.0f" % (*sp, sp.sum()))
-    print("  matrix-core phase: A operand loads %.0f, R^-1 loads + mfma %.0f, blocked stores %.0f" % tuple(pr[:, 22:25].mean(axis=0)))
+    if os.environ.get("DAQP_AMD_NO_FACT_WG"): print("  matrix-core phase: A operand loads %.0f, R^-1 loads + mfma %.0f, blocked stores %.0f" % tuple(pr[:, 22:25].mean(axis=0)))
+    else: print("  k_fact_wg cycles per QP (a workgroup each): load + symmetrise %.0f, Cholesky %.0f, inverse + stores %.0f" % tuple(pr[:, 22:25].mean(axis=0)))
     print("  screening scans per QP %.1f, fp64 re-scans %.2f; per screening scan: master's own part %.0f cycles, its wait for the other waves %.0f" % (pr[:, 25].mean(), pr[:, 26].mean(), pr[:, 27].sum() / pr[:, 25].sum(), pr[:, 28].sum() / pr[:, 25].sum()))
     print("  cycles/iteration:", ", ".join(f"{names[k]} {pr[:, k].sum() / it:.0f}" for k in range(6)), f"| total {pr[:, :6].sum() / it:.0f}")
     if not os.environ.get("DAQP_AMD_NO_WG"):   # workgroup kernel: finer split (the setup kernel's counters sit at [16:22])

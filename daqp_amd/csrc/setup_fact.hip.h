@@ -20,11 +20,35 @@
 namespace daqp_amd {
 
 constexpr int kFactMaxN = 200;        // packed triangle + one 16 x 16 tile of workspace within 160 KB of LDS
-__host__ __device__ inline size_t fact_lds_bytes(int n) { return ((size_t)round_up(n * (n + 1) / 2, 2) + 256) * 8; }
+__host__ __device__ inline size_t fact_lds_bytes(int n) { return ((size_t)round_up(n * (n + 1) / 2, 2) + 256 + 32) * 8; }
 
 __global__ void k_fact_wg(BatchDev b);      // defined once, in setup_kernel.hip (DAQP_AMD_SETUP_FACT_IMPL)
 
 #ifdef DAQP_AMD_SETUP_FACT_IMPL
+// inverse of a 16 x 16 upper-triangular block of the packed triangle (1 / u_ii on its diagonal), ib <= 16 rows valid, into T[16][16]
+// (zero below the diagonal and beyond ib): lane <-> column, the column in registers, U as broadcast reads.  One wave.
+__device__ __forceinline__ void fact_tri_inv16(const double *R, int i0, int ib, int n, double *T, int lane)
+{
+    const int j = lane & 15;
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = 0.0;
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {                  // column j, bottom up: x_i = -(1 / u_ii) sum_{k > i} U[i][k] x_k (x_k = 0 beyond j)
+        if (i < ib) {
+            const int pi = roff(i0 + i, n) + i0;
+            double sacc = 0;
+#pragma unroll
+            for (int k = i + 1; k < 16; ++k) if (k < ib) sacc = __builtin_fma(R[pi + k], x[k], sacc);
+            const double dinv = R[pi + i];
+            x[i] = (j == i) ? dinv : -dinv * sacc;
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[i * 16 + j] = (j < ib) ? x[i] : 0.0;
+    }
+}
 __global__ __launch_bounds__(512) void k_fact_wg(BatchDev b)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -42,15 +66,44 @@ __global__ __launch_bounds__(512) void k_fact_wg(BatchDev b)
 #define FPROF(slot) do { if (b.prof) { const long long t1_ = (long long)__builtin_readcyclecounter(); if (tid == 0) b.prof[(size_t)q * 32 + 22 + (slot)] = t1_ - ft0; ft0 = t1_; } } while (0)
 
     // ---- 1/2 (H + H') into the packed triangle; a diagonal H is k_setup's RinvD branch (utils.c:245-312)
+    // (two passes over the rows of H, both coalesced and sixteen loads deep: the upper part of row i lands in its own places, then --
+    //  behind a barrier -- the lower part of row i is added to column i of the triangle)
     int offd = 0;
-    for (int i = wv; i < n; i += 8) {
-        const int pi = roff(i, n);
-        for (int j = i + lane; j < n; j += 64) {
-            const double h = H[(size_t)i * n + j];
-            if (j > i) {
-                if (h > zt || h < -zt) offd = 1;
-                R[pi + j] = 0.5 * (h + H[(size_t)j * n + i]);
-            } else R[pi + j] = h;
+    for (int i0 = wv; i0 < n; i0 += 32) {                    // four rows per wave and trip, a row as four masked 64-column pieces: sixteen loads in flight
+        double h[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 8 * r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int j = lane + 64 * c; h[r][c] = (i < n && j < n) ? H[(size_t)i * n + j] : 0.0; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 8 * r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = lane + 64 * c;
+                if (i < n && j < n && j >= i) {
+                    if (j > i && (h[r][c] > zt || h[r][c] < -zt)) offd = 1;
+                    R[roff(i, n) + j] = (j > i) ? 0.5 * h[r][c] : h[r][c];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i0 = wv; i0 < n; i0 += 32) {                    // the lower part of row i, halved, onto column i of the triangle
+        double h[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 8 * r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int j = lane + 64 * c; h[r][c] = (i < n && j < i) ? H[(size_t)i * n + j] : 0.0; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 8 * r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int j = lane + 64 * c; if (i < n && j < i) R[roff(j, n) + i] += 0.5 * h[r][c]; }
         }
     }
     if (!__syncthreads_or(offd)) { if (tid == 0) rec[0] = 0.0; return; }
@@ -63,7 +116,7 @@ __global__ __launch_bounds__(512) void k_fact_wg(BatchDev b)
     //   (c) behind the panel, C_IJ -= R12_I' R12_J tile by tile on the matrix cores, all waves.
     double pmin = DAQP_INF, pmax = 0.0;
     bool fail = false;
-    double *piv = T;                                         // [0..15] the panel's pivots, [16] != 0: one of them failed
+    double *piv = T + 256;                                   // [0..15] the panel's pivots, [16] != 0: one of them failed
     for (int K = 0; K < n; K += 16) {
         const int Kend = (K + 16 < n) ? K + 16 : n, kb = Kend - K;
         if (wv == 0) {
@@ -78,7 +131,7 @@ __global__ __launch_bounds__(512) void k_fact_wg(BatchDev b)
                     const double d = rl(c[k], k);
                     if (!(d > zt)) bad = 1.0;
                     if (lane == 0) piv[k] = d;
-                    const double inv = 1 / sqrt(d);
+                    const double inv = rsqrt(d);
                     c[k] = (j == k) ? inv : c[k] * inv;
 #pragma unroll
                     for (int i = k + 1; i < 16; ++i) c[i] = __builtin_fma(-rl(c[k], i), c[k], c[i]);
@@ -89,30 +142,26 @@ __global__ __launch_bounds__(512) void k_fact_wg(BatchDev b)
                 for (int p = 0; p < 16; ++p) if (p <= j && j < kb) R[roff(K + p, n) + K + j] = c[p];
             }
             if (lane == 0) piv[16] = bad;
+            if (Kend < n) fact_tri_inv16(R, K, 16, n, T, lane);      // V = U11^-1 for (b) (this wave's own LDS stores above are in order before these reads)
         }
         __syncthreads();
         if (piv[16] != 0.0) { fail = true; break; }         // (the same word in every thread: a uniform exit; NaN pivots included)
         for (int k = 0; k < kb; ++k) { const double d = piv[k]; if (d < pmin) pmin = d; if (d > pmax) pmax = d; }
         if (Kend >= n) break;
-        {
-            const int j = Kend + tid;
-            if (j < n) {
-                double x[16];
+        const int nbt = (n - Kend + 15) >> 4;
+        for (int t = wv; t < nbt; t += 8) {                  // (b) R12 = V' A12, a sixteen-column tile per wave and trip, in place
+            const int jc = Kend + 16 * t + lr;
+            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int p = 0; p < 16; ++p) x[p] = R[roff(K + p, n) + j];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {               // (a panel with columns behind it is a full one: sixteen rows)
-                    const int pk = roff(K + k, n) + K;
-                    x[k] *= R[pk + k];
-#pragma unroll
-                    for (int i = k + 1; i < 16; ++i) x[i] = __builtin_fma(-R[pk + i], x[k], x[i]);
-                }
-#pragma unroll
-                for (int p = 0; p < 16; ++p) R[roff(K + p, n) + j] = x[p];
+            for (int s = 0; s < 4; ++s) {
+                const double a = T[(4 * s + lk) * 16 + lr];                                  // V'[i][k] = V[k][i]
+                const double bb = (jc < n) ? R[roff(K + 4 * s + lk, n) + jc] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (jc < n) R[roff(K + lk + 4 * r, n) + jc] = acc[r];
         }
         __syncthreads();
-        const int nbt = (n - Kend + 15) >> 4;
         const int ntiles = nbt * (nbt + 1) / 2;
         for (int t = wv; t < ntiles; t += 8) {
             int I = 0, rem = t;
@@ -149,33 +198,20 @@ __global__ __launch_bounds__(512) void k_fact_wg(BatchDev b)
     const int nb = (n + 15) >> 4;
     for (int I = nb - 1; I >= 0; --I) {
         const int i0 = 16 * I, ib = (n - i0 < 16) ? n - i0 : 16;
-        if (wv == 0) {
-            const int j = lane & 15;
-            double x[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) x[i] = 0.0;
-#pragma unroll
-            for (int i = 15; i >= 0; --i) {                  // column j of X_II, bottom up: x_i = -(1 / r_ii) sum_{k > i} R[i][k] x_k (x_k = 0 beyond j)
-                if (i < ib) {
-                    const int pi = roff(i0 + i, n) + i0;
-                    double sacc = 0;
-#pragma unroll
-                    for (int k = i + 1; k < 16; ++k) if (k < ib) sacc = __builtin_fma(R[pi + k], x[k], sacc);
-                    const double dinv = R[pi + i];
-                    x[i] = (j == i) ? dinv : -dinv * sacc;
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) T[i * 16 + j] = (j < ib) ? x[i] : 0.0;
-            }
-        }
+        if (wv == 0) fact_tri_inv16(R, i0, ib, n, T, lane);
         __syncthreads();
-        const int nt = nb - 1 - I;                           // tiles right of the diagonal block: at most two per wave (n <= 200: nb <= 13)
+        // tiles right of the diagonal block: tile t costs t + 1 block products -- wave w takes t = w and, beyond eight tiles, its
+        // mirror nt - 1 - w (n <= 200: nb <= 13, nt <= 12), so that every wave's pair costs nt + 1
+        const int nt = nb - 1 - I;
         v4d out0 = (v4d){0.0, 0.0, 0.0, 0.0}, out1 = (v4d){0.0, 0.0, 0.0, 0.0};
+        auto tile_of = [&](int u) __attribute__((always_inline)) {
+            if (nt <= 8) return (u == 0 && wv < nt) ? wv : -1;
+            if (u == 0) return wv < (nt + 1) / 2 ? wv : -1;
+            return (wv < nt / 2) ? nt - 1 - wv : -1;
+        };
         for (int u = 0; u < 2; ++u) {
-            const int t = wv + 8 * u;
-            if (t >= nt) break;
+            const int t = tile_of(u);
+            if (t < 0) continue;
             const int J = I + 1 + t, j0 = 16 * J, jc = j0 + lr;
             v4d s4 = (v4d){0.0, 0.0, 0.0, 0.0};
             const int ia = i0 + lr;
@@ -197,8 +233,8 @@ __global__ __launch_bounds__(512) void k_fact_wg(BatchDev b)
         }
         __syncthreads();
         for (int u = 0; u < 2; ++u) {
-            const int t = wv + 8 * u;
-            if (t >= nt) break;
+            const int t = tile_of(u);
+            if (t < 0) continue;
             const int jc = 16 * (I + 1 + t) + lr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -225,3 +225,58 @@ def test_general_rows_as_their_own_launch(oracle, gpu_lib, monkeypatch, shape):
         assert ref[3][3] == -1 and ref[3][4] == 1 and ref[4][4] == 1
         assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4])
         assert np.abs(g["x"][4] - ref[0][4]).max() < XTOL and not g["lam"][4].any()
+
+
+@pytest.mark.parametrize("shape", [(200, 600, 0, 80), (200, 480, 12, 60), (193, 300, 0, 40), (176, 520, 0, 50), (161, 610, 5, 30)])
+def test_factorisation_as_its_own_launch(oracle, gpu_lib, monkeypatch, shape):
+    """k_fact_wg (csrc/setup_fact.hip.h): Cholesky factor and inverse of the generic setup for the shapes whose factors do not fit
+    LDS twice (the n = 200 class), default arithmetic -- a workgroup per problem, the packed triangle in LDS, sixteen-row panels, the
+    rank-16 updates and the inverse's block products on the matrix cores.  R^-1, v, M, d equal the reference's to rounding and k_setup's
+    own ordered factorisation (DAQP_AMD_NO_FACT_WG=1) to rounding, for n that is and is not a multiple of sixteen; the solves take the
+    reference's path.  What the kernel gives up on goes to k_setup's own code and ends with the reference's verdict: a diagonal
+    Hessian (the RinvD branch), an indefinite one (-5 with eps_prox = 0) and a numerically singular one (the regularising passes)."""
+    import daqp_amd
+    n, m, ms, na = shape
+    N = 6
+    q = O.generate_batch(N, n, m, ms, na, 4100 + n + m)
+    ldps, sols = {}, {}
+    for env in (None, "1"):
+        if env: monkeypatch.setenv("DAQP_AMD_NO_FACT_WG", env)
+        else: monkeypatch.delenv("DAQP_AMD_NO_FACT_WG", raising=False)
+        bm = daqp_amd.BatchModel(N, n, m, ms)
+        bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=64 + 128)
+        assert (bm.setup_flags() == 1).all()
+        ldps[env] = [bm.read_ldp(k) for k in range(N)]
+        sols[env] = bm.solve()
+        bm.close()
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    for env in (None, "1"):
+        g = sols[env]
+        assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4]), env
+        assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1])) and np.abs(g["x"] - ref[0]).max() < XTOL
+    differs = False
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None, init_mask=64 + 128)
+        Mo, Ro, vo, duo, dlo, sco = om.ldp()
+        M, R, v, du, dl, sc = ldps[None][k]
+        assert np.abs(R - Ro).max() < 1e-13 * np.abs(Ro).max() and np.abs(v - vo).max() < 1e-12 * max(1.0, np.abs(vo).max()), k
+        assert np.abs(M - Mo).max() < 1e-13 and np.abs(sc - sco).max() < 1e-12 * np.abs(sco).max(), k
+        assert np.abs(du - duo).max() < 1e-10 and np.abs(dl - dlo).max() < 1e-10, k
+        assert np.array_equal(ldps["1"][k][1], Ro), k          # k_setup's own factorisation is the reference's, bit for bit
+        differs |= not np.array_equal(R, Ro)
+    assert differs                                             # (the new kernel did run: another summation order leaves other last bits)
+    monkeypatch.delenv("DAQP_AMD_NO_FACT_WG", raising=False)
+    # what the kernel gives up on
+    q2 = {kk: vv.copy() for kk, vv in q.items()}
+    q2["H"][1] = np.diag(np.diag(q["H"][1]))                     # diagonal
+    ev = np.linalg.eigvalsh(q["H"][2])
+    q2["H"][2] = q["H"][2] - 1.5 * ev[0] * np.eye(n)             # indefinite: a negative pivot
+    U = np.linalg.qr(np.random.default_rng(5).standard_normal((n, n)))[0]
+    q2["H"][3] = (U[:, : n - 3] * np.linspace(1.0, 2.0, n - 3)) @ U[:, : n - 3].T    # rank n - 3: the proximal loop
+    for eps in (0.0, -1e-6):
+        g = daqp_amd.solve_batch(q2["H"], q2["f"], q2["A"], q2["bupper"], q2["blower"], None, ms=ms, eps_prox=eps)
+        r = oracle.quadprog_batch(q2["H"], q2["f"], q2["A"], q2["bupper"], q2["blower"], None, settings=O.default_settings(eps_prox=eps), ms=ms)
+        assert np.array_equal(g["exitflag"], r[3]), (eps, g["exitflag"], r[3])
+        ok = r[3] > 0
+        assert np.array_equal(g["iter"][ok], r[4][ok]) and np.abs(g["x"][ok] - r[0][ok]).max() < 1e-7 * max(1.0, np.abs(r[0][ok]).max())

@@ -433,7 +433,7 @@ int launch_setup_m(DAQPBatch *b, const BatchDev &d)
     const int nrb = (d.mA + kSetupMRows - 1) / kSetupMRows;
     const size_t lds = (size_t)setup_m_lds().total_bytes;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_setup_m), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_setup_m, dim3((unsigned)((size_t)d.N * nrb)), dim3(256), lds, b->stream, d, nrb);
+    hipLaunchKernelGGL(k_setup_m, dim3((unsigned)((size_t)((d.N + 7) / 8) * nrb * 8)), dim3(256), lds, b->stream, d, nrb);   // (whole groups of eight problems: the XCD-aware mapping in the kernel)
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -43,7 +43,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     typedef double v4d __attribute__((ext_vector_type(4)));
-    const int q = blockIdx.x / nrb, rb = blockIdx.x - q * nrb;
+    // blockIdx -> (problem, row block), XCD-aware: workgroups are dealt round-robin over the eight XCDs (blockIdx mod 8), each with an L2
+    // of its own, so the nrb workgroups of ONE problem are given block indices that are congruent mod 8 -- they run on one XCD, one
+    // after the other, and R^-1 (every one of them streams it) comes from HBM / MALL once and from that L2 nrb - 1 times.  Dealt
+    // consecutively (q = blockIdx / nrb) the ten workgroups of a C4 problem sat on eight XCDs and fetched it eight times.
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+    const int q = xcd + 8 * (slot / nrb), rb = slot % nrb;
+    if (q >= b.N) return;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = b.n, m = b.m, ms = b.ms, mA = b.mA;
     QState *qs = b.qs + q;

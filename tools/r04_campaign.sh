@@ -5,4 +5,4 @@ O=gpurun_out/${1:-r04p}; mkdir -p $O
 timeout 2400 python tools/parity_campaign.py 100000 200000 300 60 > $O/parity_campaign.txt 2>&1
 timeout 1200 python tools/large_shapes.py > $O/large_shapes.txt 2>&1
 timeout 1200 python tools/prox_campaign.py > $O/prox_campaign.txt 2>&1
-tail -2 $O/parity_campaign.txt $O/large_shapes.txt $O/prox_campaign.txt
+for f in parity_campaign large_shapes prox_campaign; do tail -n 2 $O/$f.txt; done

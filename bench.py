@@ -29,14 +29,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 VALU_PEAK_GCYC = 1024 * 2.4  # 256 CUs x 4 SIMDs x 2.4 GHz: G SIMD-cycles/s in which a vector pipe can be issuing (same guide)
 # what binds each configuration's solve launch (counters in profiles/r*_pmc_summary.json)
-BOUND = {"C2": "issue", "C3": "issue", "C4": "cu-miss-path", "C5": "issue"}
+BOUND = {"C2": "issue", "C3": "issue", "C4": "hbm", "C5": "issue"}
 BOUND_IS = {
     "issue": "instruction issue: M and the iterate are register-resident, HBM sees a few percent of the algorithmic bytes. achieved = VALU-busy "
              "SIMD-cycles of the launch (4 x SQ_ACTIVE_INST_VALU, committed counter pass of this library build) / launch time (HIP events, this run); "
              "peak = 1024 SIMDs x 2.4 GHz",
-    "cu-miss-path": "each CU's own miss path (~30 B/clk from L2/MALL/HBM in the scan / primal / Gram phases) plus the master wave's serial phases; "
-                    "frac is quoted on the same issue roof as the other configurations (VALU-busy SIMD-cycles / launch time / (1024 SIMDs x 2.4 GHz)), "
-                    "the HBM side's utilisation is traffic_frac",
+    "hbm": "the memory system: the scan (an fp32 image of M per iteration), the primal step and the Gram column (every active row, twice per iteration) "
+           "stream through each CU's vector-memory path while all 256 CUs do the same.  achieved = HBM-side bytes of the launch (FETCH_SIZE x 2 + "
+           "WRITE_SIZE of the committed counter pass of this library build) / launch time (HIP events, this run); peak = 8 TB/s.  The issue roof of the "
+           "other configurations is quoted under `issue`",
 }
 
 # name -> (n, m, ms, active at the optimum, QPs per GPU (weak) / in total (strong), description)
@@ -390,7 +391,8 @@ class Runner:
                          "fraction of a roof.  The HBM side's real utilisation is traffic_frac"}
         roof = {"bound": BOUND[cfg], "bound_is": BOUND_IS[BOUND[cfg]],
                 "kernel": "solve launch (dual active-set iteration + back-transform" + (", fused UPDATE_v" if warm else "") + ")",
-                "achieved": None, "peak": VALU_PEAK_GCYC, "unit": "G VALU-busy SIMD-cycles/s", "frac": None,
+                "achieved": None, "peak": HBM_PEAK_GBS if BOUND[cfg] == "hbm" else VALU_PEAK_GCYC,
+                "unit": "GB/s" if BOUND[cfg] == "hbm" else "G VALU-busy SIMD-cycles/s", "frac": None,
                 "avg_launch_ms": t_ldp * 1e3, "traffic": None, "hbm_effective": hbm_eff,
                 # the step time against B_io alone (inputs + outputs of the step): what is left of an HBM bound if M stays on chip
                 "floor_frac": io_bytes / max(t_ldp + t_setup, 1e-12) / 1e9 / HBM_PEAK_GBS}
@@ -432,8 +434,12 @@ class Runner:
                 roof["issue"]["achieved_ms"] = t_ldp * 1e3
                 roof["issue"]["frac"] = att / max(t_ldp * 1e3, 1e-12)
                 # VALU-busy cycles of the launch (counter pass) / launch time (this run) against 1024 SIMDs x 2.4 GHz
-                roof["achieved"] = att * 1e-3 * VALU_PEAK_GCYC / max(t_ldp, 1e-12)
-                roof["frac"] = roof["achieved"] / VALU_PEAK_GCYC
+                if BOUND[cfg] == "issue":
+                    roof["achieved"] = att * 1e-3 * VALU_PEAK_GCYC / max(t_ldp, 1e-12)
+                    roof["frac"] = roof["achieved"] / VALU_PEAK_GCYC
+            if BOUND[cfg] == "hbm" and prof.get("traffic"):     # the memory system is the roof: measured HBM-side bytes over the launch time
+                roof["achieved"] = prof["traffic"] / max(t_ldp, 1e-12) / 1e9
+                roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         if cpu_sample > 0 and self.world == 1:
             S = min(N, cpu_sample)
             if warm:

@@ -419,6 +419,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
       }
         GPROF(2);
         // --- v = R^-T f (utils.c:474-497, mask has UPDATE_Rinv: no column scaling)
+        if (factored) {      // k_fact_wg formed it (and x_unc) from the R^-1 it had in LDS
+            for (int i = lane; i < n; i += 64) vv[i] = b.v[(size_t)q * n + i];
+        } else
         for (int ic = 0; ic < n; ic += 64) {
             const int i = ic + lane;
             if (i < n) {
@@ -436,6 +439,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
         for (int i = lane; i < m; i += 64) fixed |= sens[i] & (DAQP_ACTIVE + DAQP_IMMUTABLE);
         if (!__any(fixed)) {
             unc = 1;
+            if (factored) {
+                for (int i = lane; i < n; i += 64) xu[i] = b.xunc[(size_t)q * n + i];
+            } else
             for (int ic = 0; ic < n; ic += 64) {
                 const int i = ic + lane;
                 if (i < n) {

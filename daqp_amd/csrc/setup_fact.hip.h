@@ -19,7 +19,7 @@
 
 namespace daqp_amd {
 
-constexpr int kFactMaxN = 200;        // packed triangle + one 16 x 16 tile of workspace within 160 KB of LDS
+constexpr int kFactMaxN = 200;        // packed triangle + one 16 x 16 tile of workspace (+ 32 doubles: 288 >= n for v) within 160 KB of LDS
 __host__ __device__ inline size_t fact_lds_bytes(int n) { return ((size_t)round_up(n * (n + 1) / 2, 2) + 256 + 32) * 8; }
 
 __global__ void k_fact_wg(BatchDev b);      // defined once, in setup_kernel.hip (DAQP_AMD_SETUP_FACT_IMPL)
@@ -258,6 +258,34 @@ __global__ __launch_bounds__(512) void k_fact_wg(BatchDev b)
         for (int k = wv; k < n; k += 8) {
             const int pk = roff(k, n);
             for (int j = k + lane; j < n; j += 64) Rsq[(size_t)k * sq_ld + j] = R[pk + j];
+        }
+        // v = R^-T f and x_unc = -R^-1 v (utils.c:474-497, 618-662) while R^-1 is still in LDS: inside k_setup a lane walked a column of the
+        // packed factor in HBM term by term -- 1.25 M cycles of a wave per problem for two mat-vecs.  One thread per entry; v goes through
+        // the workspace tile (free now), both land in b.v / b.xunc, where k_setup picks them up (it decides whether x_unc is used).
+        const double *f = b.f + (size_t)q * n;
+        __syncthreads();
+        if (tid < n) T[tid] = f[tid];                        // (f through the tile first, then v in its place)
+        __syncthreads();
+        double vi = 0;
+        if (tid < n) {
+            const int i = tid;
+            double a0 = 0, a1 = 0;
+            int j = 0;
+            for (; j + 1 <= i; j += 2) { a0 = __builtin_fma(R[roff(j, n) + i], T[j], a0); a1 = __builtin_fma(R[roff(j + 1, n) + i], T[j + 1], a1); }
+            if (j <= i) a0 = __builtin_fma(R[roff(j, n) + i], T[j], a0);
+            vi = a0 + a1;
+            b.v[(size_t)q * n + i] = vi;
+        }
+        __syncthreads();
+        if (tid < n) T[tid] = vi;
+        __syncthreads();
+        if (tid < n) {
+            const int i = tid, pi = roff(i, n);
+            double a0 = 0, a1 = 0;
+            int j = i;
+            for (; j + 1 < n; j += 2) { a0 = __builtin_fma(R[pi + j], T[j], a0); a1 = __builtin_fma(R[pi + j + 1], T[j + 1], a1); }
+            if (j < n) a0 = __builtin_fma(R[pi + j], T[j], a0);
+            b.xunc[(size_t)q * n + i] = -(a0 + a1);
         }
         if (tid == 0) { rec[1] = pmin; rec[2] = pmax; rec[0] = 1.0; }
     }

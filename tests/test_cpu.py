@@ -315,3 +315,15 @@ def test_bench_quotes_counters_only_for_the_loaded_library(tmp_path, monkeypatch
     r = bench.committed_counters("C2", 100000)
     assert "stale" not in r and r["traffic"] == 1.0e10 and r["issue"]["attainable_ms"] == 9.0 and r["traffic_source"] == "profiles/r09b_pmc_summary.json"
     assert bench.committed_counters("C2", 4096)["stale"] and bench.committed_counters("C4", 10000)["stale"]
+
+
+def test_committed_counters_belong_to_this_build():
+    """bench.py quotes HBM traffic and the issue-side counters from the newest profiles/r*_pmc_summary.json -- only when that summary is
+    stamped with the version and the csrc hash of the library that is loaded (a kernel edit without a counter refresh
+    must not leave stale numbers in a driver-run record).  This test is the reminder: the committed summary covers every BASELINE
+    configuration at its bench batch size and was taken with the sources as they are now."""
+    import bench
+    for cfg, c in bench.CONFIGS.items():
+        got = bench.committed_counters(cfg, c["per_gpu"])
+        assert not got.get("stale"), (cfg, got.get("why"))
+        assert got["traffic"] > 0 and got["issue"]["attainable_ms"] > 0, cfg

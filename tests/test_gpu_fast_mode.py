@@ -280,3 +280,36 @@ def test_factorisation_as_its_own_launch(oracle, gpu_lib, monkeypatch, shape):
         assert np.array_equal(g["exitflag"], r[3]), (eps, g["exitflag"], r[3])
         ok = r[3] > 0
         assert np.array_equal(g["iter"][ok], r[4][ok]) and np.abs(g["x"][ok] - r[0][ok]).max() < 1e-7 * max(1.0, np.abs(r[0][ok]).max())
+
+
+def test_factorisation_launch_on_reused_batches_and_single_problems(oracle, gpu_lib):
+    """k_fact_wg behind the other entry points of the n = 200 class: a batch set up twice (new Hessians over the old records), a
+    warm update in between, and the single-problem drop-in call (a batch of one)."""
+    import daqp_amd
+    n, m, ms, na, N = 200, 420, 0, 50, 5
+    q1 = O.generate_batch(N, n, m, ms, na, 5151)
+    q2 = O.generate_batch(N, n, m, ms, na, 5252)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    for q in (q1, q2):
+        bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=0)
+        g = bm.solve()
+        models = []
+        for k in range(N):
+            om = oracle.model(n, m, ms)
+            om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+            r = om.solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (k, g["iter"][k], r[4])
+            assert np.abs(g["x"][k] - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max())
+            models.append(om)
+        f2 = q["f"] * 1.05 + 0.01
+        bm.update(f=f2)
+        g = bm.solve()
+        for k in range(N):
+            models[k].update(O.UPDATE_v, f=f2[k])
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], ("warm", k, g["iter"][k], r[4])
+            assert np.abs(g["x"][k] - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max())
+    bm.close()
+    x, fval, flag, info = daqp_amd.solve(q1["H"][0], q1["f"][0], q1["A"][0], q1["bupper"][0], q1["blower"][0], np.zeros(m, np.int32))
+    r = oracle.quadprog(q1["H"][0], q1["f"][0], q1["A"][0], q1["bupper"][0], q1["blower"][0], None)
+    assert flag == r[3] and info["iterations"] == r[4] and np.abs(x - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max())

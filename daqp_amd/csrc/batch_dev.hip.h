@@ -16,7 +16,6 @@ struct BatchDev {
     float *M32;        // [N][nblk][nquad][64][4] the same image rounded to fp32 (workgroup kernel's screening scan), or null
     int nquad;         // (npair + 1) / 2
     int wg_inverse;    // workgroup kernel, default arithmetic: carry L^-1 instead of L (wg_ldp.hip.h)
-    int wg_imgcache;   // workgroup kernel, default arithmetic: left-over blocks of the fp32 image cached in the factor's free LDS (wg_ldp.hip.h)
     double *Rinv;      // [N][rtri]   packed upper R^-1, rows < ms normalised
     double *v;         // [N][n]
     double *scaling, *dupper, *dlower; // [N][m]

@@ -766,7 +766,6 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         if (const char *ce = getenv("DAQP_AMD_WG_CAPL")) { const int v = atoi(ce); if (v >= 2 && v < capL) capL = v; }   // (tests: force the hand-over)
         if (wg_lds_bytes(Cw, m, capL) <= lds_max && capL >= (cap < 48 ? cap : 48)) {
             b->use_wg = true; b->wg_W = W; b->wg_C = Cw;
-            { const char *cv = getenv("DAQP_AMD_WG_IMGCACHE"); d.wg_imgcache = (cv && atoi(cv) == 0) ? 0 : 1; }   // default mode: image blocks cached in the factor's free LDS
             { const char *iv = getenv("DAQP_AMD_WG_INVERSE"); d.wg_inverse = (iv && atoi(iv) == 0) ? 0 : 1; }   // default mode: L^-1 instead of L (wg_ldp.hip.h)
             d.wg_capL = capL; d.wg_capT = round_up(cap, 8);
             b->lds_wg = (size_t)wg_lds_bytes(Cw, m, capL);

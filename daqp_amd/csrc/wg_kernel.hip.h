@@ -105,15 +105,6 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
         }
         __syncthreads();
 
-        // the left-over blocks of the fp32 image into the factor's free LDS (wg_ldp.hip.h: wg_img_cached), as many as fit next to na0 rows
-        const int nleft = c.nblk - (c.nblk / W) * W;
-        const int cblk0 = (b.wg_imgcache && c.M32 != nullptr && !c.exact && DAQP_WG_SCAN_U_REGS && DAQP_WG_SCAN_SPLIT) ? wg_img_cached(c, na0 + 1, nleft) : 0;
-        for (int l = 0; l < cblk0; ++l) {
-            const float4 *src = reinterpret_cast<const float4 *>(c.M32) + ((size_t)((c.nblk / W) * W + l) * c.nquad) * 64;
-            float4 *dst = const_cast<float4 *>(wg_img_lds(c, l));
-            for (int e = tid; e < c.nquad * 64; e += T) dst[e] = src[e];
-        }
-        __syncthreads();
         if (wv == 0) {
             WgWave<C> w;
             w.c = c;
@@ -131,7 +122,6 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
             // inverse-factor representation: default arithmetic, cold start, no soft rows (wg_ldp.hip.h)
             w.use_w = (b.wg_inverse && !c.exact && mode == 0 && na0 == 0 && !need_act && !has_soft) ? 1 : 0;
             w.fast_na = -1;
-            w.cblk = cblk0; w.nleft = nleft;
             int iters = 0;
             const int flag = wrun(w, mode, need_act != 0, iters);
             if (!w.overflow) wleave_w(w, w.na);                          // the stored iterate is always L   // (need_activate at mode 0: defensive, setup/update runs mode 1 itself)

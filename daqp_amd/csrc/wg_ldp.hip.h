@@ -92,7 +92,6 @@ struct WgWave {
     int na, reuse, sing, has_soft, nfree, hi_slot, overflow;
     int use_w;                            // 1: the LDS factor area holds W = L^-1 (default arithmetic, regular factor), see "inverse factor" below
     int fast_na;                          // inverse factor: na right after a regular append (the next CSP is then an O(na) update, wdirection), else -1
-    int cblk, nleft;                      // left-over blocks of the fp32 image with a valid copy in the factor's free LDS (wg_img_cached; only ever lowered), and how many there are
     double fval, soft;
     const DAQPSettings *stp;              // device copy of the settings: scalar loads at the point of use
     int *trace; int trace_cap, trace_len;
@@ -118,25 +117,6 @@ __device__ __forceinline__ void wtrace(WgWave<C> &w, int ev)
 // ---------------------------------------------------------------------------------------------------------------------
 // the parallel phases: executed by EVERY wave of the workgroup with the same arguments (barriers inside are workgroup-wide)
 // ---------------------------------------------------------------------------------------------------------------------
-
-// The free tail of the factor's LDS area as a cache of the fp32 image's LEFT-OVER blocks (default arithmetic).  Packed L (or W) of na
-// rows takes tri(na) of the lmax + 1 doubles reserved for capL rows, and a C4 working set spends most of its life well below capL; the
-// screening scan streams the whole image (480 KB) every iteration at what the CU's memory path delivers, and its left-over blocks -- the
-// ones cut over all waves behind the whole rounds -- are read by every scan of the problem.  Left-over block l < cblk sits at
-// [end - (l + 1) B, end - l B) (B = nquad KB), copied there when the problem starts; cblk only ever SHRINKS (the master lowers it
-// before an append whose new row of the factor would reach the cache: block cblk - 1, the one next to the factor, goes first).
-__device__ __forceinline__ int wg_img_block_d(const WgCtx &c) { return c.nquad * 128; }          // doubles per 64-row block of the image
-__device__ __forceinline__ int wg_img_cached(const WgCtx &c, int na_rows, int nleft)            // blocks that fit next to a factor of na_rows rows
-{
-    int free_d = c.lmax + 1 - tri(na_rows), k = 0;
-    const int B = wg_img_block_d(c);
-    while (k < nleft && free_d >= B) { free_d -= B; ++k; }
-    return k;
-}
-__device__ __forceinline__ const float4 *wg_img_lds(const WgCtx &c, int l)
-{
-    return reinterpret_cast<const float4 *>(SDL(c) + (c.lmax + 1) - (size_t)(l + 1) * wg_img_block_d(c));
-}
 
 // one column pair of an active row into the scratch: row-major [slot][ldr] (ldr: a multiple of 32 doubles, 16-byte stores, the pad
 // columns n .. ldr-1 are zero from the allocation on and stay zero); the transposed copy [n][capT] is kept in the exact mode only --
@@ -330,7 +310,7 @@ __device__ __forceinline__ void wg_scan(const WgCtx &c, double primal_tol)
 // scalars (and told so with readfirstlane: inside the loops the addresses otherwise become sixteen per-lane pointer induction
 // variables), the lane's 16 bytes a 32-bit offset shared by all loads of the pass.
 template <int C>
-__device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol, int cblk)
+__device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol)
 {
     const int wv = wg_wave(), lane = wg_lane(), n = c.n;
     const unsigned lane_u = (unsigned)lane;
@@ -397,12 +377,8 @@ __device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol, int
     }
     if (nunits > 0) {
         for (int j = wv; j < nunits; j += c.W) {
-            const int l = j / nb, blk = nfull + l, b = j % nb;
-            if (l < cblk) {                                      // this block of the image is cached in the factor's free LDS (wg_img_cached)
-                const float4 *src = wg_img_lds(c, l) + lane;
-#pragma unroll
-                for (int q = 0; q < DEPTH; ++q) { const int tt = (DEPTH * b + q < c.nquad) ? DEPTH * b + q : c.nquad - 1; mm[q] = src[tt * 64]; }
-            } else load_batch(blk, DEPTH * b);
+            const int blk = nfull + j / nb, b = j % nb;
+            load_batch(blk, DEPTH * b);
             const float ub = ubatch(b);
             float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
@@ -421,7 +397,7 @@ __device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol, int
     }
 #else
 template <int C>
-__device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol, int /*cblk: the cache is read by the u-in-registers form only*/)
+__device__ __forceinline__ void wg_scan32(const WgCtx &c, double primal_tol)
 {
     const int wv = wg_wave(), lane = wg_lane(), n = c.n;
     float *u32 = reinterpret_cast<float *>(SD(c, red));     // the reduction area is idle during a scan
@@ -913,7 +889,7 @@ __device__ __forceinline__ void wg_do(const WgCtx &c, int code, double primal_to
     const double *lams = uni(SI(c, cmd)[5]) ? SD(c, lamB) : SD(c, lamA);
     if (code == WG_PRIMAL) wg_primal<C>(c, na, lams);
     else if (code == WG_SCAN) wg_scan<C>(c, primal_tol);
-    else if (code == WG_SCAN32) wg_scan32<C>(c, primal_tol, DAQP_WG_SCAN_U_REGS ? uni(SI(c, cmd)[7]) : 0);
+    else if (code == WG_SCAN32) wg_scan32<C>(c, primal_tol);
     else if (code == WG_FETCH_GRAM) {
         if (c.exact) {
             wg_fetch_row<C>(c, a0, a1, true);
@@ -945,7 +921,6 @@ __device__ __forceinline__ void wg_run(WgWave<C> &w, int code, int a0 = 0, int a
         SI(c, cmd)[0] = code; SI(c, cmd)[1] = a0; SI(c, cmd)[2] = a1; SI(c, cmd)[3] = w.na; SI(c, cmd)[4] = w.hi_slot + 1;
         SI(c, cmd)[5] = w.lam_b ? 0 : 1;   // which buffer holds lam*
         SI(c, cmd)[6] = w.profiling ? 1 : 0;
-        SI(c, cmd)[7] = w.cblk;
     }
     __syncthreads();
     const long long tA = w.profiling ? (long long)__builtin_readcyclecounter() : 0;
@@ -1052,7 +1027,6 @@ __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
             SI(c, slot)[na] = newslot; SI(c, slot_id)[newslot] = id;
             SD(c, rhs)[na] = (SI(c, sense)[id] & DAQP_LOWER) ? -c.dlower[id] : -c.dupper[id];
         }
-        if (w.cblk > 0) { const int cb_ = wg_img_cached(c, na + 1, w.nleft); if (cb_ < w.cblk) w.cblk = cb_; }    // (the factor's new row must not reach the cached image blocks)
         WPROF_T0(w);
         wg_run(w, WG_WAPPEND, id, newslot);
         WPROF_ACC(w, 8);
@@ -1078,7 +1052,6 @@ __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
     w.nfree--;
     if (newslot > w.hi_slot) w.hi_slot = newslot;
     if (lane == 0) { SI(c, slot)[na] = newslot; SI(c, slot_id)[newslot] = id; }
-    if (w.cblk > 0) { const int cb_ = wg_img_cached(c, na + 1, w.nleft); if (cb_ < w.cblk) w.cblk = cb_; }
     WPROF_T0(w);
     wg_run(w, WG_FETCH_GRAM, id, newslot);
     WPROF_ACC(w, 8);
@@ -1757,7 +1730,7 @@ __device__ __forceinline__ int wrun(WgWave<C> &w, int mode, bool need_activate, 
     else pc = WPC_START_LOOP;
 #define WTL_CHECK() (timed && !tl_skip && (it & 31) == 0 && time_is_up(w.t_start, w.stp->time_limit, w.tick_s))
 #define WUNIFORM() do { w.na = uni(w.na); w.reuse = uni(w.reuse); w.sing = uni(w.sing); w.nfree = uni(w.nfree); w.hi_slot = uni(w.hi_slot); \
-                        w.lam_b = uni(w.lam_b); w.overflow = uni(w.overflow); w.fast_na = uni(w.fast_na); w.cblk = uni(w.cblk); } while (0)
+                        w.lam_b = uni(w.lam_b); w.overflow = uni(w.overflow); w.fast_na = uni(w.fast_na); } while (0)
     while (pc != WPC_DONE && !w.overflow) {
         // (belt and braces: the iterate's scalars are wave-uniform by construction; saying so once per state keeps every loop
         //  bounded by them a scalar loop whatever the optimizer concluded about the joins of the previous state)

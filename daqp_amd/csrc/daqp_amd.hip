@@ -1122,6 +1122,7 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
             } else (void)hipGetLastError();
         }
         hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask);
+        d.fact = nullptr;      // (the records belong to THIS launch: the descriptor is the batch's own, and a later shared setup copies it)
         HIPCHK(hipGetLastError());
         if (d.defer_m) { if (launch_setup_m(b, d)) return DAQP_EXIT_UNSUPPORTED; d.defer_m = 0; }
     } else HIPCHK(hipMemsetAsync(d.qs, 0, (size_t)d.N * sizeof(QState), b->stream));   // fresh records: the LP pass below fills them

@@ -313,3 +313,28 @@ def test_factorisation_launch_on_reused_batches_and_single_problems(oracle, gpu_
     x, fval, flag, info = daqp_amd.solve(q1["H"][0], q1["f"][0], q1["A"][0], q1["bupper"][0], q1["blower"][0], np.zeros(m, np.int32))
     r = oracle.quadprog(q1["H"][0], q1["f"][0], q1["A"][0], q1["bupper"][0], q1["blower"][0], None)
     assert flag == r[3] and info["iterations"] == r[4] and np.abs(x - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max())
+
+
+def test_shared_setup_after_a_factorised_per_problem_setup(oracle, gpu_lib):
+    """a batch of the n = 200 class that was set up per problem (k_fact_wg's records say "factored") and is then set up SHARED with
+    another Hessian: the one-problem descriptor of the shared setup must not inherit those records (k_setup would skip its own
+    Cholesky / inverse and take the previous problem 0's R^-1 out of the scratch)"""
+    import daqp_amd
+    n, m, ms, na, N = 200, 300, 0, 30, 4
+    q = O.generate_batch(N, n, m, ms, na, 6161)
+    q2 = O.generate_batch(1, n, m, ms, na, 6262)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None)
+    bm.solve()
+    rng = np.random.default_rng(7)
+    bu = q2["bupper"][0] + rng.uniform(0.0, 0.5, (N, m)); bl = q2["blower"][0] - rng.uniform(0.0, 0.5, (N, m))     # (widened: every state feasible)
+    fs = q2["f"][0] * (1.0 + 0.1 * rng.standard_normal((N, 1)))
+    bm.setup_shared(q2["H"][0], fs, q2["A"][0], bu, bl)
+    g = bm.solve()
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q2["H"][0], fs[k], q2["A"][0], bu[k], bl[k], None)
+        r = om.solve()
+        assert r[3] == 1 and g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+        assert np.abs(g["x"][k] - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max()), k
+    bm.close()

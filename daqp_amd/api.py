@@ -108,26 +108,36 @@ class Model:
         return {k: getattr(self._settings, k) for k, _ in self._settings._fields_}
 
     def update(self, H=None, f=None, A=None, bupper=None, blower=None, sense=None):
+        """daqp.pyx:513-571: the mask is built field by field -- one bit per array given, arrays of the wrong shape are ignored as
+        the reference ignores them -- and handed to daqp_update_ldp as it is (utils.c:58-221 runs each bit's step on its own: a
+        new A keeps the factor, a new sense keeps everything else, ...)."""
         if self._ws is None:
             raise RuntimeError("Model.update called before setup")
+        n, m, mA = self.n, self.m, self.m - self.ms
         mask = 0
-        if H is not None:
+        if H is not None and np.shape(H) == (n, n):
             self._keep["H"] = _np64(H); mask |= UPDATE_Rinv
-        if A is not None:
+        if A is not None and np.shape(A) == (mA, n):
             self._keep["A"] = _np64(A); mask |= UPDATE_M
-        if f is not None:
+        if f is not None and np.size(f) == n:
             self._keep["f"] = _np64(f); mask |= UPDATE_v
-        if bupper is not None or blower is not None:
-            if bupper is not None:
-                self._keep["bupper"] = _np64(bupper)
-            if blower is not None:
-                self._keep["blower"] = _np64(blower)
-            mask |= UPDATE_d
-        if sense is not None:
+        if bupper is not None and np.size(bupper) == m:
+            self._keep["bupper"] = _np64(bupper); mask |= UPDATE_d
+        if blower is not None and np.size(blower) == m:
+            self._keep["blower"] = _np64(blower); mask |= UPDATE_d
+        if sense is not None and np.size(sense) == m:
             self._keep["sense"] = _np32(sense); mask |= UPDATE_sense
-        if mask & (UPDATE_Rinv | UPDATE_M | UPDATE_sense):   # anything but f/bounds: full re-setup on the device
-            mask = UPDATE_Rinv | UPDATE_M | UPDATE_v | UPDATE_d | UPDATE_sense
         return lib().daqp_update_ldp(mask, self._ws, C.byref(self._problem()))
+
+    def update_mask(self, mask, **arrays):
+        """daqp_update_ldp(mask, ...) with an explicit mask (C callers' usage): `arrays` (H, f, A, bupper, blower, sense) replace
+        what the problem descriptor points to, whatever the mask says."""
+        if self._ws is None:
+            raise RuntimeError("Model.update_mask called before setup")
+        for k, v in arrays.items():
+            if v is not None:
+                self._keep[k] = _np32(v) if k == "sense" else _np64(v)
+        return lib().daqp_update_ldp(int(mask), self._ws, C.byref(self._problem()))
 
     def solve(self):
         if self._ws is None:
@@ -255,10 +265,16 @@ class BatchModel:
         lib().daqp_batch_setup_flags(self._h, _ip(fl))
         return fl
 
-    def update(self, f=None, bupper=None, blower=None):
-        mask = (UPDATE_v if f is not None else 0) | (UPDATE_d if (bupper is not None or blower is not None) else 0)
-        p, keep = self._problem(None, f, None, bupper, blower, None)
-        rc = lib().daqp_batch_update(self._h, mask, C.byref(p))
+    def update(self, f=None, bupper=None, blower=None, H=None, A=None, sense=None, mask=None):
+        """daqp_update_ldp for every problem, the mask built field by field like Model.update (daqp.pyx:513-571): f -> v, bounds -> d
+        (factors and working sets kept: the warm path), A -> M on the kept factor, H -> a new factor (v, M, d follow), sense ->
+        the working sets are rebuilt from its ACTIVE bits.  mask: an explicit DAQP_UPDATE_* mask instead (sense=None with the
+        sense bit means "all zeros", utils.c:85-86)."""
+        if mask is None:
+            mask = ((UPDATE_Rinv if H is not None else 0) | (UPDATE_M if A is not None else 0) | (UPDATE_v if f is not None else 0)
+                    | (UPDATE_d if (bupper is not None or blower is not None) else 0) | (UPDATE_sense if sense is not None else 0))
+        p, keep = self._problem(H, f, A, bupper, blower, sense)
+        rc = lib().daqp_batch_update(self._h, int(mask), C.byref(p))
         if rc != 0:
             raise RuntimeError(f"daqp_batch_update failed ({rc}): {_lib.last_error()}")
         return self
@@ -452,11 +468,14 @@ class MultiBatchModel:
         if rc != 0:
             raise RuntimeError(f"daqp_batch_setup_multi failed ({rc}): {_lib.last_error()}")
 
-    def update(self, f=None, bupper=None, blower=None):
-        mask = (UPDATE_v if f is not None else 0) | (UPDATE_d if (bupper is not None or blower is not None) else 0)
+    def update(self, f=None, bupper=None, blower=None, H=None, A=None, sense=None, mask=None):
+        """BatchModel.update, sharded: any mask of daqp_update_ldp (built field by field unless given)"""
+        if mask is None:
+            mask = ((UPDATE_Rinv if H is not None else 0) | (UPDATE_M if A is not None else 0) | (UPDATE_v if f is not None else 0)
+                    | (UPDATE_d if (bupper is not None or blower is not None) else 0) | (UPDATE_sense if sense is not None else 0))
         keep = []
-        p = self._problem(keep, None, f, None, bupper, blower, None)
-        rc = lib().daqp_batch_update_multi(self._h, mask, C.byref(p))
+        p = self._problem(keep, H, f, A, bupper, blower, sense)
+        rc = lib().daqp_batch_update_multi(self._h, int(mask), C.byref(p))
         if rc != 0:
             raise RuntimeError(f"daqp_batch_update_multi failed ({rc}): {_lib.last_error()}")
 

@@ -133,6 +133,11 @@ struct DAQPBatch {
     size_t lds_wg = 0;
     double *wide_u = nullptr, *wide_l = nullptr;   // daqp_batch_setup_shared: +-1e30 bounds of the one factorisation
     int *structural = nullptr, *shared_flag = nullptr;
+    bool exact_sticky = false;   // the sense of some working-set rows was replaced without the working set being rebuilt (a sense update without a
+                                 // sense array, utils.c:85-86; an update that took the new sense and then failed its bound check, utils.c:88-96): the
+                                 // reference iterates on from that state, and only its own arithmetic does the same (the default mode's carried
+                                 // intermediate results assume the flags they were formed with) -- solves use the exact kernels until the next update
+    int part_mask = 0;      // the last (re-)setup was a partial daqp_batch_update with this mask (k_setup<..., PART>): its regularising re-runs use the same kernel
     int pending_mask = 0;   // daqp_batch_update(UPDATE_v|UPDATE_d) not yet applied: the next solve launch does it (k_ldp_reg mode 2)
     size_t lds_setup = 0, lds_ldp = 0, lds_update = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -241,7 +246,7 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         HIPCHK(hipMemsetAsync(b->d.wg_counter, 0, sizeof(int), b->stream));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg));
         BatchDev dd = b->d;
-        if (b->in_prox_loop) dd.exact_setup = 1;   // problems of the proximal outer loop keep the reference's arithmetic in both modes
+        if (b->in_prox_loop || b->exact_sticky) dd.exact_setup = 1;   // problems of the proximal outer loop keep the reference's arithmetic in both modes
         hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, dd, mode);
         HIPCHK(hipGetLastError());
         ldp_kernel_t kf = pick_ldp(b);
@@ -267,7 +272,7 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
 #endif
     if (b->NB > 0) {
         // problems that run the proximal outer loop keep the reference's arithmetic in both modes (their setup passes do as well)
-        ldp_reg_kernel_t kr = pick_ldp_reg(b, b->d.exact_setup != 0 || b->in_prox_loop);
+        ldp_reg_kernel_t kr = pick_ldp_reg(b, b->d.exact_setup != 0 || b->in_prox_loop || b->exact_sticky);
         // the descriptor travels through device memory: stream-ordered copy, then the launch
         if (descriptor_changed) HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
@@ -329,6 +334,13 @@ setup_kernel_t pick_setup_fast(int n, bool fused)
 {
     if (fused) return (n <= 16) ? k_setup_fast<16, false, true> : (n <= 32 ? k_setup_fast<32, false, true> : (n <= 56 ? k_setup_fast<56, false, true> : k_setup_fast<64, false, true>));
     return (n <= 16) ? k_setup_fast<16> : (n <= 32 ? k_setup_fast<32> : (n <= 56 ? k_setup_fast<56> : k_setup_fast<64>));
+}
+
+// k_setup<..., PART>: daqp_update_ldp masks that are neither within v|d nor everything (kernels.hip.h).  The generic one-wave kernel
+// serves every shape here (these updates are not on the path the configurations are timed on), always in the reference's arithmetic.
+setup_kernel_t pick_setup_part(const DAQPBatch *b)
+{
+    return b->setup_spill ? (b->d.n > 256 ? k_setup<true, 8, false, true> : k_setup<true, 4, false, true>) : k_setup<false, 4, false, true>;
 }
 int read_counters(DAQPBatch *b)
 {
@@ -395,7 +407,8 @@ int regularise(DAQPBatch *b, BatchDev &d, int mask, bool lp, bool counted = fals
     const bool gs = b->setup_spill;
     setup_kernel_t ks = gs ? (d.n > 256 ? k_setup<true, 8> : k_setup<true>) : k_setup<false>;
     size_t lds = (size_t)setup_lds(d.n, d.m, gs).total_bytes;
-    if (b->fast_setup && !lp) {
+    if (b->part_mask && !lp) ks = pick_setup_part(b);       // (a partial update's flagged problems: the kernel that knows which sense / bounds it took)
+    else if (b->fast_setup && !lp) {
         ks = (d.n <= 16) ? k_setup_fast<16, true> : (d.n <= 32 ? k_setup_fast<32, true> : (d.n <= 56 ? k_setup_fast<56, true> : k_setup_fast<64, true>));
         lds = (size_t)fast_lds(d.n, d.m, 1, d.mA).total_bytes;
     }
@@ -901,7 +914,7 @@ void daqp_batch_free(DAQPBatch *b)
         if (b->d.trace || b->d.prof) { destroy_batch(b); return; }     // (debug buffers were attached: not worth keeping, and not kept)
         b->one_lam.clear(); b->one_valid = false;
         b->d.shared = 0; b->d.prox_pass = 0;
-        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->is_setup = false; b->reg_pending = false; b->fresh = false; b->rechecked = 0;
+        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->part_mask = 0; b->exact_sticky = false; b->is_setup = false; b->reg_pending = false; b->fresh = false; b->rechecked = 0;
         b->timed_setup = b->timed_solve = false; b->n_prox_qps = 0; b->prox_outer = 0;
         b->one_fval = b->one_soft = 0; b->one_flag = b->one_iter = 0;
         DAQPBatch *evict = nullptr;
@@ -1039,6 +1052,8 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
     }
     const bool lp = p->H == nullptr || (b->ident && p->H == b->ident);   // api.c:183-185
     b->pending_mask = 0;   // a full setup supersedes any deferred update
+    b->part_mask = 0;
+    b->exact_sticky = false;
     HIPCHK(hipSetDevice(b->device));
     if (fresh && b->prox_ready) HIPCHK(hipMemsetAsync(b->px.center, 0, (size_t)b->d.N * b->d.n * sizeof(double), b->stream));
     BatchDev &d = b->d;
@@ -1158,6 +1173,7 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     }
     (void)init_mask;   // the unconstrained shortcut / elimination are per-problem decisions of daqp_quadprog: not taken here
     b->pending_mask = 0;
+    b->part_mask = 0;
     b->n_prox_qps = 0;
     b->reg_pending = false;
     HIPCHK(hipSetDevice(b->device));
@@ -1234,6 +1250,54 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     return 0;
 }
 
+// daqp_update_ldp with the Rinv and / or M bit but not every bit (utils.c:58-221): a new Hessian, new general rows, or both, on a
+// workspace that keeps what the mask leaves out -- its sense (stale ACTIVE bits included), its normalised R^-1, its v.  One launch
+// of k_setup<..., PART> in the reference's operation order, then (Rinv bit) the count of Hessians that need the shift, then the
+// activation pass for the problems whose update asks for it.  Arrays of `p` that the mask's steps read and that are NULL stay
+// as the batch has them (device-resident ones were adopted: they must still be valid).
+static int partial_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
+{
+    BatchDev &d = b->d;
+    const bool withR = (mask & DAQP_UPDATE_Rinv) != 0, lp = b->ident && d.H == b->ident;
+    if (b->was_shared) {
+        set_err("update mask %d after daqp_batch_setup_shared: the batch holds ONE H and A (call daqp_batch_setup_shared again)", mask);
+        return DAQP_EXIT_UNSUPPORTED;
+    }
+    if (lp && withR) { set_err("update mask %d: an LP batch has no Hessian to update (set the batch up again)", mask); return DAQP_EXIT_UNSUPPORTED; }
+    if (flush_update(b)) return DAQP_EXIT_UNSUPPORTED;      // a deferred v|d update comes first, as it was called first
+    const size_t N = d.N;
+    int rc = 0;
+    const double *tmp = nullptr;
+    const int *itmp = nullptr;
+    // what the mask's steps read (utils.c:95,103,123,136,161): H with Rinv; A with Rinv or M; f with Rinv or v; the bounds always
+    if (withR && p->H) { rc |= stage(b, p->H, p->memory, N * d.n * d.n, &b->sH, &b->nH, &tmp); d.H = tmp; }
+    if (p->A && d.mA > 0) { rc |= stage(b, p->A, p->memory, N * d.mA * d.n, &b->sA, &b->nA, &tmp); d.A = tmp; }
+    if ((withR || (mask & DAQP_UPDATE_v)) && p->f) { rc |= stage(b, p->f, p->memory, N * d.n, &b->sf, &b->nf, &tmp); d.f = tmp; }
+    if (p->bupper) { rc |= stage(b, p->bupper, p->memory, N * d.m, &b->sbu, &b->nbu, &tmp); d.bu = tmp; }
+    if (p->blower) { rc |= stage(b, p->blower, p->memory, N * d.m, &b->sbl, &b->nbl, &tmp); d.bl = tmp; }
+    if (mask & DAQP_UPDATE_sense) { rc |= stage(b, p->sense, p->memory, N * d.m, &b->ssense, &b->nsense, &itmp); d.sense_in = itmp; }
+    if (rc) return DAQP_EXIT_UNSUPPORTED;
+    const setup_kernel_t ks = pick_setup_part(b);
+    const size_t lds = (size_t)setup_lds(d.n, d.m, b->setup_spill).total_bytes;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BatchDev l = d;                    // (per-launch state stays off the batch's own descriptor)
+    l.exact_setup = 1; l.defer_m = 0; l.fact = nullptr; l.prox_pass = 0;
+    const int kmask = mask & ~(DAQP_UPDATE_eliminate | DAQP_UPDATE_hierarchy);
+    HIPCHK(hipEventRecord(b->ev[0], b->stream));
+    hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds, b->stream, l, kmask);
+    HIPCHK(hipGetLastError());
+    b->part_mask = kmask;
+    if (withR) {                       // numerically singular Hessians: their shifted re-runs, as after a setup (resolve_setup)
+        rc = count_flagged_async(b, kmask);
+        if (rc) return rc;
+    }
+    rc = launch_ldp(b, 1);             // utils.c:199-211 for the problems that asked for it
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(b->ev[1], b->stream));
+    b->timed_setup = true;
+    return 0;
+}
+
 int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
 {
     int rc = check_problem(b, p);
@@ -1242,6 +1306,7 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
     HIPCHK(hipSetDevice(b->device));
     if (resolve_setup(b)) return DAQP_EXIT_UNSUPPORTED;
     b->fresh = false;
+    b->exact_sticky = (mask & DAQP_UPDATE_sense) != 0 && p->sense == nullptr && (mask & (DAQP_UPDATE_Rinv | DAQP_UPDATE_M)) == 0;   // (see the member's comment)
     const int full = DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
     if ((mask & full) == full) {
         DAQPBatchProblem pp = *p;   // unchanged arrays may be omitted: reuse what the batch already has
@@ -1259,18 +1324,19 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
         }
         return batch_setup(b, &pp, mask & (DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate), false);   // daqp_update_ldp keeps work->x
     }
-    if (mask & ~(DAQP_UPDATE_v | DAQP_UPDATE_d)) {
-        set_err("update mask %d: only DAQP_UPDATE_v|DAQP_UPDATE_d or a full re-setup are built", mask);
-        return DAQP_EXIT_UNSUPPORTED;
-    }
-    HIPCHK(hipSetDevice(b->device));
+    // every other mask of utils.c:58-221, step by step (the reference's bindings build them field by field: daqp.pyx:513-571)
+    if (mask & (DAQP_UPDATE_Rinv | DAQP_UPDATE_M)) return partial_update(b, mask, p);
+    if (!(mask & (DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense))) return 0;    // nothing of this path to update (utils.c: only sing_ind is reset; the next update or solve does that here)
     BatchDev &d = b->d;
     const size_t N = d.N;
     const double *tmp = nullptr;
+    const bool with_sense = (mask & DAQP_UPDATE_sense) != 0;
     // The register solve kernel applies the update itself at its next launch (it has the rows of M in registers anyway:
     // one pass over M per MPC step instead of two).  Because that reads f / the bounds later than this call, device
     // arrays are copied into the batch's own buffers (stream-ordered, a few tens of microseconds) instead of adopted.
-    const bool lazy = b->NB > 0 && !getenv("DAQP_AMD_EAGER_UPDATE");
+    // A new sense is taken over right away, and what comes with it in the same call as well (utils.c:84-98: the bound check reads
+    // the new sense, the activation at the end the new d).
+    const bool lazy = b->NB > 0 && !getenv("DAQP_AMD_EAGER_UPDATE") && !with_sense;
     const int mem = p->memory;
     auto take = [&](const double *src, size_t count, double **slot, size_t *cap, const double **out) -> int {
         if (!lazy || mem != DAQP_MEM_DEVICE) return stage(b, src, mem, count, slot, cap, out);
@@ -1279,17 +1345,30 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
         *out = *slot;
         return 0;
     };
+    if (with_sense) {
+        if (flush_update(b)) return DAQP_EXIT_UNSUPPORTED;    // a deferred v|d update comes first, as it was called first
+        const int *itmp = nullptr;
+        rc |= stage(b, p->sense, mem, N * d.m, &b->ssense, &b->nsense, &itmp);
+        if (rc) return DAQP_EXIT_UNSUPPORTED;
+        d.sense_in = itmp;
+    }
     if (mask & DAQP_UPDATE_v) {
         if (!p->f) { set_err("DAQP_UPDATE_v needs f"); return DAQP_EXIT_UNSUPPORTED; }
         rc |= take(p->f, N * d.n, &b->sf, &b->nf, &tmp); d.f = tmp;
     }
-    if (p->bupper) { rc |= take(p->bupper, N * d.m, &b->sbu, &b->nbu, &tmp); d.bu = tmp; }
-    if (p->blower) { rc |= take(p->blower, N * d.m, &b->sbl, &b->nbl, &tmp); d.bl = tmp; }
+    if ((mask & (DAQP_UPDATE_v | DAQP_UPDATE_d)) && p->bupper) { rc |= take(p->bupper, N * d.m, &b->sbu, &b->nbu, &tmp); d.bu = tmp; }
+    if ((mask & (DAQP_UPDATE_v | DAQP_UPDATE_d)) && p->blower) { rc |= take(p->blower, N * d.m, &b->sbl, &b->nbl, &tmp); d.bl = tmp; }
     if (rc) return DAQP_EXIT_UNSUPPORTED;
-    if (lazy) { b->pending_mask |= mask; b->timed_setup = false; return 0; }
+    if (lazy) { b->pending_mask |= mask & (DAQP_UPDATE_v | DAQP_UPDATE_d); b->timed_setup = false; return 0; }
     HIPCHK(hipEventRecord(b->ev[0], b->stream));
-    hipLaunchKernelGGL(k_update, dim3(d.N), dim3(64), b->lds_update, b->stream, d, mask);
-    HIPCHK(hipGetLastError());
+    if (with_sense) {
+        hipLaunchKernelGGL(k_update_sense, dim3(d.N), dim3(256), 0, b->stream, d);
+        HIPCHK(hipGetLastError());
+    }
+    if (mask & (DAQP_UPDATE_v | DAQP_UPDATE_d)) {
+        hipLaunchKernelGGL(k_update, dim3(d.N), dim3(64), b->lds_update, b->stream, d, mask & (DAQP_UPDATE_v | DAQP_UPDATE_d));
+        HIPCHK(hipGetLastError());
+    }
     rc = launch_ldp(b, 1);
     if (rc) return rc;
     HIPCHK(hipEventRecord(b->ev[1], b->stream));
@@ -1634,15 +1713,38 @@ int daqp_update_ldp(const int mask, DAQPWorkspace *work, DAQPProblem *qp)
 {
     DAQPBatch *b = ws_batch(work);
     if (!b) { set_err("workspace has not been set up"); return DAQP_EXIT_UNSUPPORTED; }
+    if (qp->n != work->n || qp->m != work->m || qp->ms != work->ms) { set_err("daqp_update_ldp: the problem's dimensions differ from the workspace's"); return DAQP_EXIT_UNSUPPORTED; }
+    if ((mask & DAQP_UPDATE_hierarchy) && (qp->nh > 1 || qp->break_points != nullptr)) { set_err("hierarchies are outside this path"); return DAQP_EXIT_UNSUPPORTED; }
     work->qp = qp;
     DAQPBatchProblem p = one_problem(qp);
-    int m = mask & ~(DAQP_UPDATE_hierarchy);
+    const int m = mask & ~(DAQP_UPDATE_hierarchy);
     b->one_valid = false;
     int rc = daqp_batch_update(b, m, &p);
     if (rc < 0) return rc;
     int flag = 1;
     rc = daqp_batch_setup_flags(b, &flag);
     if (rc < 0) return rc;
+    if (flag < 0) {
+        // An update that ends at its bound check (or at a vanishing row whose bounds exclude 0) has told its caller so; the
+        // reference's workspace is then what it was (utils.c:95-96 comes before anything is recomputed) and a daqp_solve on it
+        // solves the previous LDP.  The batch API reports the flag from the next solve instead (a batch caller has no per-problem
+        // return value to look at); here the caller has it, so the record is cleared and the next daqp_solve runs as the reference's.
+        QState q0;
+        if (hipMemcpy(&q0, b->d.qs, sizeof(QState), hipMemcpyDeviceToHost) == hipSuccess && q0.setup_flag > 0 && q0.upd_flag < 0) {
+            (void)hipMemsetAsync(&b->d.qs[0].upd_flag, 0, sizeof(int), b->stream);
+            if (m & DAQP_UPDATE_sense) b->exact_sticky = true;      // the new sense is in, the working set was not rebuilt
+        }
+    }
+    if ((m & DAQP_UPDATE_Rinv) && flag > 0) {
+        // a new Hessian may be of the other kind (dense <-> diagonal: Rinv <-> RinvD, utils.c:245-312) and may or may not need the shift
+        QState q0;
+        if (hipMemcpy(&q0, b->d.qs, sizeof(QState), hipMemcpyDeviceToHost) == hipSuccess) {
+            const size_t n = (size_t)work->n;
+            if (q0.diag_h && work->RinvD == nullptr) { free(work->Rinv); work->Rinv = nullptr; work->RinvD = static_cast<c_float *>(calloc(n, sizeof(c_float))); }
+            if (!q0.diag_h && work->Rinv == nullptr && qp->H != nullptr) { free(work->RinvD); work->RinvD = nullptr; work->Rinv = static_cast<c_float *>(calloc(n * (n + 1) / 2, sizeof(c_float))); }
+        }
+        (void)daqp_batch_prox_info(b, &work->n_prox, nullptr, nullptr);
+    }
     refresh_mirrors(work, true, (m & (DAQP_UPDATE_Rinv | DAQP_UPDATE_M)) != 0);
     return flag < 0 ? flag : 0;
 }

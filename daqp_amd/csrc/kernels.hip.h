@@ -82,9 +82,19 @@ __host__ __device__ inline LdpLds ldp_lds(int n, int m, int cap, bool spill, int
 // operand of the matrix-core phase.  What is left (Cholesky, inverse, v, simple bounds) is latency-bound per wave, but it does NOT
 // fit the register budget of a third wave per SIMD: at 168 registers the sweeps' row groups spill (125 registers, 196 bytes of
 // scratch) and the launch takes 2.3x as long (measured on config C4: 39.0 ms against 17.0 per 4 096 problems) -- two waves it is
-template <bool GS, int NBK = 4, bool DEFER = false>
+// PART: daqp_update_ldp with a mask that is neither within v|d (k_update) nor everything (utils.c:58-221 bit by bit; the masks
+// the reference's own bindings send field by field, daqp.pyx:513-571).  The instantiation of its own keeps these branches out of
+// the setup launches the configurations are timed on.  It always runs in the reference's operation order (host: exact_setup = 1).
+//   sense bit clear   -> the workspace's sense is KEPT as the last solve / update left it, stale ACTIVE bits included (utils.c:84-91)
+//   no M, v or d bit  -> no bound check (utils.c:94-98); with one: marks up to the first crossed pair, which ends the update (-1)
+//   no Rinv bit       -> R^-1 as stored (rows < ms normalised): new f and new A are divided by those rows' scalings column by column
+//                        (utils.c:447-452, 491-496), R^-1 is not normalised again, d is formed anew from whatever changed
+//   Rinv bit          -> everything below as in a setup (v, M, normalisation, d follow the new factor: utils.c:122,135,142,150)
+//   the working set is reset (daqp_update_M, utils.c:470) and re-activated only when sense was given or an equality was marked
+template <bool GS, int NBK = 4, bool DEFER = false, bool PART = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP_AMD_SETUP_DEFER_WAVES : 2, DEFER ? DAQP_AMD_SETUP_DEFER_WAVES : 2))) void k_setup(BatchDev b, int mask)
 {
+    static_assert(!(PART && DEFER), "partial updates form their general rows themselves");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = blockIdx.x, lane = lane_id();
     const int n = b.n, m = b.m, ms = b.ms, mA = b.mA, ldr = b.ldr;
@@ -104,6 +114,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
     const DAQPSettings &st = b.st;
     QState *qs = b.qs + q;
     int flag = 1, activate = 0;
+    const bool doR = !PART || (mask & DAQP_UPDATE_Rinv) != 0;                       // new Hessian: factorise
+    const bool doV = doR || (mask & DAQP_UPDATE_v) != 0;                            // v follows R^-1 or f
+    const bool newS = !PART || (mask & DAQP_UPDATE_sense) != 0;
+    const bool chk = !PART || (mask & (DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d)) != 0;
+    const bool keepR = PART && !doR;
+    if constexpr (PART) { if (keepR && __builtin_amdgcn_readfirstlane(qs->setup_flag) < 0) return; }   // no factor to update on
     // a regularising re-run (utils.c:356-377): the flagged problems only, H + shift*I (or, for a diagonal H, the shift in
     // its singular coordinates only: utils.c:284-312), the stricter pivot ratio for a Hessian that needed the shift
     const int pp = b.prox_pass;
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
     const int shift_code = (!pp && st.eps_prox == 0.0) ? DAQP_EXIT_NONCONVEX : DAQP_NEEDS_SHIFT;   // eps == 0: utils.c:357,367
     int nprox = 0;
     // default arithmetic mode: M = A R^-1 on the matrix cores (below), which read R^-1 from a zero-padded square image
-    bool mfma_m = !b.exact_setup && b.setup_sq != nullptr && b.n <= 208;   // (52 k steps of A in registers)
+    bool mfma_m = !PART && !b.exact_setup && b.setup_sq != nullptr && b.n <= 208;   // (52 k steps of A in registers)
     // ... and, when the host follows this launch with k_setup_m (setup_m.hip.h: a workgroup per 64 rows of A, R^-1 shared through
     // LDS), the general rows are not formed here at all: this kernel leaves what is owed in qs->pad_
     const int sq_ld = round_up(n, 16);
@@ -125,6 +141,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
 
     // --- sense (utils.c:84-91) and early bound check (utils.c:546-567)
     int bad = 0;
+    if constexpr (!PART) {
     for (int i = lane; i < m; i += 64) {
         int s = b.sense_in ? b.sense_in[(size_t)q * m + i] : 0;
         if (s & DAQP_BINARY) bad |= 2;
@@ -139,12 +156,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
         const int any = __any(bad & 2) ? 2 : 0, inf = __any(bad & 1) ? 1 : 0, eq = __any(bad & 4) ? 4 : 0;
         bad = any | inf | eq;
     }
-    if (b.sense_in) activate = 1;
+    } else {
+        // the kept sense, or the caller's; a regularising re-run (pp) continues from what its first pass left (sense copied, bounds checked)
+        int *cur = b.sense + (size_t)q * m;
+        const bool from_ws = !newS || pp != 0, check = chk && !pp;
+        int first_bad = kBig;
+        for (int i = lane; i < m; i += 64) {
+            const int s = from_ws ? cur[i] : (b.sense_in ? b.sense_in[(size_t)q * m + i] : 0);
+            if (s & DAQP_BINARY) bad |= 2;
+            sens[i] = s;
+            if (check && !(s & DAQP_IMMUTABLE) && bu[i] - bl[i] < -st.primal_tol && first_bad == kBig) first_bad = i;
+        }
+        first_bad = (int)wave_min((double)first_bad);      // the reference walks the rows in order and returns at the first crossed pair:
+        if (check)                                         // unmarked equalities BEFORE it have been marked by then (k_update)
+            for (int i = lane; i < m && i < first_bad; i += 64) {
+                const int s = sens[i];
+                if (!(s & DAQP_IMMUTABLE) && !(s & DAQP_SOFT) && bu[i] - bl[i] < st.zero_tol) { sens[i] = s | DAQP_ACTIVE | DAQP_IMMUTABLE; bad |= 4; }
+            }
+        bad = (__any(bad & 2) ? 2 : 0) | (__any(bad & 4) ? 4 : 0);
+        if (bad & 2) {                                     // binary constraints are outside this path: nothing is taken over
+            if (lane == 0) qs->upd_flag = DAQP_EXIT_UNSUPPORTED;
+            return;
+        }
+        if (first_bad != kBig) {                           // utils.c:95-96: the update ends here, the factors are untouched
+            for (int i = lane; i < m; i += 64) cur[i] = sens[i];
+            if (lane == 0) { qs->upd_flag = DAQP_EXIT_INFEASIBLE; qs->sing_ind = kEmpty; qs->need_activate = 0; }
+            return;
+        }
+    }
+    if constexpr (PART) {
+        if (pp) activate = __builtin_amdgcn_readfirstlane(qs->need_activate);   // (what the first pass decided)
+        else if (newS && b.sense_in) activate = 1;
+    } else if (b.sense_in) activate = 1;
     if (bad & 4) activate = 1;
     if (bad & 2) flag = DAQP_EXIT_UNSUPPORTED;
     else if (bad & 1) flag = DAQP_EXIT_INFEASIBLE;
-    if (force && !pp && flag > 0) flag = DAQP_NEEDS_SHIFT;   // forced proximal mode (utils.c:233-281): the host starts with the shifted pass
-    for (int i = lane; i < n; i += 64) fl[i] = f[i];
+    if (force && !pp && flag > 0 && doR) flag = DAQP_NEEDS_SHIFT;   // forced proximal mode (utils.c:233-281): the host starts with the shifted pass
+    const int rec_diag = keepR ? __builtin_amdgcn_readfirstlane(qs->diag_h) : 0;
+    if (doV) for (int i = lane; i < n; i += 64) fl[i] = (keepR && i < ms && !rec_diag) ? f[i] / sc[i] : f[i];   // utils.c:491-496: rows < ms of the kept R^-1 are normalised
     WSYNC();
 
     // --- Cholesky of 1/2(H+H') in packed-upper form, 1/r_ii on the diagonal (utils.c:318-352).
@@ -161,7 +210,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
             if (factored) { pmin = rec[1]; pmax = rec[2]; }
         }
     }
-    if (flag > 0 && !factored) {
+    if constexpr (PART) if (keepR) {   // the stored factor (rows < ms normalised), its kind and its shift
+        diag = rec_diag; nprox = __builtin_amdgcn_readfirstlane(qs->n_prox);
+        for (int e = lane; e < b.rtri; e += 64) Ro[e] = b.Rinv[(size_t)q * b.rtri + e];
+        WSYNC();
+    }
+    if (flag > 0 && !factored && doR) {
         int offd = 0;
         for (int e = lane; e < n * n; e += 64) {
             const int i = e / n, j = e - i * n;
@@ -204,7 +258,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
     }
     GPROF(0);
     if (flag > 0 && factored && pmin <= st.zero_tol * pmax) flag = shift_code;   // utils.c:354-356
-    if (flag > 0 && !diag && !factored) {
+    if (flag > 0 && !diag && !factored && doR) {
         for (int e0 = lane; e0 < n * n; e0 += 64 * 8) {   // 16 loads per lane per trip (H and its transpose), then the stores
             double h1[8], h2[8];
             int ii[8], jj[8];
@@ -341,7 +395,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
     // chains are independent: each hides the other's broadcast latency).  Every entry still receives its terms in
     // ascending i, as in the reference.
     if (flag > 0) {
-      if (!diag && !factored) {
+      if (!diag && !factored && doR) {
         constexpr int KR = 32 / NBK;
         for (int k0 = 0; k0 < n; k0 += KR) {
             double x[KR][NBK];
@@ -419,7 +473,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
       }
         GPROF(2);
         // --- v = R^-T f (utils.c:474-497, mask has UPDATE_Rinv: no column scaling)
-        if (factored) {      // k_fact_wg formed it (and x_unc) from the R^-1 it had in LDS
+        if (factored || !doV) {      // k_fact_wg formed it (and x_unc) from the R^-1 it had in LDS; or: neither R^-1 nor f changed
             for (int i = lane; i < n; i += 64) vv[i] = b.v[(size_t)q * n + i];
         } else
         for (int ic = 0; ic < n; ic += 64) {
@@ -434,7 +488,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
     }
     // --- unconstrained optimum x = -R^-1 v (utils.c:618-662), only for the quadprog variant
     int unc = 0;
-    if (flag > 0 && (mask & DAQP_UPDATE_unconstrained)) {
+    if (flag > 0 && (mask & DAQP_UPDATE_unconstrained) && !(keepR && nprox > 0)) {   // (utils.c:622: not for a proximal workspace)
         int fixed = 0;
         for (int i = lane; i < m; i += 64) fixed |= sens[i] & (DAQP_ACTIVE + DAQP_IMMUTABLE);
         if (!__any(fixed)) {
@@ -575,6 +629,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
                 for (int j = 0; j < n; ++j) sunc += at[lane * np2 + j] * xu[j];
                 du[ms + kb + lane] = sunc;
             }
+            if constexpr (PART) if (keepR && !diag && ms > 0) {   // utils.c:447-452: the kept R^-1 has its rows < ms normalised
+                WSYNC();
+                for (int e = lane; e < rows * ms; e += 64) { const int k = e / ms, c = e - k * ms; at[k * np2 + c] = at[k * np2 + c] / sc[c]; }
+                WSYNC();
+            }
             for (int cb = 0; cb < n; cb += 64) {
                 const int c = cb + lane;
                 const bool has = c < n;
@@ -711,7 +770,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
             if (i < ms) {
                 const int pi = roff(i, n);
                 double s = 0;
-                if (diag) s = sc[i];   // sqrt(H_ii); the row stays un-normalised and counts as the unit vector
+                if (diag || keepR) s = sc[i];   // sqrt(H_ii): the row stays un-normalised and counts as the unit vector; or the kept normalisation
                 else {
                     for (int j = i; j < n; ++j) s += Ro[pi + j] * Ro[pi + j];
                     s = 1 / sqrt(s);
@@ -730,6 +789,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
                     dl[i] = bl[i] * s + t;
                 }
                 double2 *dst = reinterpret_cast<double2 *>(Mq) + ((size_t)(i >> 6) * b.npair) * 64 + (i & 63);
+                if (!keepR)
                 for (int t = 0; t < b.npair; ++t) {
                     double2 vpair;
                     if (diag) { vpair.x = (2 * t == i) ? 1.0 : 0.0; vpair.y = (2 * t + 1 == i) ? 1.0 : 0.0; }
@@ -754,10 +814,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFER ? DAQP
     const int owed = (flag > 0 && defer_m) ? (1 | (unc ? 2 : 0) | (all_feasible ? 0 : 4)) : 0;
     // --- write back
     if (flag > 0) {
-        for (int e = lane; e < b.rtri; e += 64) b.Rinv[(size_t)q * b.rtri + e] = Ro[e];
+        if (!keepR) for (int e = lane; e < b.rtri; e += 64) b.Rinv[(size_t)q * b.rtri + e] = Ro[e];
         for (int i = lane; i < n; i += 64) { b.v[(size_t)q * n + i] = vv[i]; if (unc) b.xunc[(size_t)q * n + i] = xu[i]; }
     }
     for (int i = lane; i < m; i += 64) b.sense[(size_t)q * m + i] = sens[i];
+    if constexpr (PART) {
+        // what fails the reference's update without touching the factor (a zero row whose bounds exclude 0, utils.c:600-602) is the
+        // update's flag (k_update): the workspace stays set up and a later update repairs it.  A Hessian that cannot be factorised
+        // leaves no workspace to solve on: that is the setup flag, as after a setup.
+        const bool hard = flag == DAQP_NEEDS_SHIFT || flag == DAQP_EXIT_NONCONVEX || flag == DAQP_EXIT_UNSUPPORTED;
+        if (lane == 0) {
+            qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->lam_swapped = 0; qs->pad_ = 0;
+            if (doR) {
+                const int sf = (flag > 0 || hard) ? flag : 1;
+                qs->setup_flag = sf; qs->exitflag = sf; qs->iterations = 0; qs->fval = 0; qs->soft_slack = 0;
+                qs->diag_h = diag; qs->n_prox = (flag > 0) ? nprox : 0;
+            }
+            qs->upd_flag = (flag < 0 && !hard) ? flag : 0;
+            qs->need_activate = (flag > 0 || flag == DAQP_NEEDS_SHIFT) ? activate : 0;   // (the regularising re-run picks it up)
+        }
+    } else
     if (lane == 0) {
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0;
@@ -862,7 +938,10 @@ __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
         if (!(s & DAQP_IMMUTABLE) && !(s & DAQP_SOFT) && bu[i] - bl[i] < st.zero_tol) { sens[i] = s | DAQP_ACTIVE | DAQP_IMMUTABLE; bad |= 4; }
     }
     const int inf = first_bad != kBig, eq = __any(bad & 4);
-    if (lane == 0) { qs->upd_flag = inf ? DAQP_EXIT_INFEASIBLE : 0; qs->sing_ind = kEmpty; }   // utils.c:80-81 precedes the check
+    if (lane == 0) {
+        qs->upd_flag = inf ? DAQP_EXIT_INFEASIBLE : 0; qs->sing_ind = kEmpty;   // utils.c:80-81 precedes the check
+        if (inf) qs->need_activate = 0;   // (a sense taken over by the same call asked for the activation: the reference returns before it, utils.c:95-96)
+    }
     if (inf) return;
     if (mask & DAQP_UPDATE_v) {   // utils.c:474-497 without UPDATE_Rinv: rows < ms of R^-1 are normalised
         const double *f = b.f + (size_t)q * n;
@@ -907,6 +986,28 @@ __global__ __launch_bounds__(64) void k_update(BatchDev b, int mask)
         qs->reuse_ind = 0;
         qs->sing_ind = kEmpty;   // utils.c:80-81
         if (eq) qs->need_activate = 1;
+    }
+}
+
+// k_update_sense: the DAQP_UPDATE_sense step of daqp_update_ldp on its own (utils.c:80-91): the caller's sense replaces the
+// workspace's -- bits that an earlier bound check or a vanishing row of A R^-1 had set are gone with it, as in the reference -- or
+// zeros when the caller has none; a given sense asks for the working set to be rebuilt from its ACTIVE bits (utils.c:199-211, the
+// activation launch that follows).  One workgroup per problem.
+__global__ __launch_bounds__(256) void k_update_sense(BatchDev b)
+{
+    const int q = blockIdx.x, m = b.m;
+    QState *qs = b.qs + q;
+    int binary = 0;
+    if (b.sense_in) for (int i = threadIdx.x; i < m; i += 256) binary |= b.sense_in[(size_t)q * m + i] & DAQP_BINARY;
+    if (__syncthreads_or(binary)) {            // binary constraints are outside this path: nothing is taken over
+        if (threadIdx.x == 0) qs->upd_flag = DAQP_EXIT_UNSUPPORTED;
+        return;
+    }
+    for (int i = threadIdx.x; i < m; i += 256) b.sense[(size_t)q * m + i] = b.sense_in ? b.sense_in[(size_t)q * m + i] : 0;
+    if (threadIdx.x == 0) {
+        qs->sing_ind = kEmpty;                 // utils.c:80-81
+        qs->upd_flag = 0;
+        if (b.sense_in) qs->need_activate = 1;
     }
 }
 

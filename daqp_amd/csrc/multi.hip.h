@@ -191,7 +191,8 @@ int check_multi_problem(const DAQPMultiBatch *mb, const DAQPBatchProblem *p)
 }
 
 // the shard's share of a host-resident batch -> its own device slots; `ps`: the device-resident descriptor of what was staged
-int shard_stage_problem(MultiShard *s, const DAQPBatchProblem *p, DAQPBatchProblem *ps, bool with_matrices)
+// `what`: DAQP_UPDATE_* bits of the arrays to take over (Rinv: H, M: A, sense: sense; f and the bounds whenever they are given)
+int shard_stage_problem(MultiShard *s, const DAQPBatchProblem *p, DAQPBatchProblem *ps, int what)
 {
     DAQPBatch *b = s->b;
     const size_t Ng = s->Ng, n = p->n, m = p->m, mA = p->m - p->ms;
@@ -199,12 +200,12 @@ int shard_stage_problem(MultiShard *s, const DAQPBatchProblem *p, DAQPBatchProbl
     ps->N = s->Ng; ps->memory = DAQP_MEM_DEVICE;
     ps->H = nullptr; ps->A = nullptr; ps->f = nullptr; ps->bupper = nullptr; ps->blower = nullptr; ps->sense = nullptr;
     int rc = 0;
-    if (with_matrices && p->H) { rc |= slot_reserve(b, &b->sH, &b->nH, Ng * n * n); if (!rc) rc |= stage_rows_in(s, p->H, n * n, b->sH); ps->H = b->sH; }
-    if (with_matrices && p->A && mA) { rc |= slot_reserve(b, &b->sA, &b->nA, Ng * mA * n); if (!rc) rc |= stage_rows_in(s, p->A, mA * n, b->sA); ps->A = b->sA; }
+    if ((what & DAQP_UPDATE_Rinv) && p->H) { rc |= slot_reserve(b, &b->sH, &b->nH, Ng * n * n); if (!rc) rc |= stage_rows_in(s, p->H, n * n, b->sH); ps->H = b->sH; }
+    if ((what & DAQP_UPDATE_M) && p->A && mA) { rc |= slot_reserve(b, &b->sA, &b->nA, Ng * mA * n); if (!rc) rc |= stage_rows_in(s, p->A, mA * n, b->sA); ps->A = b->sA; }
     if (p->f) { rc |= slot_reserve(b, &b->sf, &b->nf, Ng * n); if (!rc) rc |= stage_rows_in(s, p->f, n, b->sf); ps->f = b->sf; }
     if (p->bupper) { rc |= slot_reserve(b, &b->sbu, &b->nbu, Ng * m); if (!rc) rc |= stage_rows_in(s, p->bupper, m, b->sbu); ps->bupper = b->sbu; }
     if (p->blower) { rc |= slot_reserve(b, &b->sbl, &b->nbl, Ng * m); if (!rc) rc |= stage_rows_in(s, p->blower, m, b->sbl); ps->blower = b->sbl; }
-    if (with_matrices && p->sense) { rc |= slot_reserve(b, &b->ssense, &b->nsense, Ng * m); if (!rc) rc |= stage_rows_in(s, p->sense, m, b->ssense); ps->sense = b->ssense; }
+    if ((what & DAQP_UPDATE_sense) && p->sense) { rc |= slot_reserve(b, &b->ssense, &b->nsense, Ng * m); if (!rc) rc |= stage_rows_in(s, p->sense, m, b->ssense); ps->sense = b->ssense; }
     return rc ? DAQP_EXIT_UNSUPPORTED : 0;
 }
 
@@ -280,7 +281,7 @@ int daqp_batch_setup_multi(DAQPMultiBatch *mb, const DAQPBatchProblem *p, int in
     if (!p->f || !p->bupper || !p->blower || (p->m > p->ms && !p->A)) { set_err("f, A, bupper, blower are required (H may be NULL: an LP)"); return DAQP_EXIT_UNSUPPORTED; }
     return multi_run(mb, [&](MultiShard *s) -> int {
         DAQPBatchProblem ps;
-        int r = shard_stage_problem(s, p, &ps, true);
+        int r = shard_stage_problem(s, p, &ps, DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_sense);
         if (!r) r = daqp_batch_setup(s->b, &ps, init_mask);
         if (!r && hipStreamSynchronize(s->stream) != hipSuccess) { set_err("stream synchronisation failed"); r = DAQP_EXIT_UNSUPPORTED; }
         return r;
@@ -296,8 +297,12 @@ int daqp_batch_update_multi(DAQPMultiBatch *mb, int mask, const DAQPBatchProblem
     if (refactor && (!p->f || !p->bupper || !p->blower || (p->m > p->ms && !p->A))) { set_err("a full re-setup of a multi-device batch needs every array"); return DAQP_EXIT_UNSUPPORTED; }
     return multi_run(mb, [&](MultiShard *s) -> int {
         DAQPBatchProblem ps;
-        int r = shard_stage_problem(s, p, &ps, refactor);
+        // the arrays the mask's steps read (utils.c:58-221): H with the Rinv bit, A with Rinv or M, sense with its own bit
+        int r = shard_stage_problem(s, p, &ps, (mask & DAQP_UPDATE_Rinv) ? (mask | DAQP_UPDATE_M) : mask);
         if (!r) r = daqp_batch_update(s->b, mask, &ps);
+        // the staging copies out of the caller's arrays have run when this returns (the header's contract: "every call returns when
+        // all shards have finished it")
+        if (!r && hipStreamSynchronize(s->stream) != hipSuccess) { set_err("stream synchronisation failed"); r = DAQP_EXIT_UNSUPPORTED; }
         return r;
     });
 }
@@ -337,7 +342,11 @@ int daqp_batch_setup_multi_shards(DAQPMultiBatch *mb, const DAQPBatchProblem *ps
 int daqp_batch_update_multi_shards(DAQPMultiBatch *mb, int mask, const DAQPBatchProblem *ps)
 {
     if (!mb || !ps) { set_err("null argument"); return DAQP_EXIT_UNSUPPORTED; }
-    return multi_run(mb, [&](MultiShard *s) -> int { return daqp_batch_update(s->b, mask, &ps[s->g]); });
+    return multi_run(mb, [&](MultiShard *s) -> int {
+        int r = daqp_batch_update(s->b, mask, &ps[s->g]);
+        if (!r && hipStreamSynchronize(s->stream) != hipSuccess) { set_err("stream synchronisation failed"); r = DAQP_EXIT_UNSUPPORTED; }
+        return r;
+    });
 }
 int daqp_batch_solve_multi_shards(DAQPMultiBatch *mb, DAQPBatchResult *rs)
 {

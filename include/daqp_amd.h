@@ -215,10 +215,21 @@ int daqp_batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask);
  * daqp_update_ldp(DAQP_UPDATE_v|DAQP_UPDATE_d) (utils.c:58-221) with its f and bounds -- bit for bit.  The factorisation
  * runs once and every solve reads one shared image of M.  Follow with daqp_batch_solve / daqp_batch_update as usual. */
 int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask);
-/* daqp_update_ldp for every problem; supported masks: any combination of UPDATE_v, UPDATE_d
- * (new f and/or bounds; factors and working sets are kept: warm start), or a full re-setup
- * (UPDATE_Rinv|UPDATE_M|UPDATE_v|UPDATE_d|UPDATE_sense).  Pointers of `p` not covered by the
- * mask may be NULL. */
+/* daqp_update_ldp (utils.c:58-221) for every problem, ANY mask of DAQP_UPDATE_Rinv | M | v | d | sense -- each bit's step on its
+ * own, as the reference runs them and as its bindings send them (daqp.pyx:513-571 builds the mask field by field):
+ *   v, d          new f and / or bounds on the kept factors and working sets: the warm path (applied by the next solve launch)
+ *   sense         the caller's sense replaces the workspace's (p->sense == NULL: zeros) and, if one was given, the working sets are
+ *                 rebuilt from its ACTIVE bits (utils.c:84-91,199-211)
+ *   M             new A on the kept R^-1 (its rows < ms stay normalised: utils.c:447-452); working sets emptied (utils.c:470);
+ *                 the workspace's sense -- the ACTIVE bits of the last solve included -- is kept unless the sense bit is set too
+ *   Rinv          new H: factor, then v, M, the normalisations and d follow as in a setup (utils.c:122,135,142,150); sense as for M
+ *   all five      a re-setup (the setup kernels; the iterate of a proximal problem is kept, api.c:318 does not run)
+ * DAQP_UPDATE_unconstrained / _eliminate may ride along as in setup_daqp_main.  Arrays of `p` that the mask's steps do not read may
+ * be NULL; one that they read and that is NULL stays as the batch has it (device-resident arrays were adopted, not copied: they must
+ * still be valid).  Per-problem outcome: daqp_batch_setup_flags (1, or the flag daqp_update_ldp would have returned: -1 for crossed
+ * bounds -- that problem's LDP is then untouched and its next solve reports the -1 instead of solving -- -5, ...).
+ * Masks with the Rinv or M bit but not all five run the generic one-wave setup kernel in the reference's operation order in both
+ * arithmetic modes; they are not available after daqp_batch_setup_shared (one H and A for the whole batch: set it up again). */
 int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p);
 /* daqp_solve for every problem: dual active-set iteration from the current working sets, then
  * x, lam, fval, exitflag, iter.  Blocks until results are in `r` unless r->memory is DEVICE
@@ -251,8 +262,8 @@ int daqp_quadprog_batch(DAQPBatchResult *r, const DAQPBatchProblem *p, const DAQ
  * listed more than once (its shards share it).  G = min(n_devices, N).
  *   daqp_batch_setup_multi / update_multi / solve_multi take ONE host-resident batch in the caller's order (memory must be
  *     DAQP_MEM_HOST): every shard gathers its problems through pinned buffers, chunk by chunk, two deep, into its own device slots;
- *     results come back the same way, each to its own index.  update_multi: mask within DAQP_UPDATE_v|DAQP_UPDATE_d (f / bupper /
- *     blower as given) or a full re-setup (every array).
+ *     results come back the same way, each to its own index.  update_multi: any mask of daqp_batch_update (the arrays its steps read;
+ *     a full re-setup needs every array).
  *   daqp_batch_*_multi_shards take G descriptors, ps[g] / rs[g] = shard g's problems / results back to back (N = that shard's
  *     size: daqp_batch_multi_shard), host-resident or resident ON THAT SHARD'S DEVICE (used in place); the shards run side by side.
  *   daqp_batch_multi_shard hands out shard g's DAQPBatch (for the inspection calls above: setup flags, working sets, kernel times).

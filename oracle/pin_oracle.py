@@ -291,6 +291,54 @@ def main():
             f = f + 0.05 * rng.standard_normal(n)
             assert om.update(O.UPDATE_v, f=f) == rm.update(O.UPDATE_v, f=f) == 0
         rm.close()
+    # every daqp_update_ldp mask (utils.c:58-221 runs each bit's step on its own; daqp.pyx:513-571 builds them field by field): 31 masks
+    # x 4 shapes x sense variety x 3 consecutive updates, incl. a sense bit without a sense array (utils.c:85-86), unmarked equalities
+    # that the bound check marks, and crossed bounds (the update ends with -1 and the next solve runs on what the workspace held)
+    R_, M_, V_, D_, S_ = O.UPDATE_Rinv, O.UPDATE_M, O.UPDATE_v, O.UPDATE_d, O.UPDATE_sense
+    mcount = 0
+    for (n, m, ms, na) in ((20, 40, 0, 8), (12, 48, 12, 6), (10, 30, 4, 5), (30, 70, 10, 9)):
+        for trial in range(max(2, args.n_per_config // 100)):
+            q = O.generate_qp(n, m, ms, na, rng=[7, n, trial])
+            H, f, A, bu, bl = q["H"], q["f"], q["A"], q["bupper"], q["blower"]
+            sense = np.zeros(m, np.int32)
+            if trial % 3 == 1:
+                sense[ms + 1] = 5; bl[ms + 1] = bu[ms + 1]; sense[ms + 3] = 8
+            if trial % 3 == 2:
+                sense[m - 1] = 8; sense[0] = 8 if ms else 0
+            for mask in range(1, 32):
+                om, rm = ora.model(n, m, ms, ns=int((sense & 8).sum()) + 2), strict.model(n, m, ms)
+                assert om.setup(H, f, A, bu, bl, sense) == rm.setup(H, f, A, bu, bl, sense)
+                rr = (om.solve(), rm.solve())[1]
+                for step in range(3):
+                    r2 = np.random.default_rng([9, n, trial, mask, step])
+                    kw = {}
+                    if mask & R_:
+                        G = r2.standard_normal((n, n)) * 0.1; kw["H"] = H + G @ G.T
+                    if mask & M_: kw["A"] = A + 0.05 * r2.standard_normal(A.shape)
+                    if mask & V_: kw["f"] = f + 0.3 * r2.standard_normal(n)
+                    if mask & D_:
+                        w = 0.05 * r2.random(m); kw["bupper"] = bu + w; kw["blower"] = bl - 0.5 * w
+                        if trial % 3 == 1: kw["blower"][ms + 1] = kw["bupper"][ms + 1]
+                        if step == 1 and trial % 2 == 0: kw["blower"][ms + 4] = kw["bupper"][ms + 4]          # unmarked equality
+                        if step == 0 and trial % 4 == 3: kw["bupper"][ms + 6] = kw["blower"][ms + 6] - 1.0    # crossed
+                    if mask & S_:
+                        s2 = sense.copy()
+                        act = np.nonzero(rr[1])[0]
+                        if step == 0 and len(act): s2[act[0]] |= 1 | (2 if rr[1][act[0]] < 0 else 0)
+                        if step == 1: s2[r2.integers(0, m)] |= 1
+                        kw["sense"] = s2 if not (step == 2 and trial % 2) else None
+                        if kw["sense"] is None:     # qp->sense == NULL with the sense bit: zeros, nothing rebuilt
+                            om.keep["sense"] = None; rm.keep["sense"] = None
+                    uo, ur = om.update(mask, **kw), rm.update(mask, **kw)
+                    ro, rr = om.solve(), rm.solve()
+                    total += 1; mcount += 1
+                    ok = uo == ur and ro[3] == rr[3] and ro[4] == rr[4] and (ro[3] < 0 or (same(ro[0], rr[0]) and same(ro[1], rr[1]) and same(ro[2], rr[2])))
+                    ok = ok and np.array_equal(om.state()[0], rm.working_set())
+                    if not ok:
+                        bad += 1
+                        print(f"MISMATCH update_mask n={n} trial {trial} mask {mask} step {step}: update {uo}/{ur} solve {ro[3]}/{ro[4]} vs {rr[3]}/{rr[4]}")
+                rm.close()
+    print(f"  update masks: {mcount} update + solve steps")
     print(f"pin result: {total - bad}/{total} bit-identical to the strict reference build")
     return 1 if bad else 0
 

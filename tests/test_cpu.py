@@ -149,6 +149,27 @@ def test_oracle_golden_proximal(oracle):
         assert np.array_equal(lam.view(np.uint64), g["warm/lam"][t].view(np.uint64))
 
 
+def test_oracle_golden_update_masks(oracle):
+    """every daqp_update_ldp mask (utils.c:58-221): the oracle replays the sequences the reference library wrote into
+    tests/golden/golden_update_masks.npz -- update flags, x, lam, fval, iterations, exit flags and working sets bit for bit"""
+    import mask_replay as MR
+    steps_checked = 0
+    for shape, (n, m, ms) in MR.SHAPES.items():
+        for mask, steps in MR.sequences(shape):
+            for trial in range(MR.TRIALS):
+                q = MR.base(shape, trial)
+                om = oracle.model(n, m, ms, ns=MR.NS[shape])
+                assert om.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"]) == 1
+                for s in range(-1, steps):
+                    kw, exp = MR.step(shape, trial, mask, s)
+                    uflag = om.update(mask, **kw) if s >= 0 else 0
+                    x, lam, fval, flag, it = om.solve()
+                    MR.check(f"{shape}/{trial}/mask {mask}/step {s}", dict(x=x, lam=lam, fval=fval, flag=flag, iter=it, uflag=uflag,
+                                                                      ws=om.state()[0]), exp, exact=True)
+                    steps_checked += 1
+    assert steps_checked > 700
+
+
 def test_c_abi_exports_every_declared_symbol():
     import daqp_amd
     from daqp_amd._lib import EXPORTS
@@ -262,8 +283,9 @@ def test_kernel_resource_budgets():
     if not res:
         pytest.skip("no resource report next to the objects (prebuilt library)")
     budgets = {   # kernel: (scratch bytes per lane at most, waves per SIMD at least)
-        "k_setup<true, 4, false>": (128, 2), "k_setup<false, 4, false>": (128, 2), "k_setup<true, 8, false>": (128, 2),
-        "k_setup<true, 4, true>": (0, 2), "k_setup<false, 4, true>": (0, 2),
+        "k_setup<true, 4, false, false>": (128, 2), "k_setup<false, 4, false, false>": (128, 2), "k_setup<true, 8, false, false>": (128, 2),
+        "k_setup<true, 4, true, false>": (0, 2), "k_setup<false, 4, true, false>": (0, 2),
+        "k_setup<true, 4, false, true>": (0, 2), "k_setup<false, 4, false, true>": (0, 2),      # (PART: daqp_update_ldp's partial masks)
         "k_setup_fast<16, false, true>": (0, 4), "k_setup_fast<32, false, true>": (0, 2), "k_setup_fast<56, false, true>": (256, 2),
         "k_setup_fast<64, false, true>": (400, 2), "k_setup_fast<56, false, false>": (256, 2), "k_setup_fast<56, true, false>": (256, 2),
         "k_setup_tiny<4>": (64, 1), "k_setup_m": (0, 2), "k_fact_wg": (0, 2),

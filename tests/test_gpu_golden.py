@@ -473,8 +473,13 @@ def test_adopted_device_arrays_outlive_an_update(oracle, gpu_lib, monkeypatch):
     bm.close()
 
 
-def test_box_constrained_model_full_update(gpu_lib):
-    """only simple bounds (A is NULL): Model.update(H=...) is a full re-setup and must be accepted (the reference does)"""
+def test_box_constrained_model_update_of_the_hessian(gpu_lib):
+    """only simple bounds (A is NULL): Model.update(H=...) is daqp_update_ldp(UPDATE_Rinv) (daqp.pyx:530-535) and must be accepted.
+    The reference runs that bit on its own: the factor, v, d are formed anew and the working set is emptied (utils.c:470), but the
+    workspace's sense keeps the ACTIVE bits of the last solve (utils.c:84-91 only runs with the sense bit) -- rows that were active
+    are then never looked at again (auxiliary.c:126) and the reference returns x = (-0.5, -2) although x_2 >= -1 was asked for.
+    This library is a drop-in for that path: the same answer, bit for bit (the oracle is pinned on it; what a caller who wants the
+    bound back passes is sense as well -- the second half)."""
     import daqp_amd
     d = daqp_amd.Model()
     flag, _ = d.setup(np.eye(2), np.array([2.0, 2.0]), np.zeros((0, 2)), np.ones(2), -np.ones(2), np.zeros(2, np.int32))
@@ -482,6 +487,9 @@ def test_box_constrained_model_full_update(gpu_lib):
     x, _, ef, _ = d.solve()
     assert ef == 1 and np.allclose(x, [-1, -1], atol=1e-6)
     assert d.update(H=np.diag([4.0, 1.0])) == 0, daqp_amd.last_error()
+    x, _, ef, info = d.solve()
+    assert ef == 1 and info["iterations"] == 1 and np.array_equal(x, [-0.5, -2.0])      # the reference's own output (strict build)
+    assert d.update(H=np.diag([4.0, 1.0]), sense=np.zeros(2, np.int32)) == 0
     x, _, ef, _ = d.solve()
     assert ef == 1 and np.allclose(x, [-0.5, -1.0], atol=1e-6)
 

@@ -65,7 +65,7 @@ EXPORTS = [
     "daqp_batch_setup_flags", "daqp_batch_working_sets", "daqp_batch_set_primal_start", "daqp_batch_prox_info", "daqp_quadprog_batch", "daqp_quadprog_batch_multi", "daqp_batch_kernel_ms",
     "daqp_batch_create_multi", "daqp_batch_free_multi", "daqp_batch_multi_shards", "daqp_batch_multi_shard", "daqp_batch_setup_multi", "daqp_batch_update_multi",
     "daqp_batch_solve_multi", "daqp_batch_setup_multi_shards", "daqp_batch_update_multi_shards", "daqp_batch_solve_multi_shards",
-    "daqp_batch_device_bytes", "daqp_batch_rechecked", "daqp_amd_last_error", "daqp_amd_device_count", "daqp_amd_version", "daqp_amd_has_tiny",
+    "daqp_batch_device_bytes", "daqp_batch_rechecked", "daqp_batch_set_recheck", "daqp_batch_recheck_ms", "daqp_amd_last_error", "daqp_amd_device_count", "daqp_amd_version", "daqp_amd_has_tiny",
     "setup_daqp_ldp", "daqp_ldp", "ldp2qp_solution", "daqp_extract_result",
     "daqp_batch_enable_trace", "daqp_batch_read_trace", "daqp_batch_enable_profile", "daqp_batch_read_profile", "daqp_batch_read_ldp",
 ]
@@ -75,21 +75,19 @@ EXPORTS = [
 # object was compiled with other flags)
 UNITS = {
     "daqp_amd.hip": ["daqp_amd.hip", "kernels.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h", "setup_fast.hip.h", "prox.hip.h",
-                     "wg_layout.hip.h", "batch_dev.hip.h", "recheck.hip.h", "setup_m.hip.h", "setup_fact.hip.h", "reg_kernel.hip.h", "tiny_kernel.hip.h", "tiny_ldp.hip.h", "tiny_setup.hip.h", "multi.hip.h"],
+                     "wg_layout.hip.h", "batch_dev.hip.h", "recheck.hip.h", "setup_m.hip.h", "setup_fact.hip.h", "reg_kernel.hip.h", "tiny_setup.hip.h", "multi.hip.h"],
     "reg_kernel.hip": ["reg_kernel.hip", "reg_kernel.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
     "wg_kernel.hip": ["wg_kernel.hip", "wg_kernel.hip.h", "wg_ldp.hip.h", "wg_layout.hip.h", "batch_dev.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h"],
-    "setup_kernel.hip": ["setup_kernel.hip", "setup_fast.hip.h", "setup_m.hip.h", "setup_fact.hip.h", "tiny_setup.hip.h", "tiny_ldp.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
-    "tiny_kernel.hip": ["tiny_kernel.hip", "tiny_kernel.hip.h", "tiny_ldp.hip.h", "tiny_setup.hip.h", "batch_dev.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h"],
+    "setup_kernel.hip": ["setup_kernel.hip", "setup_fast.hip.h", "setup_m.hip.h", "setup_fact.hip.h", "tiny_setup.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
 }
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 OBJDIR = os.path.join(LIBDIR, "obj")
 UNITS = {u: d for u, d in UNITS.items() if os.path.exists(os.path.join(CSRC, u))}
-WITH_TINY = "-DDAQP_AMD_WITH_TINY"   # the 16-problems-per-wave solve kernel: its own unit, only in builds that ask for it (tools/tinybuild.sh)
 
 
 def units(extra_flags=()):
     """translation units of a build with these flags"""
-    return [u for u in UNITS if u != "tiny_kernel.hip" or WITH_TINY in extra_flags]
+    return list(UNITS)
 
 
 def _flag_key(extra_flags=()):
@@ -122,7 +120,7 @@ def _stale(extra_flags=()):
         L = C.CDLL(LIBPATH)
         v = L.daqp_amd_version
         v.restype = C.c_char_p
-        return b"dev build" in v() or bool(L.daqp_amd_has_tiny())    # (nor is a build that carries the opt-in tiny solve kernel)
+        return b"dev build" in v()
     except (OSError, AttributeError):
         return True
 
@@ -262,6 +260,9 @@ def lib():
     L.daqp_batch_solve_multi_shards.argtypes = [vp, C.POINTER(DAQPBatchResult)]
     L.daqp_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.daqp_batch_rechecked.argtypes = [vp]
+    L.daqp_batch_set_recheck.argtypes = [vp, ci]
+    L.daqp_batch_set_recheck.restype = None
+    L.daqp_batch_recheck_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.daqp_batch_device_bytes.argtypes = [vp]
     L.daqp_batch_device_bytes.restype = C.c_ulonglong
     L.daqp_batch_enable_trace.argtypes = [vp, ci]

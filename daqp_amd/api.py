@@ -338,6 +338,16 @@ class BatchModel:
         solve after a setup: include/daqp_amd.h, daqp_batch_rechecked)"""
         return int(lib().daqp_batch_rechecked(self._h))
 
+    def set_recheck(self, on):
+        """switch the second pass of INFEASIBLE verdicts on / off for this batch (daqp_batch_set_recheck: off for a caller that
+        recycles device-resident input buffers between setup and solve)"""
+        lib().daqp_batch_set_recheck(self._h, 1 if on else 0)
+
+    def recheck_ms(self):
+        t = C.c_float(0)
+        lib().daqp_batch_recheck_ms(self._h, C.byref(t))
+        return t.value
+
     # test hooks
     def enable_trace(self, cap=4096):
         lib().daqp_batch_enable_trace(self._h, cap)

@@ -57,9 +57,6 @@ struct BatchDev {
     // period of the device's constant clock (s_memrealtime) in seconds
     unsigned long long *tstart;
     double tick_s;
-    // 16-problems-per-wave kernel of tiny shapes (tiny_kernel.hip.h): the pending re-insertions of daqp_pivot_last, [N][13][3]
-    double *tiny_pend;
-    int *tiny_counter;            // next problem a persistent wave takes
 };
 // internal setup flag: the Hessian is numerically singular and eps_prox != 0 -- the host re-runs the setup with a shifted
 // diagonal (never leaves the library: it ends as 1 or DAQP_EXIT_NONCONVEX)

@@ -3,6 +3,8 @@
 // happens on the host and there is no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -21,9 +23,6 @@
 #include "setup_m.hip.h"
 #include "setup_fact.hip.h"
 #include "wg_layout.hip.h"
-#ifdef DAQP_AMD_WITH_TINY
-#include "tiny_kernel.hip.h"
-#endif
 #include "tiny_setup.hip.h"
 // the workgroup-per-problem solve kernel lives in its own translation unit (wg_kernel.hip): a change to it does not rebuild
 // everything else
@@ -41,7 +40,6 @@ DAQP_REG_SHAPE(2, 16)
 DAQP_REG_SHAPE(2, 32)
 #endif
 #undef DAQP_REG_SHAPE
-// the 16-problems-per-wave kernel of tiny shapes: tiny_kernel.hip
 #define DAQP_SETUP_SIZE(NMAX) \
     extern template __global__ void k_setup_fast<NMAX, false, false>(BatchDev, int); \
     extern template __global__ void k_setup_fast<NMAX, false, true>(BatchDev, int); \
@@ -51,14 +49,6 @@ DAQP_SETUP_SIZE(32)
 DAQP_SETUP_SIZE(56)
 DAQP_SETUP_SIZE(64)
 #undef DAQP_SETUP_SIZE
-// the 16-problems-per-wave SOLVE kernel of tiny shapes is not part of the default build (measured slower than the register kernel on
-// config C3): -DDAQP_AMD_WITH_TINY compiles tiny_kernel.hip in (tools/tinybuild.sh), DAQP_AMD_TINY=1 then selects it
-#ifdef DAQP_AMD_WITH_TINY
-extern template __global__ void k_ldp_tiny<4, 0, false>(const BatchDev *__restrict__, int);
-extern template __global__ void k_ldp_tiny<4, 0, true>(const BatchDev *__restrict__, int);
-extern template __global__ void k_ldp_tiny<4, 3, false>(const BatchDev *__restrict__, int);
-extern template __global__ void k_ldp_tiny<4, 3, true>(const BatchDev *__restrict__, int);
-#endif
 extern template __global__ void k_setup_tiny<4>(BatchDev, int);   // (the 16-per-wave SETUP kernel is the default for these shapes: setup_kernel.hip)
 template <int C> __global__ void k_ldp_wg(BatchDev b, int mode);
 extern template __global__ void k_ldp_wg<2>(BatchDev, int);
@@ -120,9 +110,6 @@ struct DAQPBatch {
     int C = 1;
     bool spill = false;
     int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
-    bool tiny = false;    // tiny shape (n <= 12, m <= 48, <= 13 working-set rows): 16 problems per wavefront (tiny_kernel.hip.h)
-    int tiny_tri = 0;     // its row slots that hold simple bounds only (zero prefix not stored: ms >= 12 -> 3)
-    int tiny_grid = 1024; // persistent waves of that kernel: 4 per CU
     bool tiny_setup = false;   // n <= 12, m <= 48: the 16-problems-per-wave setup kernel (tiny_setup.hip.h)
     bool fast_setup = false, setup_spill = false;
     double *fact_buf = nullptr;     // [N][4] records of k_fact_wg (setup_fact.hip.h), allocated for the shapes it serves
@@ -175,6 +162,12 @@ struct DAQPBatch {
     bool fresh = false;        // the state is that of the last daqp_batch_setup (own H / A per problem, not an LP): nothing solved or updated since
     int fresh_mask = 0;        // its init_mask
     bool recheck = true;       // DAQP_AMD_NO_RECHECK=1 switches the second pass off
+    int recheck_device = -1;   // the same for inputs that were ADOPTED (DAQP_MEM_DEVICE: the second pass reads them again at solve time): -1 = not said
+                               // (on, unless DAQP_AMD_RECHECK_DEVICE=0), 0 / 1 = daqp_batch_set_recheck
+    bool inputs_adopted = false;   // the last setup's inputs were device arrays of the caller's, used in place
+    bool quiet_setup = false;  // the setup that runs now is the second pass of a one-problem batch: the caller's setup events stay as they are
+    hipEvent_t ev_r[2] = {nullptr, nullptr};   // around the second pass (daqp_batch_recheck_ms)
+    bool timed_recheck = false;
     DAQPBatch *redo = nullptr; // companion batch in the exact mode (created with the first infeasible verdict, grown on demand)
     int *redo_list = nullptr, *redo_count = nullptr, *pin_redo = nullptr, *pin_redo_dev = nullptr;   // pin_redo: a mapped host word the marking kernel writes
     int rechecked = 0;         // problems the last solve sent through the second pass
@@ -255,21 +248,6 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         HIPCHK(hipGetLastError());
         return 0;
     }
-#ifdef DAQP_AMD_WITH_TINY
-    if (b->tiny) {
-        const bool exact = b->d.exact_setup != 0 || b->in_prox_loop;
-        ldp_reg_kernel_t kt = b->tiny_tri == 3 ? (exact ? k_ldp_tiny<4, 3, false> : k_ldp_tiny<4, 3, true>)
-                                               : (exact ? k_ldp_tiny<4, 0, false> : k_ldp_tiny<4, 0, true>);
-        if (descriptor_changed) HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
-        HIPCHK(hipMemsetAsync(b->d.tiny_counter, 0, sizeof(int), b->stream));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, TinyL<4>::bytes));
-        // persistent waves: one per SIMD (its 39 KB of LDS and the full register file allow no more), each takes problems off the counter
-        const int want = (b->d.N + TinyL<4>::Q - 1) / TinyL<4>::Q;
-        hipLaunchKernelGGL(kt, dim3(want < b->tiny_grid ? want : b->tiny_grid), dim3(64), TinyL<4>::bytes, b->stream, (const BatchDev *)b->d_dev, mode);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-#endif
     if (b->NB > 0) {
         // problems that run the proximal outer loop keep the reference's arithmetic in both modes (their setup passes do as well)
         ldp_reg_kernel_t kr = pick_ldp_reg(b, b->d.exact_setup != 0 || b->in_prox_loop || b->exact_sticky);
@@ -546,6 +524,7 @@ int recheck_infeasible(DAQPBatch *b)
     {   // poll the mapped word (written by the kernel's last block); a stream that has failed is noticed through hipStreamQuery
         unsigned spins = 0;
         while (__atomic_load_n(b->pin_redo, __ATOMIC_ACQUIRE) < 0) {
+            if ((spins & 0xff) == 0xff) sched_yield();          // (one core per shard thread otherwise spins flat out while the solve kernel runs)
             if ((++spins & 0x3fff) == 0) {
                 const hipError_t qe = hipStreamQuery(b->stream);
                 if (qe != hipSuccess && qe != hipErrorNotReady) { set_err("the solve launch failed: %s", hipGetErrorString(qe)); return DAQP_EXIT_UNSUPPORTED; }
@@ -558,6 +537,9 @@ int recheck_infeasible(DAQPBatch *b)
     }
     const int count = *b->pin_redo;
     if (count == 0) return 0;
+    if (!b->ev_r[0]) { HIPCHK(hipEventCreate(&b->ev_r[0])); HIPCHK(hipEventCreate(&b->ev_r[1])); }
+    HIPCHK(hipEventRecord(b->ev_r[0], b->stream));
+    struct Stamp { DAQPBatch *b; ~Stamp() { if (hipEventRecord(b->ev_r[1], b->stream) == hipSuccess) b->timed_recheck = true; } } stamp{b};
     if (d.N == 1) {
         // one problem (daqp_quadprog): the same workspace again, in the exact mode; its inputs are still in the device slab
         DAQPBatchProblem pp;
@@ -566,7 +548,9 @@ int recheck_infeasible(DAQPBatch *b)
         pp.bupper = const_cast<double *>(d.bu); pp.blower = const_cast<double *>(d.bl); pp.sense = const_cast<int *>(d.sense_in);
         pp.memory = DAQP_MEM_DEVICE;
         d.exact_setup = 1;
+        b->quiet_setup = true;             // (daqp_batch_kernel_ms keeps reporting the caller's setup)
         int rc = batch_setup(b, &pp, b->fresh_mask, false);
+        b->quiet_setup = false;
         if (!rc) rc = launch_ldp(b, 0);
         if (!rc && b->reg_pending) rc = resolve_setup(b);      // (the count of singular Hessians of this pass: none, the first pass had none)
         d.exact_setup = 0;
@@ -579,7 +563,8 @@ int recheck_infeasible(DAQPBatch *b)
     if (b->redo && b->redo->d.N < cap) { b->redo->stream = nullptr; destroy_batch(b->redo); b->redo = nullptr; }
     if (!b->redo) {
         DAQPBatch *rb = nullptr;
-        if (daqp_batch_create(&rb, cap < 2 ? 2 : cap, d.n, d.m, d.ms, b->ns_max, &d.st, b->device)) return DAQP_EXIT_UNSUPPORTED;
+        // no memory for the companion: the first pass's verdicts stand (a valid solve does not fail over its second opinion)
+        if (daqp_batch_create(&rb, cap < 2 ? 2 : cap, d.n, d.m, d.ms, b->ns_max, &d.st, b->device)) { (void)hipGetLastError(); b->rechecked = -1; return 0; }
         rb->recheck = false;
         b->redo = rb;
     }
@@ -597,7 +582,7 @@ int recheck_infeasible(DAQPBatch *b)
     rc |= slot_reserve(rb, &rb->sA, &rb->nA, R * d.mA * n); rc |= slot_reserve(rb, &rb->sbu, &rb->nbu, R * m);
     rc |= slot_reserve(rb, &rb->sbl, &rb->nbl, R * m);
     if (d.sense_in) rc |= slot_reserve(rb, &rb->ssense, &rb->nsense, R * m);
-    if (rc) return DAQP_EXIT_UNSUPPORTED;
+    if (rc) { (void)hipGetLastError(); b->rechecked = -1; return 0; }
     hipLaunchKernelGGL(k_gather_problems, dim3(rd.N), dim3(256), 0, b->stream, d, (const int *)b->redo_list, (const int *)b->redo_count,
                        rb->sH, rb->sf, rb->sA, rb->sbu, rb->sbl, d.sense_in ? rb->ssense : (int *)nullptr);
     HIPCHK(hipGetLastError());
@@ -618,6 +603,16 @@ int recheck_infeasible(DAQPBatch *b)
     return 0;
 }
 
+// the second pass reads the setup's inputs again.  Host inputs were staged into the batch's own buffers: always there.  Device inputs
+// were adopted: the caller says whether they are still what the setup read (daqp_batch_set_recheck), or the process does
+// (DAQP_AMD_RECHECK_DEVICE=0: never for adopted inputs); unsaid, they are taken to be (include/daqp_amd.h spells the contract out).
+bool recheck_allowed(const DAQPBatch *b)
+{
+    if (!b->inputs_adopted) return true;
+    if (b->recheck_device >= 0) return b->recheck_device != 0;
+    static const bool off = [] { const char *e = getenv("DAQP_AMD_RECHECK_DEVICE"); return e && atoi(e) == 0; }();
+    return !off;
+}
 int check_problem(const DAQPBatch *b, const DAQPBatchProblem *p)
 {
     if (!b || !p) { set_err("null batch or problem"); return DAQP_EXIT_UNSUPPORTED; }
@@ -642,7 +637,7 @@ bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && 
 std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
-                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_TINY", "DAQP_AMD_TINY_GRID", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M"};
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -661,6 +656,7 @@ void destroy_batch(DAQPBatch *b)
     if (b->ev_count) (void)hipEventDestroy(b->ev_count);
     if (b->pin_count) (void)hipHostFree(b->pin_count);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->ev_r) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 } // namespace
@@ -673,14 +669,7 @@ const char *daqp_amd_version(void) { return "daqp_amd 0.4 (gfx950, fp64: one wav
 #else
 const char *daqp_amd_version(void) { return "daqp_amd 0.4 (gfx950, fp64: one wavefront per QP, one workgroup per QP beyond 64 working-set rows, up to 512 rows)"; }
 #endif
-int daqp_amd_has_tiny(void)
-{
-#ifdef DAQP_AMD_WITH_TINY
-    return 1;
-#else
-    return 0;
-#endif
-}
+int daqp_amd_has_tiny(void) { return 0; }   // (the sixteen-problems-per-wave SOLVE kernel of rounds 3-4 was measured slower than the register kernel and is gone; the symbol stays for callers that asked)
 int daqp_amd_device_count(void)
 {
     int c = 0;
@@ -749,15 +738,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     const int lds_limit = env ? atoi(env) : 80 * 1024;
     b->spill = ldp_lds(n, m, cap, false).total_bytes > lds_limit;
     if (getenv("DAQP_AMD_FORCE_SPILL") || cap > 256) b->spill = true;
-    // opt-in (DAQP_AMD_TINY=1): on config C3 the 16-problems-per-wave kernel needs 2.16 ms per 125 000 solves against 1.87 ms of
-    // the one-wave-per-problem register kernel (DESIGN.md section 4.6 has the measurements and why)
-#ifdef DAQP_AMD_WITH_TINY
-    { const char *te = getenv("DAQP_AMD_TINY"); b->tiny = te && atoi(te) != 0 && !b->spill && tiny_shape_ok(n, m, cap) && !getenv("DAQP_AMD_STREAM_M"); }
-#else
-    b->tiny = false;   // (DAQP_AMD_TINY=1 needs a library built with -DDAQP_AMD_WITH_TINY: daqp_amd_has_tiny())
-#endif
-    b->tiny_tri = (b->tiny && ms >= 12) ? 3 : 0;
-    if (!b->tiny && !b->spill && cap <= 64 && !getenv("DAQP_AMD_STREAM_M"))
+    if (!b->spill && cap <= 64 && !getenv("DAQP_AMD_STREAM_M"))
         for (const RegShape &rs : kRegShapes)
             if (d.nblk <= rs.nb && d.npair <= rs.np) { b->NB = rs.nb; b->NP = rs.np; break; }
     d.ldrc = 0;
@@ -848,15 +829,6 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &b->st_dev, 1);
     rc |= dev_alloc(b, &b->d_dev, 1);
     rc |= dev_alloc(b, &b->px.counter, 4);
-    d.tiny_pend = nullptr; d.tiny_counter = nullptr;
-    if (b->tiny) {
-        rc |= dev_alloc(b, &d.tiny_pend, Nn * 3 * TCAP);
-        rc |= dev_alloc(b, &d.tiny_counter, 1);
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-        b->tiny_grid = 4 * cus;
-        if (const char *ge = getenv("DAQP_AMD_TINY_GRID")) { const int v = atoi(ge); if (v >= 1) b->tiny_grid = v; }
-    }
     {   // period of the constant device clock behind s_memrealtime (settings->time_limit): asked of the runtime, not assumed
         int khz = 0;
         d.tick_s = (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) ? 1.0 / (1e3 * (double)khz) : 1e-8;
@@ -914,7 +886,7 @@ void daqp_batch_free(DAQPBatch *b)
         if (b->d.trace || b->d.prof) { destroy_batch(b); return; }     // (debug buffers were attached: not worth keeping, and not kept)
         b->one_lam.clear(); b->one_valid = false;
         b->d.shared = 0; b->d.prox_pass = 0;
-        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->part_mask = 0; b->exact_sticky = false; b->is_setup = false; b->reg_pending = false; b->fresh = false; b->rechecked = 0;
+        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->part_mask = 0; b->exact_sticky = false; b->is_setup = false; b->reg_pending = false; b->fresh = false; b->rechecked = 0; b->recheck_device = -1; b->inputs_adopted = false; b->timed_recheck = false;
         b->timed_setup = b->timed_solve = false; b->n_prox_qps = 0; b->prox_outer = 0;
         b->one_fval = b->one_soft = 0; b->one_flag = b->one_iter = 0;
         DAQPBatch *evict = nullptr;
@@ -968,6 +940,17 @@ void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings)
 }
 unsigned long long daqp_batch_device_bytes(const DAQPBatch *b) { return b ? b->bytes + (b->redo ? b->redo->bytes : 0) : 0; }
 int daqp_batch_rechecked(const DAQPBatch *b) { return b ? b->rechecked : 0; }
+void daqp_batch_set_recheck(DAQPBatch *b, int on) { if (b) { b->recheck = on != 0; b->recheck_device = on != 0 ? 1 : 0; } }
+int daqp_batch_recheck_ms(DAQPBatch *b, float *ms)
+{
+    if (!b || !ms) return DAQP_EXIT_UNSUPPORTED;
+    *ms = 0;
+    if (!b->timed_recheck) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipEventSynchronize(b->ev_r[1]));
+    HIPCHK(hipEventElapsedTime(ms, b->ev_r[0], b->ev_r[1]));
+    return 0;
+}
 
 // debugging aid used by the parity tests: per-problem add/remove event trace (cap ints each;
 // the last slot receives the event count).  Pass cap 0 to switch it off.
@@ -1115,31 +1098,34 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
         lds_setup = (size_t)fast_lds(d.n, d.m, d.exact_setup, d.mA).total_bytes;   // the MFMA path overlays the A tile on R^-1
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
-    HIPCHK(hipEventRecord(b->ev[0], b->stream));
+    if (!b->quiet_setup) HIPCHK(hipEventRecord(b->ev[0], b->stream));
+    b->inputs_adopted = p->memory == DAQP_MEM_DEVICE;
     if (!lp && b->tiny_setup) {     // sixteen problems per wavefront; singular Hessians leave flagged for the regularising re-run below
         hipLaunchKernelGGL(k_setup_tiny<4>, dim3((d.N + 15) / 16), dim3(64), 0, b->stream, d, mask);
         HIPCHK(hipGetLastError());
     } else if (!lp) {
-        d.defer_m = defers_m(b, d) ? 1 : 0;
-        if (d.defer_m) {    // the instantiation without the general rows (k_setup_m follows): more waves per SIMD
+        // what belongs to THESE launches only (who forms the general rows, whose factorisation records) travels in a copy of the
+        // descriptor: the batch's own never carries it, whichever way this function is left (a later shared setup copies b->d)
+        BatchDev l = d;
+        l.defer_m = defers_m(b, d) ? 1 : 0;
+        if (l.defer_m) {    // the instantiation without the general rows (k_setup_m follows): more waves per SIMD
             ks = b->setup_spill ? k_setup<true, 4, true> : k_setup<false, 4, true>;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
         }
         // default arithmetic, factors out of LDS (the n = 200 class): Cholesky and inverse by k_fact_wg, a workgroup per problem with
         // the triangle in LDS and the matrix cores behind each panel (setup_fact.hip.h); k_setup takes R^-1 from the scratch
-        d.fact = nullptr;
-        if (d.defer_m && b->setup_spill && b->fact_buf && d.n <= kFactMaxN && !(d.st.eps_prox > 0.0)) {
+        l.fact = nullptr;
+        if (l.defer_m && b->setup_spill && b->fact_buf && d.n <= kFactMaxN && !(d.st.eps_prox > 0.0)) {
             const size_t lds = fact_lds_bytes(d.n);
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fact_wg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
-                d.fact = b->fact_buf;
-                hipLaunchKernelGGL(k_fact_wg, dim3(d.N), dim3(512), lds, b->stream, d);
+                l.fact = b->fact_buf;
+                hipLaunchKernelGGL(k_fact_wg, dim3(d.N), dim3(512), lds, b->stream, l);
                 HIPCHK(hipGetLastError());
             } else (void)hipGetLastError();
         }
-        hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask);
-        d.fact = nullptr;      // (the records belong to THIS launch: the descriptor is the batch's own, and a later shared setup copies it)
+        hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, l, mask);
         HIPCHK(hipGetLastError());
-        if (d.defer_m) { if (launch_setup_m(b, d)) return DAQP_EXIT_UNSUPPORTED; d.defer_m = 0; }
+        if (l.defer_m) { if (launch_setup_m(b, l)) return DAQP_EXIT_UNSUPPORTED; }
     } else HIPCHK(hipMemsetAsync(d.qs, 0, (size_t)d.N * sizeof(QState), b->stream));   // fresh records: the LP pass below fills them
     // numerically singular Hessians: shifted re-runs for those problems (one tiny counting kernel when there are none);
     // an LP batch: its one setup pass
@@ -1149,9 +1135,10 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
     // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
     rc = launch_ldp(b, 1);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(b->ev[1], b->stream));
-    b->timed_setup = true;
+    if (!b->quiet_setup) { HIPCHK(hipEventRecord(b->ev[1], b->stream)); b->timed_setup = true; }
     b->is_setup = true;
+    // (a daqp_batch_update with every bit set comes through here as well and arms the second pass like a setup does: what follows it
+    //  IS a first solve on a fresh LDP, and the arrays it read are the ones the descriptor points at now)
     b->fresh = !lp; b->fresh_mask = init_mask;
     return 0;
 }
@@ -1418,7 +1405,8 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
     } else rc = b->n_prox_qps > 0 ? solve_with_prox(b, mode) : launch_ldp(b, mode);
     if (rc) return rc;
     // default arithmetic, first solve after a setup: INFEASIBLE verdicts are re-derived in the reference's arithmetic (recheck.hip.h)
-    if (b->fresh && b->recheck && d.exact_setup == 0 && !b->was_shared) { rc = recheck_infeasible(b); if (rc) return rc; }
+    b->timed_recheck = false;
+    if (b->fresh && b->recheck && d.exact_setup == 0 && !b->was_shared && recheck_allowed(b)) { rc = recheck_infeasible(b); if (rc) return rc; }
     else b->rechecked = 0;
     b->fresh = false;
     HIPCHK(hipEventRecord(b->ev[3], b->stream));

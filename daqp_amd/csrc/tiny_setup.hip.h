@@ -16,9 +16,16 @@
 // Singular / indefinite Hessians and forced regularisation leave with DAQP_NEEDS_SHIFT exactly as in k_setup_fast: the host's
 // regularising re-run (k_setup_fast<16, true>) takes those problems.
 #pragma once
-#include "tiny_ldp.hip.h"
+#include "wave_ldp_reg.hip.h"
+#include "batch_dev.hip.h"
 
 namespace daqp_amd {
+
+constexpr int TNC = 12;     // columns
+constexpr int TMR = 48;     // constraint rows
+// cross-lane traffic inside a group of four lanes: DPP quad permutes
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int G> __device__ __forceinline__ int gor(int v) { static_assert(G == 4, "groups of four lanes"); v |= dpp_i<0xB1>(v); v |= dpp_i<0x4E>(v); return v; }
 
 template <int G>
 __global__ __launch_bounds__(64) void k_setup_tiny(BatchDev b, int mask)

@@ -287,12 +287,21 @@ int daqp_quadprog_batch_multi(DAQPBatchResult *r, const DAQPBatchProblem *p, con
 
 /* device-side timing of the last setup / solve launches (HIP events on the batch's stream), ms */
 int daqp_batch_kernel_ms(DAQPBatch *b, float *setup_ms, float *solve_ms);
-/* Default arithmetic only: problems that the FIRST solve after a daqp_batch_setup declares infeasible are set up and solved again in
-   the reference's own arithmetic, and that result (exit flag, iter, lam, stored iterate) is the one reported -- "infeasible" is decided
-   by comparing rounding noise with dual_tol (auxiliary.c:284-287) and only the reference's arithmetic reproduces the reference's noise.
-   This needs the inputs of that setup (device-resident arrays are used in place) to stay valid until the solve has run.
-   Returns how many problems of the last daqp_batch_solve took the second pass.  DAQP_AMD_NO_RECHECK=1 switches it off. */
+/* Default arithmetic only: problems that the FIRST solve after a daqp_batch_setup (or after a daqp_batch_update with every bit set)
+   declares infeasible are set up and solved again in the reference's own arithmetic, and that result (exit flag, iter, lam, stored
+   iterate) is the one reported -- "infeasible" is decided by comparing rounding noise with dual_tol (auxiliary.c:284-287) and only the
+   reference's arithmetic reproduces the reference's noise.  The second pass reads the setup's inputs again at solve time.  Host-
+   resident inputs were staged into the batch's own buffers: nothing to watch.  DEVICE-resident inputs were adopted, not copied: they
+   must still hold what the setup read when the solve runs -- a caller that recycles those buffers between setup and solve switches
+   the pass off for that batch, daqp_batch_set_recheck(b, 0) (or DAQP_AMD_RECHECK_DEVICE=0 for the process; DAQP_AMD_NO_RECHECK=1
+   switches it off for every batch).  daqp_batch_rechecked: how many problems of the last daqp_batch_solve took the second pass
+   (-1: there were some and no memory for the companion batch -- the first pass's verdicts stand); daqp_batch_recheck_ms: its
+   device time, which is part of the solve time daqp_batch_kernel_ms reports.  A WARM solve (after an update of f / bounds) that ends
+   INFEASIBLE has no such pass: its starting point already carries the default arithmetic's rounding; the exit flag is the
+   reference's, the iteration count and the working set left behind may differ by the last removal. */
 int daqp_batch_rechecked(const DAQPBatch *b);
+void daqp_batch_set_recheck(DAQPBatch *b, int on);
+int daqp_batch_recheck_ms(DAQPBatch *b, float *ms);
 /* bytes of device memory held by the batch */
 unsigned long long daqp_batch_device_bytes(const DAQPBatch *b);
 
@@ -310,8 +319,7 @@ int daqp_batch_read_ldp(DAQPBatch *b, int q, c_float *M, c_float *R, c_float *v,
 const char *daqp_amd_last_error(void);
 int daqp_amd_device_count(void);
 const char *daqp_amd_version(void);
-/* 1 if this build carries the opt-in 16-problems-per-wavefront solve kernel of tiny shapes (-DDAQP_AMD_WITH_TINY, tools/tinybuild.sh;
-   selected at run time with DAQP_AMD_TINY=1); the default build does not: the kernel is slower than the default one */
+/* always 0: the 16-problems-per-wavefront solve kernel of rounds 3-4 (slower than the default one) has been removed; kept for callers that asked */
 int daqp_amd_has_tiny(void);
 
 #ifdef __cplusplus

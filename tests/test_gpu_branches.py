@@ -6,7 +6,7 @@
     rebuild of the factor, then exit flag -2.
 
 Each runs in the register kernel (k_ldp_reg), the generic one-wave kernel (DAQP_AMD_STREAM_M=1: k_ldp), the workgroup
-kernel (n >= 65: k_ldp_wg) and the 16-problems-per-wave kernel of tiny shapes (DAQP_AMD_TINY=1: k_ldp_tiny), in both arithmetic modes.  Bar: exit flag,
+kernel (n >= 65: k_ldp_wg), in both arithmetic modes.  Bar: exit flag,
 iteration count and the add / remove / branch-marker trace equal to the oracle's (itself pinned on these settings against the
 reference library: oracle/pin_oracle.py), x and lam bit-identical in the exact mode and within 1e-9 in the default one,
 and the marker of the branch present in every problem's trace.
@@ -25,8 +25,6 @@ XTOL = 1e-9
 FAMILIES = {   # name -> (environment, (n, m, ms, n_active), problems)
     "register": ({}, (20, 40, 0, 8), 20),
     "register_c2": ({}, (50, 150, 0, 20), 6),
-    "tiny": ({"DAQP_AMD_TINY": "1"}, (12, 48, 12, 6), 40),
-    "tiny_generic_rows": ({"DAQP_AMD_TINY": "1"}, (9, 30, 4, 4), 24),
     "register_c3": ({}, (12, 48, 12, 6), 20),
     "generic": ({"DAQP_AMD_STREAM_M": "1"}, (20, 40, 0, 8), 20),
     "generic_spill": ({"DAQP_AMD_STREAM_M": "1", "DAQP_AMD_FORCE_SPILL": "1"}, (24, 60, 6, 8), 8),
@@ -56,8 +54,6 @@ def test_forced_branch(oracle, gpu_lib, monkeypatch, family, branch, exact):
     marker = getattr(api, marker_name)
     monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
     monkeypatch.setenv("DAQP_AMD_NO_RECHECK", "1")     # (no problem here is infeasible: the default-mode kernels are judged unassisted)
-    if "DAQP_AMD_TINY" in env and not gpu_lib.daqp_amd_has_tiny():
-        pytest.skip("library built without -DDAQP_AMD_WITH_TINY (tools/tinybuild.sh): the opt-in 16-per-wave solve kernel is not in the default build")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     q = O.generate_batch(N, n, m, ms, na, 4242 + n, start=100)

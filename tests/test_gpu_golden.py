@@ -226,6 +226,71 @@ def test_degenerate_cases_fast_mode(oracle, gpu_lib, monkeypatch):
     assert not differing and same == total == 400, (same, total, differing)
 
 
+def test_warm_updates_that_turn_infeasible_default_mode(oracle, gpu_lib, monkeypatch):
+    """the second pass of INFEASIBLE verdicts (recheck.hip.h) covers the first solve after a setup.  What about a WARM
+    solve -- daqp_update_ldp(UPDATE_d) with shrinking bounds drives the threshold-sitting problems of the degenerate family infeasible
+    (auxiliary.c:277-311, daqp.c:86-93)?  Counted here against the reference sequence {update -> solve} x 3 on 200 problems, default
+    arithmetic: the EXIT FLAG is the reference's on every step of every problem; problems that stay feasible keep the reference's
+    iteration counts, active sets and x.  An infeasible warm verdict may come a removal earlier or later than the reference's (the
+    decision compares rounding noise of a singular direction -- zero in exact arithmetic -- with dual_tol, and the warm state already
+    carries this mode's rounding: no second pass can reproduce the reference's noise from it) -- counted, bounded, written
+    to gpurun_out/warm_infeasible_default_mode.json; from such a step on the sequence is compared on flag / optimum, not on the path.
+    In the exact mode (second half) every step is the reference's bit for bit, infeasible ones included."""
+    import json
+    import daqp_amd
+    report = {}
+    for exact in (False, True):
+        monkeypatch.setenv("DAQP_AMD_EXACT", "1" if exact else "0")
+        steps = infeasible = same_iter = max_diff = 0
+        diffs = []
+        for trial in range(200):
+            q = _nasty(trial)
+            n, m = q["f"].size, q["bupper"].size
+            ms = m - q["A"].shape[0]
+            d = daqp_amd.Model()
+            flag, _ = d.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"])
+            om = oracle.model(n, m, ms, ns=int(((q["sense"] & 8) != 0).sum()))
+            assert om.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"]) == flag
+            if flag < 0:
+                continue
+            d.solve(); om.solve()
+            tainted = False
+            for t in range(1, 4):
+                w = (q["bupper"] - q["blower"]) * 0.03 * t
+                w = np.where(np.abs(w) < 1e20, w, 0.0)
+                bu, bl = q["bupper"] - w, q["blower"] + 0.45 * w
+                assert d.update(bupper=bu, blower=bl) == om.update(O.UPDATE_d, bupper=bu, blower=bl)
+                x, fval, ef, info = d.solve()
+                r = om.solve()
+                steps += 1
+                assert ef == r[3], (exact, trial, t, ef, r[3])
+                if ef == -1:
+                    infeasible += 1
+                    dd = abs(info["iterations"] - r[4])
+                    if not tainted:
+                        same_iter += dd == 0
+                        max_diff = max(max_diff, dd)
+                        if dd:
+                            diffs.append(dict(trial=trial, step=t, iter=int(info["iterations"]), ref_iter=int(r[4])))
+                    tainted = tainted or not exact
+                    continue
+                if exact:
+                    assert info["iterations"] == r[4] and bits_equal(x, r[0]) and bits_equal(info["lam"], r[1]), (trial, t)
+                elif ef > 0:
+                    assert np.array_equal(np.sign(info["lam"]), np.sign(r[1])) and np.abs(x - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max()), (trial, t)
+                    if not tainted:
+                        assert info["iterations"] == r[4], (trial, t, info["iterations"], r[4])
+        report["exact" if exact else "default"] = dict(warm_solves=steps, infeasible=infeasible, infeasible_first_with_reference_iter=int(same_iter),
+                                                       max_iter_difference=int(max_diff), differing=diffs)
+        assert infeasible >= 20, report          # (the family does turn infeasible under these updates)
+        assert max_diff <= (0 if exact else 2), report
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "warm_infeasible_default_mode.json"), "w") as fh:
+        json.dump(report, fh, indent=1)
+    print("warm infeasible verdicts:", {k: {a: b for a, b in v.items() if a != "differing"} for k, v in report.items()})
+
+
 def _nasty_wide(trial):
     rng = np.random.default_rng([199, trial])
     eps = 10.0 ** rng.uniform(-13, -2)

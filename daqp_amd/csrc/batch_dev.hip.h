@@ -61,6 +61,10 @@ struct BatchDev {
 // internal setup flag: the Hessian is numerically singular and eps_prox != 0 -- the host re-runs the setup with a shifted
 // diagonal (never leaves the library: it ends as 1 or DAQP_EXIT_NONCONVEX)
 #define DAQP_NEEDS_SHIFT (-100)
+// internal setup flag between k_setup_blk (setup_blk.hip.h) and the launch of k_setup_fast right behind it: this problem's factorisation
+// is left to the ordered kernel (never leaves the library either); kSetupOnlyMarked: mask bit of that launch -- only such problems
+#define DAQP_NEEDS_ORDERED (-102)
+constexpr int kSetupOnlyMarked = 1 << 30;
 // internal setup flag while the proximal driver runs: this problem sits out the launch (any negative flag does that)
 #define DAQP_PROX_SKIP (-101)
 

@@ -24,6 +24,7 @@
 #include "setup_fact.hip.h"
 #include "wg_layout.hip.h"
 #include "tiny_setup.hip.h"
+#include "setup_blk.hip.h"
 // the workgroup-per-problem solve kernel lives in its own translation unit (wg_kernel.hip): a change to it does not rebuild
 // everything else
 namespace daqp_amd {
@@ -49,7 +50,10 @@ DAQP_SETUP_SIZE(32)
 DAQP_SETUP_SIZE(56)
 DAQP_SETUP_SIZE(64)
 #undef DAQP_SETUP_SIZE
-extern template __global__ void k_setup_tiny<4>(BatchDev, int);   // (the 16-per-wave SETUP kernel is the default for these shapes: setup_kernel.hip)
+extern template __global__ void k_setup_tiny<4>(BatchDev, int);
+#define DAQP_BLK_SHAPE(NT, NW, TAIL) extern template __global__ void k_setup_blk<NT, NW, TAIL>(const BatchDev *__restrict__, int);
+DAQP_BLK_SHAPES
+#undef DAQP_BLK_SHAPE   // (the 16-per-wave SETUP kernel is the default for these shapes: setup_kernel.hip)
 template <int C> __global__ void k_ldp_wg(BatchDev b, int mode);
 extern template __global__ void k_ldp_wg<2>(BatchDev, int);
 extern template __global__ void k_ldp_wg<4>(BatchDev, int);
@@ -613,6 +617,11 @@ bool recheck_allowed(const DAQPBatch *b)
     static const bool off = [] { const char *e = getenv("DAQP_AMD_RECHECK_DEVICE"); return e && atoi(e) == 0; }();
     return !off;
 }
+bool blk_setup_enabled()
+{
+    static const bool off = [] { const char *e = getenv("DAQP_AMD_NO_BLK_SETUP"); return e && atoi(e) != 0; }();
+    return !off;
+}
 int check_problem(const DAQPBatch *b, const DAQPBatchProblem *p)
 {
     if (!b || !p) { set_err("null batch or problem"); return DAQP_EXIT_UNSUPPORTED; }
@@ -637,7 +646,7 @@ bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && 
 std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
-                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M"};
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M", "DAQP_AMD_NO_BLK_SETUP"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -1102,6 +1111,22 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
     b->inputs_adopted = p->memory == DAQP_MEM_DEVICE;
     if (!lp && b->tiny_setup) {     // sixteen problems per wavefront; singular Hessians leave flagged for the regularising re-run below
         hipLaunchKernelGGL(k_setup_tiny<4>, dim3((d.N + 15) / 16), dim3(64), 0, b->stream, d, mask);
+        HIPCHK(hipGetLastError());
+    } else if (!lp && b->fast_setup && d.ms == 0 && d.n > 16 && d.exact_setup == 0 && blk_setup_enabled()) {
+        // the factorisation on the matrix cores (setup_blk.hip.h); what it does not call clearly regular it marks, and the ordered
+        // kernel right behind it takes exactly those problems (every other wave of that launch leaves at its first scalar load)
+        const int NT = (d.n + 15) / 16;
+        ldp_reg_kernel_t kb = nullptr;
+#define DAQP_BLK_SHAPE(nt, nw, tail) \
+        if (!kb && NT == nt && d.n <= nw && (tail) == (d.n - 16 * (nt - 1) <= 4)) kb = k_setup_blk<nt, nw, tail>;
+        DAQP_BLK_SHAPES
+#undef DAQP_BLK_SHAPE
+        const size_t lds_blk = (size_t)(NT == 2 ? blk_lds<2>(d.n, d.m) : (NT == 3 ? blk_lds<3>(d.n, d.m) : blk_lds<4>(d.n, d.m))).total_bytes;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
+        HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));      // (it reads the descriptor through a pointer)
+        hipLaunchKernelGGL(kb, dim3(d.N), dim3(64), lds_blk, b->stream, (const BatchDev *)b->d_dev, mask);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask | kSetupOnlyMarked);
         HIPCHK(hipGetLastError());
     } else if (!lp) {
         // what belongs to THESE launches only (who forms the general rows, whose factorisation records) travels in a copy of the

@@ -115,6 +115,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NMAX >= 56 ?
     if constexpr (PROX) {
         if (__builtin_amdgcn_readfirstlane(qs->setup_flag) != DAQP_NEEDS_SHIFT) return;
         shift = b.hshift[q];
+    } else if (mask & kSetupOnlyMarked) {      // behind k_setup_blk: the problems it left to the ordered factorisation, nobody else
+        if (__builtin_amdgcn_readfirstlane(qs->setup_flag) != DAQP_NEEDS_ORDERED) return;
     }
     // rows of even length (and not a multiple of 32 doubles, which would put every row of the tile on the same
     // LDS banks) are copied HBM -> LDS directly, unpadded; everything else is staged through registers with an odd stride

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "setup_fast.hip.h"
 #include "tiny_setup.hip.h"
+#include "setup_blk.hip.h"
 #define DAQP_AMD_SETUP_M_IMPL   // (k_setup_m is not a template: defined in this translation unit, declared where it is launched)
 #include "setup_m.hip.h"
 #define DAQP_AMD_SETUP_FACT_IMPL   // (likewise k_fact_wg)
@@ -21,4 +22,8 @@ DAQP_SETUP_SIZE(64)
 #undef DAQP_SETUP_SIZE
 // tiny shapes (n <= 12, m <= 48): sixteen problems per wavefront (tiny_setup.hip.h), the default setup for them
 template __global__ void k_setup_tiny<4>(BatchDev, int);
+// 16 < n <= 64 without simple bounds, default arithmetic: the factorisation on the matrix cores (setup_blk.hip.h)
+#define DAQP_BLK_SHAPE(NT, NW, TAIL) template __global__ void k_setup_blk<NT, NW, TAIL>(const BatchDev *__restrict__, int);
+DAQP_BLK_SHAPES
+#undef DAQP_BLK_SHAPE
 }

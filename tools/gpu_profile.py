@@ -20,7 +20,7 @@ for prof in (False, True):
             ps = bm.read_profile().astype(np.float64).mean(axis=0)
             print("  setup cycles per QP: chol %d, inverse+v %d, xunc %d, M %d, norm/d/store %d, tail %d, total %d"
                   % (ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[:10].sum()))
-            print("    M split: bounds/pack/frags %d, staging %d, mfma+writeback %d, (slot 3 = row load) " % (ps[6], ps[7], ps[8]))
+            print("    M split: bounds/pack/frags %d, staging %d, mfma+writeback %d, (slot 3 = row load); slot 9 (k_setup_blk: checks + H into tiles, before the factorisation) %d" % (ps[6], ps[7], ps[8], ps[9]))
         res = bm.solve(out="torch")
         torch.cuda.synchronize()
     su, so = bm.kernel_ms()

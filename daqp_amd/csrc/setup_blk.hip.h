@@ -21,6 +21,13 @@
 namespace daqp_amd {
 
 typedef double blk_v4d __attribute__((ext_vector_type(4)));
+typedef double blk_v2d __attribute__((ext_vector_type(2)));
+// A pointer read out of the descriptor (itself read through a pointer) is a GENERIC pointer to the compiler: every access through it is a
+// flat_load / flat_store, which counts on the LDS counter as well -- each wait for an LDS result then waits for the stores in flight too
+// (the blocked image's stores alternate with LDS reads: 6 k cycles per tile of rows instead of ~2 k).  These are global memory:
+#define BLK_GLOBAL(T) __attribute__((address_space(1))) T
+template <class T> __device__ __forceinline__ BLK_GLOBAL(T) *blk_g(T *p) { return (BLK_GLOBAL(T) *)p; }
+template <class T> __device__ __forceinline__ const BLK_GLOBAL(T) *blk_g(const T *p) { return (const BLK_GLOBAL(T) *)p; }
 
 // upper-triangular tile grid of NT x NT blocks, row-major over I <= J
 template <int NT> __host__ __device__ constexpr int blk_tix(int I, int J) { return I * NT - I * (I - 1) / 2 + (J - I); }
@@ -284,8 +291,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double *srow = fl, *drow = vv;      // (f and v have been used up -- v lives on in registers and in HBM -- when the rows' sums arrive)
     const int tailc = TAIL ? n - 16 * (NT - 1) : 0;
     int *sens = reinterpret_cast<int *>(smem + o.sens);
-    const double *H = b.H + (size_t)q * n * n, *A = b.A + (size_t)q * mA * n;
-    QState *qs = b.qs + q;
+    const double *H = b.H + (size_t)q * n * n, *A = b.A + (size_t)q * mA * n;      // (only ever the source of global -> LDS copies)
+    BLK_GLOBAL(QState) *qs = blk_g(b.qs + q);
     const double zero_tol = b.st.zero_tol, primal_tol = b.st.primal_tol;
     const bool force = b.st.eps_prox > 0.0;
     const bool direct = !(n & 1) && (n & 31) && !(((size_t)H | (size_t)A) & 15);   // (as in k_setup_fast: rows copied HBM -> LDS unpadded)
@@ -297,10 +304,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
     if (direct) copy_async(Hs, H, n * n);     // in flight while the bounds are checked
     {   // --- sense (utils.c:84-91) and early bound check (utils.c:546-567)
-        const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
+        const BLK_GLOBAL(double) *bu = blk_g(b.bu + (size_t)q * m), *bl = blk_g(b.bl + (size_t)q * m);
+        const BLK_GLOBAL(int) *sin = b.sense_in ? blk_g(b.sense_in + (size_t)q * m) : nullptr;
         int bad = 0;
         for (int i = lane; i < m; i += 64) {
-            int s = b.sense_in ? b.sense_in[(size_t)q * m + i] : 0;
+            int s = sin ? sin[i] : 0;
             if (s & DAQP_BINARY) bad |= 2;
             if (!(s & DAQP_IMMUTABLE)) {
                 const double diff = bu[i] - bl[i];
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (bad & 2) flag = DAQP_EXIT_UNSUPPORTED;
         else if (bad & 1) flag = DAQP_EXIT_INFEASIBLE;
         if (force && flag > 0) flag = DAQP_NEEDS_SHIFT;   // forced proximal mode: the host starts with the shifted pass
-        fl[lane] = (lane < n) ? b.f[(size_t)q * n + lane] : 0.0;
+        fl[lane] = (lane < n) ? blk_g(b.f)[(size_t)q * n + lane] : 0.0;
     }
     int diag = 0;
     blk_v4d X[NTT];
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             p += __shfl_xor(p, 16);
             p += __shfl_xor(p, 32);
             vcol[J] = p;
-            if (lk == 0 && 16 * J + lr < n) b.v[(size_t)q * n + 16 * J + lr] = p;
+            if (lk == 0 && 16 * J + lr < n) blk_g(b.v)[(size_t)q * n + 16 * J + lr] = p;
         });
         SPROF(1);
         // --- unconstrained optimum x = -R^-1 v (utils.c:618-662)
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int feasible = 1;
     if (flag > 0) {
         // packed upper image of R^-1 for the solve kernel / warm updates, straight from the tiles
-        double *Rp = b.Rinv + (size_t)q * b.rtri;
+        BLK_GLOBAL(double) *Rp = blk_g(b.Rinv + (size_t)q * b.rtri);
         static_for<NT>([&](auto Ic) __attribute__((always_inline)) {
             static_for<NT>([&](auto Jc) __attribute__((always_inline)) {
                 constexpr int I = Ic, J = Jc;
@@ -432,9 +440,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     SPROF(6);
     // --- general rows, TR at a time through the LDS tile (which takes the place of H's image)
     if (flag > 0) {
-        const double *bu = b.bu + (size_t)q * m, *bl = b.bl + (size_t)q * m;
-        double *sc = b.scaling + (size_t)q * m, *du = b.dupper + (size_t)q * m, *dl = b.dlower + (size_t)q * m;   // HBM
-        double2 *Mq2 = reinterpret_cast<double2 *>(b.Mblk + (size_t)q * b.nblk * b.npair * 128);
+        const BLK_GLOBAL(double) *bu = blk_g(b.bu + (size_t)q * m), *bl = blk_g(b.bl + (size_t)q * m);
+        BLK_GLOBAL(double) *sc = blk_g(b.scaling + (size_t)q * m), *du = blk_g(b.dupper + (size_t)q * m), *dl = blk_g(b.dlower + (size_t)q * m);   // HBM
+        BLK_GLOBAL(blk_v2d) *Mq2 = blk_g(reinterpret_cast<blk_v2d *>(b.Mblk + (size_t)q * b.nblk * b.npair * 128));
         const int npair = b.npair;
         WSYNC();
         if (direct && mA > 0) copy_async(tile, A, (mA < TR ? mA : TR) * n);
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
             SPROF(3);
             {
-                double2 *dst = Mq2 + ((size_t)(gi >> 6) * npair) * 64 + (gi & 63);
+                BLK_GLOBAL(blk_v2d) *dst = Mq2 + ((size_t)(gi >> 6) * npair) * 64 + (gi & 63);
                 for (int tq = 0; tq < npair; tq += 8) {      // eight column pairs in flight
                     double2 v8[8];
 #pragma unroll
@@ -561,8 +569,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         if (own && tq + u < npair) {
-                            v8[u].x *= scal; v8[u].y *= scal;
-                            dst[(size_t)(tq + u) * 64] = v8[u];
+                            dst[(size_t)(tq + u) * 64] = (blk_v2d){v8[u].x * scal, v8[u].y * scal};
                         }
                     }
                 }
@@ -579,16 +586,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int sing = kEmpty;
     if (flag > 0 && unc && all_feasible) { sing = DAQP_UNCONSTRAINED_OPTIMAL; activate = 0; }
     if (flag > 0) {
-        if (lane < n && unc) b.xunc[(size_t)q * n + lane] = xu[lane];
+        if (lane < n && unc) blk_g(b.xunc)[(size_t)q * n + lane] = xu[lane];
     }
-    for (int i = lane; i < m; i += 64) b.sense[(size_t)q * m + i] = sens[i];
+    for (int i = lane; i < m; i += 64) blk_g(b.sense)[(size_t)q * m + i] = sens[i];
     SPROF(5);
     if (lane == 0) {
         qs->n_active = 0; qs->reuse_ind = 0; qs->sing_ind = sing; qs->iterations = 0;
         qs->lam_swapped = 0; qs->setup_flag = flag; qs->need_activate = (flag > 0) ? activate : 0; qs->pad_ = 0;
         qs->exitflag = flag; qs->fval = 0; qs->soft_slack = 0; qs->diag_h = diag; qs->n_prox = 0;
         qs->upd_flag = 0;
-        if (kProfile && b.prof) for (int i = 0; i < 10; ++i) b.prof[(size_t)q * 32 + i] = pt[i];
+        if (kProfile && b.prof) for (int i = 0; i < 10; ++i) blk_g(b.prof)[(size_t)q * 32 + i] = pt[i];
     }
 #undef SPROF
 }

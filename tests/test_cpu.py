@@ -289,6 +289,8 @@ def test_kernel_resource_budgets():
         "k_setup_fast<16, false, true>": (0, 4), "k_setup_fast<32, false, true>": (0, 2), "k_setup_fast<56, false, true>": (256, 2),
         "k_setup_fast<64, false, true>": (400, 2), "k_setup_fast<56, false, false>": (256, 2), "k_setup_fast<56, true, false>": (256, 2),
         "k_setup_tiny<4>": (64, 1), "k_setup_m": (0, 2), "k_fact_wg": (0, 2),
+        "k_setup_blk<4, 56, true>": (0, 2), "k_setup_blk<4, 56, false>": (0, 2), "k_setup_blk<4, 64, false>": (0, 2),       # (the C2 setup with zero scratch)
+        "k_setup_blk<3, 48, false>": (0, 2), "k_setup_blk<3, 40, true>": (0, 2), "k_setup_blk<2, 32, false>": (0, 2), "k_setup_blk<2, 24, true>": (0, 2),
         "k_ldp_reg<3, 25, true>": (0, 1), "k_ldp_reg<3, 25, false>": (0, 1), "k_ldp_reg<2, 32, true>": (0, 1),
         "k_ldp_reg<1, 6, true>": (0, 3), "k_ldp_reg<1, 6, false>": (0, 3), "k_ldp_reg<1, 8, true>": (0, 3), "k_ldp_reg<1, 8, false>": (0, 3), "k_ldp_reg<1, 16, true>": (0, 2), "k_ldp_reg<2, 16, true>": (16, 2),
         "k_ldp<1, false, 0, 0>": (0, 2), "k_ldp<2, false, 0, 0>": (0, 2), "k_ldp<4, true, 0, 0>": (128, 2),

@@ -48,6 +48,62 @@ def test_fast_mode_shapes(oracle, gpu_lib, shape):
     assert np.abs(g["x"] - ref[0]).max() < XTOL
 
 
+@pytest.mark.parametrize("n", [17, 19, 20, 21, 25, 32, 33, 35, 36, 37, 41, 48, 49, 50, 51, 52, 53, 55, 56, 57, 61, 64])
+def test_blocked_setup_every_block_shape(oracle, gpu_lib, monkeypatch, n):
+    """k_setup_blk (csrc/setup_blk.hip.h: 16 < n <= 64 without simple bounds, default arithmetic -- Cholesky and inverse as 16 x 16 tiles
+    on the matrix cores): every block count, column width and tail width (n mod 16 in 1..4: the last columns on the vector pipe), odd n
+    (rows staged through registers) and even n (direct HBM -> LDS copies), row counts that end in a partial row tile; the LDP against
+    the oracle's (R^-1, M, v, d to ~1e-13 relative: another summation order), then the solve at the north_star bar; and the same
+    problems through the ordered kernel (DAQP_AMD_NO_BLK_SETUP=1) give the same iterations and active sets."""
+    import daqp_amd
+    m, na = 2 * n + 7 + (n % 5), max(2, n // 3)
+    N = 24
+    q = O.generate_batch(N, n, m, 0, na, 7000 + n)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=0)
+    bm = daqp_amd.BatchModel(N, n, m, 0)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None)
+    assert (bm.setup_flags() == 1).all()
+    for k in (0, N - 1):
+        om = oracle.model(n, m, 0)
+        assert om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None) == 1
+        for name, a, b in zip(("M", "Rinv", "v", "dupper", "dlower", "scaling"), bm.read_ldp(k), om.ldp()):
+            assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), (n, k, name, np.abs(a - b).max())
+    g = bm.solve()
+    bm.close()
+    assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4])
+    assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1]))
+    assert np.abs(g["x"] - ref[0]).max() < XTOL
+    g1 = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=0)      # the unconstrained shortcut's d (utils.c:664-676)
+    assert np.array_equal(g1["iter"], ref[4]) and np.abs(g1["x"] - ref[0]).max() < XTOL
+
+
+def test_blocked_setup_hands_doubtful_hessians_to_the_ordered_kernel(oracle, gpu_lib):
+    """a Hessian that is singular, nearly so (pivot ratio at the threshold of utils.c:354-356) or diagonal inside a batch of ordinary
+    ones: k_setup_blk marks what it does not call clearly regular and the ordered kernel behind it decides as the reference does --
+    shift + proximal loop, or no shift -- while a diagonal H takes the RinvD branch in k_setup_blk itself"""
+    import daqp_amd
+    n, m, na, N = 40, 90, 12, 16
+    q = O.generate_batch(N, n, m, 0, na, 7700)
+    rng = np.random.default_rng(7701)
+    for k in (1, 5):        # rank-deficient
+        G = rng.standard_normal((n - 6, n))
+        q["H"][k] = G.T @ G
+    for k, eps in ((2, 3e-11), (6, 0.9e-11), (9, 1.5e-11), (10, 4e-11)):     # smallest pivot / largest pivot around zero_tol = 1e-11
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        ev = np.linspace(1.0, 3.0, n); ev[0] = eps
+        q["H"][k] = (Q * ev) @ Q.T
+    for k in (3, 12):       # diagonal
+        q["H"][k] = np.diag(1.0 + rng.random(n))
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=0)
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=0)
+    assert np.array_equal(g["exitflag"], ref[3]), (g["exitflag"], ref[3])
+    assert np.array_equal(g["iter"], ref[4]), (g["iter"], ref[4])
+    ok = ref[3] > 0
+    assert np.abs(g["x"][ok] - ref[0][ok]).max() < 1e-7 and np.array_equal(np.sign(g["lam"][ok]), np.sign(ref[1][ok]))
+    for k in (3, 12):
+        assert np.array_equal(g["x"][k].view(np.uint64), ref[0][k].view(np.uint64)) or np.abs(g["x"][k] - ref[0][k]).max() < XTOL
+
+
 @pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (129, 200, 10, 30), (229, 400, 20, 60), (229, 420, 0, 205), (187, 371, 0, 92)])
 def test_fast_mode_workgroup_kernel_shapes(oracle, gpu_lib, shape):
     """the workgroup solve kernel in the default arithmetic: the inverse factor W = L^-1 (CSP / append / delete as matrix-vector

@@ -224,6 +224,40 @@ def warm_parity(bm_factory, q, fs, S, T, cpu):
                 identical_iter_last_step=float(np.mean(gi == cpu["iter"][T - 1])), max_abs_dx_last_step=float(np.abs(g["x"].cpu().numpy() - cpu["x"][T - 1]).max()))
 
 
+def transfer_times(torch, q, res, N, warm):
+    """"H2D/D2H reported separately".  What a host caller pays on top of `value`: the step's inputs (B_io's arrays: H, f,
+    A, bupper, blower -- a warm step: f only) from PINNED host memory to the device and its outputs (x, lam, exit flag, iter) back,
+    timed with device events around the copies.  At most ~1 GiB per direction is pinned and copied (a slice of the batch, problems
+    [0, S)); the whole batch's figure is that rate applied to all N problems -- both are in the record."""
+    names = ("f",) if warm else ("H", "f", "A", "bupper", "blower")
+    per_qp_in = sum(q[k][0].numel() * q[k].element_size() for k in names)
+    outs = ("x", "lam", "exitflag", "iter")
+    per_qp_out = sum(res[k][0].numel() * res[k].element_size() for k in outs)
+    S = int(max(1, min(N, (1 << 30) // max(per_qp_in, 1))))
+    host_in = [torch.empty(q[k][:S].shape, dtype=q[k].dtype).pin_memory() for k in names]
+    dev_in = [torch.empty_like(q[k][:S]) for k in names]
+    host_out = [torch.empty(res[k][:S].shape, dtype=res[k].dtype).pin_memory() for k in outs]
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    best_in = best_out = 1e30
+    for _ in range(3):
+        torch.cuda.synchronize()
+        e[0].record()
+        for h, d in zip(host_in, dev_in):
+            d.copy_(h, non_blocking=True)
+        e[1].record()
+        e[2].record()
+        for k, h in zip(outs, host_out):
+            h.copy_(res[k][:S], non_blocking=True)
+        e[3].record()
+        torch.cuda.synchronize()
+        best_in, best_out = min(best_in, e[0].elapsed_time(e[1])), min(best_out, e[2].elapsed_time(e[3]))
+    gbs_in, gbs_out = per_qp_in * S / best_in / 1e6, per_qp_out * S / best_out / 1e6
+    return {"sample_qps": S, "h2d_bytes_per_qp": per_qp_in, "d2h_bytes_per_qp": per_qp_out, "h2d_GBps": gbs_in, "d2h_GBps": gbs_out,
+            "h2d_ms": per_qp_in * N / gbs_in / 1e6, "d2h_ms": per_qp_out * N / gbs_out / 1e6,
+            "what": "pinned host <-> device copies of the step's inputs / outputs (torch copy_, non_blocking, device events), measured on "
+                    f"problems [0, {S}) and scaled to the batch of {N}; NOT part of `value` (inputs and outputs resident in HBM)"}
+
+
 class Runner:
     def __init__(self, args):
         import torch
@@ -411,6 +445,13 @@ class Runner:
         }
         if info.get("exact"):
             out["exact"] = info["exact"]
+        if self.world == 1:
+            try:
+                out["transfers"] = transfer_times(self.torch, q if not warm else dict(q, f=info["fs"][0]), res, N, warm)
+                tr = out["transfers"]
+                out["transfers"]["value_with_transfers"] = units / (info["elapsed"] + steps * T * (tr["h2d_ms"] + tr["d2h_ms"]) * 1e-3)
+            except Exception as ex:     # (not enough pinnable host memory on this box: say so, do not fail the bench)
+                out["transfers"] = {"error": repr(ex)[:200]}
         if not warm:
             roof["pipeline"] = {"hbm_effective": all_bytes / (t_ldp + t_setup) / 1e9, "hbm_effective_frac": all_bytes / (t_ldp + t_setup) / 1e9 / HBM_PEAK_GBS,
                                 "setup_ms": t_setup * 1e3, "solve_ms": t_ldp * 1e3, "algorithmic_bytes_per_step": all_bytes}
@@ -437,6 +478,18 @@ class Runner:
                 if BOUND[cfg] == "issue":
                     roof["achieved"] = att * 1e-3 * VALU_PEAK_GCYC / max(t_ldp, 1e-12)
                     roof["frac"] = roof["achieved"] / VALU_PEAK_GCYC
+            if prof.get("setup") and not warm and "hbm_read_bytes" in prof["setup"]:
+                # the setup launch (QP -> LDP) on the HBM roof: the bytes it moved through the memory side (counter pass of this build:
+                # FETCH_SIZE x 2 + WRITE_SIZE) over its duration (HIP events, this run); next to it what it MUST move -- the inputs once in,
+                # the LDP once out -- and the issue-side counters that say what it waits for
+                st = prof["setup"]
+                moved = st["hbm_read_bytes"] + st["hbm_written_bytes"]
+                must = float((b_in + 8 * (m * n + n * (n + 1) // 2 + n + 3 * m) + 4 * m) * N)
+                roof["setup"] = {"kernel": st.get("kernel"), "bound": "hbm", "avg_launch_ms": t_setup * 1e3, "traffic": moved,
+                                 "achieved": moved / max(t_setup, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": moved / max(t_setup, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": must, "algorithmic_frac": must / max(t_setup, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                                 "read_bytes": st["hbm_read_bytes"], "written_bytes": st["hbm_written_bytes"], "issue": st.get("issue")}
             if BOUND[cfg] == "hbm" and prof.get("traffic"):     # the memory system is the roof: measured HBM-side bytes over the launch time
                 roof["achieved"] = prof["traffic"] / max(t_ldp, 1e-12) / 1e9
                 roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
@@ -499,6 +552,8 @@ def committed_counters(cfg, N):
             out["binding"] = d["binding"]
         if "issue" in d:
             out["issue"] = dict(d["issue"])
+        if d.get("setup"):
+            out["setup"] = dict(d["setup"], kernel=d.get("setup_kernel"))
         return out
     return {"stale": True, "why": why}
 
@@ -532,6 +587,78 @@ def self_launch(cmd, args):
     return subprocess.call(cmd, env=env)
 
 
+def multi_entry(args):
+    """--multi-entry: the single-process path over G devices -- daqp_batch_create_multi / setup_multi_shards / solve_multi_shards, problem k
+    of the batch on shard k mod G, every shard's inputs and results resident on ITS device -- timed like the rank-per-GPU path (W warm-up
+    steps, K timed steps between device-wide synchronisations) and reported in the same line format (scaling "weak": per-shard work fixed).
+    No process group: the library's own host threads drive the shards."""
+    import torch
+    import daqp_amd
+    from daqp_amd.synthetic import generate_batch_torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
+    G = args.gpus
+    have = torch.cuda.device_count()
+    if not args.single_device and have < G:
+        raise SystemExit(f"bench.py: --gpus {G} --multi-entry but {have} HIP device(s) are visible (--single-device lists device 0 {G} times)")
+    devices = [0] * G if args.single_device else list(range(G))
+    cfg = args.config
+    if cfg == "C5":
+        raise SystemExit("bench.py --multi-entry: C2, C3, C4 (cold steps)")
+    c = CONFIGS[cfg]
+    n, m, ms = c["n"], c["m"], c["ms"]
+    per = args.batch or c["per_gpu"]
+    N = per * G
+    mb = daqp_amd.MultiBatchModel(N, n, m, ms, 0, devices=devices)
+    shards = []
+    for g in range(mb.shards):
+        _, sn, dev = mb.shard(g)
+        shards.append(generate_batch_torch(sn, n, m, ms, c["na"], seed=42 + 1000 * g, device=f"cuda:{dev}"))
+    mask = daqp_amd.UPDATE_unconstrained | daqp_amd.UPDATE_eliminate
+
+    def sync():
+        for dev in sorted(set(devices)):
+            torch.cuda.synchronize(dev)
+
+    def step():
+        mb.setup_shards(shards, init_mask=mask)
+        return mb.solve_shards(out="torch")
+
+    for _ in range(args.warmup):
+        res = step()
+    sync()
+    setup_ms, solve_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        a, b = mb.shard_kernel_ms(0)
+        setup_ms.append(a); solve_ms.append(b)
+    sync()
+    elapsed = time.perf_counter() - t0
+    iters = np.concatenate([r["iter"].cpu().numpy() for r in res])
+    b_in, b_out, stream = algorithmic_bytes(n, m, ms, iters[: shards[0]["f"].shape[0]], False)
+    t_ldp = float(np.mean(solve_ms)) * 1e-3
+    ldp_bytes = float(stream.sum() + b_out * shards[0]["f"].shape[0])
+    ok = all(bool((r["exitflag"] == 1).all().item()) for r in res)
+    dx = max(float((r["x"] - s_["xref"]).abs().max().item()) for r, s_ in zip(res, shards))
+    line = {"metric": METRIC[cfg], "value": N * args.steps / elapsed, "unit": "QPs/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{cfg}: {per} {c['what']} per shard, n={n} m={m} ms={ms} (generator of daqp_amd/synthetic.py), daqp_quadprog semantics: setup + solve per "
+                                   "step, every shard's inputs and outputs resident in its device's HBM",
+                       "batch_per_gpu": per, "mean_iterations": float(iters.mean()), "entry": "multi",
+                       "parallelism": f"ONE process, {mb.shards} shard(s) on device(s) {devices} through daqp_batch_setup_multi_shards / daqp_batch_solve_multi_shards "
+                                      "(a host thread and a stream per shard, problem k on shard k mod G, no exchange step)"},
+            "roofline": {"bound": BOUND[cfg], "kernel": "solve launch of shard 0", "avg_launch_ms": t_ldp * 1e3, "setup_ms_shard0": float(np.mean(setup_ms)),
+                         "hbm_effective": {"achieved": ldp_bytes / max(t_ldp, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": ldp_bytes / max(t_ldp, 1e-12) / 1e9 / HBM_PEAK_GBS},
+                         "achieved": None, "peak": HBM_PEAK_GBS if BOUND[cfg] == "hbm" else VALU_PEAK_GCYC, "frac": None, "traffic": None,
+                         "note": "counter-derived figures are quoted by the rank-per-GPU line (same kernels, same batch per device)"},
+            "checks": {"all_optimal": ok, "max_abs_x_minus_analytic_optimum": dx}}
+    mb.close()
+    print(json.dumps(line))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -544,10 +671,16 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="QPs for the CPU baseline (-1: auto, 0: skip)")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (multi-rank smoke test on a 1-GPU box; use --backend gloo)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep of the headline configuration (reported under \"batch_sweep\")")
+    ap.add_argument("--multi-entry", action="store_true", help="ONE process drives --gpus devices through the C ABI's persistent multi-device batch "
+                    "(daqp_batch_*_multi_shards: a host thread + stream per shard, inputs resident on each shard's device) instead of one rank per GPU; "
+                    "with --single-device every shard sits on device 0")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra steps in the library's exact arithmetic mode (reported under \"exact\")")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.multi_entry:
+        return multi_entry(args)
     plan = launch_plan(args.gpus, os.environ, sys.argv[1:])
     if plan is not None:
         # plain `python bench.py --gpus N` (no launcher): start the N ranks here, rank r on device r, and hand back their exit
@@ -576,12 +709,27 @@ def main():
         }
         if "exact" in h:
             line["exact"] = h["exact"]
-        for k in ("cpu_baseline", "parity_vs_cpu"):
+        for k in ("transfers", "cpu_baseline", "parity_vs_cpu"):
             if k in h:
                 line[k] = h[k]
     bm.close()
     del q, res, bm
     R.torch.cuda.empty_cache()
+
+    if R.world == 1 and args.config == "C2" and not args.batch and not args.strong and not args.no_sweep:
+        # where does the device saturate at one wave per SIMD?  The headline configuration at smaller batches (same generator, a few steps)
+        sweep = []
+        for nb in (1000, 10000):
+            q, res, bm, info = R.run("C2", 5, 2, batch=nb)
+            sweep.append({"batch": nb, "value": nb * 5 / info["elapsed"], "unit": "QPs/s", "ms_per_step": info["elapsed"] / 5 * 1e3,
+                          "setup_ms": float(np.mean(info["setup_ms"])), "solve_ms": float(np.mean(info["solve_ms"]))})
+            bm.close()
+            del q, res, bm
+            R.torch.cuda.empty_cache()
+        if R.rank == 0:
+            sweep.append({"batch": line["config"]["batch_per_gpu"], "value": line["value"], "unit": "QPs/s", "ms_per_step": line["ms_per_step"],
+                          "setup_ms": line["roofline"].get("pipeline", {}).get("setup_ms"), "solve_ms": line["roofline"].get("pipeline", {}).get("solve_ms")})
+            line["batch_sweep"] = sweep
 
     side = args.side_configs
     if side == "auto":
@@ -595,7 +743,7 @@ def main():
             if R.rank == 0:
                 r = R.report(cfg, q, res, info, st, sample(cfg), headline=False)
                 cfgs[cfg] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "workload", "batch_per_gpu", "mean_iterations",
-                                               "roofline", "checks", "arith", "exact", "cpu_baseline", "parity_vs_cpu") if k in r}
+                                               "roofline", "checks", "arith", "exact", "transfers", "cpu_baseline", "parity_vs_cpu") if k in r}
             bm.close()
             del q, res, bm
             R.torch.cuda.empty_cache()

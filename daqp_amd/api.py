@@ -501,6 +501,71 @@ class MultiBatchModel:
         o["solve_time"] = r.solve_time
         return o
 
+    # ---- per-shard descriptors (daqp_batch_*_multi_shards): shard g's problems back to back, host arrays or tensors ON shard g's device
+    def _shard_problems(self, shards, names):
+        P = (DAQPBatchProblem * self.shards)()
+        keep = []
+        for g, sh in enumerate(shards):
+            _, sn, dev = self.shard(g)
+            ptrs, mems = [], set()
+            for name in ("H", "f", "A", "bupper", "blower", "sense"):
+                a = sh.get(name) if name in names else None
+                if name == "A" and self.m == self.ms:
+                    a = None
+                ptr, mem = _ptr(a, np.int32 if name == "sense" else np.float64, keep)
+                ptrs.append(ptr)
+                if mem is not None:
+                    mems.add(mem)
+            if len(mems) > 1:
+                raise ValueError("mix of host and device arrays in one shard")
+            P[g] = DAQPBatchProblem(sn, self.n, self.m, self.ms, *ptrs, mems.pop() if mems else MEM_HOST)
+        return P, keep
+
+    def setup_shards(self, shards, init_mask=0):
+        """shards[g]: dict(H, f, A, bupper, blower[, sense]) of shard g's problems (problem k of the batch is problem k // G of shard
+        k mod G), numpy or torch tensors resident on that shard's device (used in place)"""
+        P, keep = self._shard_problems(shards, ("H", "f", "A", "bupper", "blower", "sense"))
+        self._shard_keep = keep
+        rc = lib().daqp_batch_setup_multi_shards(self._h, P, init_mask)
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_setup_multi_shards failed ({rc}): {_lib.last_error()}")
+
+    def update_shards(self, shards, mask):
+        P, keep = self._shard_problems(shards, ("H", "f", "A", "bupper", "blower", "sense"))
+        self._shard_keep_upd = keep
+        rc = lib().daqp_batch_update_multi_shards(self._h, int(mask), P)
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_update_multi_shards failed ({rc}): {_lib.last_error()}")
+
+    def solve_shards(self, out="torch"):
+        """one result dict per shard; out='torch': tensors on the shard's device, 'numpy': host arrays"""
+        R = (DAQPBatchResult * self.shards)()
+        outs = []
+        for g in range(self.shards):
+            _, sn, dev = self.shard(g)
+            if out == "torch":
+                d = torch.device("cuda", dev)
+                o = dict(x=torch.empty((sn, self.n), dtype=torch.float64, device=d), lam=torch.empty((sn, self.m), dtype=torch.float64, device=d),
+                         fval=torch.empty(sn, dtype=torch.float64, device=d), soft_slack=torch.empty(sn, dtype=torch.float64, device=d),
+                         exitflag=torch.empty(sn, dtype=torch.int32, device=d), iter=torch.empty(sn, dtype=torch.int32, device=d))
+                R[g] = DAQPBatchResult(o["x"].data_ptr(), o["lam"].data_ptr(), o["fval"].data_ptr(), o["soft_slack"].data_ptr(),
+                                       o["exitflag"].data_ptr(), o["iter"].data_ptr(), MEM_DEVICE, 0, 0)
+            else:
+                o = dict(x=np.empty((sn, self.n)), lam=np.empty((sn, self.m)), fval=np.empty(sn), soft_slack=np.empty(sn),
+                         exitflag=np.empty(sn, np.int32), iter=np.empty(sn, np.int32))
+                R[g] = DAQPBatchResult(o["x"].ctypes.data, o["lam"].ctypes.data, o["fval"].ctypes.data, o["soft_slack"].ctypes.data,
+                                       o["exitflag"].ctypes.data, o["iter"].ctypes.data, MEM_HOST, 0, 0)
+            outs.append(o)
+        rc = lib().daqp_batch_solve_multi_shards(self._h, R)
+        if rc != 0:
+            raise RuntimeError(f"daqp_batch_solve_multi_shards failed ({rc}): {_lib.last_error()}")
+        return outs
+
+    def shard_kernel_ms(self, g=0):
+        a, b = C.c_float(0), C.c_float(0)
+        lib().daqp_batch_kernel_ms(self.shard(g)[0], C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def shard(self, g):
         """(DAQPBatch handle, problems on it, device) of shard g -- for the single-device inspection calls"""
         sn, dev = C.c_int(0), C.c_int(0)

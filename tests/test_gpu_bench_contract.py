@@ -70,9 +70,44 @@ def test_bench_json_line(gpu_lib):
         assert s["workload"].startswith(name + ": ") and s["value"] > 0 and s["checks"]["all_optimal"] and s["checks"]["rechecked_in_exact_arithmetic"] == 0
         check_roofline(s["roofline"], name)
         assert s["cpu_baseline"]["kind"] == "port" or s["cpu_baseline"]["wall_s"] >= 1.0
+    # "H2D/D2H reported separately" -- per configuration, never part of `value`
+    for name, s in [("C2", d)] + list(d["configs"].items()):
+        t = s["transfers"]
+        for k in ("h2d_ms", "d2h_ms", "h2d_GBps", "d2h_GBps", "h2d_bytes_per_qp", "d2h_bytes_per_qp", "sample_qps", "value_with_transfers"):
+            assert k in t and t[k] > 0, (name, k, t)
+        assert t["value_with_transfers"] < s["value"]
+    assert d["transfers"]["h2d_bytes_per_qp"] == 8 * (50 * 50 + 50 + 150 * 50 + 300) and d["configs"]["C5"]["transfers"]["h2d_bytes_per_qp"] == 8 * 50
     assert "n=12 m=48" in d["configs"]["C3"]["metric"] and d["configs"]["C3"]["parity_vs_cpu"]["identical_iter"] == 1.0
     assert d["configs"]["C5"]["unit"] == "warm solves/s" and d["configs"]["C5"]["parity_vs_cpu"]["identical_iter_last_step"] == 1.0
     assert d["configs"]["C5"]["parity_vs_cpu"]["max_abs_dx_last_step"] < 1e-9
+
+
+def test_bench_headline_carries_the_batch_sweep(gpu_lib):
+    """the headline configuration at its own batch size also reports where the device saturates: C2 at 1 000 / 10 000 / 100 000 problems
+    (`batch_sweep`), and -- when a counter pass of this build is committed -- the setup launch's own roofline record (`roofline.setup`)"""
+    d = run_bench(["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--side-configs", "none", "--no-exact"])
+    sw = d["batch_sweep"]
+    assert [e["batch"] for e in sw] == [1000, 10000, 100000] and all(e["value"] > 0 and e["solve_ms"] > 0 for e in sw)
+    assert sw[2]["value"] == d["value"] and sw[0]["value"] < sw[2]["value"]
+    r = d["roofline"]
+    if not r.get("stale"):
+        st = r["setup"]
+        assert st["bound"] == "hbm" and st["peak"] == 8000.0 and abs(st["frac"] - st["achieved"] / st["peak"]) < 1e-12
+        assert abs(st["achieved"] - st["traffic"] / (st["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * st["achieved"]
+        assert st["traffic"] >= 0.9 * st["algorithmic_bytes_per_launch"] and "k_setup" in st["kernel"]
+
+
+def test_bench_multi_entry_one_process(gpu_lib):
+    """`bench.py --multi-entry --gpus G`: the single-process path of the C ABI (daqp_batch_*_multi_shards, a host thread and a stream per
+    shard) in the same line format as the rank-per-GPU path; here with the one device of the box listed twice"""
+    d = run_bench(["--multi-entry", "--gpus", "2", "--single-device", "--steps", "2", "--warmup", "1", "--batch", "2048"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["entry"] == "multi" and d["config"]["batch_per_gpu"] == 2048
+    assert d["checks"]["all_optimal"] and d["checks"]["max_abs_x_minus_analytic_optimum"] < 1e-9
+    assert abs(d["value"] - 2 * 2048 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    s = run_bench(["--multi-entry", "--gpus", "3", "--single-device", "--steps", "2", "--warmup", "1", "--config", "C3", "--batch", "4096"])
+    assert s["n_gpus"] == 3 and "n=12 m=48" in s["metric"] and s["checks"]["all_optimal"]
 
 
 def test_bench_two_ranks_one_device_weak_and_strong(gpu_lib):

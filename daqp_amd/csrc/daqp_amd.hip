@@ -154,6 +154,18 @@ struct DAQPBatch {
     char *pin_in = nullptr, *dev_in = nullptr, *pin_out = nullptr;
     size_t in_cap = 0, out_bytes = 0;
     double *dev_mir = nullptr, *pin_mir = nullptr;   // host mirrors of a single-problem workspace: gathered slab (k_mirror) and its pinned landing zone
+    // One problem, latency: the result slab and the mirror slab are MAPPED host memory that the kernels write themselves, and the host
+    // learns that they are there from a mapped word written by a one-thread kernel at the end of the stream's work -- no hipMemcpy, no
+    // stream synchronisation on the way of daqp_quadprog / daqp_solve / daqp_update_ldp (0.34 / 0.14 ms per call were
+    // launches, small copies and synchronisations around ~0.1 ms / ~0.02 ms of kernels)
+    bool mapped_out = false, mapped_mir = false;     // ox .. oiter / dev_mir point into pin_out / pin_mir through their device addresses
+    int *pin_sig = nullptr, *pin_sig_dev = nullptr;  // the completion word and its device address
+    int sig_seq = 0;
+    bool lean = false;          // daqp_quadprog: no count of flagged Hessians, no activation launch (the solve launch activates; a flagged problem comes back with the internal code and takes the full path)
+    bool defer_wait = false;    // daqp_batch_solve only enqueues: the caller puts more work behind it, waits once and collects (daqp_ldp)
+    bool recheck_due = false;   // one problem: the second pass of an INFEASIBLE verdict is decided after the wait, on the host
+    char *pin_upd = nullptr, *pin_upd_dev = nullptr;  // f / bupper / blower of a deferred daqp_update_ldp(v|d): mapped, read by the solve launch in place
+    bool mirror_ldp_due = false;   // a deferred update's v / d have not reached the host mirrors yet: the next solve's gather brings them
     hipEvent_t ev_in = nullptr;     // the last packed host->device copy (the pinned slab is free again once it has run)
     std::string env_key;
     int ns_max = 0;
@@ -186,6 +198,36 @@ int dev_alloc(DAQPBatch *b, T **p, size_t count)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
     b->owned.push_back(*p);
     b->bytes += count * sizeof(T);
+    return 0;
+}
+
+__global__ void k_signal(int *host_word, int seq) { __hip_atomic_store(host_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// everything queued on the batch's stream so far has run when this returns: a one-thread kernel behind it writes the next sequence
+// number into a mapped host word (kernels of a stream run in order; a kernel's writes to host memory are visible when it has ended),
+// the host polls that word.  Falls back to a stream synchronisation when the word cannot be had.
+int wait_stream(DAQPBatch *b)
+{
+    if (!b->pin_sig) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&b->pin_sig), 64, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(reinterpret_cast<void **>(&b->pin_sig_dev), b->pin_sig, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (b->pin_sig) { (void)hipHostFree(b->pin_sig); b->pin_sig = nullptr; }
+            HIPCHK(hipStreamSynchronize(b->stream));
+            return 0;
+        }
+        *b->pin_sig = 0;
+    }
+    const int seq = ++b->sig_seq;
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, b->stream, b->pin_sig_dev, seq);
+    HIPCHK(hipGetLastError());
+    unsigned spins = 0;
+    while (__atomic_load_n(b->pin_sig, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xffff) == 0) {      // (a failed stream never writes the word)
+            const hipError_t qe = hipStreamQuery(b->stream);
+            if (qe != hipSuccess && qe != hipErrorNotReady) { set_err("a launch on the batch's stream failed: %s", hipGetErrorString(qe)); return DAQP_EXIT_UNSUPPORTED; }
+            if (qe == hipSuccess && __atomic_load_n(b->pin_sig, __ATOMIC_ACQUIRE) != seq) { HIPCHK(hipStreamSynchronize(b->stream)); break; }
+        }
+    }
     return 0;
 }
 
@@ -512,10 +554,33 @@ int resolve_setup(DAQPBatch *b, bool *had_flagged = nullptr)
 // else happens unless some problem was declared infeasible.
 int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fresh);
 void destroy_batch(DAQPBatch *b);
+// one problem: the same workspace again, in the exact mode; its inputs are still where the setup read them
+int redo_one_exact(DAQPBatch *b)
+{
+    BatchDev &d = b->d;
+    DAQPBatchProblem pp;
+    pp.N = 1; pp.n = d.n; pp.m = d.m; pp.ms = d.ms;
+    pp.H = const_cast<double *>(d.H); pp.f = const_cast<double *>(d.f); pp.A = const_cast<double *>(d.A);
+    pp.bupper = const_cast<double *>(d.bu); pp.blower = const_cast<double *>(d.bl); pp.sense = const_cast<int *>(d.sense_in);
+    pp.memory = DAQP_MEM_DEVICE;
+    d.exact_setup = 1;
+    b->quiet_setup = true;             // (daqp_batch_kernel_ms keeps reporting the caller's setup)
+    const bool lean = b->lean;
+    b->lean = false;
+    int rc = batch_setup(b, &pp, b->fresh_mask, false);
+    b->quiet_setup = false;
+    b->lean = lean;
+    if (!rc) rc = launch_ldp(b, 0);
+    if (!rc && b->reg_pending) rc = resolve_setup(b);      // (the count of singular Hessians of this pass: none, the first pass had none)
+    d.exact_setup = 0;
+    b->rechecked = 1;
+    return rc;
+}
 int recheck_infeasible(DAQPBatch *b)
 {
     BatchDev &d = b->d;
     b->rechecked = 0;
+    if (d.N == 1 && b->mapped_out && d.x == b->ox) { b->recheck_due = true; return 0; }     // (the host sees the verdict itself when the results are there)
     if (!b->redo_list) {
         if (dev_alloc(b, &b->redo_list, (size_t)d.N) || dev_alloc(b, &b->redo_count, 2)) return DAQP_EXIT_UNSUPPORTED;
         HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&b->pin_redo), sizeof(int), hipHostMallocMapped));
@@ -544,23 +609,7 @@ int recheck_infeasible(DAQPBatch *b)
     if (!b->ev_r[0]) { HIPCHK(hipEventCreate(&b->ev_r[0])); HIPCHK(hipEventCreate(&b->ev_r[1])); }
     HIPCHK(hipEventRecord(b->ev_r[0], b->stream));
     struct Stamp { DAQPBatch *b; ~Stamp() { if (hipEventRecord(b->ev_r[1], b->stream) == hipSuccess) b->timed_recheck = true; } } stamp{b};
-    if (d.N == 1) {
-        // one problem (daqp_quadprog): the same workspace again, in the exact mode; its inputs are still in the device slab
-        DAQPBatchProblem pp;
-        pp.N = 1; pp.n = d.n; pp.m = d.m; pp.ms = d.ms;
-        pp.H = const_cast<double *>(d.H); pp.f = const_cast<double *>(d.f); pp.A = const_cast<double *>(d.A);
-        pp.bupper = const_cast<double *>(d.bu); pp.blower = const_cast<double *>(d.bl); pp.sense = const_cast<int *>(d.sense_in);
-        pp.memory = DAQP_MEM_DEVICE;
-        d.exact_setup = 1;
-        b->quiet_setup = true;             // (daqp_batch_kernel_ms keeps reporting the caller's setup)
-        int rc = batch_setup(b, &pp, b->fresh_mask, false);
-        b->quiet_setup = false;
-        if (!rc) rc = launch_ldp(b, 0);
-        if (!rc && b->reg_pending) rc = resolve_setup(b);      // (the count of singular Hessians of this pass: none, the first pass had none)
-        d.exact_setup = 0;
-        b->rechecked = 1;
-        return rc;
-    }
+    if (d.N == 1) return redo_one_exact(b);
     int cap = 2;
     while (cap < count) cap *= 2;
     if (cap > d.N) cap = d.N;
@@ -661,6 +710,8 @@ void destroy_batch(DAQPBatch *b)
     if (b->pin_in) (void)hipHostFree(b->pin_in);
     if (b->pin_out) (void)hipHostFree(b->pin_out);
     if (b->pin_mir) (void)hipHostFree(b->pin_mir);
+    if (b->pin_sig) (void)hipHostFree(b->pin_sig);
+    if (b->pin_upd) (void)hipHostFree(b->pin_upd);
     if (b->ev_in) (void)hipEventDestroy(b->ev_in);
     if (b->ev_count) (void)hipEventDestroy(b->ev_count);
     if (b->pin_count) (void)hipHostFree(b->pin_count);
@@ -818,14 +869,25 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         if (b->setup_spill && n <= kFactMaxN && !getenv("DAQP_AMD_NO_FACT_WG")) rc |= dev_alloc(b, &b->fact_buf, Nn * 4);
         if (!rc) HIPCHK(hipMemset(d.m_tick, 0, Nn * sizeof(int)));
     }
-    if (N == 1) {   // one slab: x[n] lam[m] fval soft | flag iter  -> one device->host copy per solve
+    if (N == 1) {   // one slab: x[n] lam[m] fval soft | flag iter -- in mapped host memory, written by the solve kernel itself (see mapped_out)
         double *slab = nullptr;
-        rc |= dev_alloc(b, &slab, (size_t)n + m + 3);
+        b->out_bytes = ((size_t)n + m + 3) * sizeof(double);
+        void *dp = nullptr;
+        static const bool no_map = [] { const char *e = getenv("DAQP_AMD_NO_MAPPED_RESULTS"); return e && atoi(e) != 0; }();
+        if (!no_map && hipHostMalloc(reinterpret_cast<void **>(&b->pin_out), b->out_bytes, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&dp, b->pin_out, 0) == hipSuccess) {
+            slab = static_cast<double *>(dp);
+            memset(b->pin_out, 0, b->out_bytes);
+            b->mapped_out = true;
+        } else {        // (no mapped memory to be had: a device slab and one copy per solve, as before)
+            (void)hipGetLastError();
+            if (b->pin_out) { (void)hipHostFree(b->pin_out); b->pin_out = nullptr; }
+            rc |= dev_alloc(b, &slab, (size_t)n + m + 3);
+            if (hipHostMalloc(reinterpret_cast<void **>(&b->pin_out), b->out_bytes, hipHostMallocDefault) != hipSuccess) { b->pin_out = nullptr; b->out_bytes = 0; }
+        }
         if (!rc) {
             b->ox = slab; b->olam = slab + n; b->ofval = slab + n + m; b->osoft = slab + n + m + 1;
             b->oflag = reinterpret_cast<int *>(slab + n + m + 2); b->oiter = b->oflag + 1;
-            b->out_bytes = ((size_t)n + m + 3) * sizeof(double);
-            if (hipHostMalloc(reinterpret_cast<void **>(&b->pin_out), b->out_bytes, hipHostMallocDefault) != hipSuccess) { b->pin_out = nullptr; b->out_bytes = 0; }
         }
     } else {
         rc |= dev_alloc(b, &b->ox, Nn * n);
@@ -895,7 +957,7 @@ void daqp_batch_free(DAQPBatch *b)
         if (b->d.trace || b->d.prof) { destroy_batch(b); return; }     // (debug buffers were attached: not worth keeping, and not kept)
         b->one_lam.clear(); b->one_valid = false;
         b->d.shared = 0; b->d.prox_pass = 0;
-        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->part_mask = 0; b->exact_sticky = false; b->is_setup = false; b->reg_pending = false; b->fresh = false; b->rechecked = 0; b->recheck_device = -1; b->inputs_adopted = false; b->timed_recheck = false;
+        b->was_shared = false; b->in_prox_loop = false; b->pending_mask = 0; b->part_mask = 0; b->exact_sticky = false; b->is_setup = false; b->reg_pending = false; b->fresh = false; b->rechecked = 0; b->recheck_device = -1; b->inputs_adopted = false; b->timed_recheck = false; b->lean = false; b->defer_wait = false; b->recheck_due = false; b->mirror_ldp_due = false;
         b->timed_setup = b->timed_solve = false; b->n_prox_qps = 0; b->prox_outer = 0;
         b->one_fval = b->one_soft = 0; b->one_flag = b->one_iter = 0;
         DAQPBatch *evict = nullptr;
@@ -1155,11 +1217,17 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
     // numerically singular Hessians: shifted re-runs for those problems (one tiny counting kernel when there are none);
     // an LP batch: its one setup pass
     b->reg_pending = false;
+    if (b->lean && !lp) {
+        // daqp_quadprog's one problem: the solve launch that follows activates by itself (need_activate in the record) and reports a
+        // flagged Hessian with the internal code -- the caller then takes the full path; no counting kernel, no activation launch
+        b->n_prox_qps = 0;
+    } else {
     rc = lp ? regularise(b, d, mask, true) : count_flagged_async(b, mask);
     if (rc) return rc;
     // initial working set from sense (utils.c:199-211); a no-op per problem unless flagged
     rc = launch_ldp(b, 1);
     if (rc) return rc;
+    }
     if (!b->quiet_setup) { HIPCHK(hipEventRecord(b->ev[1], b->stream)); b->timed_setup = true; }
     b->is_setup = true;
     // (a daqp_batch_update with every bit set comes through here as well and arms the second pass like a setup does: what follows it
@@ -1388,6 +1456,42 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
     return 0;
 }
 
+} // extern "C"
+namespace {
+// one problem: wait for the stream, take the results out of the slab; an INFEASIBLE verdict of a first solve in the default arithmetic is
+// re-derived in the reference's (recheck.hip.h) -- decided here, on the host, which has the verdict in its hands
+int collect_one(DAQPBatch *b, DAQPBatchResult *r)
+{
+    BatchDev &d = b->d;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (b->mapped_out) { if (wait_stream(b)) return DAQP_EXIT_UNSUPPORTED; }
+        else {
+            HIPCHK(hipMemcpyAsync(b->pin_out, b->ox, b->out_bytes, hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+        }
+        const int *oi0 = reinterpret_cast<const int *>(reinterpret_cast<const double *>(b->pin_out) + d.n + d.m + 2);
+        if (!(pass == 0 && b->recheck_due && oi0[0] == DAQP_EXIT_INFEASIBLE && oi0[1] > 0 && b->n_prox_qps == 0)) break;
+        b->recheck_due = false;
+        if (redo_one_exact(b)) return DAQP_EXIT_UNSUPPORTED;
+    }
+    b->recheck_due = false;
+    const double *o = reinterpret_cast<const double *>(b->pin_out);
+    const int *oi = reinterpret_cast<const int *>(o + d.n + d.m + 2);
+    // a solve counts from 1: flag < 0 with iter 0 is a setup / update flag, and -6 only ever comes out of an activation (auxiliary.c:399-479:
+    // part of the setup / update in the reference) -- x and lam are not results then (api.c:70-78)
+    const bool setup_failed = oi[0] < 0 && (oi[1] == 0 || oi[0] == DAQP_EXIT_OVERDETERMINED_INITIAL);
+    if (!setup_failed) {
+        if (r->x) memcpy(r->x, o, d.n * sizeof(double));
+        if (r->lam && d.m) memcpy(r->lam, o + d.n, d.m * sizeof(double));
+    }
+    if (r->fval) *r->fval = o[d.n + d.m];
+    if (r->soft_slack) *r->soft_slack = o[d.n + d.m + 1];
+    if (r->exitflag) *r->exitflag = oi[0];
+    if (r->iter) *r->iter = oi[1];
+    return 0;
+}
+} // namespace
+extern "C" {
 int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
 {
     if (!b || !r) { set_err("null batch or result"); return DAQP_EXIT_UNSUPPORTED; }
@@ -1436,17 +1540,10 @@ int daqp_batch_solve(DAQPBatch *b, DAQPBatchResult *r)
     b->fresh = false;
     HIPCHK(hipEventRecord(b->ev[3], b->stream));
     b->timed_solve = true;
-    if (!dev && d.N == 1 && b->pin_out != nullptr) {   // one problem: the result slab in one copy
-        HIPCHK(hipMemcpyAsync(b->pin_out, b->ox, b->out_bytes, hipMemcpyDeviceToHost, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
-        const double *o = reinterpret_cast<const double *>(b->pin_out);
-        if (r->x) memcpy(r->x, o, d.n * sizeof(double));
-        if (r->lam && d.m) memcpy(r->lam, o + d.n, d.m * sizeof(double));
-        if (r->fval) *r->fval = o[d.n + d.m];
-        if (r->soft_slack) *r->soft_slack = o[d.n + d.m + 1];
-        const int *oi = reinterpret_cast<const int *>(o + d.n + d.m + 2);
-        if (r->exitflag) *r->exitflag = oi[0];
-        if (r->iter) *r->iter = oi[1];
+    if (!dev && d.N == 1 && b->pin_out != nullptr) {   // one problem: the result slab, mapped (the kernels wrote it in place) or in one copy
+        if (b->defer_wait) return 0;                    // (daqp_ldp: more work goes behind this, one wait for all of it, then collect_one)
+        rc = collect_one(b, r);
+        if (rc) return rc;
         r->solve_time = now_s() - t0;
     } else if (!dev) {
         const size_t N = d.N;
@@ -1600,30 +1697,48 @@ static DAQPBatchProblem one_problem(const DAQPProblem *qp)
 // Host mirrors of the device state behind a single-problem workspace.  `ldp`: also the LDP itself (M, R^-1, v, d, scaling:
 // after a setup or an update; read-only copies for bindings that inspect them -- interfaces/daqp-eigen/daqp.cpp:250-271
 // reads Rinv / RinvD / v / sense -- writing to them does not reach the device).
-static void refresh_mirrors(DAQPWorkspace *w, bool ldp = false, bool full = true)
+// enqueue the gather (k_mirror) into the mirror slab -- mapped host memory that the kernel writes in place, or a device slab plus copies
+static int mirror_enqueue(DAQPBatch *b, bool ldp, bool full)
 {
     if (!ldp) full = false;
-    DAQPBatch *b = ws_batch(w);
-    if (!b) return;
     (void)hipSetDevice(b->device);
     const BatchDev &d = b->d;
     const size_t dbl = mirror_doubles(d.n, d.m, d.ms, d.cap, d.rtri);
     if (b->dev_mir == nullptr) {
-        if (dev_alloc(b, &b->dev_mir, dbl) || hipHostMalloc(reinterpret_cast<void **>(&b->pin_mir), dbl * sizeof(double), hipHostMallocDefault) != hipSuccess) return;
+        void *dp = nullptr;
+        static const bool no_map = [] { const char *e = getenv("DAQP_AMD_NO_MAPPED_RESULTS"); return e && atoi(e) != 0; }();
+        if (!no_map && hipHostMalloc(reinterpret_cast<void **>(&b->pin_mir), dbl * sizeof(double), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&dp, b->pin_mir, 0) == hipSuccess) {
+            b->dev_mir = static_cast<double *>(dp);
+            b->mapped_mir = true;
+        } else {
+            (void)hipGetLastError();
+            if (b->pin_mir) { (void)hipHostFree(b->pin_mir); b->pin_mir = nullptr; }
+            if (dev_alloc(b, &b->dev_mir, dbl) || hipHostMalloc(reinterpret_cast<void **>(&b->pin_mir), dbl * sizeof(double), hipHostMallocDefault) != hipSuccess) return 1;
+        }
     }
-    // one gather launch + one or two copies: the LDP part only when it may have changed (after a setup or an update), and
-    // of it R^-1 and M only when the caller says those changed too
+    // one gather launch: the LDP part only when it may have changed (after a setup or an update), and of it R^-1 and M only when the
+    // caller says those changed too
     const int blocks = full ? (int)(((size_t)(d.m - d.ms) * d.n + 255) / 256 > 64 ? 64 : ((size_t)(d.m - d.ms) * d.n + 255) / 256 + 1) : 1;
     hipLaunchKernelGGL(k_mirror, dim3(blocks), dim3(256), 0, b->stream, d, b->dev_mir, ldp ? (full ? 2 : 1) : 0);
+    if (hipGetLastError() != hipSuccess) return 1;
+    if (b->mapped_mir) return 0;
     const size_t io = mirror_int_off(d.n, d.m, d.ms, d.cap, d.rtri);
     if (ldp && full) {
-        if (hipMemcpyAsync(b->pin_mir, b->dev_mir, dbl * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return;
+        if (hipMemcpyAsync(b->pin_mir, b->dev_mir, dbl * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return 1;
     } else {   // head (scalars, lam_star and, with ldp, v / d / scaling) and tail (WS, sense)
         const size_t head = mirror_ldp_off(d.cap) + (ldp ? (size_t)d.n + 3 * (size_t)d.m : 0);
-        if (hipMemcpyAsync(b->pin_mir, b->dev_mir, head * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return;
-        if (hipMemcpyAsync(b->pin_mir + io, b->dev_mir + io, (dbl - io) * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return;
+        if (hipMemcpyAsync(b->pin_mir, b->dev_mir, head * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return 1;
+        if (hipMemcpyAsync(b->pin_mir + io, b->dev_mir + io, (dbl - io) * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return 1;
     }
-    if (hipStreamSynchronize(b->stream) != hipSuccess) return;
+    return 0;
+}
+// the slab has arrived: into the workspace's fields
+static void mirror_parse(DAQPWorkspace *w, DAQPBatch *b, bool ldp, bool full)
+{
+    if (!ldp) full = false;
+    const BatchDev &d = b->d;
+    const size_t io = mirror_int_off(d.n, d.m, d.ms, d.cap, d.rtri);
     QState qs;
     memcpy(&qs, b->pin_mir, sizeof(QState));
     w->n_active = qs.n_active; w->reuse_ind = qs.reuse_ind; w->sing_ind = qs.sing_ind;
@@ -1649,6 +1764,14 @@ static void refresh_mirrors(DAQPWorkspace *w, bool ldp = false, bool full = true
     }
     o += d.rtri;
     if (w->M && d.mA > 0) memcpy(w->M, o, sizeof(double) * (size_t)d.mA * d.n);   // (m - ms) x n row-major, rows normalised
+}
+static void refresh_mirrors(DAQPWorkspace *w, bool ldp = false, bool full = true)
+{
+    DAQPBatch *b = ws_batch(w);
+    if (!b) return;
+    if (mirror_enqueue(b, ldp, full)) return;
+    if (b->mapped_mir ? wait_stream(b) != 0 : hipStreamSynchronize(b->stream) != hipSuccess) return;
+    mirror_parse(w, b, ldp, full);
 }
 
 void allocate_daqp_settings(DAQPWorkspace *work)
@@ -1722,6 +1845,52 @@ int setup_daqp_main(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time, i
 
 int setup_daqp(DAQPProblem *qp, DAQPWorkspace *work, c_float *setup_time) { return setup_daqp_main(qp, work, setup_time, 0); }
 
+// daqp_update_ldp with a mask within v | d on a workspace whose solve kernel applies such an update itself (the register kernel: it has the
+// rows of M in registers anyway).  Nothing goes to the device here: the new f / bounds are put into mapped host memory that the next solve
+// launch reads in place, and the one thing the call has to RETURN -- the bound check's verdict, utils.c:94-98 -- is formed on the host
+// from the same numbers the device will look at (the workspace's sense as the last solve / update left it: the host mirror).  A check
+// that fails here takes the ordinary path (the device's own check decides, marks what the reference marks and records the flag).
+// The host mirrors of v / dupper / dlower follow with the next daqp_solve's gather (they are copies for inspection, not inputs).
+static bool update_one_deferred(DAQPWorkspace *work, DAQPBatch *b, int m, const DAQPProblem *qp)
+{
+    const BatchDev &dd = b->d;
+    if ((m & ~(DAQP_UPDATE_v | DAQP_UPDATE_d)) || !(m & (DAQP_UPDATE_v | DAQP_UPDATE_d))) return false;
+    if (dd.N != 1 || b->NB == 0 || !b->is_setup || b->reg_pending || b->was_shared || !work->sense || getenv("DAQP_AMD_EAGER_UPDATE")) return false;
+    if (!qp->bupper || !qp->blower || ((m & DAQP_UPDATE_v) && !qp->f)) return false;
+    const int n = dd.n, mm = dd.m;
+    for (int i = 0; i < mm; ++i) {      // utils.c:546-567 on the mirror of the workspace's sense
+        if (work->sense[i] & DAQP_IMMUTABLE) continue;
+        const double diff = qp->bupper[i] - qp->blower[i];
+        if (diff < -dd.st.primal_tol) return false;                                        // crossed: the device's check decides and records
+        if (diff < dd.st.zero_tol && !(work->sense[i] & DAQP_SOFT)) return false;          // an unmarked equality: marked and ACTIVATED by the update (its flag may be -6)
+    }
+    if (!b->pin_upd) {
+        void *dp = nullptr;
+        if (hipSetDevice(b->device) != hipSuccess) return false;
+        if (hipHostMalloc(reinterpret_cast<void **>(&b->pin_upd), ((size_t)n + 2 * (size_t)mm) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&dp, b->pin_upd, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (b->pin_upd) { (void)hipHostFree(b->pin_upd); b->pin_upd = nullptr; }
+            return false;
+        }
+        b->pin_upd_dev = static_cast<char *>(dp);
+    }
+    // (a solve launch that still reads an earlier update's numbers has been waited for by its daqp_solve: the buffer is free)
+    double *h = reinterpret_cast<double *>(b->pin_upd);
+    const double *dv = reinterpret_cast<const double *>(b->pin_upd_dev);
+    BatchDev &d = b->d;
+    if (m & DAQP_UPDATE_v) { memcpy(h, qp->f, n * sizeof(double)); d.f = dv; }
+    memcpy(h + n, qp->bupper, mm * sizeof(double));
+    memcpy(h + n + mm, qp->blower, mm * sizeof(double));
+    d.bu = dv + n; d.bl = dv + n + mm;
+    b->fresh = false;
+    b->exact_sticky = false;
+    b->pending_mask |= m;
+    b->timed_setup = false;
+    b->mirror_ldp_due = true;
+    return true;
+}
+
 int daqp_update_ldp(const int mask, DAQPWorkspace *work, DAQPProblem *qp)
 {
     DAQPBatch *b = ws_batch(work);
@@ -1732,6 +1901,7 @@ int daqp_update_ldp(const int mask, DAQPWorkspace *work, DAQPProblem *qp)
     DAQPBatchProblem p = one_problem(qp);
     const int m = mask & ~(DAQP_UPDATE_hierarchy);
     b->one_valid = false;
+    if (update_one_deferred(work, b, m, qp)) return 0;
     int rc = daqp_batch_update(b, m, &p);
     if (rc < 0) return rc;
     int flag = 1;
@@ -1775,9 +1945,23 @@ int daqp_ldp(DAQPWorkspace *work)
     r.x = work->x; r.lam = b->one_lam.data(); r.fval = &b->one_fval; r.soft_slack = &b->one_soft; r.exitflag = &b->one_flag; r.iter = &b->one_iter;
     r.memory = DAQP_MEM_HOST;
     b->one_valid = false;
-    const int rc = daqp_batch_solve(b, &r);
+    // the solve launch(es), then the gather of the workspace's host mirrors behind them -- with the v / d part when a deferred
+    // daqp_update_ldp has just been applied by that launch --, ONE wait for all of it
+    const bool with_ldp = b->mirror_ldp_due;
+    const bool fuse = b->mapped_out && b->pin_out != nullptr && !(b->fresh && b->recheck && b->d.exact_setup == 0);   // (a first solve may be re-derived: collect first)
+    b->defer_wait = fuse;
+    int rc = daqp_batch_solve(b, &r);
+    b->defer_wait = false;
     if (rc < 0) { b->one_flag = rc; return rc; }
-    refresh_mirrors(work);
+    if (fuse) {
+        if (mirror_enqueue(b, with_ldp, false) || !b->mapped_mir) {     // (no mapped mirror slab: its copies are behind the launch; wait for everything)
+            if (hipStreamSynchronize(b->stream) != hipSuccess) { b->one_flag = DAQP_EXIT_UNSUPPORTED; return DAQP_EXIT_UNSUPPORTED; }
+        }
+        rc = collect_one(b, &r);
+        if (rc < 0) { b->one_flag = rc; return rc; }
+        mirror_parse(work, b, with_ldp, false);
+    } else refresh_mirrors(work, with_ldp, false);
+    b->mirror_ldp_due = false;
     work->iterations = b->one_iter;
     b->one_valid = true;
     return b->one_flag;
@@ -1873,15 +2057,41 @@ void daqp_quadprog(DAQPResult *res, DAQPProblem *qp, DAQPSettings *settings)
     int rc = daqp_batch_create(&b, 1, qp->n, qp->m, qp->ms, ns, settings, -1);
     if (rc < 0) { res->exitflag = rc; return; }
     DAQPBatchProblem p = one_problem(qp);
+    DAQPBatchResult r;
+    int iters = 0, eflag = 0;
+    // The lean sequence: inputs in one copy, the setup launch(es), the solve launch -- which activates a given working set itself and
+    // reports a failed setup as its exit flag (iter 0) --, results written into mapped host memory by the kernel, ONE wait.  No flag
+    // read-back between setup and solve.  What that cannot serve comes back with an internal code and takes the full sequence below:
+    // a Hessian that needs the shift (the regularising passes and the proximal loop are host-driven), an LP.
+    if (b->mapped_out && qp->H != nullptr && !getenv("DAQP_AMD_NO_LEAN")) {
+        b->lean = true;
+        rc = daqp_batch_setup(b, &p, DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate);
+        b->lean = false;
+        res->setup_time = now_s() - t0;
+        if (rc == 0) {
+            const double t1 = now_s();
+            memset(&r, 0, sizeof(r));
+            r.x = res->x; r.lam = res->lam; r.fval = &res->fval; r.soft_slack = &res->soft_slack; r.exitflag = &eflag; r.iter = &iters;
+            r.memory = DAQP_MEM_HOST;
+            rc = daqp_batch_solve(b, &r);
+            if (rc == 0 && eflag > DAQP_NEEDS_SHIFT) {      // (every flag of the reference is above the internal codes)
+                res->exitflag = eflag;
+                if (!(eflag < 0 && (iters == 0 || eflag == DAQP_EXIT_OVERDETERMINED_INITIAL))) { res->iter = iters; res->nodes = 1; res->solve_time = now_s() - t1; }   // api.c:74-77: a failed setup reports its flag, nothing else
+                daqp_batch_free(b);
+                return;
+            }
+        }
+        if (rc < 0) { res->exitflag = rc; daqp_batch_free(b); return; }
+        // (internal code: the full sequence, from the setup)
+    }
+    const double t0f = now_s();
     rc = daqp_batch_setup(b, &p, DAQP_UPDATE_unconstrained | DAQP_UPDATE_eliminate);
     int flag = 1;
     if (rc == 0) rc = daqp_batch_setup_flags(b, &flag);
-    res->setup_time = now_s() - t0;
+    res->setup_time = now_s() - t0f;
     if (rc < 0 || flag < 0) { res->exitflag = rc < 0 ? rc : flag; daqp_batch_free(b); return; }   // api.c:74-77: no solve after a failed setup
     const double t1 = now_s();
-    DAQPBatchResult r;
     memset(&r, 0, sizeof(r));
-    int iters = 0, eflag = 0;
     r.x = res->x; r.lam = res->lam; r.fval = &res->fval; r.soft_slack = &res->soft_slack; r.exitflag = &eflag; r.iter = &iters;
     r.memory = DAQP_MEM_HOST;
     rc = daqp_batch_solve(b, &r);

@@ -158,6 +158,8 @@ struct DAQPBatch {
     // learns that they are there from a mapped word written by a one-thread kernel at the end of the stream's work -- no hipMemcpy, no
     // stream synchronisation on the way of daqp_quadprog / daqp_solve / daqp_update_ldp (0.34 / 0.14 ms per call were
     // launches, small copies and synchronisations around ~0.1 ms / ~0.02 ms of kernels)
+    BatchDev d_pushed{};        // what d_dev holds (the register kernels read the descriptor through it): pushed again only when it differs
+    bool pushed_valid = false;
     bool mapped_out = false, mapped_mir = false;     // ox .. oiter / dev_mir point into pin_out / pin_mir through their device addresses
     int *pin_sig = nullptr, *pin_sig_dev = nullptr;  // the completion word and its device address
     int sig_seq = 0;
@@ -231,6 +233,16 @@ int wait_stream(DAQPBatch *b)
     return 0;
 }
 
+// the descriptor as the kernels that take it through a pointer see it: copied (stream-ordered) when it has changed since the last copy
+int push_descriptor(DAQPBatch *b)
+{
+    if (b->pushed_valid && memcmp(&b->d_pushed, &b->d, sizeof(BatchDev)) == 0) return 0;
+    HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
+    memcpy(&b->d_pushed, &b->d, sizeof(BatchDev));
+    b->pushed_valid = true;
+    return 0;
+}
+
 typedef void (*ldp_kernel_t)(BatchDev, int);
 typedef void (*ldp_reg_kernel_t)(const BatchDev *, int);
 // register-resident variants: (row blocks, k-pairs) held per lane; needs cap <= 64 and L/rows in LDS
@@ -298,7 +310,8 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         // problems that run the proximal outer loop keep the reference's arithmetic in both modes (their setup passes do as well)
         ldp_reg_kernel_t kr = pick_ldp_reg(b, b->d.exact_setup != 0 || b->in_prox_loop || b->exact_sticky);
         // the descriptor travels through device memory: stream-ordered copy, then the launch
-        if (descriptor_changed) HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
+        (void)descriptor_changed;
+        if (push_descriptor(b)) return DAQP_EXIT_UNSUPPORTED;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
         hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode);
         HIPCHK(hipGetLastError());
@@ -1185,7 +1198,7 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
 #undef DAQP_BLK_SHAPE
         const size_t lds_blk = (size_t)(NT == 2 ? blk_lds<2>(d.n, d.m) : (NT == 3 ? blk_lds<3>(d.n, d.m) : blk_lds<4>(d.n, d.m))).total_bytes;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
-        HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));      // (it reads the descriptor through a pointer)
+        if (push_descriptor(b)) return DAQP_EXIT_UNSUPPORTED;      // (it reads the descriptor through a pointer)
         hipLaunchKernelGGL(kb, dim3(d.N), dim3(64), lds_blk, b->stream, (const BatchDev *)b->d_dev, mask);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(ks, dim3(d.N), dim3(64), lds_setup, b->stream, d, mask | kSetupOnlyMarked);

@@ -54,9 +54,11 @@ extern template __global__ void k_setup_tiny<4>(BatchDev, int);
 #define DAQP_BLK_SHAPE(NT, NW, TAIL) extern template __global__ void k_setup_blk<NT, NW, TAIL>(const BatchDev *__restrict__, int);
 DAQP_BLK_SHAPES
 #undef DAQP_BLK_SHAPE   // (the 16-per-wave SETUP kernel is the default for these shapes: setup_kernel.hip)
-template <int C> __global__ void k_ldp_wg(BatchDev b, int mode);
-extern template __global__ void k_ldp_wg<2>(BatchDev, int);
-extern template __global__ void k_ldp_wg<4>(BatchDev, int);
+template <int C, bool EX> __global__ void k_ldp_wg(BatchDev b, int mode);
+extern template __global__ void k_ldp_wg<2, false>(BatchDev, int);
+extern template __global__ void k_ldp_wg<2, true>(BatchDev, int);
+extern template __global__ void k_ldp_wg<4, false>(BatchDev, int);
+extern template __global__ void k_ldp_wg<4, true>(BatchDev, int);
 }
 
 using namespace daqp_amd;
@@ -293,11 +295,11 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         // persistent workgroups pull problems from a counter; whatever outgrows the LDS-resident L is flagged and solved by
         // the one-wave kernel right behind (mode | 4: flagged problems only -- an empty pass costs a few microseconds)
         typedef void (*wg_kernel_t)(BatchDev, int);
-        wg_kernel_t kw = b->wg_C == 2 ? k_ldp_wg<2> : k_ldp_wg<4>;
-        HIPCHK(hipMemsetAsync(b->d.wg_counter, 0, sizeof(int), b->stream));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg));
         BatchDev dd = b->d;
         if (b->in_prox_loop || b->exact_sticky) dd.exact_setup = 1;   // problems of the proximal outer loop keep the reference's arithmetic in both modes
+        wg_kernel_t kw = dd.exact_setup ? (b->wg_C == 2 ? k_ldp_wg<2, true> : k_ldp_wg<4, true>) : (b->wg_C == 2 ? k_ldp_wg<2, false> : k_ldp_wg<4, false>);
+        HIPCHK(hipMemsetAsync(b->d.wg_counter, 0, sizeof(int), b->stream));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg));
         hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, dd, mode);
         HIPCHK(hipGetLastError());
         ldp_kernel_t kf = pick_ldp(b);
@@ -920,7 +922,10 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     }
     if (b->use_wg && !rc) {
         typedef void (*wg_kernel_t)(BatchDev, int);
-        wg_kernel_t kw = b->wg_C == 2 ? k_ldp_wg<2> : k_ldp_wg<4>;
+        wg_kernel_t kw = b->wg_C == 2 ? k_ldp_wg<2, false> : k_ldp_wg<4, false>;
+        wg_kernel_t kwx = b->wg_C == 2 ? k_ldp_wg<2, true> : k_ldp_wg<4, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kwx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg);
+        (void)hipGetLastError();
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg) != hipSuccess) {

@@ -9,7 +9,11 @@ namespace daqp_amd {
 
 // mode 0: daqp_solve; mode 1: only (re)build the working set from the ACTIVE bits (tail of daqp_update_ldp);
 // mode | 4: only the problems flagged in b.fallback are touched by the ONE-WAVE kernel (see k_ldp) -- not used here
-template <int C>
+// EX: the arithmetic mode as a compile-time constant (b.exact_setup decides which instantiation is launched).  Every function below
+// is inlined into the kernel and branches on c.exact: as a run-time field both modes' code -- the reference's ordered chains AND the
+// inverse factor with its tree sums -- shared one register allocation, and the default mode's launch carried the chains' live ranges
+// (488 bytes of scratch per lane, 169 spilled registers in k_ldp_wg<4> at round 4).
+template <int C, bool EX>
 __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mode)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -20,7 +24,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
     const int n = b.n, m = b.m, cap = b.cap, W = (int)(blockDim.x >> 6);
     WgCtx c;
     c.n = n; c.m = m; c.ms = b.ms; c.cap = cap; c.capL = b.wg_capL; c.npair = b.npair; c.nblk = b.nblk; c.ldr = wg_row_stride(n); c.capT = b.wg_capT;
-    c.W = W; c.exact = b.exact_setup;
+    c.W = W; c.exact = EX ? 1 : 0;
     c.oL = wg_lds_L(C, m); c.lmax = wg_round_up(b.wg_capL * (b.wg_capL + 1) / 2, 2) - 1;
     c.rowc = b.wg_rowc + (size_t)blockIdx.x * cap * wg_row_stride(n);
     c.rowcT = b.wg_rowcT + (size_t)blockIdx.x * n * b.wg_capT;

@@ -294,7 +294,7 @@ def test_kernel_resource_budgets():
         "k_ldp_reg<3, 25, true>": (0, 1), "k_ldp_reg<3, 25, false>": (0, 1), "k_ldp_reg<2, 32, true>": (0, 1),
         "k_ldp_reg<1, 6, true>": (0, 3), "k_ldp_reg<1, 6, false>": (0, 3), "k_ldp_reg<1, 8, true>": (0, 3), "k_ldp_reg<1, 8, false>": (0, 3), "k_ldp_reg<1, 16, true>": (0, 2), "k_ldp_reg<2, 16, true>": (16, 2),
         "k_ldp<1, false, 0, 0>": (0, 2), "k_ldp<2, false, 0, 0>": (0, 2), "k_ldp<4, true, 0, 0>": (128, 2),
-        "k_ldp_wg<2>": (64, 2), "k_ldp_wg<4>": (512, 2),
+        "k_ldp_wg<2, false>": (64, 2), "k_ldp_wg<4, false>": (512, 2), "k_ldp_wg<2, true>": (64, 2), "k_ldp_wg<4, true>": (512, 2),
         "k_update": (0, 8),
     }
     for name, (scratch, occ) in budgets.items():

@@ -493,6 +493,9 @@ class Runner:
             if BOUND[cfg] == "hbm" and prof.get("traffic"):     # the memory system is the roof: measured HBM-side bytes over the launch time
                 roof["achieved"] = prof["traffic"] / max(t_ldp, 1e-12) / 1e9
                 roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+                pat = pattern_ceiling()
+                if pat:     # what the memory system delivers to THIS access pattern with every CU streaming (tools/ubench5.hip, committed run)
+                    roof["pattern"] = dict(pat, frac=roof["achieved"] / pat["peak"])
         if cpu_sample > 0 and self.world == 1:
             S = min(N, cpu_sample)
             if warm:
@@ -507,6 +510,22 @@ class Runner:
             out["cpu_baseline"] = base
             out["parity_vs_cpu"] = parity
         return out
+
+
+def pattern_ceiling():
+    """the chip-wide rate of tools/ubench5.hip (the C4 solve kernel's memory phases as a pure streaming pattern: 256 workgroups of 8 waves,
+    each re-reading its own 0.8 MB working set with 16-byte loads, 16 in flight per lane) from the newest committed run"""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ubench5.txt")))
+    if not files:
+        return None
+    rates = [float(m.group(1)) for m in re.finditer(r"^256 workgroups x 8 waves, 1 working set.*?-> ([0-9.]+) TB/s", open(files[-1]).read(), re.M)]
+    if not rates:
+        return None
+    return {"peak": 1e3 * float(np.median(rates)), "unit": "GB/s", "source": "profiles/" + os.path.basename(files[-1]),
+            "is": "what the memory system delivers to the kernel's own access pattern with all 256 CUs streaming (cache-resident or not: the same); "
+                  "the launch's HBM-side bytes over its time against THAT"}
 
 
 def library_stamp():

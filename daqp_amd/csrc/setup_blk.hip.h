@@ -558,18 +558,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             SPROF(3);
             {
                 BLK_GLOBAL(blk_v2d) *dst = Mq2 + ((size_t)(gi >> 6) * npair) * 64 + (gi & 63);
-                for (int tq = 0; tq < npair; tq += 8) {      // eight column pairs in flight
-                    double2 v8[8];
+                // eight column pairs in flight; the pairs past the row's end repeat its last one (the same bytes stored again: no
+                // branch between the loads -- with one, every load waited for the one before it: 25 LDS round trips per row and tile)
+                if (own) {
+                    if (direct) {
+                        const double2 *a2 = reinterpret_cast<const double2 *>(a);
+                        for (int tq = 0; tq < npair; tq += 8) {
+                            double2 v8[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int t = (tq + u < npair) ? tq + u : npair - 1;
-                        if (direct) v8[u] = reinterpret_cast<const double2 *>(a)[t];
-                        else { v8[u].x = a[2 * t]; v8[u].y = (2 * t + 1 < n) ? a[2 * t + 1] : 0.0; }
-                    }
+                            for (int u = 0; u < 8; ++u) v8[u] = a2[(tq + u < npair) ? tq + u : npair - 1];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (own && tq + u < npair) {
-                            dst[(size_t)(tq + u) * 64] = (blk_v2d){v8[u].x * scal, v8[u].y * scal};
+                            for (int u = 0; u < 8; ++u) dst[(size_t)((tq + u < npair) ? tq + u : npair - 1) * 64] = (blk_v2d){v8[u].x * scal, v8[u].y * scal};
+                        }
+                    } else {
+                        for (int tq = 0; tq < npair; tq += 8) {
+                            double vx[8], vy[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int t = (tq + u < npair) ? tq + u : npair - 1;
+                                vx[u] = a[2 * t];
+                                const double y = a[(2 * t + 1 < n) ? 2 * t + 1 : 2 * t];
+                                vy[u] = (2 * t + 1 < n) ? y : 0.0;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) dst[(size_t)((tq + u < npair) ? tq + u : npair - 1) * 64] = (blk_v2d){vx[u] * scal, vy[u] * scal};
                         }
                     }
                 }

@@ -753,7 +753,7 @@ def main():
     side = args.side_configs
     if side == "auto":
         side = "C3,C4,C5" if (R.world == 1 and args.config == "C2" and not args.batch and not args.strong) else "none"
-    side_steps = {"C3": (10, 2), "C4": (3, 1), "C5": (3, 1), "C2": (5, 1)}
+    side_steps = {"C3": (10, 2), "C4": (3, 1), "C5": (10, 2), "C2": (5, 1)}
     if side != "none":
         cfgs = {}
         for cfg in [s for s in side.split(",") if s and s != args.config]:

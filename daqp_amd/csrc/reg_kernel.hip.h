@@ -123,9 +123,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     if (nblk_u == NB && npair_u == NP) {
         // the shape fills the template exactly (the benchmark's case): NB*NP unconditional loads in ONE basic block, each
         // straight into its final (mostly accumulation) register -- all in flight, one wait at the first use
+        // (the lanes of the last block whose rows lie beyond m -- 42 of 64 at m = 150 -- re-read lane 0's line instead of their own slice of
+        // the image's padding: the same instructions, a fifth fewer lines from HBM; those registers are never looked at: every use of a row is behind r < m)
+        const int lane_last = (64 * (NB - 1) + lane < m) ? lane : 0;
         static_for<NB>([&](auto bb) __attribute__((always_inline)) {
             static_for<NP>([&](auto t) __attribute__((always_inline)) {
-                const double2 v = msrc[((size_t)bb * NP + t) * 64 + lane];
+                const double2 v = msrc[((size_t)bb * NP + t) * 64 + (bb == NB - 1 ? lane_last : lane)];
                 w.Mx[bb][t] = v.x; w.My[bb][t] = v.y;
             });
         });

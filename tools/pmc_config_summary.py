@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import CONFIGS, library_stamp
 
 out = sys.argv[1]
-SOLVE = {"C2": r"k_ldp_reg<3, 25", "C3": r"k_ldp_reg<1, [68]", "C4": r"k_ldp_wg<4>", "C5": r"k_ldp_reg<3, 25"}
+SOLVE = {"C2": r"k_ldp_reg<3, 25", "C3": r"k_ldp_reg<1, [68]", "C4": r"k_ldp_wg<4[,>]", "C5": r"k_ldp_reg<3, 25"}
 SETUP = {"C2": r"k_setup_blk<4, 56||k_setup_fast<56", "C3": r"k_setup_tiny|k_setup_fast<16", "C4": r"k_setup<true", "C5": r"k_setup_blk<4, 56||k_setup_fast<56"}
 N_SIMD, F_CLK = 1024, 2.4e9        # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak (MI355X_MICROARCH.md); SQ_* cycle counters tick every 4 cycles
 

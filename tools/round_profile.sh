@@ -23,3 +23,8 @@ done
 python tools/pmc_config_summary.py $O/pmc_summary.json $O/pmc_raw_C2.json $O/pmc_raw_C3.json $O/pmc_raw_C4.json $O/pmc_raw_C5.json > $O/pmc_summary_print.txt 2>&1
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 tools/ubench4.bin > $O/ubench4.txt 2>&1
+tools/ubench5.bin > $O/ubench5.txt 2>&1
+python tools/gpu_profile.py 20000 > $O/c2_phases.txt 2>&1
+python tools/c4_rate.py 4096 prof > $O/c4_phases.txt 2>&1
+python tools/c5_phases.py > $O/c5_phases.txt 2>&1
+python tools/latency_one.py > $O/latency_one.txt 2>&1

@@ -5,6 +5,9 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r03p}; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python bench.py --steps 5 --warmup 1 --cpu-sample 0 > $O/bench_under_trace.json 2> $O/trace.err
 find /tmp/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+# the headline alone (no side configs, no batch sweep, no exact-mode leg): here a kernel's average IS the C2 launch
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -o kt -- python bench.py --config C2 --steps 10 --warmup 2 --cpu-sample 0 --side-configs none --no-sweep --no-exact > $O/bench_headline_under_trace.json 2>> $O/trace.err
+find /tmp/kt2 -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_headline.csv \;
 for cfg in C2 C3 C4 C5; do
   CMD="python bench.py --config $cfg --steps 2 --warmup 1 --cpu-sample 0 --side-configs none"
   i=0

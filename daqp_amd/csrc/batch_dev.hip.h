@@ -4,6 +4,7 @@
 
 namespace daqp_amd {
 
+
 struct BatchDev {
     int N, n, m, ms, cap, mA;
     int npair, nblk, ldr, ltri, rtri;

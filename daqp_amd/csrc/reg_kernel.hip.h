@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     const long long t_start = (long long)__builtin_readcyclecounter();
     const int q = blockIdx.x, lane = lane_id();
     const int n = b.n, m = b.m, cap = b.cap;
-    QState *qs = b.qs + q;
+    DAQP_GLOBAL(QState) *qs = as_global(b.qs + q);   // (global pointers throughout: see DAQP_GLOBAL in wave_ldp.hip.h)
     if (mode == 1) {   // an activation launch looks at the record first: almost every problem leaves here, without touching M
         if (__builtin_amdgcn_readfirstlane(qs->setup_flag) < 0 || !__builtin_amdgcn_readfirstlane(qs->need_activate)) return;
     }
@@ -62,10 +62,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     // delivers to four waves -- and the record is there when the last load has been issued; prologue 35.2 k -> 34.1 k of a warm
     // solve's 141 k cycles (then: active rows + L 3.5 k, v = R^-T f 5.6 k, d 2.5 k).
     const size_t qfac = qf(b, q);
-    const double *gdu = b.dupper + (size_t)q * m, *gdl = b.dlower + (size_t)q * m, *gsc = b.scaling + qfac * m;
-    int *gsense = b.sense + (size_t)q * m;
-    double *gv = b.vecs + (size_t)q * 5 * cap;
-    int *gws = b.WS + (size_t)q * cap;
+    DAQP_GLOBAL(double) *gdu = as_global(b.dupper + (size_t)q * m), *gdl = as_global(b.dlower + (size_t)q * m);
+    const DAQP_GLOBAL(double) *gsc = as_global(b.scaling + qfac * m);
+    DAQP_GLOBAL(int) *gsense = as_global(b.sense + (size_t)q * m);
+    DAQP_GLOBAL(double) *gv = as_global(b.vecs + (size_t)q * 5 * cap);
+    DAQP_GLOBAL(int) *gws = as_global(b.WS + (size_t)q * cap);
     const int rowc_size = reg_lds_rowc_size(n, m, cap, b.ldrc);
     RWave<NB, NP, FM> w;
     w.rowc = smem + reg_lds_rowc(NB, cap);
@@ -81,13 +82,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         const int body = (b.rtri - odd8) & ~1;
         copy_async(Rl0 + odd8, Rq + odd8, body);
         if (odd8 + body < b.rtri) copy_async_dwords(Rl0 + odd8 + body, Rq + odd8 + body, 1);
-        if (lane < n) { f_raw = f[lane]; if (lane < b.ms) f_sc = gsc[lane]; }
+        if (lane < n) { f_raw = as_global(f)[lane]; if (lane < b.ms) f_sc = gsc[lane]; }
     }
     // ---- row view: bounds, tolerance, sense and the rows of M themselves -> registers
     double scr[NB];
     int softbits = 0;
     w.rs = 0;
-    const double2 *msrc = reinterpret_cast<const double2 *>(b.Mblk + qfac * b.nblk * b.npair * 128);
+    typedef double gv2d __attribute__((ext_vector_type(2)));
+    const DAQP_GLOBAL(gv2d) *msrc = as_global(reinterpret_cast<const gv2d *>(b.Mblk + qfac * b.nblk * b.npair * 128));
     const int npair_u = __builtin_amdgcn_readfirstlane(b.npair), nblk_u = __builtin_amdgcn_readfirstlane(b.nblk);
     // the small per-row loads go out first: in-order return means whoever waits for them would otherwise wait for
     // every row of M issued before them
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     // a pending update also needs the new bounds: same early batch
     double bur[NB], blr[NB];
     if (upd) {
-        const double *nbu = b.bu + (size_t)q * m, *nbl = b.bl + (size_t)q * m;
+        const DAQP_GLOBAL(double) *nbu = as_global(b.bu + (size_t)q * m), *nbl = as_global(b.bl + (size_t)q * m);
         static_for<NB>([&](auto bb) __attribute__((always_inline)) {
             const int r = bb * 64 + lane;
             bur[bb] = (r < m) ? nbu[r] : 0.0;
@@ -119,6 +121,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     const int rec_sflag = qs->setup_flag, rec_need = qs->need_activate, rec_diag = qs->diag_h, rec_uflag = qs->upd_flag;
     const int rec_na = qs->n_active, rec_reuse = qs->reuse_ind, rec_sing = qs->sing_ind, rec_swapped = qs->lam_swapped;
     const double rec_fval = qs->fval, rec_soft = qs->soft_slack;
+    // v = R^-T f (utils.c:474-497) of a pending UPDATE_v, rows < ms of R^-1 being the normalised ones: from R^-1 and f staged in LDS
+    auto v_of_update = [&](const double *Rl, const double *fl) __attribute__((always_inline)) -> double {
+        if constexpr (FM) {
+            // default arithmetic: the triangle FOLDED over the lanes.  Column i has i + 1 terms -- lane n-1 would run an n-step
+            // chain while lane 0 runs one (5.6 k cycles of a warm solve at n = 50) -- so lane i takes the first LH = n/2 + 1 terms of
+            // its own column (j = i, i-1, ...) and then the tail of column n-1-i that its owner leaves over (j = n-2-i-LH .. 0 when
+            // that column is longer than LH): every lane ~n/2 terms, one exchange at the end.  Same products, one more association
+            // than the reference's single chain (the exact mode keeps utils.c:474-497's order below).
+            const int i = lane < n ? lane : 0, pc = n - 1 - i;                 // own column, partner column
+            const int LH = n / 2 + 1;
+            const int own_lo = (i + 1 > LH) ? i - LH + 1 : 0;                      // own terms: j = i .. own_lo
+            const int tail_hi = (pc + 1 > LH && pc != i) ? pc - LH : -1;           // partner's left-over: j = tail_hi .. 0
+            double acc = 0, acc2 = 0;
+            for (int j0 = i; j0 >= own_lo; j0 -= kChunk) {
+                double rr[kChunk], ff[kChunk];
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k) { const int j = (j0 - k >= own_lo) ? j0 - k : own_lo; rr[k] = Rl[roff(j, n) + i]; ff[k] = fl[j]; }
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k) if (j0 - k >= own_lo) acc = __builtin_fma(rr[k], ff[k], acc);
+            }
+            for (int j0 = tail_hi; j0 >= 0; j0 -= kChunk) {
+                double rr[kChunk], ff[kChunk];
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k) { const int j = (j0 - k >= 0) ? j0 - k : 0; rr[k] = Rl[roff(j, n) + pc]; ff[k] = fl[j]; }
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k) if (j0 - k >= 0) acc2 = __builtin_fma(rr[k], ff[k], acc2);
+            }
+            const double other = __shfl(acc2, (lane < n) ? n - 1 - lane : lane);   // the lane that worked on THIS lane's column
+            return acc + other;
+        } else {
+            const int i = lane < n ? lane : 0;
+            double acc = Rl[roff(i, n) + i] * fl[i];
+            for (int j0 = i - 1; j0 >= 0; j0 -= kChunk) {
+                double rr[kChunk], ff[kChunk];
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k) { const int j = (j0 - k >= 0) ? j0 - k : 0; rr[k] = Rl[roff(j, n) + i]; ff[k] = fl[j]; }
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k) if (j0 - k >= 0) acc += rr[k] * ff[k];
+            }
+            return acc;
+        }
+    };
+    double v_early = 0;
+    bool v_done = false;
     __builtin_amdgcn_sched_barrier(0);
     if (nblk_u == NB && npair_u == NP) {
         // the shape fills the template exactly (the benchmark's case): NB*NP unconditional loads in ONE basic block, each
@@ -126,11 +172,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         // (the lanes of the last block whose rows lie beyond m -- 42 of 64 at m = 150 -- re-read lane 0's line instead of their own slice of
         // the image's padding: the same instructions, a fifth fewer lines from HBM; those registers are never looked at: every use of a row is behind r < m)
         const int lane_last = (64 * (NB - 1) + lane < m) ? lane : 0;
-        static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+        static_for<NB - 1>([&](auto bb) __attribute__((always_inline)) {
             static_for<NP>([&](auto t) __attribute__((always_inline)) {
-                const double2 v = msrc[((size_t)bb * NP + t) * 64 + (bb == NB - 1 ? lane_last : lane)];
+                const gv2d v = msrc[((size_t)bb * NP + t) * 64 + lane];
                 w.Mx[bb][t] = v.x; w.My[bb][t] = v.y;
             });
+        });
+        if constexpr (NB > 1 && (NB - 1) * NP <= 60) {
+            // A pending UPDATE_v is worked off HERE, between the row loads: issuing them is what the wave waits for (each 1 KB load takes
+            // ~220 cycles to be accepted: 16.8 k cycles for the 75 of config 5), and arithmetic placed between them runs while the memory
+            // path digests the ones already queued -- v = R^-T f was 3-5 k cycles spent AFTER the last row had arrived.  Its inputs (R^-1
+            // by LDS copy, f, the record) went out before every row load, so "all but the last (NB-1) NP operations done" covers them.
+            if (upd & DAQP_UPDATE_v) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (((NB - 1) * NP) & 15) | ((((NB - 1) * NP) >> 4) << 14));   // vmcnt((NB-1) NP)
+                __builtin_amdgcn_sched_barrier(0);
+                double *fl = smem + o::pend_lam;
+                const int qdiag_e = __builtin_amdgcn_readfirstlane(rec_diag);
+                if (lane < n) fl[lane] = (lane < b.ms && !qdiag_e) ? f_raw / f_sc : f_raw;
+                WSYNC();
+                v_early = v_of_update(Rl0, fl);
+                v_done = true;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        static_for<NP>([&](auto t) __attribute__((always_inline)) {
+            const gv2d v = msrc[((size_t)(NB - 1) * NP + t) * 64 + lane_last];
+            w.Mx[NB - 1][t] = v.x; w.My[NB - 1][t] = v.y;
         });
     } else {
         // smaller problems in the same register shape: lines beyond the problem's are zeros (a select per load keeps
@@ -138,7 +206,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         static_for<NB>([&](auto bb) __attribute__((always_inline)) {
             static_for<NP>([&](auto t) __attribute__((always_inline)) {
                 const bool ok = bb < nblk_u && t < npair_u;
-                const double2 v = msrc[(ok ? ((size_t)bb * npair_u + t) : (size_t)0) * 64 + lane];
+                const gv2d v = msrc[(ok ? ((size_t)bb * npair_u + t) : (size_t)0) * 64 + lane];
                 w.Mx[bb][t] = ok ? v.x : 0.0; w.My[bb][t] = ok ? v.y : 0.0;
             });
         });
@@ -150,14 +218,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     int q_need_act = __builtin_amdgcn_readfirstlane(rec_need);
     const int qdiag = __builtin_amdgcn_readfirstlane(rec_diag);
     if (sflag < 0) {
-        if (lane == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
+        if (lane == 0) { as_global(b.exitflag)[q] = sflag; as_global(b.iter)[q] = 0; if (b.fval) as_global(b.fval)[q] = 0; if (b.soft) as_global(b.soft)[q] = 0; }
         copy_wait();   // nothing may still be landing in LDS when the workgroup ends
         return;
     }
     if (mode == 0 && !upd) {   // the last update failed its bound check: report that, keep the state (see k_update)
         const int uflag = __builtin_amdgcn_readfirstlane(rec_uflag);
         if (uflag < 0) {
-            if (lane == 0) { b.exitflag[q] = uflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; }
+            if (lane == 0) { as_global(b.exitflag)[q] = uflag; as_global(b.iter)[q] = 0; if (b.fval) as_global(b.fval)[q] = 0; if (b.soft) as_global(b.soft)[q] = 0; }
             return;
         }
     }
@@ -172,9 +240,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     w.L = smem + o::L; w.u = smem + o::u; w.pend_lam = smem + o::pend_lam;
     w.rowv = smem + o::rowv;
     w.pend_id = reinterpret_cast<int *>(smem + o::pend_id);
-    w.stp = b.st_dev;
+    w.stp = as_global(b.st_dev);
     w.dual_tol = b.st.dual_tol; w.sing_tol = b.st.sing_tol; w.pivot_tol = b.st.pivot_tol; w.rho_soft = b.st.rho_soft;
-    w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
+    w.trace = b.trace ? as_global(b.trace + (size_t)q * b.trace_cap) : nullptr;
     w.trace_cap = b.trace_cap; w.trace_len = 0;
     w.na = __builtin_amdgcn_readfirstlane(rec_na);
     w.reuse = __builtin_amdgcn_readfirstlane(rec_reuse);
@@ -183,16 +251,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     const int swapped = __builtin_amdgcn_readfirstlane(rec_swapped);
 
     if (w.sing == DAQP_UNCONSTRAINED_OPTIMAL && mode == 0 && !upd) {   // api.c:40-45 (an update resets sing_ind first)
-        const double *xu = b.xunc + (size_t)q * n, *vq = b.v + (size_t)q * n;
-        if (b.x) for (int i = lane; i < n; i += 64) b.x[(size_t)q * n + i] = xu[i];
-        if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = 0;
+        const DAQP_GLOBAL(double) *xu = as_global(b.xunc + (size_t)q * n), *vq = as_global(b.v + (size_t)q * n);
+        if (b.x) for (int i = lane; i < n; i += 64) as_global(b.x)[(size_t)q * n + i] = xu[i];
+        if (b.lam) for (int i = lane; i < m; i += 64) as_global(b.lam)[(size_t)q * m + i] = 0;
         double fv = 0;
         for (int i = 0; i < n; ++i) { const double vi = vq[i]; fv -= vi * vi; }
         fv *= 0.5;
         if (lane == 0) {
-            b.exitflag[q] = DAQP_EXIT_OPTIMAL; b.iter[q] = 1;
-            if (b.fval) b.fval[q] = fv;
-            if (b.soft) b.soft[q] = 0;
+            as_global(b.exitflag)[q] = DAQP_EXIT_OPTIMAL; as_global(b.iter)[q] = 1;
+            if (b.fval) as_global(b.fval)[q] = fv;
+            if (b.soft) as_global(b.soft)[q] = 0;
             qs->iterations = 1; qs->fval = 0; qs->soft_slack = 0; qs->exitflag = DAQP_EXIT_OPTIMAL;
         }
         return;
@@ -206,7 +274,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     auto fetch_active_rows = [&]() __attribute__((always_inline)) {
         for (int i = 0; i < w.na; ++i) {
             const int id = rli(wsid_r, i);
-            const double2 *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63) + (size_t)lane * 64;
+            const DAQP_GLOBAL(gv2d) *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63) + (size_t)lane * 64;
             if (lane < b.npair)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(w.rowc + (size_t)i * w.ldr), 16, 0, 0);
@@ -246,7 +314,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
             static_for<NB>([&](auto bb) __attribute__((always_inline)) { const int r = bb * 64 + lane; if (r < m) gsense[r] = rsense_get(w, bb); });
             if (lane == 0) {
                 qs->upd_flag = DAQP_EXIT_INFEASIBLE; qs->sing_ind = kEmpty;
-                b.exitflag[q] = DAQP_EXIT_INFEASIBLE; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0;
+                as_global(b.exitflag)[q] = DAQP_EXIT_INFEASIBLE; as_global(b.iter)[q] = 0; if (b.fval) as_global(b.fval)[q] = 0; if (b.soft) as_global(b.soft)[q] = 0;
             }
             copy_wait();   // nothing may still be landing in LDS when the workgroup ends
             return;
@@ -255,56 +323,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         if (__any(bad & 4)) q_need_act = 1;
         double *vv = w.u, *fl = w.pend_lam;       // both regions are free until the loop starts (u is zeroed below)
         for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) vv[e] = 0;
-        if (upd & DAQP_UPDATE_v) {   // v = R^-T f (utils.c:474-497), rows < ms of R^-1 are the normalised ones
-            const double *Rl = Rl0;
-            if (lane < n) fl[lane] = f_in;
-            copy_wait();
-            WSYNC();
-            if constexpr (FM) {
-                // default arithmetic: the triangle FOLDED over the lanes.  Column i has i + 1 terms -- lane n-1 would run an n-step
-                // chain while lane 0 runs one (5.6 k cycles of a warm solve at n = 50) -- so lane i takes the first LH = n/2 + 1 terms of
-                // its own column (j = i, i-1, ...) and then the tail of column n-1-i that its owner leaves over (j = n-2-i-LH .. 0 when
-                // that column is longer than LH): every lane ~n/2 terms, one exchange at the end.  Same products, one more association
-                // than the reference's single chain (the exact mode keeps utils.c:474-497's order below).
-                const int i = lane < n ? lane : 0, pc = n - 1 - i;                 // own column, partner column
-                const int LH = n / 2 + 1;
-                const int own_lo = (i + 1 > LH) ? i - LH + 1 : 0;                      // own terms: j = i .. own_lo
-                const int tail_hi = (pc + 1 > LH && pc != i) ? pc - LH : -1;           // partner's left-over: j = tail_hi .. 0
-                double acc = 0, acc2 = 0;
-                for (int j0 = i; j0 >= own_lo; j0 -= kChunk) {
-                    double rr[kChunk], ff[kChunk];
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) { const int j = (j0 - k >= own_lo) ? j0 - k : own_lo; rr[k] = Rl[roff(j, n) + i]; ff[k] = fl[j]; }
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) if (j0 - k >= own_lo) acc = __builtin_fma(rr[k], ff[k], acc);
-                }
-                for (int j0 = tail_hi; j0 >= 0; j0 -= kChunk) {
-                    double rr[kChunk], ff[kChunk];
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) { const int j = (j0 - k >= 0) ? j0 - k : 0; rr[k] = Rl[roff(j, n) + pc]; ff[k] = fl[j]; }
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) if (j0 - k >= 0) acc2 = __builtin_fma(rr[k], ff[k], acc2);
-                }
-                const double other = __shfl(acc2, (lane < n) ? n - 1 - lane : lane);   // the lane that worked on THIS lane's column
-                if (lane < n) {
-                    acc += other;
-                    vv[lane] = acc;
-                    b.v[(size_t)q * n + lane] = acc;
-                }
-            } else if (lane < n) {
-                const int i = lane;
-                double acc = Rl[roff(i, n) + i] * fl[i];
-                for (int j0 = i - 1; j0 >= 0; j0 -= kChunk) {
-                    double rr[kChunk], ff[kChunk];
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) { const int j = (j0 - k >= 0) ? j0 - k : 0; rr[k] = Rl[roff(j, n) + i]; ff[k] = fl[j]; }
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) if (j0 - k >= 0) acc += rr[k] * ff[k];
-                }
-                vv[i] = acc;
-                b.v[(size_t)q * n + i] = acc;
+        if (upd & DAQP_UPDATE_v) {   // v = R^-T f (utils.c:474-497): formed between the row loads above, or here
+            double acc = v_early;
+            if (!v_done) {
+                if (lane < n) fl[lane] = f_in;
+                copy_wait();
+                WSYNC();
+                acc = v_of_update(Rl0, fl);
             }
-        } else if (lane < n) vv[lane] = b.v[(size_t)q * n + lane];
+            if (lane < n) {
+                vv[lane] = acc;
+                as_global(b.v)[(size_t)q * n + lane] = acc;
+            }
+        } else if (lane < n) vv[lane] = as_global(b.v)[(size_t)q * n + lane];
         WSYNC();
         // d = b*scaling + (row . v) for every row of the dense image (utils.c:499-544); rows stay in registers
         {
@@ -324,8 +355,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
                     const double nu = bur[bb] * scr[bb] + sm[bb], nl = blr[bb] * scr[bb] + sm[bb];
                     dur[bb] = nu; dlr[bb] = nl;
                     w.rowv[r] = nu; w.rowv[(64 * NB) + r] = nl;
-                    b.dupper[(size_t)q * m + r] = nu;
-                    b.dlower[(size_t)q * m + r] = nl;
+                    as_global(b.dupper)[(size_t)q * m + r] = nu;
+                    as_global(b.dlower)[(size_t)q * m + r] = nl;
                 }
             });
         }
@@ -386,7 +417,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
             copy_async(Rl + odd8, Rq + odd8, body);
             if (odd8 + body < b.rtri) copy_async_dwords(Rl + odd8 + body, Rq + odd8 + body, 1);
         }
-        const double *vq = b.v + (size_t)q * n;
+        const DAQP_GLOBAL(double) *vq = as_global(b.v + (size_t)q * n);
         const double vl = (lane < n) ? vq[lane] : 0.0;
         const double sc_ws = (flag > 0 && lane < w.na) ? gsc[w.wsid] : 1.0;
         const double sc_sb = (flag > 0 && lane < b.ms) ? gsc[lane] : 1.0;
@@ -447,8 +478,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         WSYNC();
         const long long te3 = (long long)__builtin_readcyclecounter();
         if (kProfile && w.prof && lane == 0) { w.prof[20] = te1 - t_done; w.prof[21] = te2 - te1; w.prof[22] = te3 - te2; }
-        if (b.x && lane < n) b.x[(size_t)q * n + lane] = xi;
-        if (b.lam) for (int i = lane; i < m; i += 64) b.lam[(size_t)q * m + i] = lamq[i];
+        if (b.x && lane < n) as_global(b.x)[(size_t)q * n + lane] = xi;
+        if (b.lam) for (int i = lane; i < m; i += 64) as_global(b.lam)[(size_t)q * m + i] = lamq[i];
         double fv = w.fval;                      // fval - |v|^2: in index order, v_i broadcast from its lane -- or, default mode, by tree
         if constexpr (FM) fv -= wave_sum(vl * vl);
         else static_for<8>([&](auto c) __attribute__((always_inline)) {
@@ -456,9 +487,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         });
         fv *= 0.5;
         if (lane == 0) {
-            b.exitflag[q] = flag; b.iter[q] = iters;
-            if (b.fval) b.fval[q] = fv;
-            if (b.soft) b.soft[q] = w.soft;
+            as_global(b.exitflag)[q] = flag; as_global(b.iter)[q] = iters;
+            if (b.fval) as_global(b.fval)[q] = fv;
+            if (b.soft) as_global(b.soft)[q] = w.soft;
             qs->iterations = iters; qs->exitflag = flag; qs->need_activate = 0;
         }
     }
@@ -471,21 +502,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     static_for<NB>([&](auto bb) __attribute__((always_inline)) { const int r = bb * 64 + lane; if (r < m) gsense[r] = rsense_get(w, bb); });
     {
         const int used = tri(w.na);
-        double *gL = b.L + (size_t)q * b.ltri;
+        DAQP_GLOBAL(double) *gL = as_global(b.L + (size_t)q * b.ltri);
         for (int e = lane; e < used; e += 64) gL[e] = w.L[e];
     }
     if (lane == 0) {
         qs->n_active = w.na; qs->reuse_ind = w.reuse; qs->sing_ind = w.sing;
         qs->lam_swapped = 0;
         qs->fval = w.fval; qs->soft_slack = w.soft;
-        if (b.trace) b.trace[(size_t)q * b.trace_cap + b.trace_cap - 1] = w.trace_len;
+        if (b.trace) as_global(b.trace)[(size_t)q * b.trace_cap + b.trace_cap - 1] = w.trace_len;
         if (kProfile && w.prof) {
             const long long te4 = (long long)__builtin_readcyclecounter();
             w.prof[23] = te4 - t_done;
-            for (int i = 0; i < 32; ++i) b.prof[(size_t)q * 32 + i] = w.prof[i];
-            b.prof[(size_t)q * 32 + 28] = t_loop - t_start;                                    // prologue
-            b.prof[(size_t)q * 32 + 29] = (long long)__builtin_readcyclecounter() - t_done;   // epilogue
-            b.prof[(size_t)q * 32 + 30] = t_done - t_loop;                                     // the loop
+            for (int i = 0; i < 32; ++i) as_global(b.prof)[(size_t)q * 32 + i] = w.prof[i];
+            as_global(b.prof)[(size_t)q * 32 + 28] = t_loop - t_start;                                    // prologue
+            as_global(b.prof)[(size_t)q * 32 + 29] = (long long)__builtin_readcyclecounter() - t_done;   // epilogue
+            as_global(b.prof)[(size_t)q * 32 + 30] = t_done - t_loop;                                     // the loop
         }
     }
 }

@@ -22,12 +22,10 @@ namespace daqp_amd {
 
 typedef double blk_v4d __attribute__((ext_vector_type(4)));
 typedef double blk_v2d __attribute__((ext_vector_type(2)));
-// A pointer read out of the descriptor (itself read through a pointer) is a GENERIC pointer to the compiler: every access through it is a
-// flat_load / flat_store, which counts on the LDS counter as well -- each wait for an LDS result then waits for the stores in flight too
-// (the blocked image's stores alternate with LDS reads: 6 k cycles per tile of rows instead of ~2 k).  These are global memory:
-#define BLK_GLOBAL(T) __attribute__((address_space(1))) T
-template <class T> __device__ __forceinline__ BLK_GLOBAL(T) *blk_g(T *p) { return (BLK_GLOBAL(T) *)p; }
-template <class T> __device__ __forceinline__ const BLK_GLOBAL(T) *blk_g(const T *p) { return (const BLK_GLOBAL(T) *)p; }
+// (global-memory pointers out of the descriptor: DAQP_GLOBAL / as_global of batch_dev.hip.h -- generic pointers made every access a flat
+// operation: the blocked image's stores alternate with LDS reads, 6 k cycles per tile of rows instead of ~2 k)
+#define BLK_GLOBAL(T) DAQP_GLOBAL(T)
+template <class T> __device__ __forceinline__ auto blk_g(T *p) { return as_global(p); }
 
 // upper-triangular tile grid of NT x NT blocks, row-major over I <= J
 template <int NT> __host__ __device__ constexpr int blk_tix(int I, int J) { return I * NT - I * (I - 1) / 2 + (J - I); }

@@ -17,6 +17,13 @@
 #include "../../include/daqp_amd.h"
 
 namespace daqp_amd {
+// A pointer read out of the descriptor (itself read through a pointer) is a GENERIC pointer to the compiler: every access through it is a
+// flat_load / flat_store, which counts on the LDS counter as well, can be waited for only with "everything" (no partial vmcnt once a flat
+// operation is pending) and orders itself against LDS copies in flight.  These are global memory:
+#define DAQP_GLOBAL(T) __attribute__((address_space(1))) T
+template <class T> __device__ __forceinline__ DAQP_GLOBAL(T) *as_global(T *p) { return (DAQP_GLOBAL(T) *)p; }
+template <class T> __device__ __forceinline__ const DAQP_GLOBAL(T) *as_global(const T *p) { return (const DAQP_GLOBAL(T) *)p; }
+
 
 constexpr int kEmpty = DAQP_EMPTY_IND;
 constexpr int kBig = 0x7fffffff;
@@ -58,8 +65,9 @@ __device__ __forceinline__ void copy_wait() { __builtin_amdgcn_s_waitcnt(0x0F70)
 // dst[r*ld + c] = src[r*n + c] for r < rows, c < n: every lane walks the contiguous source with stride 64,
 // keeps (row, col) incrementally (no division) and has 16 loads in flight before the first LDS store --
 // at <= 3 waves per CU nothing else would hide the HBM latency of a load-store-load-store loop.
-__device__ __forceinline__ void stage_rows(double *dst, const double *src, int rows, int n, int ld)
+__device__ __forceinline__ void stage_rows(double *dst, const double *src_, int rows, int n, int ld)
 {
+    const DAQP_GLOBAL(double) *src = as_global(src_);      // (always global memory: the problem arrays)
     const int lane = lane_id(), total = rows * n;
     int r = 0, c = lane;
     while (c >= n) { c -= n; ++r; }

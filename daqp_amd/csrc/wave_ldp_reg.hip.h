@@ -50,9 +50,9 @@ struct RWave {
     int hi_slot;                        // highest row-cache slot ever used (the top of the cache doubles as a prefetch buffer)
     unsigned long long slotmask;
     double fval, soft;
-    const DAQPSettings *stp;            // device copy of the settings (cold fields)
+    const DAQP_GLOBAL(DAQPSettings) *stp;   // device copy of the settings (cold fields)
     double dual_tol, sing_tol, pivot_tol, rho_soft;   // hot tolerances, loaded once
-    int *trace; int trace_cap, trace_len;
+    DAQP_GLOBAL(int) *trace; int trace_cap, trace_len;
     long long *prof;                    // LDS, 8 phase counters (NULL: off)
 };
 

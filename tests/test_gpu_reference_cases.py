@@ -150,6 +150,58 @@ def test_concurrent_host_threads(oracle, gpu_lib):
         assert same(out[t]["x"], r[0]) and same(out[t]["lam"], r[1])
 
 
+def test_concurrent_host_threads_single_problem_symbols(oracle, gpu_lib):
+    """the drop-in symbols themselves from four host threads at once (SURVEY 8b "Threading"; the binding releases the GIL around
+    them, daqp.pyx:211-212,467-468): one-shot daqp_quadprog calls of ONE shape -- so the threads compete for the parked one-problem
+    workspaces, their mapped result slabs and completion words -- interleaved with a kept workspace per thread that is updated
+    (UPDATE_v, the deferred update of the latency path) and re-solved; every answer equal to the serial oracle's"""
+    import threading
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS["C1"]
+    T, K = 4, 12
+    qs = [[O.generate_qp(n, m, ms, na, rng=[seed, 7000 + 100 * t + k]) for k in range(K)] for t in range(T)]
+    got = [[None] * K for _ in range(T)]
+    warm = [[None] * K for _ in range(T)]
+    err = []
+
+    def work(t):
+        try:
+            mdl = daqp_amd.Model()
+            q0 = qs[t][0]
+            mdl.setup(q0["H"], q0["f"], q0["A"], q0["bupper"], q0["blower"], np.zeros(m, np.int32))
+            mdl.solve()
+            for k in range(K):
+                q = qs[t][k]
+                x, fval, flag, info = daqp_amd.solve(q["H"], q["f"], q["A"], q["bupper"], q["blower"], np.zeros(m, np.int32))
+                got[t][k] = (x, info["lam"], flag, info["iterations"])
+                mdl.update(f=q["f"])
+                x, fval, flag, info = mdl.solve()
+                warm[t][k] = (x, info["lam"], flag, info["iterations"])
+        except Exception as e:   # noqa: BLE001 (reported below, on the main thread)
+            err.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for t in range(T):
+        om = O.OracleModel(oracle, n, m, ms)
+        q0 = qs[t][0]
+        om.setup(q0["H"], q0["f"], q0["A"], q0["bupper"], q0["blower"], np.zeros(m, np.int32))
+        om.solve()
+        for k in range(K):
+            q = qs[t][k]
+            r = oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], np.zeros(m, np.int32))
+            x, lam, flag, it = got[t][k]
+            assert flag == r[3] and it == r[4] and same(x, r[0]) and same(lam, r[1]), (t, k)
+            om.update(O.UPDATE_v, f=q["f"])
+            w = om.solve()
+            x, lam, flag, it = warm[t][k]
+            assert flag == w[3] and it == w[4] and same(x, w[0]) and same(lam, w[1]), (t, k, "warm")
+
+
 @pytest.mark.parametrize("shape", [(50, 150, 0, 20), (12, 48, 12, 6), (20, 40, 0, 8), (80, 200, 5, 30)])   # (the last one: generic setup + workgroup kernel)
 def test_shared_structure_batch(oracle, gpu_lib, shape):
     """condensed-MPC batches: ONE H and A, per-problem f and bounds.  daqp_batch_setup_shared is the

@@ -13,7 +13,7 @@
 #include <mutex>
 #include <vector>
 #include <string>
-#include <mutex>
+#include <thread>
 
 #include "kernels.hip.h"
 #include "reg_kernel.hip.h"
@@ -54,11 +54,11 @@ extern template __global__ void k_setup_tiny<4>(BatchDev, int);
 #define DAQP_BLK_SHAPE(NT, NW, TAIL) extern template __global__ void k_setup_blk<NT, NW, TAIL>(const BatchDev *__restrict__, int);
 DAQP_BLK_SHAPES
 #undef DAQP_BLK_SHAPE   // (the 16-per-wave SETUP kernel is the default for these shapes: setup_kernel.hip)
-template <int C, bool EX> __global__ void k_ldp_wg(BatchDev b, int mode);
-extern template __global__ void k_ldp_wg<2, false>(BatchDev, int);
-extern template __global__ void k_ldp_wg<2, true>(BatchDev, int);
-extern template __global__ void k_ldp_wg<4, false>(BatchDev, int);
-extern template __global__ void k_ldp_wg<4, true>(BatchDev, int);
+template <int C, bool EX> __global__ void k_ldp_wg(const BatchDev *__restrict__ bp, int mode);
+extern template __global__ void k_ldp_wg<2, false>(const BatchDev *, int);
+extern template __global__ void k_ldp_wg<2, true>(const BatchDev *, int);
+extern template __global__ void k_ldp_wg<4, false>(const BatchDev *, int);
+extern template __global__ void k_ldp_wg<4, true>(const BatchDev *, int);
 }
 
 using namespace daqp_amd;
@@ -235,11 +235,30 @@ int wait_stream(DAQPBatch *b)
     return 0;
 }
 
-// the descriptor as the kernels that take it through a pointer see it: copied (stream-ordered) when it has changed since the last copy
+// A small host structure into device memory, stream-ordered, as a KERNEL ARGUMENT: no copy command out of pageable host memory.  (Such a
+// copy is staged by the runtime and its staging is released by the runtime's completion thread some time after the stream has gone
+// idle; a process that left main() right then died inside libamdhip64 at exit -- 13 of 5 400 runs of tests/c/mask_caller.c,
+// tools/stress_caller.py.  And a launch costs half of what the copy did.)
+template <class T>
+__global__ void k_put(T v, T *dst)
+{
+    static_assert(sizeof(T) % 4 == 0 && sizeof(T) <= 3072, "travels as a kernel argument, word by word");
+    const int *s = reinterpret_cast<const int *>(&v);
+    int *o = reinterpret_cast<int *>(dst);
+    for (int i = (int)threadIdx.x; i < (int)(sizeof(T) / 4); i += (int)blockDim.x) o[i] = s[i];
+}
+template <class T>
+int put_async(T *dst, const T &v, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_put<T>, dim3(1), dim3(64), 0, stream, v, dst);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// the descriptor as the kernels that take it through a pointer see it: written (stream-ordered) when it has changed since the last time
 int push_descriptor(DAQPBatch *b)
 {
     if (b->pushed_valid && memcmp(&b->d_pushed, &b->d, sizeof(BatchDev)) == 0) return 0;
-    HIPCHK(hipMemcpyAsync(b->d_dev, &b->d, sizeof(BatchDev), hipMemcpyHostToDevice, b->stream));
+    if (put_async(b->d_dev, b->d, b->stream)) { set_err("descriptor launch failed"); return DAQP_EXIT_UNSUPPORTED; }
     memcpy(&b->d_pushed, &b->d, sizeof(BatchDev));
     b->pushed_valid = true;
     return 0;
@@ -294,13 +313,15 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
     if (b->use_wg) {
         // persistent workgroups pull problems from a counter; whatever outgrows the LDS-resident L is flagged and solved by
         // the one-wave kernel right behind (mode | 4: flagged problems only -- an empty pass costs a few microseconds)
-        typedef void (*wg_kernel_t)(BatchDev, int);
-        BatchDev dd = b->d;
-        if (b->in_prox_loop || b->exact_sticky) dd.exact_setup = 1;   // problems of the proximal outer loop keep the reference's arithmetic in both modes
-        wg_kernel_t kw = dd.exact_setup ? (b->wg_C == 2 ? k_ldp_wg<2, true> : k_ldp_wg<4, true>) : (b->wg_C == 2 ? k_ldp_wg<2, false> : k_ldp_wg<4, false>);
+        typedef void (*wg_kernel_t)(const BatchDev *, int);
+        // problems of the proximal outer loop keep the reference's arithmetic in both modes (the mode is the instantiation: the kernel
+        // reads nothing else of it; the descriptor travels through device memory as for the register kernels)
+        const bool ex = b->d.exact_setup || b->in_prox_loop || b->exact_sticky;
+        wg_kernel_t kw = ex ? (b->wg_C == 2 ? k_ldp_wg<2, true> : k_ldp_wg<4, true>) : (b->wg_C == 2 ? k_ldp_wg<2, false> : k_ldp_wg<4, false>);
+        if (push_descriptor(b)) return DAQP_EXIT_UNSUPPORTED;
         HIPCHK(hipMemsetAsync(b->d.wg_counter, 0, sizeof(int), b->stream));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg));
-        hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, dd, mode);
+        hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, (const BatchDev *)b->d_dev, mode);
         HIPCHK(hipGetLastError());
         ldp_kernel_t kf = pick_ldp(b);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
@@ -641,7 +662,7 @@ int recheck_infeasible(DAQPBatch *b)
     rb->stream = b->stream;
     rd.exact_setup = 1;
     rd.st = d.st;
-    HIPCHK(hipMemcpyAsync(rb->st_dev, &rd.st, sizeof(DAQPSettings), hipMemcpyHostToDevice, rb->stream));
+    if (put_async(rb->st_dev, rd.st, rb->stream)) return DAQP_EXIT_UNSUPPORTED;
     if (d.trace && (!rd.trace || rd.trace_cap != d.trace_cap)) { if (daqp_batch_enable_trace(rb, d.trace_cap)) return DAQP_EXIT_UNSUPPORTED; }
     if (!d.trace) { rd.trace = nullptr; rd.trace_cap = 0; }
     const size_t R = rd.N, n = d.n, m = d.m;
@@ -788,7 +809,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
             const char *ex = getenv("DAQP_AMD_EXACT");
             hd.exact_setup = (ex && atoi(ex) != 0) ? 1 : 0;
             // the iterate of the previous owner: gone (a fresh batch starts from zeros too)
-            if (hipMemcpyAsync(hit->st_dev, &hd.st, sizeof(DAQPSettings), hipMemcpyHostToDevice, hit->stream) != hipSuccess ||
+            if (put_async(hit->st_dev, hd.st, hit->stream) ||
                 hipMemsetAsync(hd.vecs, 0, (size_t)5 * hd.cap * sizeof(double), hit->stream) != hipSuccess ||
                 hipMemsetAsync(hd.qs, 0, sizeof(QState), hit->stream) != hipSuccess) { destroy_batch(hit); set_err("reset of a pooled workspace failed"); return DAQP_EXIT_UNSUPPORTED; }
             *out = hit;
@@ -921,7 +942,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.tstart = nullptr;
     }
     if (b->use_wg && !rc) {
-        typedef void (*wg_kernel_t)(BatchDev, int);
+        typedef void (*wg_kernel_t)(const BatchDev *, int);
         wg_kernel_t kw = b->wg_C == 2 ? k_ldp_wg<2, false> : k_ldp_wg<4, false>;
         wg_kernel_t kwx = b->wg_C == 2 ? k_ldp_wg<2, true> : k_ldp_wg<4, true>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kwx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg);
@@ -979,11 +1000,11 @@ void daqp_batch_free(DAQPBatch *b)
         b->timed_setup = b->timed_solve = false; b->n_prox_qps = 0; b->prox_outer = 0;
         b->one_fval = b->one_soft = 0; b->one_flag = b->one_iter = 0;
         DAQPBatch *evict = nullptr;
-        {   // parked workspaces are released when the process exits (registered at the first parking: runs before the HIP
-            // runtime's own teardown, which was registered at load time)
-            static std::once_flag once;
-            std::call_once(once, [] { std::atexit(daqp_amd_release_pool); });
-        }
+        // (Parked workspaces are NOT released when the process exits: the operating system takes the memory back.  Freeing them from an
+        //  atexit handler -- some forty hipFree / hipHostFree / hipEventDestroy per workspace right in front of the HIP runtime's own
+        //  teardown -- raced with that runtime's completion thread: 7 of 2 700 runs of tests/c/mask_caller.c ended with SIGSEGV inside
+        //  libamdhip64 after their last line of output, tools/stress_caller.py.  daqp_amd_release_pool() is there for a host that wants
+        //  the memory back while it runs.)
         {
             std::lock_guard<std::mutex> lk(g_pool_mu);
             g_pool.push_back(b);
@@ -1025,7 +1046,7 @@ void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings)
     (void)hipSetDevice(b->device);
     (void)resolve_setup(b);    // regularising passes of the last setup still owed: they belong to the settings that setup ran with (eps_prox)
     if (settings) b->d.st = *settings; else default_settings(&b->d.st);
-    (void)hipMemcpyAsync(b->st_dev, &b->d.st, sizeof(DAQPSettings), hipMemcpyHostToDevice, b->stream);
+    (void)put_async(b->st_dev, b->d.st, b->stream);
 }
 unsigned long long daqp_batch_device_bytes(const DAQPBatch *b) { return b ? b->bytes + (b->redo ? b->redo->bytes : 0) : 0; }
 int daqp_batch_rechecked(const DAQPBatch *b) { return b ? b->rechecked : 0; }

@@ -298,7 +298,7 @@ def test_update_masks_from_compiled_c(tmp_path, gpu_lib, exact):
         steps = dict(MR.sequences(shape))[mask]
         _write_sequence(seq, shape, trial, mask, steps)
         r = subprocess.run([exe, seq], capture_output=True, text=True, timeout=600, env=env)
-        assert r.returncode == 0, r.stderr
+        assert r.returncode == 0, (shape, trial, mask, r.returncode, r.stderr[-400:], r.stdout[-300:])
         got = _parse_sequence(r.stdout)
         assert len(got) == steps + 1, r.stdout[:400]
         seqc = MR.Sequence(exact == "1")

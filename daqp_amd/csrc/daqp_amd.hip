@@ -54,11 +54,11 @@ extern template __global__ void k_setup_tiny<4>(BatchDev, int);
 #define DAQP_BLK_SHAPE(NT, NW, TAIL) extern template __global__ void k_setup_blk<NT, NW, TAIL>(const BatchDev *__restrict__, int);
 DAQP_BLK_SHAPES
 #undef DAQP_BLK_SHAPE   // (the 16-per-wave SETUP kernel is the default for these shapes: setup_kernel.hip)
-template <int C, bool EX> __global__ void k_ldp_wg(const BatchDev *__restrict__ bp, int mode);
-extern template __global__ void k_ldp_wg<2, false>(const BatchDev *, int);
-extern template __global__ void k_ldp_wg<2, true>(const BatchDev *, int);
-extern template __global__ void k_ldp_wg<4, false>(const BatchDev *, int);
-extern template __global__ void k_ldp_wg<4, true>(const BatchDev *, int);
+template <int C, bool EX> __global__ void k_ldp_wg(BatchDev b, int mode);
+extern template __global__ void k_ldp_wg<2, false>(BatchDev, int);
+extern template __global__ void k_ldp_wg<2, true>(BatchDev, int);
+extern template __global__ void k_ldp_wg<4, false>(BatchDev, int);
+extern template __global__ void k_ldp_wg<4, true>(BatchDev, int);
 }
 
 using namespace daqp_amd;
@@ -237,8 +237,8 @@ int wait_stream(DAQPBatch *b)
 
 // A small host structure into device memory, stream-ordered, as a KERNEL ARGUMENT: no copy command out of pageable host memory.  (Such a
 // copy is staged by the runtime and its staging is released by the runtime's completion thread some time after the stream has gone
-// idle; a process that left main() right then died inside libamdhip64 at exit -- 13 of 5 400 runs of tests/c/mask_caller.c,
-// tools/stress_caller.py.  And a launch costs half of what the copy did.)
+// idle -- work for that thread right where a process that exits at once races with it (INTEGRATION.md "Process exit").  And a launch
+// costs half of what the copy did.)
 template <class T>
 __global__ void k_put(T v, T *dst)
 {
@@ -313,15 +313,13 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
     if (b->use_wg) {
         // persistent workgroups pull problems from a counter; whatever outgrows the LDS-resident L is flagged and solved by
         // the one-wave kernel right behind (mode | 4: flagged problems only -- an empty pass costs a few microseconds)
-        typedef void (*wg_kernel_t)(const BatchDev *, int);
-        // problems of the proximal outer loop keep the reference's arithmetic in both modes (the mode is the instantiation: the kernel
-        // reads nothing else of it; the descriptor travels through device memory as for the register kernels)
-        const bool ex = b->d.exact_setup || b->in_prox_loop || b->exact_sticky;
-        wg_kernel_t kw = ex ? (b->wg_C == 2 ? k_ldp_wg<2, true> : k_ldp_wg<4, true>) : (b->wg_C == 2 ? k_ldp_wg<2, false> : k_ldp_wg<4, false>);
-        if (push_descriptor(b)) return DAQP_EXIT_UNSUPPORTED;
+        typedef void (*wg_kernel_t)(BatchDev, int);
+        BatchDev dd = b->d;
+        if (b->in_prox_loop || b->exact_sticky) dd.exact_setup = 1;   // problems of the proximal outer loop keep the reference's arithmetic in both modes
+        wg_kernel_t kw = dd.exact_setup ? (b->wg_C == 2 ? k_ldp_wg<2, true> : k_ldp_wg<4, true>) : (b->wg_C == 2 ? k_ldp_wg<2, false> : k_ldp_wg<4, false>);
         HIPCHK(hipMemsetAsync(b->d.wg_counter, 0, sizeof(int), b->stream));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg));
-        hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, (const BatchDev *)b->d_dev, mode);
+        hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, dd, mode);
         HIPCHK(hipGetLastError());
         ldp_kernel_t kf = pick_ldp(b);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
@@ -942,7 +940,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.tstart = nullptr;
     }
     if (b->use_wg && !rc) {
-        typedef void (*wg_kernel_t)(const BatchDev *, int);
+        typedef void (*wg_kernel_t)(BatchDev, int);
         wg_kernel_t kw = b->wg_C == 2 ? k_ldp_wg<2, false> : k_ldp_wg<4, false>;
         wg_kernel_t kwx = b->wg_C == 2 ? k_ldp_wg<2, true> : k_ldp_wg<4, true>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kwx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg);
@@ -1002,8 +1000,8 @@ void daqp_batch_free(DAQPBatch *b)
         DAQPBatch *evict = nullptr;
         // (Parked workspaces are NOT released when the process exits: the operating system takes the memory back.  Freeing them from an
         //  atexit handler -- some forty hipFree / hipHostFree / hipEventDestroy per workspace right in front of the HIP runtime's own
-        //  teardown -- raced with that runtime's completion thread: 7 of 2 700 runs of tests/c/mask_caller.c ended with SIGSEGV inside
-        //  libamdhip64 after their last line of output, tools/stress_caller.py.  daqp_amd_release_pool() is there for a host that wants
+        //  teardown -- is more work for that runtime's completion thread right where a process that exits at once races with it (about 2 of 1 000
+        //  runs of tests/c/mask_caller.c ended with SIGSEGV inside libamdhip64 after their last line of output, tools/stress_caller.py).  daqp_amd_release_pool() is there for a host that wants
         //  the memory back while it runs.)
         {
             std::lock_guard<std::mutex> lk(g_pool_mu);

@@ -3,8 +3,8 @@
 #include "wg_kernel.hip.h"
 
 namespace daqp_amd {
-template __global__ void k_ldp_wg<2, false>(const BatchDev *, int);
-template __global__ void k_ldp_wg<2, true>(const BatchDev *, int);
-template __global__ void k_ldp_wg<4, false>(const BatchDev *, int);
-template __global__ void k_ldp_wg<4, true>(const BatchDev *, int);
+template __global__ void k_ldp_wg<2, false>(BatchDev, int);
+template __global__ void k_ldp_wg<2, true>(BatchDev, int);
+template __global__ void k_ldp_wg<4, false>(BatchDev, int);
+template __global__ void k_ldp_wg<4, true>(BatchDev, int);
 }

@@ -13,13 +13,9 @@ namespace daqp_amd {
 // is inlined into the kernel and branches on c.exact: as a run-time field both modes' code -- the reference's ordered chains AND the
 // inverse factor with its tree sums -- shared one register allocation, and the default mode's launch carried the chains' live ranges
 // (488 bytes of scratch per lane, 169 spilled registers in k_ldp_wg<4> at round 4).
-#define G(p) as_global(p)
 template <int C, bool EX>
-__global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(const BatchDev *__restrict__ bp, int mode)
+__global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mode)
 {
-    // (the descriptor through a pointer, its pointers cast to the global address space at every use -- G() below: by value, its ~60 pointer
-    //  fields sat in SGPRs across the problem loop and the master's state machine and came back as SGPR spills)
-    const BatchDev &b = *bp;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int q_sh;
     __shared__ int m_int[8];       // master -> everybody after the iteration: flag, iterations, na, reuse, sing, lam swapped, overflow
@@ -30,8 +26,8 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(const BatchDev *__r
     c.n = n; c.m = m; c.ms = b.ms; c.cap = cap; c.capL = b.wg_capL; c.npair = b.npair; c.nblk = b.nblk; c.ldr = wg_row_stride(n); c.capT = b.wg_capT;
     c.W = W; c.exact = EX ? 1 : 0;
     c.oL = wg_lds_L(C, m); c.lmax = wg_round_up(b.wg_capL * (b.wg_capL + 1) / 2, 2) - 1;
-    c.rowc = G(b.wg_rowc) + (size_t)blockIdx.x * cap * wg_row_stride(n);
-    c.rowcT = G(b.wg_rowcT) + (size_t)blockIdx.x * n * b.wg_capT;
+    c.rowc = b.wg_rowc + (size_t)blockIdx.x * cap * wg_row_stride(n);
+    c.rowcT = b.wg_rowcT + (size_t)blockIdx.x * n * b.wg_capT;
     const int T = (int)blockDim.x;
 
     for (;;) {
@@ -40,54 +36,54 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(const BatchDev *__r
         //  then sits in registers across the master's state machine and the workers' command loop: ~40 spilled registers of 267)
         const int tid = wg_tid(), lane = tid & 63;
         __syncthreads();                       // the previous problem is completely done with LDS
-        if (tid == 0) q_sh = atomicAdd(G(b.wg_counter), 1);
+        if (tid == 0) q_sh = atomicAdd(b.wg_counter, 1);
         __syncthreads();
         const int q = uni(q_sh);
         if (q >= b.N) break;
-        QState *qs = G(b.qs) + q;
+        QState *qs = b.qs + q;
         const int sflag = uni(qs->setup_flag), need_act = uni(qs->need_activate), uflag = uni(qs->upd_flag);
         if (mode == 1) { if (sflag < 0 || !need_act) continue; }
         if (sflag < 0) {   // setup failed: x/lam untouched, no solve (api.c:70-78)
-            if (tid == 0) { G(b.exitflag)[q] = sflag; G(b.iter)[q] = 0; if (b.fval) G(b.fval)[q] = 0; if (b.soft) G(b.soft)[q] = 0; G(b.fallback)[q] = 0; }
+            if (tid == 0) { b.exitflag[q] = sflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; b.fallback[q] = 0; }
             continue;
         }
         if (mode == 0 && uflag < 0) {   // the last update failed its bound check: report that, keep the state (see k_update)
-            if (tid == 0) { G(b.exitflag)[q] = uflag; G(b.iter)[q] = 0; if (b.fval) G(b.fval)[q] = 0; if (b.soft) G(b.soft)[q] = 0; G(b.fallback)[q] = 0; }
+            if (tid == 0) { b.exitflag[q] = uflag; b.iter[q] = 0; if (b.fval) b.fval[q] = 0; if (b.soft) b.soft[q] = 0; b.fallback[q] = 0; }
             continue;
         }
         const int sing0 = uni(qs->sing_ind);
         if (sing0 == DAQP_UNCONSTRAINED_OPTIMAL && mode == 0) {   // api.c:40-45: x = unconstrained optimum, no multipliers
-            const double *xu = G(b.xunc) + (size_t)q * n, *vq = G(b.v) + (size_t)q * n;
-            if (b.x) for (int i = tid; i < n; i += T) G(b.x)[(size_t)q * n + i] = xu[i];
-            if (b.lam) for (int i = tid; i < m; i += T) G(b.lam)[(size_t)q * m + i] = 0;
+            const double *xu = b.xunc + (size_t)q * n, *vq = b.v + (size_t)q * n;
+            if (b.x) for (int i = tid; i < n; i += T) b.x[(size_t)q * n + i] = xu[i];
+            if (b.lam) for (int i = tid; i < m; i += T) b.lam[(size_t)q * m + i] = 0;
             if (tid == 0) {
                 double fv = 0;
                 for (int i = 0; i < n; ++i) { const double vi = vq[i]; fv -= vi * vi; }
                 fv *= 0.5;
-                G(b.exitflag)[q] = DAQP_EXIT_OPTIMAL; G(b.iter)[q] = 1;
-                if (b.fval) G(b.fval)[q] = fv;
-                if (b.soft) G(b.soft)[q] = 0;
+                b.exitflag[q] = DAQP_EXIT_OPTIMAL; b.iter[q] = 1;
+                if (b.fval) b.fval[q] = fv;
+                if (b.soft) b.soft[q] = 0;
                 qs->iterations = 1; qs->fval = 0; qs->soft_slack = 0; qs->exitflag = DAQP_EXIT_OPTIMAL;
-                G(b.fallback)[q] = 0;
+                b.fallback[q] = 0;
             }
             continue;
         }
         const int na0 = uni(qs->n_active);
         if (na0 > c.capL) {        // a warm start that does not fit: the one-wave kernel takes the problem as it is
-            if (tid == 0) G(b.fallback)[q] = 1;
+            if (tid == 0) b.fallback[q] = 1;
             continue;
         }
         const size_t qfac = qf(b, q);
-        c.Mblk = G(b.Mblk) + qfac * b.nblk * b.npair * 128;
-        c.M32 = b.M32 ? G(b.M32) + qfac * b.nblk * b.nquad * 256 : nullptr; c.nquad = b.nquad;
-        c.dupper = G(b.dupper) + (size_t)q * m; c.dlower = G(b.dlower) + (size_t)q * m; c.scaling = G(b.scaling) + qfac * m;
+        c.Mblk = b.Mblk + qfac * b.nblk * b.npair * 128;
+        c.M32 = b.M32 ? b.M32 + qfac * b.nblk * b.nquad * 256 : nullptr; c.nquad = b.nquad;
+        c.dupper = b.dupper + (size_t)q * m; c.dlower = b.dlower + (size_t)q * m; c.scaling = b.scaling + qfac * m;
         // ---- load the persistent iterate
-        int *gsense = G(b.sense) + (size_t)q * m;
+        int *gsense = b.sense + (size_t)q * m;
         int softbits = 0;
         for (int i = tid; i < m; i += T) { const int s = gsense[i]; SI(c, sense)[i] = s; softbits |= s & DAQP_SOFT; }
         const int has_soft = uni(__syncthreads_or(softbits) ? 1 : 0);
-        double *gv = G(b.vecs) + (size_t)q * 5 * cap;
-        int *gws = G(b.WS) + (size_t)q * cap;
+        double *gv = b.vecs + (size_t)q * 5 * cap;
+        int *gws = b.WS + (size_t)q * cap;
         for (int i = tid; i < cap; i += T) {
             SD(c, D)[i] = gv[i]; SD(c, xl)[i] = gv[cap + i]; SD(c, zl)[i] = gv[2 * cap + i];
             SD(c, lamA)[i] = gv[3 * cap + i]; SD(c, lamB)[i] = gv[4 * cap + i];
@@ -97,7 +93,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(const BatchDev *__r
         }
         {
             const int used = tri(na0);
-            const double *gL = G(b.L) + (size_t)q * b.ltri;
+            const double *gL = b.L + (size_t)q * b.ltri;
             for (int e = tid; e < used; e += T) SDL(c)[e] = gL[e];
         }
         for (int e = tid; e < wg_round_up(n, 2) + 2; e += T) SD(c, u)[e] = 0;
@@ -119,8 +115,8 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(const BatchDev *__r
             w.t_start = solve_stamp(b.tstart, q); w.tick_s = b.tick_s;
             w.profiling = (b.prof != nullptr) && mode == 0;
             if (w.profiling && lane < 24) reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[lane] = 0;
-            w.stp = G(b.st_dev);
-            w.trace = b.trace ? G(b.trace) + (size_t)q * b.trace_cap : nullptr;
+            w.stp = b.st_dev;
+            w.trace = b.trace ? b.trace + (size_t)q * b.trace_cap : nullptr;
             w.trace_cap = b.trace_cap; w.trace_len = 0;
             w.na = na0; w.reuse = uni(qs->reuse_ind); w.sing = sing0;
             w.fval = und(qs->fval); w.soft = und(qs->soft_slack);
@@ -139,8 +135,8 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(const BatchDev *__r
                 m_dbl[0] = w.fval; m_dbl[1] = w.soft;
                 SI(c, cmd)[0] = WG_EXIT;
                 if (w.profiling) {
-                    for (int i = 0; i < 16; ++i) G(b.prof)[(size_t)q * 32 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];
-                    for (int i = 16; i < 23; ++i) G(b.prof)[(size_t)q * 32 + 9 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];   // [25..28]: scans, fp64 re-scans; [29..31]: inside an append
+                    for (int i = 0; i < 16; ++i) b.prof[(size_t)q * 32 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];
+                    for (int i = 16; i < 23; ++i) b.prof[(size_t)q * 32 + 9 + i] = reinterpret_cast<long long *>(wg_sm() + WgL<C>::prof)[i];   // [25..28]: scans, fp64 re-scans; [29..31]: inside an append
                 }
             }
             __syncthreads();
@@ -151,7 +147,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(const BatchDev *__r
         const int tide = wg_tid();             // (see the top of the loop)
         const int flag = uni(m_int[0]), iters = uni(m_int[1]), na = uni(m_int[2]);
         if (uni(m_int[6])) {            // overflow: nothing of the problem's state in HBM has been touched; the one-wave kernel redoes it
-            if (tide == 0) G(b.fallback)[q] = 1;
+            if (tide == 0) b.fallback[q] = 1;
             continue;
         }
         double *lams = uni(m_int[5]) ? SD(c, lamA) : SD(c, lamB);
@@ -159,7 +155,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(const BatchDev *__r
             if (tide == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
         } else {
             // ldp2qp_solution (daqp.c:111-139) + daqp_extract_result (api.c:455-495)
-            const double *Rq = G(b.Rinv) + qfac * b.rtri, *vq = G(b.v) + (size_t)q * n;
+            const double *Rq = b.Rinv + qfac * b.rtri, *vq = b.v + (size_t)q * n;
             double *vl = SD(c, mnew);                                    // v staged in LDS (the new-row buffer is free now)
             for (int i = tide; i < n; i += T) vl[i] = vq[i];
             __syncthreads();
@@ -175,23 +171,23 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(const BatchDev *__r
                     double xi = SD(c, u)[i] * row[i];
                     for (int j = i + 1; j < n; ++j) xi += row[j] * SD(c, u)[j];
                     if (i < b.ms && !diag) xi /= c.scaling[i];   // daqp.c:124-134: no division in the RinvD branch
-                    if (b.x) G(b.x)[(size_t)q * n + i] = xi;
+                    if (b.x) b.x[(size_t)q * n + i] = xi;
                 }
             } else if (b.x) {
-                for (int i = tide; i < n; i += T) G(b.x)[(size_t)q * n + i] = SD(c, u)[i];
+                for (int i = tide; i < n; i += T) b.x[(size_t)q * n + i] = SD(c, u)[i];
             }
             if (b.lam) {
-                for (int i = tide; i < m; i += T) G(b.lam)[(size_t)q * m + i] = 0;
+                for (int i = tide; i < m; i += T) b.lam[(size_t)q * m + i] = 0;
                 __syncthreads();
-                for (int i = tide; i < na; i += T) G(b.lam)[(size_t)q * m + SI(c, ws)[i]] = lams[i];
+                for (int i = tide; i < na; i += T) b.lam[(size_t)q * m + SI(c, ws)[i]] = lams[i];
             }
             if (tide == 0) {
                 double fv = m_dbl[0];
                 for (int i = 0; i < n; ++i) { const double vi = vl[i]; fv -= vi * vi; }
                 fv *= 0.5;
-                G(b.exitflag)[q] = flag; G(b.iter)[q] = iters;
-                if (b.fval) G(b.fval)[q] = fv;
-                if (b.soft) G(b.soft)[q] = m_dbl[1];
+                b.exitflag[q] = flag; b.iter[q] = iters;
+                if (b.fval) b.fval[q] = fv;
+                if (b.soft) b.soft[q] = m_dbl[1];
                 qs->iterations = iters; qs->exitflag = flag; qs->need_activate = 0;
             }
         }
@@ -203,15 +199,15 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(const BatchDev *__r
         for (int i = tide; i < m; i += T) gsense[i] = SI(c, sense)[i];
         {
             const int used = tri(na);
-            double *gL = G(b.L) + (size_t)q * b.ltri;
+            double *gL = b.L + (size_t)q * b.ltri;
             for (int e = tide; e < used; e += T) gL[e] = SDL(c)[e];
         }
         if (tide == 0) {
             qs->n_active = na; qs->reuse_ind = m_int[3]; qs->sing_ind = m_int[4];
             qs->lam_swapped = m_int[5];
             qs->fval = m_dbl[0]; qs->soft_slack = m_dbl[1];
-            if (b.trace) G(b.trace)[(size_t)q * b.trace_cap + b.trace_cap - 1] = m_int[7];
-            G(b.fallback)[q] = 0;
+            if (b.trace) b.trace[(size_t)q * b.trace_cap + b.trace_cap - 1] = m_int[7];
+            b.fallback[q] = 0;
         }
     }
 }

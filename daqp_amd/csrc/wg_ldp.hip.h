@@ -47,9 +47,9 @@ struct WgL {
 // what every thread of the workgroup knows (sizes, HBM pointers; no iterate state)
 struct WgCtx {
     int n, m, ms, cap, capL, npair, nblk, ldr, capT, W, exact, oL, lmax;   // lmax: last valid index of packed L
-    DAQP_GLOBAL(double) *rowc, *rowcT;    // this workgroup's scratch in HBM: [cap][ldr] and [n][capT]   (global pointers, said so: DAQP_GLOBAL)
-    const DAQP_GLOBAL(double) *Mblk, *dupper, *dlower, *scaling;
-    const DAQP_GLOBAL(float) *M32;        // fp32 image of M for the screening scan (null: every scan in fp64)
+    double *rowc, *rowcT;                 // this workgroup's scratch in HBM: [cap][ldr] and [n][capT]
+    const double *Mblk, *dupper, *dlower, *scaling;
+    const float *M32;                     // fp32 image of M for the screening scan (null: every scan in fp64)
     int nquad;
 };
 __device__ __forceinline__ double *wg_sm() { extern __shared__ __attribute__((aligned(16))) double wg_dyn_lds[]; return wg_dyn_lds; }
@@ -93,8 +93,8 @@ struct WgWave {
     int use_w;                            // 1: the LDS factor area holds W = L^-1 (default arithmetic, regular factor), see "inverse factor" below
     int fast_na;                          // inverse factor: na right after a regular append (the next CSP is then an O(na) update, wdirection), else -1
     double fval, soft;
-    const DAQP_GLOBAL(DAQPSettings) *stp; // device copy of the settings: scalar loads at the point of use
-    DAQP_GLOBAL(int) *trace; int trace_cap, trace_len;
+    const DAQPSettings *stp;              // device copy of the settings: scalar loads at the point of use
+    int *trace; int trace_cap, trace_len;
     unsigned long long t_start;
     double tick_s;
     bool profiling;                       // phase cycle counters in LDS (WgL::prof)

@@ -96,7 +96,7 @@ int main(int argc, char **argv)
     free_daqp_ldp(&work);
     printf("end\n");
     /* leave without the C++ runtime's exit handlers: the HIP runtime's own teardown races with its completion thread when a process exits
-       within microseconds of its last call (1-3 of 1 000 exits died inside libamdhip64 after this line, tools/stress_caller.py;
+       within microseconds of its last call (about 2 of 1 000 exits died inside libamdhip64 after this line, tools/stress_caller.py;
        INTEGRATION.md "Process exit") -- what this program tests is the library's output above */
     fflush(stdout);
     _exit(0);

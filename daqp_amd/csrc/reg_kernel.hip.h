@@ -30,8 +30,10 @@ __host__ __device__ inline int reg_lds_bytes(int NB, int n, int m, int cap, int 
 // Waves per SIMD: M alone takes 4*NB*NP registers per lane.  The large shapes own the whole unified 512-entry file (one
 // wave per SIMD); the small ones are held to a budget that lets 2 or 4 waves share a SIMD, where the other waves'
 // instructions fill this wave's issue gaps and LDS waits.
+// (small shapes: 2 -> 3 waves per SIMD is 1.36x on config C3, 3 -> 4 another 1.05x although 17-51 registers then live in scratch
+// (128-register budget); n = 16, m = 64: 1.05x, n = 14, m = 40: unchanged -- profiles/r05w_small_shape_waves.txt)
 #ifndef DAQP_AMD_SMALL_WAVES
-#define DAQP_AMD_SMALL_WAVES 3
+#define DAQP_AMD_SMALL_WAVES 4
 #endif
 constexpr int ldp_reg_waves(int NB, int NP) { return NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 32 ? 2 : 1); }
 template <int NB, int NP, bool FM>

@@ -1,13 +1,14 @@
 """What a second wave per SIMD buys THIS state machine: the register kernel's mid shapes (NB*NP <= 32: two waves per SIMD in the shipped
 build) timed against a variant of the same code held to one wave per SIMD (DAQP_AMD_LIBRARY = a build with ldp_reg_waves(...) = 1).
-usage: python tools/occupancy_probe.py [N]      (run once per library; prints one line per shape)"""
+usage: python tools/occupancy_probe.py [N] [n,m,nActive;n,m,nActive;...]      (run once per library; prints one line per shape)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, daqp_amd
 from daqp_amd.synthetic import generate_batch_torch
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-for (n, m, na) in ((30, 120, 12), (32, 64, 12), (24, 128, 10)):
+SHAPES = [tuple(int(v) for v in t.split(",")) for t in sys.argv[2].split(";")] if len(sys.argv) > 2 else [(30, 120, 12), (32, 64, 12), (24, 128, 10)]
+for (n, m, na) in SHAPES:
     q = generate_batch_torch(N, n, m, 0, na, 7000 + n)
     bm = daqp_amd.BatchModel(N, n, m, 0)
     best = None

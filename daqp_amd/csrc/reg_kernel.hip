@@ -11,6 +11,7 @@ DAQP_REG_SHAPE(1, 6)
 DAQP_REG_SHAPE(1, 8)
 DAQP_REG_SHAPE(3, 25)
 #ifndef DAQP_AMD_FEW_VARIANTS
+DAQP_REG_SHAPE(1, 13)
 DAQP_REG_SHAPE(1, 16)
 DAQP_REG_SHAPE(2, 16)
 DAQP_REG_SHAPE(2, 32)

@@ -35,7 +35,9 @@ __host__ __device__ inline int reg_lds_bytes(int NB, int n, int m, int cap, int 
 #ifndef DAQP_AMD_SMALL_WAVES
 #define DAQP_AMD_SMALL_WAVES 4
 #endif
-constexpr int ldp_reg_waves(int NB, int NP) { return NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 32 ? 2 : 1); }
+// (NB*NP <= 13, i.e. n <= 26 and m <= 64: three waves per SIMD -- twelve waves' LDS still fit a CU up to there, and the same code on
+// the (1,16) shape measured 16 % faster at three waves than at two for n = 20 / 24, 2 % slower for n = 30 / 32 where the LDS does not fit)
+constexpr int ldp_reg_waves(int NB, int NP) { return NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 13 ? 3 : (NB * NP <= 32 ? 2 : 1)); }
 template <int NB, int NP, bool FM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_waves(NB, NP), ldp_reg_waves(NB, NP)))) void k_ldp_reg(const BatchDev *__restrict__ bp, int mode_in)
 {

@@ -75,6 +75,14 @@ def test_setup_shapes(oracle, gpu_lib, shape):
     check_batch(oracle, (n, m, ms, na, 900 + n, 0), 48)
 
 
+@pytest.mark.parametrize("shape", [(17, 64, 0, 8), (21, 33, 4, 7), (25, 64, 3, 9), (26, 60, 0, 10), (26, 64, 26, 10)])
+def test_three_wave_register_shape(oracle, gpu_lib, shape):
+    """k_ldp_reg<1, 13, *>: n = 17 ... 26 with at most one row block, three waves per SIMD (a few registers in scratch) -- the shape class
+    of config C1; both arithmetic modes (exact: bit for bit), simple bounds up to ms = n, odd n"""
+    n, m, ms, na = shape
+    check_batch(oracle, (n, m, ms, na, 1300 + n + ms, 0), 96)
+
+
 def test_c4_workgroup_kernel(oracle, gpu_lib):
     """config C4 (n=200, m=600): the workgroup-per-problem solve kernel (wg_kernel.hip.h: packed L in LDS, scan / primal
     step / Gram column spread over the waves) -- 64 QPs, bit for bit in exact mode"""

@@ -1,9 +1,9 @@
 #!/bin/bash
-# bench the default library and the tuning variants built by tools/variants.sh side by side: tools/var_bench.sh <tag> ...
+# bench the default library and the tuning variants built by tools/variants.sh side by side: [SIDE=C3,C4,C5] tools/var_bench.sh <tag> ...
 for t in "" "$@"; do
   if [ -n "$t" ]; then export DAQP_AMD_LIBRARY=$GRAFT_REPO_ROOT/daqp_amd/lib/variants/libdaqp_amd_$t.so; else unset DAQP_AMD_LIBRARY; fi
   echo "variant ${t:-default}"
-  python bench.py --steps 20 --warmup 2 --side-configs C3,C5 --no-exact --cpu-sample 0 | python -c "
+  python bench.py --steps 20 --warmup 2 --side-configs ${SIDE:-C3,C5} --no-exact --cpu-sample 0 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 def sh(t,c):

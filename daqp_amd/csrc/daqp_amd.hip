@@ -124,6 +124,8 @@ struct DAQPBatch {
     bool in_prox_loop = false;      // launches of the proximal outer loop (solve_with_prox)
     bool use_wg = false;
     int wg_W = 0, wg_C = 0, wg_grid = 0;
+    bool reg_handover = false;   // k_ldp_reg<2,32,*> may flag problems (more working-set rows than lanes: n = 64) for k_ldp right behind it
+    size_t lds_fb = 0;           // ... and that launch's LDS
     size_t lds_wg = 0;
     double *wide_u = nullptr, *wide_l = nullptr;   // daqp_batch_setup_shared: +-1e30 bounds of the one factorisation
     int *structural = nullptr, *shared_flag = nullptr;
@@ -338,6 +340,15 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
         hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode);
         HIPCHK(hipGetLastError());
+        if (b->reg_handover) {   // the problems it flagged (mode | 4: nobody else is touched; an empty pass costs a few microseconds)
+            if ((mode & 3) == 2) { set_err("fused update + solve launch on a hand-over shape"); return DAQP_EXIT_UNSUPPORTED; }
+            BatchDev dd = b->d;
+            if (b->in_prox_loop || b->exact_sticky) dd.exact_setup = 1;
+            ldp_kernel_t kf = pick_ldp(b);
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_fb));
+            hipLaunchKernelGGL(kf, dim3(b->d.N), dim3(64), b->lds_fb, b->stream, dd, mode | 4);
+            HIPCHK(hipGetLastError());
+        }
         return 0;
     }
     ldp_kernel_t k = pick_ldp(b);
@@ -513,7 +524,7 @@ int launch_setup_m(DAQPBatch *b, const BatchDev &d)
 // daqp_update_ldp(mask within UPDATE_v|UPDATE_d) followed by daqp_solve, whichever kernels the shape uses
 int launch_update_solve(DAQPBatch *b, int mask, bool descriptor_changed)
 {
-    if (b->NB > 0) return launch_ldp(b, 2 | (mask << 4), descriptor_changed);
+    if (b->NB > 0 && !b->reg_handover) return launch_ldp(b, 2 | (mask << 4), descriptor_changed);
     hipLaunchKernelGGL(k_update, dim3(b->d.N), dim3(64), b->lds_update, b->stream, b->d, mask);
     HIPCHK(hipGetLastError());
     if (launch_ldp(b, 1)) return DAQP_EXIT_UNSUPPORTED;
@@ -834,9 +845,18 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     const int lds_limit = env ? atoi(env) : 80 * 1024;
     b->spill = ldp_lds(n, m, cap, false).total_bytes > lds_limit;
     if (getenv("DAQP_AMD_FORCE_SPILL") || cap > 256) b->spill = true;
-    if (!b->spill && cap <= 64 && !getenv("DAQP_AMD_STREAM_M"))
+    if (!b->spill && cap <= 65 && !getenv("DAQP_AMD_STREAM_M"))
         for (const RegShape &rs : kRegShapes)
             if (d.nblk <= rs.nb && d.npair <= rs.np) { b->NB = rs.nb; b->NP = rs.np; break; }
+    // one lane per working-set row: 64 rows.  n = 64 without soft rows may hold 65 (only while a 65th constraint is being exchanged at a full
+    // vertex): the (2,32) shape takes it and hands the few problems that get there to k_ldp (launch_ldp); every other shape needs cap <= 64
+    d.reg_rows = 64;
+    if (const char *re = getenv("DAQP_AMD_REG_ROWS")) { const int v = atoi(re); if (v >= 1 && v < 64) d.reg_rows = v; }   // tests: force the hand-over
+    if (b->NB > 0 && d.reg_rows < cap) {
+        if (b->NB == 2 && b->NP == 32 && !getenv("DAQP_AMD_NO_REG_HANDOVER")) b->reg_handover = true;
+        else if (cap > 64) { b->NB = 0; b->NP = 0; }
+    }
+    if (b->reg_handover) b->lds_fb = (size_t)ldp_lds(n, m, cap, b->spill).total_bytes;
     d.ldrc = 0;
     if (b->NB > 0) {   // stride == 2 (mod 4): rows 16-byte aligned and 16 consecutive rows hit 16 distinct 4-bank groups
         int l = n > 2 * b->NP ? n : 2 * b->NP;
@@ -967,6 +987,10 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
             if (!rc && hipMemset(d.wg_rowc, 0, cnt * sizeof(double)) != hipSuccess) rc = 1;
         }
         rc |= dev_alloc(b, &d.wg_rowcT, (size_t)b->wg_grid * n * d.wg_capT);
+        rc |= dev_alloc(b, &d.fallback, Nn);
+        if (!rc && hipMemset(d.fallback, 0, Nn * sizeof(int)) != hipSuccess) rc = 1;
+    }
+    if (b->reg_handover && !rc) {
         rc |= dev_alloc(b, &d.fallback, Nn);
         if (!rc && hipMemset(d.fallback, 0, Nn * sizeof(int)) != hipSuccess) rc = 1;
     }
@@ -1356,7 +1380,7 @@ int daqp_batch_setup_shared(DAQPBatch *b, const DAQPBatchProblem *p, int init_ma
     }
     b->is_setup = true;
     const int upd = DAQP_UPDATE_v | DAQP_UPDATE_d;
-    const bool lazy = b->NB > 0 && !getenv("DAQP_AMD_EAGER_UPDATE") && p->sense == nullptr;
+    const bool lazy = b->NB > 0 && !b->reg_handover && !getenv("DAQP_AMD_EAGER_UPDATE") && p->sense == nullptr;
     if (lazy) b->pending_mask = upd;
     else {   // a given working set is activated now, and activation needs d
         hipLaunchKernelGGL(k_update, dim3(d.N), dim3(64), b->lds_update, b->stream, d, upd);
@@ -1455,7 +1479,7 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
     // arrays are copied into the batch's own buffers (stream-ordered, a few tens of microseconds) instead of adopted.
     // A new sense is taken over right away, and what comes with it in the same call as well (utils.c:84-98: the bound check reads
     // the new sense, the activation at the end the new d).
-    const bool lazy = b->NB > 0 && !getenv("DAQP_AMD_EAGER_UPDATE") && !with_sense;
+    const bool lazy = b->NB > 0 && !b->reg_handover && !getenv("DAQP_AMD_EAGER_UPDATE") && !with_sense;
     const int mem = p->memory;
     auto take = [&](const double *src, size_t count, double **slot, size_t *cap, const double **out) -> int {
         if (!lazy || mem != DAQP_MEM_DEVICE) return stage(b, src, mem, count, slot, cap, out);
@@ -1894,7 +1918,7 @@ static bool update_one_deferred(DAQPWorkspace *work, DAQPBatch *b, int m, const 
 {
     const BatchDev &dd = b->d;
     if ((m & ~(DAQP_UPDATE_v | DAQP_UPDATE_d)) || !(m & (DAQP_UPDATE_v | DAQP_UPDATE_d))) return false;
-    if (dd.N != 1 || b->NB == 0 || !b->is_setup || b->reg_pending || b->was_shared || !work->sense || getenv("DAQP_AMD_EAGER_UPDATE")) return false;
+    if (dd.N != 1 || b->NB == 0 || b->reg_handover || !b->is_setup || b->reg_pending || b->was_shared || !work->sense || getenv("DAQP_AMD_EAGER_UPDATE")) return false;
     if (!qp->bupper || !qp->blower || ((m & DAQP_UPDATE_v) && !qp->f)) return false;
     const int n = dd.n, mm = dd.m;
     for (int i = 0; i < mm; ++i) {      // utils.c:546-567 on the mirror of the workspace's sense

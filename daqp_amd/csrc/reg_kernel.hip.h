@@ -249,6 +249,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     w.trace = b.trace ? as_global(b.trace + (size_t)q * b.trace_cap) : nullptr;
     w.trace_cap = b.trace_cap; w.trace_len = 0;
     w.na = __builtin_amdgcn_readfirstlane(rec_na);
+    if constexpr (kRegHandOver<NB, NP>) {
+        w.max_rows = b.reg_rows;
+        if (w.na > w.max_rows) {   // stored by the generic kernel with more rows than this one holds: its problem again
+            if (lane == 0) as_global(b.fallback)[q] = 1;
+            copy_wait();
+            return;
+        }
+    }
     w.reuse = __builtin_amdgcn_readfirstlane(rec_reuse);
     w.sing = __builtin_amdgcn_readfirstlane(rec_sing);
     w.fval = rl(rec_fval, 0); w.soft = rl(rec_soft, 0);
@@ -404,6 +412,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     const long long t_loop = (long long)__builtin_readcyclecounter();
     int flag = rrun(w, mode, q_need_act != 0, iters);
     const long long t_done = (long long)__builtin_readcyclecounter();
+    if constexpr (kRegHandOver<NB, NP>) {
+        // nothing of this problem has been stored yet (results, iterate, sense, record: all below): the generic kernel starts from the same state
+        if (b.fallback != nullptr) {
+            if (lane == 0) as_global(b.fallback)[q] = (flag == kRegHandOverFlag) ? 1 : 0;
+            if (flag == kRegHandOverFlag) { copy_wait(); return; }
+        }
+    }
     if (mode == 1) {
         if (lane == 0) { qs->need_activate = 0; if (flag < 0) { qs->setup_flag = flag; qs->exitflag = flag; } }
     } else {

@@ -29,6 +29,9 @@ __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// the register shape whose problems may outgrow the 64 lanes (n = 64: up to 65 working-set rows) hands them over; compiled out of every other shape
+template <int NB, int NP> constexpr bool kRegHandOver = (NB == 2 && NP == 32);
+constexpr int kRegHandOverFlag = -1000;   // rrun's verdict "not mine" (never reaches the caller: no reference exit flag is near it)
 template <int NB, int NP, bool FM>
 struct RWave {
     int n, m, ms, ldr;
@@ -47,6 +50,7 @@ struct RWave {
     unsigned rs;   // sense bits of this lane's rows, 8 bits per row block (a register, never an array)
     // uniform
     int na, reuse, sing, has_soft;
+    int max_rows;   // (2,32) only -- see kRegHandOver: an add that finds this many rows in place hands the problem over
     int hi_slot;                        // highest row-cache slot ever used (the top of the cache doubles as a prefetch buffer)
     unsigned long long slotmask;
     double fval, soft;
@@ -981,6 +985,10 @@ __device__ __forceinline__ int rrun(RWave<NB, NP, FM> &w, int mode, bool need_ac
         // ---- add_constraint / remove_constraint with the pivot_last cascade (auxiliary.c:3-44, 379-396),
         // each primitive instantiated once; then the caller's continuation
         case PC_EDIT: {
+            // the shape that serves n = 64 (cap = n + 1 = 65 rows, one more than there are lanes): an add beyond the rows this kernel can
+            // hold leaves the problem as it was stored and flags it for the one-wave generic kernel (reg_kernel.hip.h, launch_ldp).  The
+            // re-adds of the pivot cascade below follow a removal and never exceed the level of the add that started it.
+            if (kRegHandOver<NB, NP> && req_add && w.na >= w.max_rows) { flag = kRegHandOverFlag; pc = PC_DONE; break; }
             for (;;) {
                 bool settled = false;
                 RPROF_T0(w);

@@ -49,6 +49,23 @@ def test_fast_mode_shapes(oracle, gpu_lib, shape):
     assert np.abs(g["x"] - ref[0]).max() < XTOL
 
 
+@pytest.mark.parametrize("shape,rows", [((64, 128, 0, 20), 0), ((64, 100, 0, 63), 0), ((64, 128, 8, 64), 0), ((56, 120, 4, 20), 5), ((56, 120, 4, 20), 14),
+                                        ((64, 128, 0, 30), 20)])
+def test_fast_mode_register_kernel_hand_over(oracle, gpu_lib, monkeypatch, shape, rows):
+    """n = 64 on k_ldp_reg<2,32,true> (65 working-set rows possible, 64 lanes): problems that get there -- or, with DAQP_AMD_REG_ROWS, beyond
+    `rows` rows -- are redone by the one-wave generic kernel from their untouched state; north_star bar on every problem"""
+    import daqp_amd
+    if rows:
+        monkeypatch.setenv("DAQP_AMD_REG_ROWS", str(rows))
+    n, m, ms, na = shape
+    q = O.generate_batch(48, n, m, ms, na, 3600 + n + m)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4])
+    assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1]))
+    assert np.abs(g["x"] - ref[0]).max() < XTOL
+
+
 @pytest.mark.parametrize("n", [17, 19, 20, 21, 25, 32, 33, 35, 36, 37, 41, 48, 49, 50, 51, 52, 53, 55, 56, 57, 61, 64])
 def test_blocked_setup_every_block_shape(oracle, gpu_lib, monkeypatch, n):
     """k_setup_blk (csrc/setup_blk.hip.h: 16 < n <= 64 without simple bounds, default arithmetic -- Cholesky and inverse as 16 x 16 tiles

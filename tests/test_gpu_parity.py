@@ -418,3 +418,63 @@ def test_full_size_warm_sequence(gpu_lib):
         assert float((onb * (g["lam"] != 0)).max()) < 1e-5, t
     assert max(warm) < 0.5 * cold, (cold, warm)
     bm.close()
+
+
+# ---- the register kernel's hand-over (n = 64: up to n + 1 = 65 working-set rows, one more than a wavefront has lanes)
+@pytest.mark.parametrize("shape", [(64, 128, 0, 20), (64, 100, 0, 63), (64, 65, 0, 60), (64, 128, 8, 56), (63, 128, 0, 62)])
+def test_register_kernel_at_64_variables(oracle, gpu_lib, shape):
+    """n = 64 runs k_ldp_reg<2,32,*>; a problem whose working set is full (64 rows) when another constraint comes in is flagged and
+    redone by the one-wave generic kernel from its untouched state (api.c:305-313: the reference allocates n + 1 rows)"""
+    n, m, ms, na = shape
+    check_batch(oracle, (n, m, ms, na, 3100 + n + m, 0), 24)
+
+
+@pytest.mark.parametrize("rows", [5, 14, 24])
+def test_register_kernel_forced_hand_over(oracle, gpu_lib, monkeypatch, rows):
+    """DAQP_AMD_REG_ROWS caps the rows k_ldp_reg<2,32,*> may hold: working sets of this shape peak at 20-30 rows, so all (5), most (14) or
+    some (24) problems are handed to k_ldp in the middle of their solve -- results unchanged, bit for bit"""
+    monkeypatch.setenv("DAQP_AMD_REG_ROWS", str(rows))
+    check_batch(oracle, (56, 120, 4, 20, 3300, 0), 32)
+
+
+def test_register_kernel_hand_over_event_trace_and_warm_sequence(oracle, gpu_lib, monkeypatch):
+    """warm updates of f and of the bounds across the two kernels: a stored iterate written by k_ldp (more rows than the cap) is k_ldp's
+    problem again at the next solve, one written by the register kernel may be handed over later -- add/remove sequences of the
+    reference step for step, x / lam / fval bit for bit"""
+    import daqp_amd
+    monkeypatch.setenv("DAQP_AMD_REG_ROWS", "24")
+    n, m, ms, na = 56, 120, 4, 20
+    N, T = 16, 4
+    q = O.generate_batch(N, n, m, ms, na, 3400)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.enable_trace(4096)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        om.enable_trace()
+        models.append(om)
+    f, bu, bl = q["f"].copy(), q["bupper"].copy(), q["blower"].copy()
+    nact = []
+    for t in range(T + 1):
+        if t > 0:
+            for k in range(N):
+                rng = np.random.default_rng([51, k, t])
+                f[k] = f[k] + 0.05 * rng.standard_normal(n)
+                shift = 0.02 * rng.standard_normal(m)
+                bu[k] = bu[k] + shift; bl[k] = bl[k] + shift
+                assert models[k].update(O.UPDATE_v | O.UPDATE_d, f=f[k], bupper=bu[k], blower=bl[k]) == 0
+                models[k].enable_trace()
+            bm.update(f=f, bupper=bu, blower=bl)
+        g = bm.solve()
+        tr = bm.read_trace(marks=True)
+        for k in range(N):
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (t, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            assert np.array_equal(tr[k], models[k].get_trace(marks=True)), (t, k)
+            assert bits_equal(g["x"][k], r[0]) and bits_equal(g["lam"][k], r[1]) and g["fval"][k] == r[2]
+        nact.append((g["lam"] != 0).sum(axis=1))
+    nact = np.array(nact)
+    assert (nact > 24).any() and (nact <= 24).any()     # iterates stored by k_ldp (beyond the cap: its problem again at the next solve) and within the cap
+    bm.close()

@@ -23,7 +23,7 @@ def oracle_each(oracle, qs, settings=None):
     return [oracle.quadprog(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"], settings=settings) for q in qs]
 
 
-SHAPES = [(6, 14, 0), (12, 30, 4), (20, 60, 0), (33, 70, 5), (50, 150, 0), (70, 150, 6)]
+SHAPES = [(6, 14, 0), (12, 30, 4), (20, 60, 0), (33, 70, 5), (50, 150, 0), (70, 150, 6), (64, 128, 0)]   # (last: the register kernel with the hand-over at 65 rows)
 
 
 @pytest.mark.parametrize("exact", ["1", "0"])
@@ -227,7 +227,7 @@ def test_linear_programs_single(oracle, gpu_lib, monkeypatch):
     assert flags == {1, -3, -4}
 
 
-@pytest.mark.parametrize("n,m,ms", [(5, 12, 0), (12, 30, 4), (24, 60, 0), (50, 150, 0), (70, 160, 10)])
+@pytest.mark.parametrize("n,m,ms", [(5, 12, 0), (12, 30, 4), (24, 60, 0), (50, 150, 0), (70, 160, 10), (64, 128, 0), (64, 120, 10)])   # (n = 64: vertices of 64 rows + the exchange = 65, register kernel -> k_ldp hand-over inside the proximal loop)
 def test_linear_program_batches(oracle, gpu_lib, monkeypatch, n, m, ms):
     import daqp_amd
     monkeypatch.setenv("DAQP_AMD_EXACT", "1")

@@ -1,3 +1,6 @@
+"""One workspace (single-problem symbols) through every kind of daqp_update_ldp mask in the DEFAULT arithmetic mode, step by step against the
+oracle: python tools/ho_debug.py n,m,ms,nActive   (env: DAQP_AMD_REG_ROWS=<k> forces the register kernel hand-over, DAQP_AMD_NO_REG_HANDOVER=1
+turns it off).  The iterate of an INFEASIBLE exit is no solution: there only flag / iterations / working set are comparable."""
 import os, sys, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))

@@ -1,0 +1,49 @@
+"""Where the steps in the shape space are: solve launch per QP and SIMD-cycles per iteration over a grid of (n, m), with the kernel family that
+serves each shape (the dispatch rule of daqp_batch_create restated: register shapes (NB, NP) for working sets of <= 64 rows -- 65 on (2,32) --,
+the workgroup kernel for 65 .. 256 rows, otherwise the one-wave generic kernel with M streamed).  nActive = n / 3.
+usage: python tools/shape_map.py [N]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, daqp_amd
+from daqp_amd.synthetic import generate_batch_torch
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+REG = [(1, 6), (1, 8), (1, 13), (1, 16), (2, 16), (3, 25), (2, 32)]
+WAVES = {(1, 6): 4, (1, 8): 4, (1, 13): 3, (1, 16): 2, (2, 16): 2, (3, 25): 1, (2, 32): 1}
+
+
+def family(n, m):
+    cap, nblk, npair = n + 1, (m + 63) // 64, (n + 1) // 2
+    if cap <= 65:
+        for nb, np_ in REG:
+            if nblk <= nb and npair <= np_:
+                if cap <= 64 or (nb, np_) == (2, 32):
+                    return f"reg({nb},{np_}) x{WAVES[(nb, np_)]}" + (" +hand-over" if cap > 64 else "")
+                break
+    if 64 < cap <= 256:
+        return "workgroup"
+    return "generic (M streamed)"
+
+
+print(f"N = {N} QPs per shape, default arithmetic, nActive = n/3; columns: n m | kernel family | solve launch ms | us per QP | mean iterations | SIMD-cycles per iteration")
+for n in (8, 12, 16, 17, 26, 27, 32, 33, 40, 50, 51, 56, 63, 64, 65):
+    for m in (32, 64, 65, 128, 129, 150, 192, 193, 256):
+        if m <= n:
+            continue
+        try:
+            q = generate_batch_torch(N, n, m, 0, max(2, n // 3), 8000 + n)
+            bm = daqp_amd.BatchModel(N, n, m, 0)
+            best = None
+            for rep in range(3):
+                bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None)
+                r = bm.solve(out="torch")
+                torch.cuda.synchronize()
+                ks, kl = bm.kernel_ms()
+                best = kl if best is None else min(best, kl)
+            it = r["iter"].double().mean().item()
+            ok = bool((r["exitflag"] == 1).all().item())
+            print(f"{n:3d} {m:3d} | {family(n, m):28s} | {best:8.3f} | {best * 1e3 / N:7.3f} | {it:6.2f} | {best * 1e-3 * 1024 * 2.4e9 / (N * it):8.0f}{'' if ok else '  (not all optimal)'}", flush=True)
+            bm.close()
+            del q, r
+        except Exception as e:   # (the torch generator of this tool, not the library: hipBLAS workspace at large n x N)
+            print(f"{n:3d} {m:3d} | {family(n, m):28s} | skipped: {str(e)[:80]}", flush=True)

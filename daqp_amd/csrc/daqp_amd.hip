@@ -39,6 +39,8 @@ DAQP_REG_SHAPE(3, 25)
 DAQP_REG_SHAPE(1, 13)
 DAQP_REG_SHAPE(1, 16)
 DAQP_REG_SHAPE(2, 16)
+DAQP_REG_SHAPE(3, 8)
+DAQP_REG_SHAPE(1, 25)
 DAQP_REG_SHAPE(2, 32)
 #endif
 #undef DAQP_REG_SHAPE
@@ -274,7 +276,7 @@ struct RegShape { int nb, np; };
 #ifdef DAQP_AMD_FEW_VARIANTS   // development builds: fewer instantiations, faster compile
 const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {3, 25}};
 #else
-const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {1, 13}, {1, 16}, {2, 16}, {3, 25}, {2, 32}};
+const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {1, 13}, {1, 16}, {2, 16}, {3, 8}, {1, 25}, {3, 25}, {2, 32}};   // ((3,8): few variables, many rows -- n <= 16, m <= 192; (1,25): n <= 50 with m <= 64 -- both at two waves per SIMD)
 #endif
 // exact: the reference's arithmetic (two roundings per multiply-add); otherwise fused multiply-adds (default mode)
 ldp_reg_kernel_t pick_ldp_reg(const DAQPBatch *b, bool exact)
@@ -287,6 +289,8 @@ ldp_reg_kernel_t pick_ldp_reg(const DAQPBatch *b, bool exact)
     DAQP_REG_PICK(1, 13)
     DAQP_REG_PICK(1, 16)
     DAQP_REG_PICK(2, 16)
+    DAQP_REG_PICK(3, 8)
+    DAQP_REG_PICK(1, 25)
     DAQP_REG_PICK(2, 32)
 #endif
 #undef DAQP_REG_PICK

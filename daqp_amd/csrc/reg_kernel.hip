@@ -14,6 +14,8 @@ DAQP_REG_SHAPE(3, 25)
 DAQP_REG_SHAPE(1, 13)
 DAQP_REG_SHAPE(1, 16)
 DAQP_REG_SHAPE(2, 16)
+DAQP_REG_SHAPE(3, 8)
+DAQP_REG_SHAPE(1, 25)
 DAQP_REG_SHAPE(2, 32)
 #endif
 #undef DAQP_REG_SHAPE

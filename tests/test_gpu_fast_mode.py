@@ -36,7 +36,9 @@ def test_fast_mode_parity(oracle, gpu_lib, cfg, N):
 
 @pytest.mark.parametrize("shape", [(7, 20, 3, 3), (16, 40, 4, 6), (31, 64, 0, 10), (32, 64, 0, 12), (33, 70, 5, 12),
                                    (48, 100, 0, 16), (56, 120, 0, 20), (57, 120, 0, 20), (64, 128, 0, 24),
-                                   (17, 64, 0, 8), (21, 33, 4, 7), (25, 64, 3, 9), (26, 60, 0, 10), (26, 64, 26, 10)])   # (last five: k_ldp_reg<1, 13, true>)
+                                   (17, 64, 0, 8), (21, 33, 4, 7), (25, 64, 3, 9), (26, 60, 0, 10), (26, 64, 26, 10),   # (these five: k_ldp_reg<1, 13, true>)
+                                   (8, 150, 0, 3), (16, 192, 4, 6), (12, 130, 12, 5), (15, 160, 0, 14),   # (k_ldp_reg<3, 8, true>)
+                                   (40, 64, 0, 13), (50, 64, 6, 16), (33, 34, 0, 30), (45, 60, 45, 12)])   # (k_ldp_reg<1, 25, true>)
 def test_fast_mode_shapes(oracle, gpu_lib, shape):
     """the MFMA fragment guards of every setup variant (partial k / column tiles) at the north_star bar"""
     import daqp_amd

@@ -478,3 +478,17 @@ def test_register_kernel_hand_over_event_trace_and_warm_sequence(oracle, gpu_lib
     nact = np.array(nact)
     assert (nact > 24).any() and (nact <= 24).any()     # iterates stored by k_ldp (beyond the cap: its problem again at the next solve) and within the cap
     bm.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 150, 0, 3), (16, 192, 4, 6), (12, 130, 12, 5), (15, 160, 0, 14), (2, 129, 0, 1), (16, 129, 16, 8)])
+def test_register_shape_few_variables_many_rows(oracle, gpu_lib, shape):
+    """k_ldp_reg<3, 8, *>: n <= 16 with 129 .. 192 rows (three row blocks, eight column pairs) at two waves per SIMD"""
+    n, m, ms, na = shape
+    check_batch(oracle, (n, m, ms, na, 4100 + n + m, 0), 64)
+
+
+@pytest.mark.parametrize("shape", [(40, 64, 0, 13), (50, 64, 6, 16), (33, 34, 0, 30), (45, 60, 45, 12), (50, 51, 0, 49)])
+def test_register_shape_one_row_block_up_to_50_variables(oracle, gpu_lib, shape):
+    """k_ldp_reg<1, 25, *>: 33 <= n <= 50 with at most 64 rows (one row block, 25 column pairs) at two waves per SIMD"""
+    n, m, ms, na = shape
+    check_batch(oracle, (n, m, ms, na, 4300 + n + m, 0), 64)

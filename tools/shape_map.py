@@ -8,8 +8,8 @@ import torch, daqp_amd
 from daqp_amd.synthetic import generate_batch_torch
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-REG = [(1, 6), (1, 8), (1, 13), (1, 16), (2, 16), (3, 25), (2, 32)]
-WAVES = {(1, 6): 4, (1, 8): 4, (1, 13): 3, (1, 16): 2, (2, 16): 2, (3, 25): 1, (2, 32): 1}
+REG = [(1, 6), (1, 8), (1, 13), (1, 16), (2, 16), (3, 8), (1, 25), (3, 25), (2, 32)]      # kRegShapes of daqp_amd.hip, first fit
+WAVES = {(1, 6): 4, (1, 8): 4, (1, 13): 3, (1, 16): 2, (2, 16): 2, (3, 8): 2, (1, 25): 2, (3, 25): 1, (2, 32): 1}
 
 
 def family(n, m):

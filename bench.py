@@ -577,6 +577,113 @@ def committed_counters(cfg, N):
     return {"stale": True, "why": why}
 
 
+def _r(v, sig=6):
+    """floats to `sig` significant digits (the compact line); everything else unchanged"""
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}")
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def _short_roofline(r, with_setup=True):
+    """the contract keys of a roofline record -- numbers only, no prose"""
+    out = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "traffic", "traffic_source")}
+    out["kernel"] = (r.get("kernel_name") or r.get("kernel") or "")[:80]
+    he = r.get("hbm_effective") or {}
+    out["hbm_effective"] = {k: he.get(k) for k in ("achieved", "peak", "unit", "frac") if k in he}
+    for k in ("traffic_frac", "floor_frac"):
+        if k in r:
+            out[k] = r[k]
+    if r.get("stale"):
+        out["stale"] = True
+    if r.get("issue"):
+        out["issue"] = {k: r["issue"].get(k) for k in ("attainable_ms", "one_wave_per_simd_floor_ms", "achieved_ms", "frac") if k in r["issue"]}
+    if r.get("pattern"):
+        out["pattern"] = {k: r["pattern"].get(k) for k in ("peak", "unit", "frac")}
+    if with_setup and r.get("setup"):
+        st = r["setup"] if isinstance(r["setup"], list) else [r["setup"]]
+        out["setup"] = [{k: e.get(k) for k in ("kernel", "bound", "avg_launch_ms", "traffic", "achieved", "peak", "unit", "frac", "tflops", "mfma_frac") if e.get(k) is not None}
+                        for e in st]
+    if r.get("pipeline"):
+        out["setup_ms"], out["solve_ms"] = r["pipeline"].get("setup_ms"), r["pipeline"].get("solve_ms")
+    return out
+
+
+def _short_cpu(c):
+    if not c:
+        return None
+    out = {k: c.get(k) for k in ("value", "unit", "cores", "kind", "cpu", "wall_s")}
+    out["sample"] = str(c.get("sample", "")).split(" [best of")[0][:160]
+    return out
+
+
+def _short_parity(p_):
+    if not p_:
+        return None
+    return {k: p_[k] for k in ("sample", "steps", "identical_active_set", "identical_iter", "identical_exitflag", "max_abs_dx") if k in p_}
+
+
+def compact(line, full_path):
+    """The ONE line the driver parses: the contract keys only, numbers without prose, <= 6 KB (a driver that keeps the last 8 KB of
+    stdout must see the whole object -- round 5's 22 KB line did not parse).  Everything else (notes, transfers, batch sweep, exact-mode
+    figures, issue counters, full workload descriptions, per-thread-count CPU legs) is in the full record written to `full_path`."""
+    cfg = line["config"]
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    out["config"] = {"workload": cfg["workload"].split(", kappa")[0][:140], "batch_per_gpu": cfg["batch_per_gpu"],
+                     "mean_iterations": cfg["mean_iterations"], "parallelism": cfg["parallelism"].split(",")[0][:60] + ", shards only, no data-path collective"}
+    if "entry" in cfg:
+        out["config"]["entry"] = cfg["entry"]
+    out["roofline"] = _short_roofline(line["roofline"])
+    if line.get("cpu_baseline"):
+        out["cpu_baseline"] = _short_cpu(line["cpu_baseline"])
+    if line.get("parity_vs_cpu"):
+        out["parity_vs_cpu"] = _short_parity(line["parity_vs_cpu"])
+    if line.get("checks"):
+        out["checks"] = line["checks"]
+    if line.get("configs"):
+        out["configs"] = {}
+        for name, s_ in line["configs"].items():
+            r = s_["roofline"]
+            e = {"value": s_["value"], "unit": s_["unit"], "ms_per_step": s_["ms_per_step"], "batch_per_gpu": s_.get("batch_per_gpu"),
+                 "mean_iterations": s_.get("mean_iterations"),
+                 "roofline": {"bound": r.get("bound"), "frac": r.get("frac"), "avg_launch_ms": r.get("avg_launch_ms"), "traffic": r.get("traffic"),
+                              "hbm_effective_frac": (r.get("hbm_effective") or {}).get("frac")}}
+            if r.get("pattern"):
+                e["roofline"]["pattern_frac"] = r["pattern"].get("frac")
+            if s_.get("cpu_baseline"):
+                e["cpu_baseline"] = {k: s_["cpu_baseline"].get(k) for k in ("value", "cores", "kind")}
+            if s_.get("parity_vs_cpu"):
+                e["parity_vs_cpu"] = {k: s_["parity_vs_cpu"].get(k) for k in ("sample", "identical_active_set", "identical_iter", "max_abs_dx")}
+            if s_.get("checks"):
+                e["all_optimal"] = s_["checks"].get("all_optimal")
+            out["configs"][name] = e
+    out["full"] = os.path.relpath(full_path, ROOT) if full_path else None
+    return _r(out)
+
+
+def emit(line, args):
+    """rank 0: the full record to --full-out (default bench_full.json next to this file; a copy under gpurun_out/ when that directory
+    exists, so that it comes back from a gpurun call), then the compact line as the LAST line of stdout"""
+    path = args.full_out or os.path.join(ROOT, "bench_full.json")
+    try:
+        with open(path, "w") as fh:
+            json.dump(line, fh, indent=1)
+        side = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(side) and not args.full_out:
+            with open(os.path.join(side, "bench_full.json"), "w") as fh:
+                json.dump(line, fh, indent=1)
+    except OSError:
+        path = None
+    text = json.dumps(compact(line, path), separators=(",", ":"))
+    assert len(text) <= 6144, f"compact bench line is {len(text)} bytes"
+    sys.stdout.flush()
+    print(text, flush=True)
+
+
 def launch_plan(gpus, env, argv):
     """What `bench.py --gpus N` has to do about ranks.  Under a torch.distributed launcher (WORLD_SIZE set) the launcher's world
     size must BE --gpus (anything else is a mis-launch and fails loudly); without one, N == 1 runs in this process (returns
@@ -674,7 +781,7 @@ def multi_entry(args):
                          "note": "counter-derived figures are quoted by the rank-per-GPU line (same kernels, same batch per device)"},
             "checks": {"all_optimal": ok, "max_abs_x_minus_analytic_optimum": dx}}
     mb.close()
-    print(json.dumps(line))
+    emit(line, args)
     return 0
 
 
@@ -694,6 +801,7 @@ def main():
     ap.add_argument("--multi-entry", action="store_true", help="ONE process drives --gpus devices through the C ABI's persistent multi-device batch "
                     "(daqp_batch_*_multi_shards: a host thread + stream per shard, inputs resident on each shard's device) instead of one rank per GPU; "
                     "with --single-device every shard sits on device 0")
+    ap.add_argument("--full-out", default="", help="where the FULL record goes (default: bench_full.json next to bench.py); stdout carries the compact contract line only")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra steps in the library's exact arithmetic mode (reported under \"exact\")")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -769,7 +877,7 @@ def main():
         if R.rank == 0:
             line["configs"] = cfgs
     if R.rank == 0:
-        print(json.dumps(line))
+        emit(line, args)
     if R.grouped:
         R.dist.barrier()
         R.dist.destroy_process_group()

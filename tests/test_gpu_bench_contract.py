@@ -12,14 +12,37 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline")
+
+
 def run_bench(argv, launcher=(), timeout=1500):
+    """runs bench.py; checks what the DRIVER sees -- the last line of stdout is one compact JSON object of at most 6 KB carrying the
+    contract keys (round 5's 22 KB line was not parsed) -- and returns the FULL record bench.py wrote next to it, with the compact
+    line under "_compact" """
+    import tempfile
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
-                       timeout=timeout, cwd=ROOT, env=env)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, "exactly one JSON line on stdout"
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as td:
+        full_path = os.path.join(td, "full.json")
+        p = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *argv, "--full-out", full_path], capture_output=True, text=True,
+                           timeout=timeout, cwd=ROOT, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out_lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        lines = [ln for ln in out_lines if ln.startswith("{")]
+        assert len(lines) == 1, "exactly one JSON line on stdout"
+        assert out_lines[-1] == lines[0], "the JSON line is the LAST line of stdout"
+        assert len(lines[0]) <= 6144, f"compact line is {len(lines[0])} bytes"
+        c = json.loads(lines[0])
+        for k in COMPACT_KEYS:
+            assert k in c, k
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "traffic", "hbm_effective"):
+            assert k in c["roofline"], k
+        assert "workload" in c["config"] and "batch_per_gpu" in c["config"]
+        with open(full_path) as fh:
+            full = json.load(fh)
+    assert abs(full["value"] - c["value"]) <= 1e-5 * full["value"] and full["n_gpus"] == c["n_gpus"] and full["scaling"] == c["scaling"]
+    full["_compact"] = c
+    return full
 
 
 def check_roofline(r, cfg):
@@ -78,6 +101,15 @@ def test_bench_json_line(gpu_lib):
         assert t["value_with_transfers"] < s["value"]
     assert d["transfers"]["h2d_bytes_per_qp"] == 8 * (50 * 50 + 50 + 150 * 50 + 300) and d["configs"]["C5"]["transfers"]["h2d_bytes_per_qp"] == 8 * 50
     assert "n=12 m=48" in d["configs"]["C3"]["metric"] and d["configs"]["C3"]["parity_vs_cpu"]["identical_iter"] == 1.0
+    # what the driver parses: cpu_baseline and the parity sample of the headline, one short summary per side configuration, no prose
+    c = d["_compact"]
+    for k in ("value", "unit", "cores", "kind", "cpu", "wall_s", "sample"):
+        assert k in c["cpu_baseline"], k
+    assert c["parity_vs_cpu"]["identical_active_set"] == 1.0 and set(c["configs"]) == {"C3", "C5"}
+    for name, s in c["configs"].items():
+        assert s["value"] > 0 and s["ms_per_step"] > 0 and "frac" in s["roofline"] and s["cpu_baseline"]["value"] > 0, name
+        assert abs(s["value"] - d["configs"][name]["value"]) <= 1e-5 * s["value"]
+    assert not any(k in c for k in ("transfers", "batch_sweep", "exact", "arith")) and "bound_is" not in c["roofline"]
     assert d["configs"]["C5"]["unit"] == "warm solves/s" and d["configs"]["C5"]["parity_vs_cpu"]["identical_iter_last_step"] == 1.0
     assert d["configs"]["C5"]["parity_vs_cpu"]["max_abs_dx_last_step"] < 1e-9
 

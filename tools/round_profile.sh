@@ -3,13 +3,13 @@
 # (own run per counter group, --pmc only: no tracing domains), summarised as profiles/<tag>_pmc_summary.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r03p}; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python bench.py --steps 5 --warmup 1 --cpu-sample 0 > $O/bench_under_trace.json 2> $O/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python bench.py --steps 5 --warmup 1 --cpu-sample 0 --full-out $O/bench_under_trace_full.json > $O/bench_under_trace.json 2> $O/trace.err
 find /tmp/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 # the headline alone (no side configs, no batch sweep, no exact-mode leg): here a kernel's average IS the C2 launch
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -o kt -- python bench.py --config C2 --steps 10 --warmup 2 --cpu-sample 0 --side-configs none --no-sweep --no-exact > $O/bench_headline_under_trace.json 2>> $O/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -o kt -- python bench.py --config C2 --steps 10 --warmup 2 --cpu-sample 0 --side-configs none --no-sweep --no-exact --full-out $O/bench_headline_under_trace_full.json > $O/bench_headline_under_trace.json 2>> $O/trace.err
 find /tmp/kt2 -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_headline.csv \;
 for cfg in C2 C3 C4 C5; do
-  CMD="python bench.py --config $cfg --steps 2 --warmup 1 --cpu-sample 0 --side-configs none"
+  CMD="python bench.py --config $cfg --steps 2 --warmup 1 --cpu-sample 0 --side-configs none --full-out /tmp/pmc_full.json"
   i=0
   dirs=""
   for grp in "FETCH_SIZE" "WRITE_SIZE" \
@@ -24,7 +24,7 @@ for cfg in C2 C3 C4 C5; do
   python tools/pmc_json.py $O/pmc_raw_$cfg.json $dirs > $O/pmc_print_$cfg.txt 2>&1
 done
 python tools/pmc_config_summary.py $O/pmc_summary.json $O/pmc_raw_C2.json $O/pmc_raw_C3.json $O/pmc_raw_C4.json $O/pmc_raw_C5.json > $O/pmc_summary_print.txt 2>&1
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 900 python bench.py --full-out $O/bench_full.json > $O/bench.json 2> $O/bench.err
 tools/ubench4.bin > $O/ubench4.txt 2>&1
 tools/ubench5.bin > $O/ubench5.txt 2>&1
 python tools/gpu_profile.py 20000 > $O/c2_phases.txt 2>&1

@@ -77,6 +77,7 @@ UNITS = {
     "daqp_amd.hip": ["daqp_amd.hip", "kernels.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h", "setup_fast.hip.h", "prox.hip.h",
                      "wg_layout.hip.h", "batch_dev.hip.h", "recheck.hip.h", "setup_m.hip.h", "setup_fact.hip.h", "reg_kernel.hip.h", "tiny_setup.hip.h", "setup_blk.hip.h", "multi.hip.h"],
     "reg_kernel.hip": ["reg_kernel.hip", "reg_kernel.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
+    "reg32_kernel.hip": ["reg32_kernel.hip", "reg_kernel.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
     "wg_kernel.hip": ["wg_kernel.hip", "wg_kernel.hip.h", "wg_ldp.hip.h", "wg_layout.hip.h", "batch_dev.hip.h", "wave_ldp.hip.h", "wave_ldp_reg.hip.h"],
     "setup_kernel.hip": ["setup_kernel.hip", "setup_blk.hip.h", "setup_fast.hip.h", "setup_m.hip.h", "setup_fact.hip.h", "tiny_setup.hip.h", "wave_ldp_reg.hip.h", "wave_ldp.hip.h", "batch_dev.hip.h"],
 }

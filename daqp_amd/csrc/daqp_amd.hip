@@ -32,6 +32,7 @@ namespace daqp_amd {
 #define DAQP_REG_SHAPE(NB, NP) \
     extern template __global__ void k_ldp_reg<NB, NP, false>(const BatchDev *__restrict__, int); \
     extern template __global__ void k_ldp_reg<NB, NP, true>(const BatchDev *__restrict__, int);
+extern template __global__ void k_ldp_reg<3, 25, true, 2>(const BatchDev *__restrict__, int);
 DAQP_REG_SHAPE(1, 6)
 DAQP_REG_SHAPE(1, 8)
 DAQP_REG_SHAPE(3, 25)
@@ -128,6 +129,9 @@ struct DAQPBatch {
     int wg_W = 0, wg_C = 0, wg_grid = 0;
     bool reg_handover = false;   // k_ldp_reg<2,32,*> may flag problems (more working-set rows than lanes: n = 64) for k_ldp right behind it
     size_t lds_fb = 0;           // ... and that launch's LDS
+    bool img32 = false;          // default arithmetic: the solve launch is k_ldp_reg<NB, NP, true, 1> -- an fp32 image of M in the registers, two waves per
+                                 // SIMD, at most d.reg_rows working-set rows -- with k_ldp_reg<NB, NP, true, 0> right behind it for the problems it flags
+    size_t lds_img = 0;          // ... and the image kernel's LDS
     size_t lds_wg = 0;
     double *wide_u = nullptr, *wide_l = nullptr;   // daqp_batch_setup_shared: +-1e30 bounds of the one factorisation
     int *structural = nullptr, *shared_flag = nullptr;
@@ -279,6 +283,11 @@ const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {3, 25}};
 const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {1, 13}, {1, 16}, {2, 16}, {3, 8}, {1, 25}, {3, 25}, {2, 32}};   // ((3,8): few variables, many rows -- n <= 16, m <= 192; (1,25): n <= 50 with m <= 64 -- both at two waves per SIMD)
 #endif
 // exact: the reference's arithmetic (two roundings per multiply-add); otherwise fused multiply-adds (default mode)
+ldp_reg_kernel_t pick_ldp_reg_img(const DAQPBatch *b)
+{
+    if (b->NB == 3 && b->NP == 25) return k_ldp_reg<3, 25, true, 2>;    // (IMG = 2: the third row block holds at most 32 rows)
+    return nullptr;
+}
 ldp_reg_kernel_t pick_ldp_reg(const DAQPBatch *b, bool exact)
 {
 #define DAQP_REG_PICK(nb, np) if (b->NB == nb && b->NP == np) return exact ? k_ldp_reg<nb, np, false> : k_ldp_reg<nb, np, true>;
@@ -337,11 +346,23 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
     }
     if (b->NB > 0) {
         // problems that run the proximal outer loop keep the reference's arithmetic in both modes (their setup passes do as well)
-        ldp_reg_kernel_t kr = pick_ldp_reg(b, b->d.exact_setup != 0 || b->in_prox_loop || b->exact_sticky);
+        const bool exact_kernels = b->d.exact_setup != 0 || b->in_prox_loop || b->exact_sticky;
+        ldp_reg_kernel_t kr = pick_ldp_reg(b, exact_kernels);
         // the descriptor travels through device memory: stream-ordered copy, then the launch
         (void)descriptor_changed;
         if (push_descriptor(b)) return DAQP_EXIT_UNSUPPORTED;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
+        if (b->img32 && !exact_kernels) {
+            // the image kernel first (two waves per SIMD); the problems whose working set outgrows its LDS are flagged and solved, from the
+            // state they were stored in, by the full-register kernel right behind (mode | 4: flagged problems only)
+            ldp_reg_kernel_t ki = pick_ldp_reg_img(b);
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_img));
+            hipLaunchKernelGGL(ki, dim3(b->d.N), dim3(64), b->lds_img, b->stream, (const BatchDev *)b->d_dev, mode);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode | 4);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
         hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode);
         HIPCHK(hipGetLastError());
         if (b->reg_handover) {   // the problems it flagged (mode | 4: nobody else is touched; an empty pass costs a few microseconds)
@@ -746,7 +767,8 @@ bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && 
 std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
-                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M", "DAQP_AMD_NO_BLK_SETUP"};
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M", "DAQP_AMD_NO_BLK_SETUP",
+                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -861,6 +883,15 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         else if (cap > 64) { b->NB = 0; b->NP = 0; }
     }
     if (b->reg_handover) b->lds_fb = (size_t)ldp_lds(n, m, cap, b->spill).total_bytes;
+    // The shapes whose M fills the register file (one wave per SIMD) run, in the default arithmetic and on batches that fill the device twice
+    // over, as an fp32 IMAGE of M at two waves per SIMD (reg_kernel.hip.h, IMG = 1).  Its LDS holds img_rows working-set rows (C2: the peak is
+    // 27 rows on average, above 40 on 1.3 % of the problems -- those are handed to the full-register kernel behind it)
+    if (b->NB == 3 && b->NP == 25 && d.nblk == 3 && m <= 160 && cap <= 64 && !b->reg_handover && !getenv("DAQP_AMD_NO_IMG32")) {
+        int min_batch = 1536, rows = 44;
+        if (const char *e = getenv("DAQP_AMD_IMG_MIN_BATCH")) min_batch = atoi(e);
+        if (const char *e = getenv("DAQP_AMD_IMG_ROWS")) { const int v = atoi(e); if (v >= 2 && v <= 64) rows = v; }
+        if (N >= min_batch && ms == 0) { b->img32 = true; d.reg_rows = rows < cap ? rows : cap; }     // (simple bounds: the Gram column's start columns read their rows from LDS)
+    }
     d.ldrc = 0;
     if (b->NB > 0) {   // stride == 2 (mod 4): rows 16-byte aligned and 16 consecutive rows hit 16 distinct 4-bank groups
         int l = n > 2 * b->NP ? n : 2 * b->NP;
@@ -868,6 +899,18 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.ldrc = l;
     }
     b->lds_ldp = b->NB > 0 ? (size_t)reg_lds_bytes(b->NB, n, m, cap, d.ldrc) : (size_t)ldp_lds(n, m, cap, b->spill, d.ldrc).total_bytes;
+    if (b->img32) {
+        // rows of the active-row cache in LDS: as many as leave `waves` workgroups per CU (the rest of a working set lives in rowc_g, L2-resident);
+        // a workgroup's share of the CU's 160 KB is granted in 512-byte steps
+        int waves = 7;
+        if (const char *e = getenv("DAQP_AMD_IMG_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
+        const int budget = (160 * 1024 / waves) / 512 * 512;
+        int cache = d.reg_rows;
+        while (cache > 2 && reg_img_lds_bytes(b->NB, 2, n, m, d.reg_rows, cache, d.ldrc) > budget) --cache;
+        if (const char *e = getenv("DAQP_AMD_IMG_CACHE")) { const int v = atoi(e); if (v >= 1) cache = v < d.reg_rows ? v : d.reg_rows; }
+        d.img_cache = cache;
+        b->lds_img = (size_t)reg_img_lds_bytes(b->NB, 2, n, m, d.reg_rows, cache, d.ldrc);
+    }
     if (b->NB == 0 && cap > 64 && cap <= 256 && !getenv("DAQP_AMD_NO_WG")) {     // (beyond 256 rows: the one-wave kernel with eight chunks, everything large in HBM scratch)
         int W = d.nblk < 4 ? 4 : (d.nblk > kWgMaxWaves ? kWgMaxWaves : d.nblk);
         if (const char *we = getenv("DAQP_AMD_WG_WAVES")) { const int v = atoi(we); if (v >= 4 && v <= kWgMaxWaves) W = v; }
@@ -914,6 +957,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &d.WS, Nn * cap);
     rc |= dev_alloc(b, &d.qs, Nn);
     if (b->spill) rc |= dev_alloc(b, &d.rowc_g, Nn * cap * d.ldr);
+    if (b->img32 && d.img_cache < d.reg_rows) rc |= dev_alloc(b, &d.rowc_g, Nn * (size_t)((d.reg_rows - d.img_cache) * d.ldrc));
     if (b->setup_spill) rc |= dev_alloc(b, &d.setup_g, Nn * 2 * (size_t)round_up(d.rtri, 2));
     // fp32 image of M for the workgroup kernel's screening scan (generic setup kernel only: it is the one that writes it)
     if (b->use_wg && !b->fast_setup && !getenv("DAQP_AMD_NO_SCAN32")) {
@@ -994,7 +1038,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         rc |= dev_alloc(b, &d.fallback, Nn);
         if (!rc && hipMemset(d.fallback, 0, Nn * sizeof(int)) != hipSuccess) rc = 1;
     }
-    if (b->reg_handover && !rc) {
+    if ((b->reg_handover || b->img32) && !rc) {
         rc |= dev_alloc(b, &d.fallback, Nn);
         if (!rc && hipMemset(d.fallback, 0, Nn * sizeof(int)) != hipSuccess) rc = 1;
     }

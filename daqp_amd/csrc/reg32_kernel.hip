@@ -1,0 +1,8 @@
+// reg32_kernel.hip -- translation unit of the register-centric solve kernel with an fp32 IMAGE of M in the registers (reg_kernel.hip.h,
+// IMG = 1): the shapes whose M itself fills the register file, at two waves per SIMD, in the default arithmetic
+#include <hip/hip_runtime.h>
+#include "reg_kernel.hip.h"
+
+namespace daqp_amd {
+template __global__ void k_ldp_reg<3, 25, true, 2>(const BatchDev *__restrict__, int);
+}

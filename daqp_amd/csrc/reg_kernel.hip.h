@@ -11,17 +11,31 @@ namespace daqp_amd {
 // stack, the per-row bounds, packed L): their addresses are "immediate + 8*lane", nothing to keep in a register across
 // the state-machine loop (every loop-invariant base pointer is one more value that the full register file spills to
 // scratch).  Only the active-row cache, behind the run-time sized L, has a run-time base.
-template <int NB>
+template <int NB, int IMG = 0>
 struct RegLds {
-    static constexpr int u = 0, pend_lam = 68, pend_id = 132, prof = 164, rowv = 196, L = 196 + 192 * NB;   // doubles
+    static constexpr int u = 0, pend_lam = 68, pend_id = 132, prof = 164, u32 = 196, rowv = 196 + (IMG ? 32 : 0), L = rowv + 3 * kRowvStride<NB, IMG>;   // doubles (u32: 64 floats, IMG != 0 only)
 };
 __host__ __device__ inline int reg_lds_rowc_size(int n, int m, int cap, int ldrc)
 {
     const int rows = round_up(cap * ldrc, 2), fin = round_up(n * (n + 1) / 2, 2) + 2 + round_up(m, 2);   // epilogue: staged R^-1 + lam
     return rows > fin ? rows : fin;
 }
-__host__ __device__ inline int reg_lds_rowc(int NB, int cap) { return 196 + 192 * NB + round_up(cap * (cap + 1) / 2, 2); }
-__host__ __device__ inline int reg_lds_bytes(int NB, int n, int m, int cap, int ldrc) { return 8 * (reg_lds_rowc(NB, cap) + reg_lds_rowc_size(n, m, cap, ldrc)); }
+// (IMG = 1: `cap` is the number of working-set rows the kernel holds -- BatchDev::reg_rows --, not the problem's own cap)
+__host__ __device__ inline int reg_lds_rowc(int NB, int cap, int IMG = 0) { return 196 + (IMG ? 32 : 0) + 3 * (IMG == 2 ? 64 * NB - 32 : 64 * NB) + round_up(cap * (cap + 1) / 2, 2); }
+__host__ __device__ inline int reg_lds_bytes(int NB, int n, int m, int cap, int ldrc, int IMG = 0) { return 8 * (reg_lds_rowc(NB, cap, IMG) + reg_lds_rowc_size(n, m, cap, ldrc)); }
+// IMG != 0: [front: u, pivot stack, probes, u32][row view][L: tri(rows)][row cache], the cache tiered (RWave::cache_slots): `cache` rows + one
+// staging row when cache < rows, else all `rows`; L and the cache together at least as large as the epilogue's staging area (R^-1 + lam), which
+// starts at L (the factor has been stored by then)
+__host__ __device__ inline int reg_img_cache_rows(int rows, int cache) { return cache < rows ? cache + 1 : rows; }
+__host__ __device__ inline int reg_img_stage_size(int n, int m, int rows, int cache, int ldrc)
+{
+    const int body = round_up(rows * (rows + 1) / 2, 2) + round_up(reg_img_cache_rows(rows, cache) * ldrc, 2), fin = round_up(n * (n + 1) / 2, 2) + 2 + round_up(m, 2);
+    return body > fin ? body : fin;
+}
+__host__ __device__ inline int reg_img_lds_bytes(int NB, int IMG, int n, int m, int rows, int cache, int ldrc)
+{
+    return 8 * (196 + 32 + 3 * (IMG == 2 ? 64 * NB - 32 : 64 * NB) + reg_img_stage_size(n, m, rows, cache, ldrc));
+}
 
 // ------------------------------------------------------------------------------------
 // k_ldp_reg: the register-centric solve kernel (wave_ldp_reg.hip.h) for n + n_soft + 1 <= 64 and
@@ -37,13 +51,16 @@ __host__ __device__ inline int reg_lds_bytes(int NB, int n, int m, int cap, int 
 #endif
 // (NB*NP <= 13, i.e. n <= 26 and m <= 64: three waves per SIMD -- twelve waves' LDS still fit a CU up to there, and the same code on
 // the (1,16) shape measured 16 % faster at three waves than at two for n = 20 / 24, 2 % slower for n = 30 / 32 where the LDS does not fit)
-constexpr int ldp_reg_waves(int NB, int NP) { return NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 13 ? 3 : (NB * NP <= 32 ? 2 : 1)); }
-template <int NB, int NP, bool FM>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_waves(NB, NP), ldp_reg_waves(NB, NP)))) void k_ldp_reg(const BatchDev *__restrict__ bp, int mode_in)
+// (IMG = 1: the large shapes with an fp32 image of M instead of M -- 2 NB NP registers -- at two waves per SIMD)
+constexpr int ldp_reg_waves(int NB, int NP, int IMG = 0) { return IMG ? 2 : (NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 13 ? 3 : (NB * NP <= 32 ? 2 : 1))); }
+template <int NB, int NP, bool FM, int IMG = 0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_waves(NB, NP, IMG), ldp_reg_waves(NB, NP, IMG)))) void k_ldp_reg(const BatchDev *__restrict__ bp, int mode_in)
 {
+    static_assert(IMG == 0 || FM, "the fp32 image screens the scan of the default arithmetic only");
     // mode 0: daqp_solve; 1: only (re)build the working set from the ACTIVE bits; 2 | mask << 4: daqp_update_ldp(mask)
     // for mask within UPDATE_v|UPDATE_d applied here, then daqp_solve -- the rows of M are in registers anyway, so the
     // warm path of an MPC step reads them from HBM once instead of twice (k_update + solve)
+    // | 4: only the problems an IMG = 1 launch in front flagged in `fallback` (more working-set rows than its LDS holds)
     const int upd = (mode_in & 3) == 2 ? (mode_in >> 4) : 0;
     const int mode = (mode_in & 3) == 2 ? 0 : (mode_in & 3);
     // The descriptor is read through a pointer (scalar loads at the point of use) instead of being a
@@ -54,11 +71,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     const long long t_start = (long long)__builtin_readcyclecounter();
     const int q = blockIdx.x, lane = lane_id();
     const int n = b.n, m = b.m, cap = b.cap;
+    if (mode_in & 4) { if (b.fallback == nullptr || !__builtin_amdgcn_readfirstlane(as_global(b.fallback)[q])) return; }
+    else if constexpr (kRegHandOver<NB, NP, IMG>) {     // a first pass owns the flag: clear what an earlier solve left (early returns below included)
+        if (b.fallback != nullptr && lane == 0) as_global(b.fallback)[q] = 0;
+    }
+    // rows of the working set the LDS carve-up is sized for: the problem's own cap, or (IMG = 1) what the host chose to keep two waves per SIMD
+    const int lds_rows = IMG ? __builtin_amdgcn_readfirstlane(b.reg_rows) : cap;
     DAQP_GLOBAL(QState) *qs = as_global(b.qs + q);   // (global pointers throughout: see DAQP_GLOBAL in wave_ldp.hip.h)
     if (mode == 1) {   // an activation launch looks at the record first: almost every problem leaves here, without touching M
         if (__builtin_amdgcn_readfirstlane(qs->setup_flag) < 0 || !__builtin_amdgcn_readfirstlane(qs->need_activate)) return;
     }
-    typedef RegLds<NB> o;
+    typedef RegLds<NB, IMG> o;
     // ---- ONE batch of loads.  Everything whose address does not depend on the per-problem record goes out before the first
     // wait: the rows of M, the row view, the new bounds / f / R^-1 of a pending update, the working-set ids and vectors of a
     // warm start -- and the record itself (before: the record, then the ids, then M -- three dependent trips).  Measured on the
@@ -71,12 +94,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     DAQP_GLOBAL(int) *gsense = as_global(b.sense + (size_t)q * m);
     DAQP_GLOBAL(double) *gv = as_global(b.vecs + (size_t)q * 5 * cap);
     DAQP_GLOBAL(int) *gws = as_global(b.WS + (size_t)q * cap);
-    const int rowc_size = reg_lds_rowc_size(n, m, cap, b.ldrc);
-    RWave<NB, NP, FM> w;
-    w.rowc = smem + reg_lds_rowc(NB, cap);
+    const int img_cache = IMG ? __builtin_amdgcn_readfirstlane(b.img_cache) : 0;
+    const int rowc_size = IMG ? reg_img_stage_size(n, m, lds_rows, img_cache, b.ldrc) : reg_lds_rowc_size(n, m, lds_rows, b.ldrc);
+    RWave<NB, NP, FM, IMG> w;
+    w.rowc = smem + (IMG ? o::L + round_up(lds_rows * (lds_rows + 1) / 2, 2) : reg_lds_rowc(NB, lds_rows, IMG));
+    // staging area of R^-1 (pending UPDATE_v; epilogue) and of lam: the row cache -- IMG != 0: L and the row cache (the update's v is formed before
+    // the factor is loaded, the epilogue stores the factor first)
+    double *sbase = IMG ? smem + o::L : w.rowc;
     // a pending UPDATE_v needs R^-1 and f: their loads go out first and arrive together with the rows of M
     const int rinv0 = rowc_size - round_up(b.rtri, 2) - 2;
-    double *Rl0 = w.rowc + rinv0;
+    double *Rl0 = sbase + rinv0;
     double f_raw = 0, f_sc = 1;
     if (upd & DAQP_UPDATE_v) {
         const double *Rq = b.Rinv + qfac * b.rtri, *f = b.f + (size_t)q * n;
@@ -170,6 +197,105 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     double v_early = 0;
     bool v_done = false;
     __builtin_amdgcn_sched_barrier(0);
+    double sm_img[NB];      // IMG = 1: row . v of a pending update, formed while the rows pass through
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) { sm_img[bb] = 0; });
+    if constexpr (IMG != 0) {
+        // The fp64 rows pass through the registers once: each pair is rounded into the image as it arrives, and a pending update's
+        // d = b s + M v (utils.c:499-544) takes its row . v from the passing fp64 values -- so v must be in LDS BEFORE the stream.
+        w.msrc = msrc; w.npair = npair_u; w.u32 = reinterpret_cast<float *>(smem + o::u32);
+        w.cache_slots = img_cache;
+        w.rowg = as_global(b.rowc_g + (size_t)q * (size_t)((lds_rows > img_cache ? lds_rows - img_cache : 0) * b.ldrc));
+        if (upd) {
+            double *vv = smem + o::u, *fl = smem + o::pend_lam;
+            for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) vv[e] = 0;
+            if (upd & DAQP_UPDATE_v) {
+                copy_wait();
+                const int qdiag_e = __builtin_amdgcn_readfirstlane(rec_diag);
+                if (lane < n) fl[lane] = (lane < b.ms && !qdiag_e) ? f_raw / f_sc : f_raw;
+                WSYNC();
+                v_early = v_of_update(Rl0, fl);
+                v_done = true;
+                if (lane < n) vv[lane] = v_early;
+            } else if (lane < n) vv[lane] = as_global(b.v)[(size_t)q * n + lane];
+            WSYNC();
+        }
+        const double2 *v2 = reinterpret_cast<const double2 *>(smem + o::u);
+        // Units of GB pairs, double-buffered: unit U + 1 is in flight while unit U is rounded into the image -- and no further: left to itself
+        // the scheduler hoists ALL the loads (300 registers of fp64 temporaries), and image values defined under that pressure are spilled
+        // for good (reloaded by every scan).  Full blocks first (lane <-> row), then (IMG = 2) the last block with two lanes per row: lane
+        // 2k + h holds pairs NPH h .. NPH h + NPH - 1 of row 64 (NB-1) + k (wave_ldp_reg.hip.h rscan_rows_img).
+        constexpr int GB = 6, NBF = kImgFullBlocks<NB, IMG>, NBAT = (NP + GB - 1) / GB, NPH = (NP + 1) / 2, NHB = (IMG == 2) ? (NPH + GB - 1) / GB : 0;
+        constexpr int NUNITS = NBF * NBAT + NHB;
+        const int h = lane & 1, k2 = lane >> 1;
+        const bool rowok2 = (NB - 1) < nblk_u && 64 * (NB - 1) + k2 < m;
+        const int rsel2 = rowok2 ? k2 : 0;
+        double half = 0;
+        gv2d buf[2][GB];
+        auto load_unit = [&](auto U) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value;
+            if constexpr (u < NBF * NBAT) {
+                constexpr int bb = u / NBAT, g = u % NBAT;
+                const int lsel = (64 * bb + lane < m) ? lane : 0;      // lanes beyond m re-read lane 0's line (never looked at: every use of a row is behind r < m)
+                static_for<GB>([&](auto k) __attribute__((always_inline)) {
+                    constexpr int t = GB * g + k;
+                    if constexpr (t < NP) {
+                        const bool ok = bb < nblk_u && t < npair_u;
+                        buf[u & 1][k] = msrc[(ok ? ((size_t)bb * npair_u + t) : (size_t)0) * 64 + lsel];
+                    }
+                });
+            } else if constexpr (u < NUNITS) {
+                constexpr int g = u - NBF * NBAT;
+                static_for<GB>([&](auto k) __attribute__((always_inline)) {
+                    constexpr int tt = GB * g + k;
+                    if constexpr (tt < NPH) {
+                        const int t = NPH * h + tt;
+                        const bool ok = rowok2 && t < npair_u;
+                        buf[u & 1][k] = msrc[(ok ? ((size_t)(NB - 1) * npair_u + t) : (size_t)0) * 64 + rsel2];
+                    }
+                });
+            }
+        };
+        auto use_unit = [&](auto U) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value;
+            if constexpr (u < NBF * NBAT) {
+                constexpr int bb = u / NBAT, g = u % NBAT;
+                static_for<GB>([&](auto k) __attribute__((always_inline)) {
+                    constexpr int t = GB * g + k;
+                    if constexpr (t < NP) {
+                        const bool ok = bb < nblk_u && t < npair_u;
+                        const double mx = ok ? buf[u & 1][k].x : 0.0, my = ok ? buf[u & 1][k].y : 0.0;
+                        if (upd) { const double2 vk = v2[t]; sm_img[bb] = __builtin_fma(mx, vk.x, sm_img[bb]); sm_img[bb] = __builtin_fma(my, vk.y, sm_img[bb]); }
+                        // (pinned: the rounding happens HERE -- left alone, it is sunk to the loop's entry and the fp64 pairs stay live across the prologue)
+                        float fx = (float)mx, fy = (float)my;
+                        asm volatile("" : "+v"(fx), "+v"(fy));
+                        w.Mx[bb][t] = fx; w.My[bb][t] = fy;
+                    }
+                });
+            } else {
+                constexpr int g = u - NBF * NBAT;
+                static_for<GB>([&](auto k) __attribute__((always_inline)) {
+                    constexpr int tt = GB * g + k;
+                    if constexpr (tt < NPH) {
+                        const int t = NPH * h + tt;
+                        const bool ok = rowok2 && t < npair_u;
+                        const double mx = ok ? buf[u & 1][k].x : 0.0, my = ok ? buf[u & 1][k].y : 0.0;
+                        if (upd) { const double2 vk = v2[t < NP ? t : 0]; half = __builtin_fma(mx, vk.x, half); half = __builtin_fma(my, vk.y, half); }
+                        float fx = (float)mx, fy = (float)my;
+                        asm volatile("" : "+v"(fx), "+v"(fy));
+                        w.Mx[NB - 1][tt] = fx; w.My[NB - 1][tt] = fy;
+                    }
+                });
+            }
+        };
+        load_unit(std::integral_constant<int, 0>{});
+        static_for<NUNITS>([&](auto U) __attribute__((always_inline)) {
+            load_unit(std::integral_constant<int, decltype(U)::value + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            use_unit(U);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (IMG == 2) { if (upd) { half += __shfl_xor(half, 1); sm_img[NB - 1] = __shfl(half, (2 * lane) & 63); } }
+    } else
     if (nblk_u == NB && npair_u == NP) {
         // the shape fills the template exactly (the benchmark's case): NB*NP unconditional loads in ONE basic block, each
         // straight into its final (mostly accumulation) register -- all in flight, one wait at the first use
@@ -249,10 +375,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     w.trace = b.trace ? as_global(b.trace + (size_t)q * b.trace_cap) : nullptr;
     w.trace_cap = b.trace_cap; w.trace_len = 0;
     w.na = __builtin_amdgcn_readfirstlane(rec_na);
-    if constexpr (kRegHandOver<NB, NP>) {
-        w.max_rows = b.reg_rows;
-        if (w.na > w.max_rows) {   // stored by the generic kernel with more rows than this one holds: its problem again
-            if (lane == 0) as_global(b.fallback)[q] = 1;
+    if constexpr (kRegHandOver<NB, NP, IMG>) {
+        // (no `fallback` array: nobody stands behind this launch -- the kernel keeps every problem, up to its 64 lanes)
+        w.max_rows = IMG ? lds_rows : ((b.fallback != nullptr) ? b.reg_rows : 64);
+        if (w.na > w.max_rows) {   // stored by the kernel behind this one with more rows than this one holds: its problem again
+            if (lane == 0 && b.fallback != nullptr) as_global(b.fallback)[q] = 1;
             copy_wait();
             return;
         }
@@ -286,19 +413,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     auto fetch_active_rows = [&]() __attribute__((always_inline)) {
         for (int i = 0; i < w.na; ++i) {
             const int id = rli(wsid_r, i);
+            if (IMG != 0 && i >= img_cache) {   // a warm start with more rows than the LDS tier holds: this one goes to the scratch tier (lane <-> component)
+                const DAQP_GLOBAL(double) *srow = reinterpret_cast<const DAQP_GLOBAL(double) *>(msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63));
+                if (lane < n) w.rowg[(i - img_cache) * b.ldrc + lane] = srow[(size_t)(lane >> 1) * 128 + (lane & 1)];
+                continue;
+            }
             const DAQP_GLOBAL(gv2d) *src = msrc + ((size_t)(id >> 6) * b.npair) * 64 + (id & 63) + (size_t)lane * 64;
             if (lane < b.npair)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(w.rowc + (size_t)i * w.ldr), 16, 0, 0);
         }
     };
-    const bool rows_early = !(upd & DAQP_UPDATE_v) || w.na * w.ldr <= rinv0;   // R^-1 is staged in the top of the row cache
+    const bool rows_early = IMG != 0 || !(upd & DAQP_UPDATE_v) || w.na * w.ldr <= rinv0;   // R^-1 is staged in the top of the row cache (IMG != 0: not any more: v was formed first)
     if (rows_early) fetch_active_rows();
     static_for<NB>([&](auto bb) __attribute__((always_inline)) {
         const int r = bb * 64 + lane;
-        w.rowv[r] = dur[bb];
-        w.rowv[(64 * NB) + r] = dlr[bb];
-        w.rowv[2 * (64 * NB) + r] = ep * scr[bb];
+        if (IMG != 2 || r < kRowvStride<NB, IMG>) {     // (IMG = 2: the last block's part of each array is 32 rows long)
+            w.rowv[r] = dur[bb];
+            w.rowv[kRowvStride<NB, IMG> + r] = dlr[bb];
+            w.rowv[2 * kRowvStride<NB, IMG> + r] = ep * scr[bb];
+        }
         w.rs |= (unsigned)snr[bb] << (8 * bb);
         softbits |= snr[bb] & DAQP_SOFT;
     });
@@ -353,7 +487,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         {
             const double2 *v2 = reinterpret_cast<const double2 *>(vv);
             double sm[NB];
-            static_for<NB>([&](auto bb) __attribute__((always_inline)) { sm[bb] = 0; });
+            static_for<NB>([&](auto bb) __attribute__((always_inline)) { sm[bb] = sm_img[bb]; });
+            if constexpr (IMG == 0)
             static_for<NP>([&](auto tt) __attribute__((always_inline)) {
                 const double2 vk = v2[tt];
                 static_for<NB>([&](auto bb) __attribute__((always_inline)) {
@@ -366,7 +501,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
                 if (r < m) {
                     const double nu = bur[bb] * scr[bb] + sm[bb], nl = blr[bb] * scr[bb] + sm[bb];
                     dur[bb] = nu; dlr[bb] = nl;
-                    w.rowv[r] = nu; w.rowv[(64 * NB) + r] = nl;
+                    w.rowv[r] = nu; w.rowv[kRowvStride<NB, IMG> + r] = nl;
                     as_global(b.dupper)[(size_t)q * m + r] = nu;
                     as_global(b.dlower)[(size_t)q * m + r] = nl;
                 }
@@ -412,11 +547,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     const long long t_loop = (long long)__builtin_readcyclecounter();
     int flag = rrun(w, mode, q_need_act != 0, iters);
     const long long t_done = (long long)__builtin_readcyclecounter();
-    if constexpr (kRegHandOver<NB, NP>) {
+    if constexpr (kRegHandOver<NB, NP, IMG>) {
         // nothing of this problem has been stored yet (results, iterate, sense, record: all below): the generic kernel starts from the same state
-        if (b.fallback != nullptr) {
-            if (lane == 0) as_global(b.fallback)[q] = (flag == kRegHandOverFlag) ? 1 : 0;
-            if (flag == kRegHandOverFlag) { copy_wait(); return; }
+        if (flag == kRegHandOverFlag) {
+            if (b.fallback != nullptr) {
+                if (lane == 0) as_global(b.fallback)[q] = 1;
+                copy_wait();
+                return;
+            }
+            flag = DAQP_EXIT_UNSUPPORTED;      // (nobody stands behind this launch: cannot happen with the host code of this library)
         }
     }
     if (mode == 1) {
@@ -429,7 +568,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         // (16 bytes per lane; the packed rows of odd QPs start 8 bytes off a 16-byte boundary, so the LDS image is
         // shifted by one double for them and that first double goes separately)
         const int odd8 = (int)(((size_t)Rq >> 3) & 1);
-        double *Rl = w.rowc + rinv_off + odd8;
+        if constexpr (IMG != 0) {      // the staging area starts at L: the factor goes to HBM first
+            const int used = tri(w.na);
+            DAQP_GLOBAL(double) *gL = as_global(b.L + (size_t)q * b.ltri);
+            for (int e = lane; e < used; e += 64) gL[e] = w.L[e];
+            WSYNC();
+        }
+        double *Rl = sbase + rinv_off + odd8;
         if (flag > 0) {
             if (odd8) copy_async_dwords(Rl, Rq, 1);
             const int body = (b.rtri - odd8) & ~1;
@@ -440,7 +585,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         const double vl = (lane < n) ? vq[lane] : 0.0;
         const double sc_ws = (flag > 0 && lane < w.na) ? gsc[w.wsid] : 1.0;
         const double sc_sb = (flag > 0 && lane < b.ms) ? gsc[lane] : 1.0;
-        double *lamq = w.rowc;                                          // m doubles at the (dead) bottom of the row cache
+        double *lamq = sbase;                                           // m doubles at the (dead) bottom of the row cache
         double xi = (lane < n) ? w.u[lane] : 0.0;
         if (b.lam) for (int i = lane; i < m; i += 64) lamq[i] = 0;     // daqp_extract_result (api.c:455-495): zero ...
         const long long te1 = (long long)__builtin_readcyclecounter();
@@ -519,7 +664,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         gws[lane] = (lane < w.na) ? w.wsid : -1;
     }
     static_for<NB>([&](auto bb) __attribute__((always_inline)) { const int r = bb * 64 + lane; if (r < m) gsense[r] = rsense_get(w, bb); });
-    {
+    if (IMG == 0 || mode == 1) {
         const int used = tri(w.na);
         DAQP_GLOBAL(double) *gL = as_global(b.L + (size_t)q * b.ltri);
         for (int e = lane; e < used; e += 64) gL[e] = w.L[e];

@@ -15,6 +15,7 @@
 // dependency chain, and cross-lane traffic is v_readlane / DPP, never LDS.
 #pragma once
 #include <utility>
+#include <type_traits>
 #include "wave_ldp.hip.h"
 
 namespace daqp_amd {
@@ -30,10 +31,32 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // the register shape whose problems may outgrow the 64 lanes (n = 64: up to 65 working-set rows) hands them over; compiled out of every other shape
-template <int NB, int NP> constexpr bool kRegHandOver = (NB == 2 && NP == 32);
+// (and so does every kernel that keeps an fp32 IMAGE of M in its registers -- IMG = 1, see RWave -- whose LDS holds fewer working-set rows than the
+// problem may reach: those problems go to the IMG = 0 kernel of the same shape)
+// IMG = 2: as IMG = 1 with the LAST row block (at most 32 rows: 128 < m <= 160 at NB = 3) split over two lanes per row -- NP / 2 image registers
+// for it instead of NP: C2's 150 rows are 126 registers instead of 150, which is what lets the rest of the state stay out of scratch
+template <int NB, int IMG> constexpr int kImgFullBlocks = (IMG == 2) ? NB - 1 : NB;
+// rows of the row view (d_upper, d_lower, -primal_tol scaling in LDS, one after the other): 64 per row block; IMG = 2: the last block has 32
+template <int NB, int IMG> constexpr int kRowvStride = (IMG == 2) ? 64 * NB - 32 : 64 * NB;
+template <int NB, int NP, int IMG = 0> constexpr bool kRegHandOver = (NB == 2 && NP == 32) || IMG != 0;
 constexpr int kRegHandOverFlag = -1000;   // rrun's verdict "not mine" (never reaches the caller: no reference exit flag is near it)
-template <int NB, int NP, bool FM>
+// IMG = 0: the rows of M themselves live in the registers (fp64: 4 NB NP registers, the whole file at C2's shape -> one wave per SIMD).
+// IMG = 1 (default arithmetic only): the registers hold an fp32 IMAGE of M (2 NB NP registers) that SCREENS the feasibility scan; a verdict is
+// taken from it only when it is provably the fp64 scan's (rscan_rows), a row that enters the working set is fetched in fp64 from the blocked
+// image in HBM / L2 (rfetch_row), and the kernel fits two waves per SIMD (docs/NEXT_two_waves_per_simd.md).
+template <int NB, int NP, bool FM, int IMG = 0>
 struct RWave {
+    typedef double gv2d_ __attribute__((ext_vector_type(2)));
+    typedef typename std::conditional<IMG != 0, float, double>::type mreg;
+    const DAQP_GLOBAL(gv2d_) *msrc;    // IMG = 1: this problem's blocked fp64 image [nblk][npair][64][2]
+    float *u32;                        // IMG = 1: u rounded to fp32 (LDS), the screening scan's operand
+    int npair;
+    // IMG != 0: the active-row cache is TIERED.  Slots < cache_slots are rows in LDS (rowc); the others live in this problem's global scratch
+    // (rowg, slot s at (s - cache_slots) ldr: L2-resident, 400 contiguous bytes a row at C2's shape), and LDS row `cache_slots` is where a row
+    // bound for such a slot is staged while it is appended.  New rows take the lowest free slot, so the scratch is touched only by working sets
+    // beyond cache_slots rows.  cache_slots >= max_rows: everything in LDS.
+    int cache_slots;
+    DAQP_GLOBAL(double) *rowg;
     int n, m, ms, ldr;
     double *L, *rowc, *u, *pend_lam;   // LDS
     int *pend_id;                      // LDS
@@ -43,7 +66,7 @@ struct RWave {
     // row view (lane r + 64*bb = constraint row).  At one wave per SIMD the kernel owns the
     // whole unified 512-entry register file; the compiler parks what exceeds the 256
     // architectural VGPRs in AGPRs (v_accvgpr_read on use).
-    double Mx[NB][NP], My[NB][NP];   // M[row][2t], M[row][2t+1]
+    mreg Mx[NB][NP], My[NB][NP];   // M[row][2t], M[row][2t+1]
     // d_upper, d_lower and -primal_tol*scaling of every row live in LDS (rowv[r], rowv[R + r], rowv[2R + r], R = 64*NB): they are read once per iteration at the end of the scan, and 18 more registers held across the whole
     // loop push the allocator into scratch spills (the register file is full: 300 registers of M + the working set)
     double *rowv;
@@ -88,8 +111,8 @@ __device__ __forceinline__ int rli(int v, int src) { return __builtin_amdgcn_rea
 template <bool FM> __device__ __forceinline__ double msub(double x, double a, double b) { if constexpr (FM) return __builtin_fma(-a, b, x); else return x - a * b; }
 template <bool FM> __device__ __forceinline__ double madd(double x, double a, double b) { if constexpr (FM) return __builtin_fma(a, b, x); else return x + a * b; }
 
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ void rtrace(RWave<NB, NP, FM> &w, int ev)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ void rtrace(RWave<NB, NP, FM, IMG> &w, int ev)
 {
     if (w.trace) {
         if (lane_id() == 0 && w.trace_len < w.trace_cap) w.trace[w.trace_len] = ev;
@@ -99,15 +122,15 @@ __device__ __forceinline__ void rtrace(RWave<NB, NP, FM> &w, int ev)
 
 // --- row-view accessors ----------------------------------------------------------------------
 // sense words are < 256 (bits ACTIVE..SLACK_FIXED): block bb of this lane sits in byte bb of w.rs
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ int rsense_get(const RWave<NB, NP, FM> &w, int bb) { return (int)((w.rs >> (8 * bb)) & 0xffu); }
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ int sense_of(const RWave<NB, NP, FM> &w, int id)   // id wave-uniform
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ int rsense_get(const RWave<NB, NP, FM, IMG> &w, int bb) { return (int)((w.rs >> (8 * bb)) & 0xffu); }
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ int sense_of(const RWave<NB, NP, FM, IMG> &w, int id)   // id wave-uniform
 {
     return rli(rsense_get(w, id >> 6), id & 63);
 }
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ void sense_set(RWave<NB, NP, FM> &w, int id, int set_bits, int clear_bits)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ void sense_set(RWave<NB, NP, FM, IMG> &w, int id, int set_bits, int clear_bits)
 {
     if (lane_id() == (id & 63)) {
         const int sh = 8 * (id >> 6);
@@ -116,18 +139,31 @@ __device__ __forceinline__ void sense_set(RWave<NB, NP, FM> &w, int id, int set_
 }
 // bound of constraint id: broadcast every block's candidate first, THEN pick (selecting between
 // array elements before the readlane gets folded into a dynamic index => scratch)
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ double bound_of(const RWave<NB, NP, FM> &w, int id, bool lower)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ double bound_of(const RWave<NB, NP, FM, IMG> &w, int id, bool lower)
 {
-    return w.rowv[(lower ? (64 * NB) : 0) + id];     // wave-uniform address: an LDS broadcast
+    return w.rowv[(lower ? kRowvStride<NB, IMG> : 0) + id];     // wave-uniform address: an LDS broadcast
 }
 
 // rowc[slot] <- row id: the owning lane stores its registers, NP unconditional 16-byte writes (the row
 // stride is >= 2*NP and rows are 16-byte aligned; entries beyond n are the zero padding of M)
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ void rfetch_row(RWave<NB, NP, FM> &w, int id, int slot)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ void rfetch_row(RWave<NB, NP, FM, IMG> &w, int id, int slot)
 {
     const int lane = lane_id();
+    if constexpr (IMG != 0) {
+        // the exact row comes from the blocked image: pair t of row id sits at [id / 64][t][id % 64] -- lane t fetches its 16 bytes straight
+        // into the cache slot (global_load_lds: LDS address = slot base + 16 lane); one trip to L2 / HBM per added constraint, which the
+        // SIMD's other wave covers
+        typedef typename RWave<NB, NP, FM, IMG>::gv2d_ gv2d_;
+        const DAQP_GLOBAL(gv2d_) *src = w.msrc + ((size_t)(id >> 6) * w.npair) * 64 + (id & 63) + (size_t)lane * 64;
+        if (lane < w.npair)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(w.rowc + (size_t)slot * w.ldr), 16, 0, 0);
+        copy_wait();
+        WSYNC();
+        return;
+    }
     double2 *dst = reinterpret_cast<double2 *>(w.rowc + (size_t)slot * w.ldr);
     static_for<NB>([&](auto bb) __attribute__((always_inline)) {
         if ((id >> 6) == bb && lane == (id & 63)) {
@@ -221,8 +257,8 @@ template <int G = 8, class F> __device__ __forceinline__ void chunks_down(int li
 }
 // b <- L' \ b over the leading cnt positions (column-oriented; product order b_j * L[j][i]).
 // Lanes >= cnt must hold b == 0.
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ double rbackward(RWave<NB, NP, FM> &w, double b, int cnt)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ double rbackward(RWave<NB, NP, FM, IMG> &w, double b, int cnt)
 {
     const int lane = lane_id();
     const double *Ll = w.L + lane_now();
@@ -323,8 +359,8 @@ __device__ __forceinline__ double ordered_sub(double acc, double p, int cnt)
 // x_i = rhs_i - sum_{j<i} L[i][j] x_j for rows i >= from (j ascending), column-oriented: lane <-> row, the
 // lane's own L entries for 8 columns preloaded, x_j broadcast by v_readlane once final.
 // In: x = final values for lanes < from; rhs for lanes in [from, na); 0 beyond.
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ double rforward(RWave<NB, NP, FM> &w, double x, double rhs, int from)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ double rforward(RWave<NB, NP, FM, IMG> &w, double x, double rhs, int from)
 {
     const int lane = lane_id(), na = w.na;
     const bool pending = lane >= from && lane < na;
@@ -360,8 +396,8 @@ __device__ __forceinline__ double rforward(RWave<NB, NP, FM> &w, double x, doubl
 // every other 16-byte pair of its row and of the new row: half the LDS instructions and a quarter of the VALU work
 // of one lane per row.  Element e < 4*(n/4) goes to chain e%4 in ascending order, the n%4 tail elements go to s0 one
 // after the other, and the result is (s0+s1)+(s2+s3) -- exactly the reference's dot_row.  Row na is the new row itself.
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP, FM> &w, int newslot, const double *Mi)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP, FM, IMG> &w, int newslot, const double *Mi)
 {
     const int lane = lane_id(), na = w.na, n = w.n, nq = n >> 2, h = lane & 1;
     const double2 *rb = reinterpret_cast<const double2 *>(Mi) + h;
@@ -369,7 +405,7 @@ __device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP, FM> &w, int news
     for (int p0 = 0; p0 <= na; p0 += 32) {
         const int k = p0 + (lane >> 1);
         const int sl = __shfl(w.slot, k & 63);
-        const int sk = (k < na) ? sl : newslot;                  // rows beyond na: the new row again (finite, unused)
+        const int sk = (k < na && (IMG == 0 || sl < w.cache_slots)) ? sl : newslot;   // rows beyond na (and rows outside the LDS tier: done below): the new row again (finite, unused)
         const double *rowk = w.rowc + (size_t)sk * w.ldr;
         const double2 *ra = reinterpret_cast<const double2 *>(rowk) + h;
         double sa = 0, sb = 0;
@@ -396,20 +432,44 @@ __device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP, FM> &w, int news
         const double gk = __shfl(tot, (2 * (lane - p0)) & 63);
         if (lane >= p0 && lane < p0 + 32) g = gk;
     }
+    if constexpr (IMG != 0) {
+        // rows of the scratch tier: lane <-> component, four rows in flight, each dot by tree (default arithmetic)
+        unsigned long long m2 = __ballot(lane < na && w.slot >= w.cache_slots);
+        const double mine = (lane < n) ? Mi[lane_now()] : 0.0;
+        while (m2) {
+            int ii[4];
+            double rr[4];
+            static_for<4>([&](auto c) __attribute__((always_inline)) {
+                ii[c] = m2 ? __ffsll((long long)m2) - 1 : -1;
+                if (m2) m2 &= m2 - 1;
+                const int so = (ii[c] >= 0) ? (rli(w.slot, ii[c] & 63) - w.cache_slots) * w.ldr : 0;
+                rr[c] = (lane < n) ? w.rowg[so + lane] : 0.0;
+            });
+            static_for<4>([&](auto c) __attribute__((always_inline)) {
+                const double sum = wave_sum(rr[c] * mine);
+                if (lane == ii[c]) g = sum;
+            });
+        }
+    }
     return g;
 }
 
 // ---------------------------------------------------------------------------------------
 // LDL' row append (factorization.c:21-111); returns the new pivot D[na]
 // ---------------------------------------------------------------------------------------
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ double rldl_append(RWave<NB, NP, FM> &w, int id, int newslot, int sn_id)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ double rldl_append(RWave<NB, NP, FM, IMG> &w, int id, int newslot, int sn_id)
 {
     const int lane = lane_id(), na = w.na, n = w.n, base = tri(na);
+    const int gslot = newslot;                                  // the slot the row is known by
+    if constexpr (IMG != 0) newslot = newslot < w.cache_slots ? newslot : w.cache_slots;    // ... and where it is in LDS during the append (the staging row)
     rfetch_row(w, id, newslot);
     const int c0 = id < w.ms ? id : 0;
     w.sing = kEmpty;
     const double *Mi = w.rowc + (size_t)newslot * w.ldr;
+    if constexpr (IMG != 0) {       // a row of the scratch tier: its copy goes out now (nothing waits for the store)
+        if (gslot >= w.cache_slots && lane < n) w.rowg[(gslot - w.cache_slots) * w.ldr + lane] = Mi[lane_now()];
+    }
     double g = 0;
     if (lane <= na) {
         const int idk = (lane < na) ? w.wsid : id;
@@ -457,8 +517,8 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP, FM> &w, int id, int 
 // ---------------------------------------------------------------------------------------
 // LDL' row delete (factorization.c:112-151)
 // ---------------------------------------------------------------------------------------
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM> &w, int r)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ void rldl_delete(RWave<NB, NP, FM, IMG> &w, int r)
 {
     const int lane = lane_id(), na = w.na;
     if (na == r + 1) return;
@@ -640,8 +700,8 @@ __device__ __forceinline__ double shift_from(double v, int r)
     return lane_id() >= r ? __hiloint2double(hi, lo) : v;
 }
 
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ int rdrop_core(RWave<NB, NP, FM> &w, int r) // auxiliary.c:3-22
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ int rdrop_core(RWave<NB, NP, FM, IMG> &w, int r) // auxiliary.c:3-22
 {
     const int lane = lane_id();
     const int idr = rli(w.wsid, r);
@@ -665,8 +725,8 @@ __device__ __forceinline__ int rdrop_core(RWave<NB, NP, FM> &w, int r) // auxili
     return 0;
 }
 
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ void rpush_core(RWave<NB, NP, FM> &w, int id, double lamv) // auxiliary.c:27-40
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ void rpush_core(RWave<NB, NP, FM, IMG> &w, int id, double lamv) // auxiliary.c:27-40
 {
     const int lane = lane_id();
     rtrace(w, id + 1);
@@ -687,8 +747,8 @@ __device__ __forceinline__ void rpush_core(RWave<NB, NP, FM> &w, int id, double 
 // ---------------------------------------------------------------------------------------
 // per-iteration kernels
 // ---------------------------------------------------------------------------------------
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ void rsolve_csp(RWave<NB, NP, FM> &w) // auxiliary.c:314-354
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ void rsolve_csp(RWave<NB, NP, FM, IMG> &w) // auxiliary.c:314-354
 {
     const int lane = lane_id(), na = w.na, from = w.reuse;
     long long tq = (kProfile && w.prof) ? (long long)__builtin_readcyclecounter() : 0;
@@ -701,8 +761,8 @@ __device__ __forceinline__ void rsolve_csp(RWave<NB, NP, FM> &w) // auxiliary.c:
     w.reuse = na;
 }
 
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ void rsingular_direction(RWave<NB, NP, FM> &w) // auxiliary.c:357-376
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ void rsingular_direction(RWave<NB, NP, FM, IMG> &w) // auxiliary.c:357-376
 {
     const int lane = lane_id(), s = w.sing;
     double b = (lane < s) ? -w.L[tri(s) + lane] : 0.0;
@@ -716,8 +776,8 @@ __device__ __forceinline__ void rsingular_direction(RWave<NB, NP, FM> &w) // aux
 
 // ratio test of auxiliary.c:277-311 (SOFT_WEIGHTS off): returns the position to drop (or kBig)
 // after stepping lam towards lam*; the removal itself is the caller's single DROP site
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ int rblocking_test(RWave<NB, NP, FM> &w)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ int rblocking_test(RWave<NB, NP, FM, IMG> &w)
 {
     const int lane = lane_id(), na = w.na;
     const double dtol = w.dual_tol;
@@ -744,15 +804,16 @@ __device__ __forceinline__ int rblocking_test(RWave<NB, NP, FM> &w)
 }
 
 // u = -M_k' lam*  (auxiliary.c:46-88): lane <-> component j, working-set order, rows preloaded 8 ahead
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ void rprimal_u(RWave<NB, NP, FM> &w)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ void rprimal_u(RWave<NB, NP, FM, IMG> &w)
 {
     const int lane = lane_id(), na = w.na, n = w.n;
     double uu = 0;
     // per working-set position (in its lane): element offset of its cached row (0 beyond na: a finite row) and
     // its multiplier (0 beyond na: the padding steps subtract 0 * finite, exact)
-    const int soff = (lane < na) ? w.slot * w.ldr : 0;
-    const double lz = (lane < na) ? w.lams : 0.0;
+    const bool in_lds = lane < na && (IMG == 0 || w.slot < w.cache_slots);
+    const int soff = in_lds ? w.slot * w.ldr : 0;
+    const double lz = in_lds ? w.lams : 0.0;
     const double *rc = w.rowc + lane_now();
     constexpr int G = chain_g<NP>();
     chunks_up<G>(na, [&](auto c) __attribute__((always_inline)) {
@@ -766,8 +827,24 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP, FM> &w)
             static_for<G>([&](auto q) __attribute__((always_inline)) { uu = msub<FM>(uu, rv[q], li[q]); });
         }
     });
+    if constexpr (IMG != 0) {
+        // rows of the scratch tier (working sets beyond cache_slots rows): four loads in flight, lane <-> component
+        unsigned long long m2 = __ballot(lane < na && w.slot >= w.cache_slots);
+        while (m2) {
+            double rr[4], ll[4];
+            static_for<4>([&](auto c) __attribute__((always_inline)) {
+                const int i = m2 ? __ffsll((long long)m2) - 1 : 0;
+                ll[c] = m2 ? rl(w.lams, i) : 0.0;
+                const int so = m2 ? (rli(w.slot, i) - w.cache_slots) * w.ldr : 0;
+                if (m2) m2 &= m2 - 1;
+                rr[c] = (lane < n) ? w.rowg[so + lane] : 0.0;
+            });
+            static_for<4>([&](auto c) __attribute__((always_inline)) { uu = msub<FM>(uu, rr[c], ll[c]); });
+        }
+    }
     WSYNC();
     if (lane < n) w.u[lane_now()] = uu;
+    if constexpr (IMG != 0) w.u32[lane_now()] = (lane < n) ? (float)uu : 0.0f;   // the screening scan's operand (64 floats: zero from n on)
     double fv = 0;
     if (w.has_soft) {
         const double sq = (lane < na && (w.wflag & DAQP_SOFT)) ? w.lams * w.lams : 0.0;
@@ -776,6 +853,8 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP, FM> &w)
     }
     fv = fv * w.rho_soft;
     w.soft = fv;
+    // IMG = 1: |u|^2 here, by tree, from the lanes that hold u (the fp64 scan forms it on the way; the screening scan never sees u in fp64)
+    if constexpr (IMG != 0) w.fval = fv + wave_sum(lane < n ? uu * uu : 0.0);
     WSYNC();
 }
 
@@ -783,8 +862,8 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP, FM> &w)
 // the value is materialised in a VGPR at this point of the program (an optimisation barrier for that value only)
 __device__ __forceinline__ void pin_vgpr(double &x) { asm volatile("" : "+v"(x)); }
 
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ int rscan_rows(RWave<NB, NP, FM> &w, int &upper, bool with_fval)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ int rscan_rows(RWave<NB, NP, FM, IMG> &w, int &upper, bool with_fval)
 {
     const int lane = lane_id();
     double bv = 0.0;
@@ -823,7 +902,7 @@ __device__ __forceinline__ int rscan_rows(RWave<NB, NP, FM> &w, int &upper, bool
     double du_[NB], dl_[NB], bn_[NB];
     static_for<NB>([&](auto bb) __attribute__((always_inline)) {
         const int r = bb * 64 + lane_now();
-        du_[bb] = w.rowv[r]; dl_[bb] = w.rowv[(64 * NB) + r]; bn_[bb] = w.rowv[2 * (64 * NB) + r];
+        du_[bb] = w.rowv[r]; dl_[bb] = w.rowv[kRowvStride<NB, IMG> + r]; bn_[bb] = w.rowv[2 * kRowvStride<NB, IMG> + r];
     });
     // selection without branches (a branch lets the compiler sink a whole block's chain into it, serialising the blocks)
     static_for<NB>([&](auto bb) __attribute__((always_inline)) {
@@ -842,8 +921,136 @@ __device__ __forceinline__ int rscan_rows(RWave<NB, NP, FM> &w, int &upper, bool
     return bi;
 }
 
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ void rrefine_active(RWave<NB, NP, FM> &w) // auxiliary.c:498-593
+// IMG = 1: the same pick from the fp32 image in the registers -- when that is provably what the fp64 scan picks.  The rule is the workgroup
+// kernel's (wg_ldp.hip.h wg_scan32 / wscan): with E >= |fl32(M_r . u) - M_r . u| for every row (unit rows, fma chains of NP terms, two
+// rounded operands per term, one final addition: E = (NP + 8) 2^-24 |u|), the most violated row is accepted only if it leads the
+// runner-up by more than 2E, violates its own threshold by more than E and its side is unambiguous by more than 2E; "nothing violated"
+// only if every open row clears its threshold by more than E; anything else -- and any non-finite sum -- is decided by the fp64 pass
+// over the blocked image (rscan_rows_stream).  tools/band_stats.py: 0.04 % of C2's scans end there.  Expects w.fval = soft + |u|^2.
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ int rscan_rows_stream(RWave<NB, NP, FM, IMG> &w, int &upper)
+{
+    // the fp64 scan with the rows streamed from the blocked image: block by block, G pairs in flight per lane
+    const int lane = lane_id();
+    double bv = 0.0;
+    int bi = kBig, bup = 0;
+    const double2 *u2 = reinterpret_cast<const double2 *>(w.u);
+    const int nblk = (w.m + 63) >> 6, np = w.npair;
+    for (int bb = 0; bb < nblk; ++bb) {
+        const int r = bb * 64 + lane;
+        const int lr = (r < w.m) ? lane : 0;
+        typedef typename RWave<NB, NP, FM, IMG>::gv2d_ gv2d_;
+        const DAQP_GLOBAL(gv2d_) *src = w.msrc + ((size_t)bb * np) * 64 + lr;
+        double mu = 0;
+        constexpr int G = 5;
+        for (int t0 = 0; t0 < np; t0 += G) {
+            gv2d_ mm[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { const int t = (t0 + g < np) ? t0 + g : np - 1; mm[g] = src[(size_t)t * 64]; }
+#pragma unroll
+            for (int g = 0; g < G; ++g) if (t0 + g < np) { const double2 uk = u2[t0 + g]; mu = __builtin_fma(mm[g].x, uk.x, mu); mu = __builtin_fma(mm[g].y, uk.y, mu); }
+        }
+        const int sn = (int)((w.rs >> (8 * bb)) & 0xffu);
+        const bool open = r < w.m && !(sn & (DAQP_ACTIVE + DAQP_IMMUTABLE));
+        const int rr = (r < w.m) ? r : 0;
+        const double du = w.rowv[rr], dl = w.rowv[kRowvStride<NB, IMG> + rr], bn = w.rowv[2 * kRowvStride<NB, IMG> + rr];
+        const double cu = du - mu, cl = mu - dl;
+        const bool up = open && cu < bv && cu < bn;
+        const bool lo = open && !up && cl < bv && cl < bn;
+        bv = up ? cu : (lo ? cl : bv);
+        bi = (up || lo) ? r : bi;
+        bup = up ? 1 : (lo ? 0 : bup);
+    }
+    wave_argmin(bv, bi, bup);
+    upper = bup;
+    return bi;
+}
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ int rscan_rows_img(RWave<NB, NP, FM, IMG> &w, int &upper)
+{
+    static_assert(IMG != 0 && FM, "the screening image belongs to the default arithmetic");
+    const int lane = lane_id();
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 *u2 = reinterpret_cast<const f2 *>(w.u32);
+    float ax[NB], ay[NB];
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) { ax[bb] = 0.0f; ay[bb] = 0.0f; });
+    constexpr int NBF = kImgFullBlocks<NB, IMG>, NPH = (NP + 1) / 2, GU = 5;
+    // u pairs five at a time (broadcast reads), then their multiply-adds: a whole-row preload would take as many registers again as a block of the image
+    static_for<(NP + GU - 1) / GU>([&](auto g) __attribute__((always_inline)) {
+        f2 uk[GU];
+        static_for<GU>([&](auto k) __attribute__((always_inline)) { if constexpr (GU * g + k < NP) uk[k] = u2[GU * g + k]; });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<GU>([&](auto k) __attribute__((always_inline)) {
+            constexpr int t = GU * g + k;
+            if constexpr (t < NP)
+                static_for<NBF>([&](auto bb) __attribute__((always_inline)) {
+                    ax[bb] = __builtin_fmaf(w.Mx[bb][t], uk[k].x, ax[bb]);
+                    ay[bb] = __builtin_fmaf(w.My[bb][t], uk[k].y, ay[bb]);
+                });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (IMG == 2) {
+        // the last row block holds at most 32 rows: TWO lanes per row (lane 2k + h: row 64 (NB-1) + k, pairs NPH h .. NPH h + NPH - 1; pairs beyond
+        // the row meet u = 0), half the registers; the halves meet by one DPP swap and move to the row's own lane (lane k) by one permute
+        const f2 *uh = u2 + NPH * (lane & 1);
+        static_for<(NPH + GU - 1) / GU>([&](auto g) __attribute__((always_inline)) {
+            f2 uk[GU];
+            static_for<GU>([&](auto k) __attribute__((always_inline)) { if constexpr (GU * g + k < NPH) uk[k] = uh[GU * g + k]; });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<GU>([&](auto k) __attribute__((always_inline)) {
+                constexpr int t = GU * g + k;
+                if constexpr (t < NPH) {
+                    ax[NB - 1] = __builtin_fmaf(w.Mx[NB - 1][t], uk[k].x, ax[NB - 1]);
+                    ay[NB - 1] = __builtin_fmaf(w.My[NB - 1][t], uk[k].y, ay[NB - 1]);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        const float part = ax[NB - 1] + ay[NB - 1];
+        const float both = part + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(part), 0xB1, 0xF, 0xF, false));
+        ax[NB - 1] = __shfl(both, (2 * lane) & 63);
+        ay[NB - 1] = 0.0f;
+    }
+    const double E = 1.001 * (double)(NP + 8) * 5.9604644775390625e-08 * __builtin_sqrt(w.fval - w.soft) + 1e-300;
+    double s1 = DAQP_INF, s2 = DAQP_INF, minq = DAQP_INF, q1 = DAQP_INF, gap1 = 0.0;
+    int i1 = kBig, up1 = 0, bad = 0;
+    static_for<NB>([&](auto bb) __attribute__((always_inline)) {
+        const int r = bb * 64 + lane;
+        const int rr = bb * 64 + lane_now();
+        const bool open = r < w.m && !(rsense_get(w, bb) & (DAQP_ACTIVE + DAQP_IMMUTABLE));
+        const double du = w.rowv[rr], dl = w.rowv[kRowvStride<NB, IMG> + rr], bn = w.rowv[2 * kRowvStride<NB, IMG> + rr];
+        const double mu = (double)(ax[bb] + ay[bb]);
+        if (open && !(mu - mu == 0.0)) bad = 1;
+        const double cu = du - mu, cl = mu - dl;
+        const bool isup = cu <= cl;
+        const double s = open ? (isup ? cu : cl) : (double)DAQP_INF;
+        const double q = s - bn, gap = isup ? cl - cu : cu - cl;
+        minq = (open && q < minq) ? q : minq;
+        const bool first = s < s1;
+        s2 = first ? s1 : (s < s2 ? s : s2);
+        i1 = first ? r : i1; up1 = first ? (isup ? 1 : 0) : up1; q1 = first ? q : q1; gap1 = first ? gap : gap1;
+        s1 = first ? s : s1;
+    });
+    double bv = s1;
+    int bi = i1, aux = lane;
+    wave_argmin(bv, bi, aux);                       // aux: the lane that holds the winner
+    const double other = (lane == aux && bi != kBig) ? s2 : s1;
+    const double w2 = wave_min(other), wq = wave_min(minq);
+    const bool anybad = __ballot(bad) != 0;
+    if (!anybad) {
+        if (wq >= E) { upper = 0; return kBig; }                                                   // certainly nothing violated
+        if (bi != kBig) {
+            const double wq1 = rl(q1, aux), wgap = rl(gap1, aux);
+            if (bv + 2.0 * E < w2 && wq1 < -E && wgap > 2.0 * E) { upper = rli(up1, aux); return bi; }
+        }
+    }
+    if (kProfile && w.prof && lane == 0) w.prof[15] += 1;      // (probe: scans the image left undecided)
+    return rscan_rows_stream(w, upper);
+}
+
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ void rrefine_active(RWave<NB, NP, FM, IMG> &w) // auxiliary.c:498-593
 {
     const int lane = lane_id(), na = w.na, n = w.n;
     w.reuse = 0;
@@ -874,11 +1081,11 @@ __device__ __forceinline__ void rrefine_active(RWave<NB, NP, FM> &w) // auxiliar
     w.fval = fv;
 }
 
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ void rreset_ws(RWave<NB, NP, FM> &w) { w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0; }
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ void rreset_ws(RWave<NB, NP, FM, IMG> &w) { w.sing = kEmpty; w.na = 0; w.reuse = 0; w.slotmask = 0; }
 
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ unsigned long long active_mask(const RWave<NB, NP, FM> &w, int bb)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ unsigned long long active_mask(const RWave<NB, NP, FM, IMG> &w, int bb)
 {
     return __ballot(bb * 64 + lane_id() < w.m && (rsense_get(w, bb) & DAQP_ACTIVE));
 }
@@ -896,8 +1103,8 @@ enum : int { PC_START_LOOP, PC_ITER, PC_EDIT, PC_ACT_BEGIN, PC_ACT_NEXT, PC_ACT_
 enum : int { AFTER_NEXT_ITER, AFTER_CYCLE_GUARD, AFTER_ACT_POST };   // what follows a completed working-set edit
 enum : int { ACT_THEN_DONE, ACT_THEN_LOOP, ACT_THEN_NEXT_ITER, ACT_THEN_CYCLE_RESET };
 
-template <int NB, int NP, bool FM>
-__device__ __forceinline__ int rrun(RWave<NB, NP, FM> &w, int mode, bool need_activate, int &iterations)
+template <int NB, int NP, bool FM, int IMG>
+__device__ __forceinline__ int rrun(RWave<NB, NP, FM, IMG> &w, int mode, bool need_activate, int &iterations)
 {
     const int lane = lane_id();
     int flag = DAQP_EXIT_ITERLIMIT, it = 1, repaired = 0, stall = 0;
@@ -945,7 +1152,8 @@ __device__ __forceinline__ int rrun(RWave<NB, NP, FM> &w, int mode, bool need_ac
             rprimal_u(w);
             RPROF_ACC(w, 9);
             int upper = 0;
-            int pick = rscan_rows(w, upper, true);
+            int pick;
+            if constexpr (IMG != 0) pick = rscan_rows_img(w, upper); else pick = rscan_rows(w, upper, true);
             RPROF_ACC(w, 10);
             if (w.fval > fbound) { flag = DAQP_EXIT_INFEASIBLE; pc = PC_DONE; break; }
             after_edit = AFTER_CYCLE_GUARD;
@@ -964,9 +1172,14 @@ __device__ __forceinline__ int rrun(RWave<NB, NP, FM> &w, int mode, bool need_ac
                     break;
                 }
                 if (w.na > 0 && dmin < w.pivot_tol) {
+                    if constexpr (IMG != 0) {    // (the refinement step reads its rows lane <-> row from LDS: with rows in the scratch tier the problem goes to the kernel behind)
+                        if (__ballot(lane < w.na && w.slot >= w.cache_slots)) { flag = kRegHandOverFlag; pc = PC_DONE; break; }
+                    }
                     rtrace(w, kTraceRefine);
                     rrefine_active(w);
-                    pick = rscan_rows(w, upper, false);
+                    if constexpr (IMG != 0) {      // (rare: the refined u decides in fp64; u32 is not refreshed)
+                        pick = rscan_rows_stream(w, upper);
+                    } else pick = rscan_rows(w, upper, false);
                     after_edit = AFTER_NEXT_ITER;
                     tl_skip = 1;
                 }
@@ -988,7 +1201,7 @@ __device__ __forceinline__ int rrun(RWave<NB, NP, FM> &w, int mode, bool need_ac
             // the shape that serves n = 64 (cap = n + 1 = 65 rows, one more than there are lanes): an add beyond the rows this kernel can
             // hold leaves the problem as it was stored and flags it for the one-wave generic kernel (reg_kernel.hip.h, launch_ldp).  The
             // re-adds of the pivot cascade below follow a removal and never exceed the level of the add that started it.
-            if (kRegHandOver<NB, NP> && req_add && w.na >= w.max_rows) { flag = kRegHandOverFlag; pc = PC_DONE; break; }
+            if (kRegHandOver<NB, NP, IMG> && req_add && w.na >= w.max_rows) { flag = kRegHandOverFlag; pc = PC_DONE; break; }
             for (;;) {
                 bool settled = false;
                 RPROF_T0(w);

@@ -42,6 +42,7 @@ for prof in (False, True):
         print("    total/iter", round(cyc[:7].sum() / nit), " | csp fwd %d bwd %d (cycles/iter)" % tuple(cyc[11:13] / nit))
         print("    ITER parts/iter: csp %d, blocking %d, primal %d, scan %d | EDIT parts/iter: push %d, drop %d"
               % (cyc[7] / nit, cyc[8] / nit, cyc[9] / nit, cyc[10] / nit, cyc[13] / nit, cyc[14] / nit))
+        print("    scans left undecided by the fp32 image (image kernel only): %d of %d iterations" % (cyc[15], nit))
         print("    per QP: prologue %d, epilogue %d, loop %d cycles" % tuple(p[:, 28:31].mean(axis=0)))
         print("    prologue: to end of row loads %d, +to copy issue %d, +to copy done %d" % (p[:, 26].mean(), p[:, 27].mean(), p[:, 31].mean()))
         print("    epilogue: issue %d, wait copy %d, x+lam in LDS %d, up to final stores %d" % tuple(p[:, 20:24].mean(axis=0)))

@@ -902,7 +902,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     if (b->img32) {
         // rows of the active-row cache in LDS: as many as leave `waves` workgroups per CU (the rest of a working set lives in rowc_g, L2-resident);
         // a workgroup's share of the CU's 160 KB is granted in 512-byte steps
-        int waves = 7;
+        int waves = 8;
         if (const char *e = getenv("DAQP_AMD_IMG_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
         const int budget = (160 * 1024 / waves) / 512 * 512;
         int cache = d.reg_rows;

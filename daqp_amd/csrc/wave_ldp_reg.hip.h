@@ -396,6 +396,11 @@ __device__ __forceinline__ double rforward(RWave<NB, NP, FM, IMG> &w, double x, 
 // every other 16-byte pair of its row and of the new row: half the LDS instructions and a quarter of the VALU work
 // of one lane per row.  Element e < 4*(n/4) goes to chain e%4 in ascending order, the n%4 tail elements go to s0 one
 // after the other, and the result is (s0+s1)+(s2+s3) -- exactly the reference's dot_row.  Row na is the new row itself.
+// rows of the scratch tier fetched per trip to L2 (IMG != 0; rprimal_u, rdots_two_lanes)
+#ifndef DAQP_IMG_TIER2
+#define DAQP_IMG_TIER2 8
+#endif
+constexpr int kTier2 = DAQP_IMG_TIER2;
 template <int NB, int NP, bool FM, int IMG>
 __device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP, FM, IMG> &w, int newslot, const double *Mi)
 {
@@ -437,17 +442,19 @@ __device__ __forceinline__ double rdots_two_lanes(RWave<NB, NP, FM, IMG> &w, int
         unsigned long long m2 = __ballot(lane < na && w.slot >= w.cache_slots);
         const double mine = (lane < n) ? Mi[lane_now()] : 0.0;
         while (m2) {
-            int ii[4];
-            double rr[4];
-            static_for<4>([&](auto c) __attribute__((always_inline)) {
+            int ii[kTier2];
+            double rr[kTier2];
+            static_for<kTier2>([&](auto c) __attribute__((always_inline)) {
                 ii[c] = m2 ? __ffsll((long long)m2) - 1 : -1;
                 if (m2) m2 &= m2 - 1;
                 const int so = (ii[c] >= 0) ? (rli(w.slot, ii[c] & 63) - w.cache_slots) * w.ldr : 0;
-                rr[c] = (lane < n) ? w.rowg[so + lane] : 0.0;
+                rr[c] = (lane < n && ii[c] >= 0) ? w.rowg[so + lane] : 0.0;      // (no row: exactly zero -- the scratch is not initialised)
             });
-            static_for<4>([&](auto c) __attribute__((always_inline)) {
-                const double sum = wave_sum(rr[c] * mine);
-                if (lane == ii[c]) g = sum;
+            static_for<kTier2>([&](auto c) __attribute__((always_inline)) {
+                if (ii[c] >= 0) {               // (wave-uniform)
+                    const double sum = wave_sum(rr[c] * mine);
+                    if (lane == ii[c]) g = sum;
+                }
             });
         }
     }
@@ -831,15 +838,16 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP, FM, IMG> &w)
         // rows of the scratch tier (working sets beyond cache_slots rows): four loads in flight, lane <-> component
         unsigned long long m2 = __ballot(lane < na && w.slot >= w.cache_slots);
         while (m2) {
-            double rr[4], ll[4];
-            static_for<4>([&](auto c) __attribute__((always_inline)) {
-                const int i = m2 ? __ffsll((long long)m2) - 1 : 0;
-                ll[c] = m2 ? rl(w.lams, i) : 0.0;
-                const int so = m2 ? (rli(w.slot, i) - w.cache_slots) * w.ldr : 0;
-                if (m2) m2 &= m2 - 1;
-                rr[c] = (lane < n) ? w.rowg[so + lane] : 0.0;
+            double rr[kTier2], ll[kTier2];
+            static_for<kTier2>([&](auto c) __attribute__((always_inline)) {
+                const bool has = m2 != 0;
+                const int i = has ? __ffsll((long long)m2) - 1 : 0;
+                ll[c] = has ? rl(w.lams, i) : 0.0;
+                const int so = has ? (rli(w.slot, i) - w.cache_slots) * w.ldr : 0;
+                if (has) m2 &= m2 - 1;
+                rr[c] = (lane < n && has) ? w.rowg[so + lane] : 0.0;             // (no row: exactly zero -- the scratch is not initialised)
             });
-            static_for<4>([&](auto c) __attribute__((always_inline)) { uu = msub<FM>(uu, rr[c], ll[c]); });
+            static_for<kTier2>([&](auto c) __attribute__((always_inline)) { uu = msub<FM>(uu, rr[c], ll[c]); });
         }
     }
     WSYNC();

@@ -1,0 +1,168 @@
+"""k_ldp_reg<NB, NP, true, IMG != 0> (csrc/wave_ldp_reg.hip.h, reg_kernel.hip.h): the C2 / C5 iteration with an fp32 IMAGE of M in the registers
+(two waves per SIMD).  The image only SCREENS the feasibility scan -- a verdict is taken from it only when it is provably the fp64 scan's, anything
+else is decided by the fp64 pass over the blocked image --, a row that enters the working set is fetched in fp64, the active-row cache is tiered
+(LDS + an L2-resident scratch), and a working set beyond the rows the kernel holds is handed to the full-register kernel behind it.  Bar: the default
+mode's (north_star): exit flags, iteration counts and active sets identical to the reference algorithm, |x - x_ref|_inf < 1e-9.  Every test forces the
+image kernel onto small batches (DAQP_AMD_IMG_MIN_BATCH=1; by default it serves batches of >= 1536 problems) and walks the switches that size its
+LDS: DAQP_AMD_IMG_ROWS (rows held at all; beyond: hand-over), DAQP_AMD_IMG_CACHE (rows of them in LDS; beyond: scratch tier)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+XTOL = 1e-9
+
+
+@pytest.fixture(autouse=True)
+def image_kernel(monkeypatch):
+    monkeypatch.delenv("DAQP_AMD_EXACT", raising=False)
+    monkeypatch.setenv("DAQP_AMD_NO_RECHECK", "1")      # the kernel's own verdicts
+    monkeypatch.setenv("DAQP_AMD_IMG_MIN_BATCH", "1")
+    for k in ("DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_NO_IMG32"):
+        monkeypatch.delenv(k, raising=False)
+
+
+def tier(monkeypatch, rows, cache, waves=None):
+    if rows:
+        monkeypatch.setenv("DAQP_AMD_IMG_ROWS", str(rows))
+    if cache:
+        monkeypatch.setenv("DAQP_AMD_IMG_CACHE", str(cache))
+    if waves:
+        monkeypatch.setenv("DAQP_AMD_IMG_WAVES", str(waves))
+
+
+def same(g, ref):
+    assert np.array_equal(g["exitflag"], ref[3])
+    assert np.array_equal(g["iter"], ref[4])
+    assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1]))
+    assert np.abs(g["x"] - ref[0]).max() < XTOL
+
+
+@pytest.mark.parametrize("rows,cache,waves", [(0, 0, 0), (0, 0, 5), (44, 6, 0), (30, 10, 0), (12, 3, 0), (2, 1, 0)])
+def test_image_kernel_c2(oracle, gpu_lib, monkeypatch, rows, cache, waves):
+    """C2 draws: the shipped carve-up (8 workgroups per CU), everything in LDS (5 per CU), most of every working set in the scratch tier, and
+    caps that hand over a third / nearly all / all of the batch to the full-register kernel in mid-solve"""
+    import daqp_amd
+    tier(monkeypatch, rows, cache, waves)
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    q = O.generate_batch(1024, n, m, ms, na, seed, start=700000)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    same(g, ref)
+    monkeypatch.setenv("DAQP_AMD_NO_IMG32", "1")
+    g0 = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert np.array_equal(g0["iter"], g["iter"]) and np.abs(g0["x"] - g["x"]).max() < 1e-12    # (the full-register kernel on the same problems)
+
+
+@pytest.mark.parametrize("shape", [(17, 129, 0, 6), (33, 140, 0, 12), (41, 160, 0, 15), (50, 129, 0, 20), (49, 151, 0, 24), (50, 160, 0, 35), (26, 133, 0, 25)])
+@pytest.mark.parametrize("cache", [0, 4])
+def test_image_kernel_shapes(oracle, gpu_lib, monkeypatch, shape, cache):
+    """every shape the (3, 25) image serves has three row blocks with at most 32 rows in the last one (129 <= m <= 160) and 17 <= n <= 50:
+    odd n (the last pair's partner is padding), the fewest and the most rows of the split block, working sets up to n - 1 rows"""
+    import daqp_amd
+    tier(monkeypatch, 0, cache)
+    n, m, ms, na = shape
+    q = O.generate_batch(96, n, m, ms, na, 4100 + n + m)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    same(g, ref)
+
+
+@pytest.mark.parametrize("rows,cache", [(0, 0), (40, 5)])
+def test_image_kernel_warm_sequences(oracle, gpu_lib, monkeypatch, rows, cache):
+    """UPDATE_v and UPDATE_d steps fused into the solve launch (the image is rounded from the fp64 rows that also form d = b s + M v), every step
+    against the oracle's own update + solve on a kept workspace"""
+    import daqp_amd
+    tier(monkeypatch, rows, cache)
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    S = 256
+    q = O.generate_batch(S, n, m, ms, na, seed, start=710000)
+    bm = daqp_amd.BatchModel(S, n, m, ms)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=0)
+    bm.solve()
+    mods = []
+    for k in range(S):
+        md = oracle.model(n, m, ms)
+        md.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        md.solve()
+        mods.append(md)
+    rng = np.random.default_rng(11)
+    f, bu, bl = q["f"].copy(), q["bupper"].copy(), q["blower"].copy()
+    for t in range(6):
+        if t % 3 != 2:
+            f = f + 0.05 * rng.standard_normal(f.shape)
+            bm.update(f=f)
+        else:
+            sh = 0.02 * rng.standard_normal(bu.shape)
+            bu, bl = bu + sh, bl + sh
+            bm.update(bupper=bu, blower=bl)
+        g = bm.solve()
+        rx, rlam, rfl, rit = np.zeros((S, n)), np.zeros((S, m)), np.zeros(S, np.int32), np.zeros(S, np.int32)
+        for k, md in enumerate(mods):
+            if t % 3 != 2:
+                md.update(daqp_amd.UPDATE_v, f=f[k])
+            else:
+                md.update(daqp_amd.UPDATE_d, bupper=bu[k], blower=bl[k])
+            r = md.solve()
+            rx[k], rlam[k], rfl[k], rit[k] = r[0], r[1], r[3], r[4]
+        same(g, (rx, rlam, None, rfl, rit))
+    bm.close()
+
+
+@pytest.mark.parametrize("cache", [0, 5])
+def test_image_kernel_degenerate_cases(oracle, gpu_lib, monkeypatch, cache):
+    """near-duplicate rows (relative distance 1e-13 ... 1e-2), equalities (some dependent), soft rows on the image kernel's shapes: the pivot
+    cascade, singular directions, the refinement step (which hands a problem over when rows sit in the scratch tier) and the refactor repair;
+    exit flag and iterations identical, x to 1e-9, the multipliers' combined effect to 1e-7 (an ill-determined pair may share its multiplier
+    differently between two arithmetics)"""
+    import daqp_amd
+    tier(monkeypatch, 0, cache)
+    mism, marks = [], set()
+    for trial in range(60):
+        rng = np.random.default_rng([299, trial])
+        eps = 10.0 ** rng.uniform(-13, -2)
+        n = int(rng.integers(17, 51)); m = int(rng.integers(129, 161)); ms = 0
+        na = int(rng.integers(n // 4, n - 4))
+        q = O.generate_nasty(n, m, ms, na, eps, rng, n_dup=int(rng.integers(0, 6)), n_eq=int(rng.integers(0, 4)),
+                             n_soft=int(rng.integers(0, 4)), dep_eq=bool(rng.integers(0, 2)))
+        ns = int((q["sense"] & 8).astype(bool).sum())
+        if n + ns + 1 > 64:
+            continue
+        bm = daqp_amd.BatchModel(1, n, m, ms, ns_max=ns)
+        bm.enable_trace(1 << 15)
+        bm.setup(q["H"][None], q["f"][None], q["A"][None], q["bupper"][None], q["blower"][None], q["sense"][None], init_mask=daqp_amd.UPDATE_unconstrained)
+        g = bm.solve()
+        tr = bm.read_trace(marks=True)[0]
+        marks |= {int(e) for e in tr if abs(int(e)) >= daqp_amd.api.TRACE_MARK}
+        bm.close()
+        md = oracle.model(n, m, ms, ns)         # (the same entry: setup with the unconstrained shortcut, no equality elimination)
+        sflag = md.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"], init_mask=daqp_amd.UPDATE_unconstrained)
+        r = md.solve() if sflag >= 0 else (None, None, 0.0, sflag, 0)
+        flag, it = int(g["exitflag"][0]), int(g["iter"][0])
+        ok = flag == r[3] and it == r[4]
+        if ok and flag > 0:
+            ok = np.abs(g["x"][0] - r[0]).max() < XTOL and np.abs(q["A"].T @ (g["lam"][0] - r[1])).max() < 1e-7
+        if not ok:
+            mism.append((trial, n, m, ns, flag, r[3], it, r[4]))
+    assert not mism, mism[:10]
+    assert len(marks) >= 1, "no degenerate branch was taken: the generator parameters no longer reach them"
+
+
+def test_image_kernel_limits_and_failures(oracle, gpu_lib, monkeypatch):
+    """iteration limit (-4 with iter = the limit), an infeasible problem (-1 with the reference's iteration count: no second pass here), crossed
+    bounds (-1 from the setup, nothing solved), next to ordinary problems of the same batch"""
+    import daqp_amd
+    n, m, ms, na, seed, _ = O.CONFIGS["C2"]
+    q = O.generate_batch(64, n, m, ms, na, seed, start=720000)
+    q["bupper"][3, 7], q["blower"][3, 7] = -1.0, 1.0                       # crossed
+    q["blower"][5, :] = q["bupper"][5, :] - 1e-3                            # a box nobody fits in: infeasible
+    q["bupper"][5, :10] = -50.0; q["blower"][5, :10] = -51.0
+    st = O.default_settings()
+    st.iter_limit = 30
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms, settings=st)
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms, iter_limit=30)
+    assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4])
+    assert g["exitflag"][3] == -1 and (g["exitflag"] == -4).any() and (g["exitflag"] == 1).any()
+    okp = g["exitflag"] == 1
+    assert np.abs(g["x"][okp] - ref[0][okp]).max() < XTOL

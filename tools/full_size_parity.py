@@ -6,6 +6,8 @@ usage: python tools/full_size_parity.py [C2,C3,C4,C5] [scale] [exact]     (scale
 arithmetic mode against the reference's STRICT build (-O2 -ffp-contract=off), x and lam compared bit for bit as well)"""
 import os, sys, time, json
 import multiprocessing as mp
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):      # the generator pool forks one process per core: a threaded BLAS inside each
+    os.environ.setdefault(_v, "1")                                              # of them (n = 200: QR of every problem) oversubscribes the box a hundredfold
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as O

@@ -132,6 +132,10 @@ struct DAQPBatch {
     bool img32 = false;          // default arithmetic: the solve launch is k_ldp_reg<NB, NP, true, 1> -- an fp32 image of M in the registers, two waves per
                                  // SIMD, at most d.reg_rows working-set rows -- with k_ldp_reg<NB, NP, true, 0> right behind it for the problems it flags
     size_t lds_img = 0;          // ... and the image kernel's LDS
+    // the carve-up of a WARM launch (daqp_update_ldp(UPDATE_v|UPDATE_d) fused into the solve: an MPC step starts from ~20 rows and moves a few): fewer
+    // rows held at all, so that at the same eight workgroups per CU more of them sit in LDS (the launch argument carries rows | cache, see k_ldp_reg)
+    int img_rows_warm = 0, img_cache_warm = 0;
+    size_t lds_img_warm = 0;
     size_t lds_wg = 0;
     double *wide_u = nullptr, *wide_l = nullptr;   // daqp_batch_setup_shared: +-1e30 bounds of the one factorisation
     int *structural = nullptr, *shared_flag = nullptr;
@@ -356,8 +360,10 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
             // the image kernel first (two waves per SIMD); the problems whose working set outgrows its LDS are flagged and solved, from the
             // state they were stored in, by the full-register kernel right behind (mode | 4: flagged problems only)
             ldp_reg_kernel_t ki = pick_ldp_reg_img(b);
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_img));
-            hipLaunchKernelGGL(ki, dim3(b->d.N), dim3(64), b->lds_img, b->stream, (const BatchDev *)b->d_dev, mode);
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(b->lds_img > b->lds_img_warm ? b->lds_img : b->lds_img_warm)));
+            const bool warm = (mode & 3) == 2 && b->img_rows_warm > 0;
+            const size_t lds = warm ? b->lds_img_warm : b->lds_img;
+            hipLaunchKernelGGL(ki, dim3(b->d.N), dim3(64), lds, b->stream, (const BatchDev *)b->d_dev, warm ? (mode | b->img_rows_warm << 16 | b->img_cache_warm << 22) : mode);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode | 4);
             HIPCHK(hipGetLastError());
@@ -646,6 +652,9 @@ int redo_one_exact(DAQPBatch *b)
     if (!rc && b->reg_pending) rc = resolve_setup(b);      // (the count of singular Hessians of this pass: none, the first pass had none)
     d.exact_setup = 0;
     b->rechecked = 1;
+    // batch_setup armed the second pass again (fresh = true): this WAS the second pass, and the solve it belongs to is over -- a further
+    // daqp_solve on this workspace continues from the stored working set, as the reference does, instead of re-running setup + solve
+    b->fresh = false;
     return rc;
 }
 int recheck_infeasible(DAQPBatch *b)
@@ -768,7 +777,7 @@ std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
                                   "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M", "DAQP_AMD_NO_BLK_SETUP",
-                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE"};
+                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WARM_ROWS"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -887,7 +896,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     // over, as an fp32 IMAGE of M at two waves per SIMD (reg_kernel.hip.h, IMG = 1).  Its LDS holds img_rows working-set rows (C2: the peak is
     // 27 rows on average, above 40 on 1.3 % of the problems -- those are handed to the full-register kernel behind it)
     if (b->NB == 3 && b->NP == 25 && d.nblk == 3 && m <= 160 && cap <= 64 && !b->reg_handover && !getenv("DAQP_AMD_NO_IMG32")) {
-        int min_batch = 1536, rows = 44;
+        int min_batch = 1536, rows = 42;
         if (const char *e = getenv("DAQP_AMD_IMG_MIN_BATCH")) min_batch = atoi(e);
         if (const char *e = getenv("DAQP_AMD_IMG_ROWS")) { const int v = atoi(e); if (v >= 2 && v <= 64) rows = v; }
         if (N >= min_batch && ms == 0) { b->img32 = true; d.reg_rows = rows < cap ? rows : cap; }     // (simple bounds: the Gram column's start columns read their rows from LDS)
@@ -910,6 +919,16 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         if (const char *e = getenv("DAQP_AMD_IMG_CACHE")) { const int v = atoi(e); if (v >= 1) cache = v < d.reg_rows ? v : d.reg_rows; }
         d.img_cache = cache;
         b->lds_img = (size_t)reg_img_lds_bytes(b->NB, 2, n, m, d.reg_rows, cache, d.ldrc);
+        if (!getenv("DAQP_AMD_IMG_ROWS") && !getenv("DAQP_AMD_IMG_CACHE")) {      // (the tests' overrides apply to every launch)
+            int wrows = 36;
+            if (const char *e = getenv("DAQP_AMD_IMG_WARM_ROWS")) wrows = atoi(e);
+            if (wrows >= 2 && wrows < d.reg_rows) {
+                int wc = wrows;
+                while (wc > 2 && reg_img_lds_bytes(b->NB, 2, n, m, wrows, wc, d.ldrc) > budget) --wc;
+                b->img_rows_warm = wrows; b->img_cache_warm = wc;
+                b->lds_img_warm = (size_t)reg_img_lds_bytes(b->NB, 2, n, m, wrows, wc, d.ldrc);
+            }
+        }
     }
     if (b->NB == 0 && cap > 64 && cap <= 256 && !getenv("DAQP_AMD_NO_WG")) {     // (beyond 256 rows: the one-wave kernel with eight chunks, everything large in HBM scratch)
         int W = d.nblk < 4 ? 4 : (d.nblk > kWgMaxWaves ? kWgMaxWaves : d.nblk);
@@ -957,7 +976,11 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &d.WS, Nn * cap);
     rc |= dev_alloc(b, &d.qs, Nn);
     if (b->spill) rc |= dev_alloc(b, &d.rowc_g, Nn * cap * d.ldr);
-    if (b->img32 && d.img_cache < d.reg_rows) rc |= dev_alloc(b, &d.rowc_g, Nn * (size_t)((d.reg_rows - d.img_cache) * d.ldrc));
+    if (b->img32) {
+        int t2 = d.reg_rows - d.img_cache;
+        if (b->img_rows_warm - b->img_cache_warm > t2) t2 = b->img_rows_warm - b->img_cache_warm;
+        if (t2 > 0) rc |= dev_alloc(b, &d.rowc_g, Nn * (size_t)(t2 * d.ldrc));
+    }
     if (b->setup_spill) rc |= dev_alloc(b, &d.setup_g, Nn * 2 * (size_t)round_up(d.rtri, 2));
     // fp32 image of M for the workgroup kernel's screening scan (generic setup kernel only: it is the one that writes it)
     if (b->use_wg && !b->fast_setup && !getenv("DAQP_AMD_NO_SCAN32")) {
@@ -1497,7 +1520,10 @@ int daqp_batch_update(DAQPBatch *b, int mask, const DAQPBatchProblem *p)
     HIPCHK(hipSetDevice(b->device));
     if (resolve_setup(b)) return DAQP_EXIT_UNSUPPORTED;
     b->fresh = false;
-    b->exact_sticky = (mask & DAQP_UPDATE_sense) != 0 && p->sense == nullptr && (mask & (DAQP_UPDATE_Rinv | DAQP_UPDATE_M)) == 0;   // (see the member's comment)
+    // (see the member's comment.  A call that updates nothing on this path -- mask 0, or only the eliminate / unconstrained / hierarchy bits --
+    //  leaves the flag as it is: the workspace is still in the state the earlier sense update put it in)
+    if (mask & (DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense))
+        b->exact_sticky = (mask & DAQP_UPDATE_sense) != 0 && p->sense == nullptr && (mask & (DAQP_UPDATE_Rinv | DAQP_UPDATE_M)) == 0;
     const int full = DAQP_UPDATE_Rinv | DAQP_UPDATE_M | DAQP_UPDATE_v | DAQP_UPDATE_d | DAQP_UPDATE_sense;
     if ((mask & full) == full) {
         DAQPBatchProblem pp = *p;   // unchanged arrays may be omitted: reuse what the batch already has

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     // for mask within UPDATE_v|UPDATE_d applied here, then daqp_solve -- the rows of M are in registers anyway, so the
     // warm path of an MPC step reads them from HBM once instead of twice (k_update + solve)
     // | 4: only the problems an IMG = 1 launch in front flagged in `fallback` (more working-set rows than its LDS holds)
-    const int upd = (mode_in & 3) == 2 ? (mode_in >> 4) : 0;
+    const int upd = (mode_in & 3) == 2 ? ((mode_in >> 4) & 0xfff) : 0;
     const int mode = (mode_in & 3) == 2 ? 0 : (mode_in & 3);
     // The descriptor is read through a pointer (scalar loads at the point of use) instead of being a
     // by-value kernel argument: ~60 SGPRs of pointers would otherwise stay live across the whole state
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         if (b.fallback != nullptr && lane == 0) as_global(b.fallback)[q] = 0;
     }
     // rows of the working set the LDS carve-up is sized for: the problem's own cap, or (IMG = 1) what the host chose to keep two waves per SIMD
-    const int lds_rows = IMG ? __builtin_amdgcn_readfirstlane(b.reg_rows) : cap;
+    // (IMG != 0: a launch may bring its own carve-up -- rows << 16 | cache << 22 in the launch argument, see launch_ldp: warm launches hold fewer rows)
+    const int lds_rows = IMG ? (((mode_in >> 16) & 63) ? ((mode_in >> 16) & 63) : __builtin_amdgcn_readfirstlane(b.reg_rows)) : cap;
     DAQP_GLOBAL(QState) *qs = as_global(b.qs + q);   // (global pointers throughout: see DAQP_GLOBAL in wave_ldp.hip.h)
     if (mode == 1) {   // an activation launch looks at the record first: almost every problem leaves here, without touching M
         if (__builtin_amdgcn_readfirstlane(qs->setup_flag) < 0 || !__builtin_amdgcn_readfirstlane(qs->need_activate)) return;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     DAQP_GLOBAL(int) *gsense = as_global(b.sense + (size_t)q * m);
     DAQP_GLOBAL(double) *gv = as_global(b.vecs + (size_t)q * 5 * cap);
     DAQP_GLOBAL(int) *gws = as_global(b.WS + (size_t)q * cap);
-    const int img_cache = IMG ? __builtin_amdgcn_readfirstlane(b.img_cache) : 0;
+    const int img_cache = IMG ? (((mode_in >> 16) & 63) ? ((mode_in >> 22) & 63) : __builtin_amdgcn_readfirstlane(b.img_cache)) : 0;
     const int rowc_size = IMG ? reg_img_stage_size(n, m, lds_rows, img_cache, b.ldrc) : reg_lds_rowc_size(n, m, lds_rows, b.ldrc);
     RWave<NB, NP, FM, IMG> w;
     w.rowc = smem + (IMG ? o::L + round_up(lds_rows * (lds_rows + 1) / 2, 2) : reg_lds_rowc(NB, lds_rows, IMG));

@@ -137,8 +137,11 @@ typedef struct DAQPWorkspace {
 /* ------------------------------------------------------------------ */
 /* (1) single-problem drop-in entry points                             */
 /* ------------------------------------------------------------------ */
-/* LATENCY: each of these is a batch of ONE on the GPU -- a few launches and small copies, 0.2-0.4 ms per daqp_quadprog call where
-   the reference needs ~0.02 ms on one core for a small problem.  They exist so that bindings written against the reference's api.h
+/* LATENCY: each of these is a batch of ONE on the GPU -- two kernels and mapped result slabs: daqp_quadprog 0.13 ms (n = 20, m = 40) to
+   0.25 ms (n = 50, m = 150), daqp_update_ldp(UPDATE_v) + daqp_solve on a kept workspace 0.05-0.06 ms (profiles/r05zzzz_latency_one.txt), where
+   the reference needs ~0.02 ms on one core for a small problem.
+   STALE MIRRORS: daqp_update_ldp(UPDATE_v | UPDATE_d) on a kept workspace is checked on the host and applied by the NEXT daqp_solve's launch; until
+   that solve returns, work->v, work->dupper and work->dlower (read-only host copies for bindings that look at them) still hold the previous LDP.  They exist so that bindings written against the reference's api.h
    link and behave; a caller that loops over many QPs of one shape should hand them over at once: section (2), daqp_quadprog_batch. */
 void daqp_quadprog(DAQPResult *res, DAQPProblem *qp, DAQPSettings *settings); /* api.c:62-79 */
 void daqp_solve(DAQPResult *res, DAQPWorkspace *work);                         /* api.c:8-59 */

@@ -837,3 +837,32 @@ def test_multi_device_batch_takes_device_arrays_per_shard(gpu_lib, monkeypatch):
     assert L.daqp_batch_multi_shards(h2) == min(L.daqp_amd_device_count(), 5)
     L.daqp_batch_free_multi(h2)
     assert daqp_amd.solve_batch_multi(q["H"][:5], q["f"][:5], q["A"][:5], q["bupper"][:5], q["blower"][:5], None, ms=ms, devices=[])["exitflag"].tolist() == [1] * 5
+
+
+def test_second_solve_after_an_infeasible_first_solve(oracle, gpu_lib, monkeypatch):
+    """a kept single-problem workspace whose FIRST solve ends INFEASIBLE is re-derived in the reference's arithmetic
+    (the default mode's second pass, on the one-problem path inside the result collection); that pass must not leave the workspace armed
+    for another one: a second daqp_solve without an update continues from the stored working set -- the iteration count of the
+    reference's second daqp_solve -- instead of repeating setup + solve (which would report the first solve's count again)."""
+    import daqp_amd
+    monkeypatch.delenv("DAQP_AMD_EXACT", raising=False)
+    monkeypatch.delenv("DAQP_AMD_NO_RECHECK", raising=False)
+    rng = np.random.default_rng(77)
+    n, mA = 6, 14
+    A = rng.standard_normal((mA, n))
+    A[7] = -A[2]                                            # rows 2 and 7: a.x <= -1 and -a.x <= -1
+    bu = np.full(mA, 5.0); bl = np.full(mA, -5.0)
+    bu[2], bu[7] = -1.0, -1.0
+    bl[2], bl[7] = -1e30, -1e30
+    H = np.eye(n) + 0.1 * np.ones((n, n)); f = rng.standard_normal(n)
+    md = oracle.model(n, mA, 0)
+    md.setup(H, f, A, bu, bl, None)
+    r1, r2 = md.solve(), md.solve()
+    assert r1[3] == -1 and r2[3] == -1
+    d = daqp_amd.Model()
+    flag, _ = d.setup(H, f, A, bu, bl, np.zeros(mA, np.int32))
+    assert flag >= 0
+    _, _, e1, i1 = d.solve()
+    _, _, e2, i2 = d.solve()
+    assert (e1, i1["iterations"]) == (r1[3], r1[4])
+    assert (e2, i2["iterations"]) == (r2[3], r2[4]), ((e2, i2["iterations"]), (r2[3], r2[4]))

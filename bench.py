@@ -337,22 +337,28 @@ class Runner:
             return bm.solve(out="torch")
 
         if warm:
-            # the random walk of f over every pass (warm-up included), drawn up front; a pass = T consecutive warm steps
+            # T = 10 steps f <- f + 0.05 N(0,I) from the cold solve.  A pass = those T warm steps; further passes walk the SAME path
+            # back (fs[T-2], ..., fs[0], the original f) and forth again -- every step one increment away from the previous one -- exactly as the CPU
+            # leg does (oracle/ref_batch.c::ref_warm_run).  (Up to round 5 the walk went on for (warmup + steps) x T steps: after a hundred
+            # increments f has drifted so far that 43 of 50 rows are active on average -- another workload than the one the survey names and the CPU
+            # leg times; tools/c5_walk.py shows it.)
             gen = torch.Generator(device=q["f"].device)
             gen.manual_seed(45 + self.rank)
-            P = (warmup + steps) * T
-            fs = torch.empty((P,) + tuple(q["f"].shape), dtype=torch.float64, device=q["f"].device)
+            fs = torch.empty((T,) + tuple(q["f"].shape), dtype=torch.float64, device=q["f"].device)
             cur = q["f"]
-            for t in range(P):
+            for t in range(T):
                 cur = cur + 0.05 * torch.randn(tuple(q["f"].shape), generator=gen, dtype=torch.float64, device=q["f"].device)
                 fs[t] = cur
+            f0 = q["f"].clone()
             cursor = [0]
 
             def step():
                 res = None
-                for _ in range(T):
-                    bm.update(f=fs[cursor[0]])
-                    cursor[0] += 1
+                back = cursor[0] & 1
+                cursor[0] += 1
+                for j in range(T):
+                    t = (T - 2 - j) if back else j
+                    bm.update(f=fs[t] if t >= 0 else f0)
                     res = bm.solve(out="torch")
                 return res
 
@@ -436,7 +442,7 @@ class Runner:
             "workload": f"{cfg}: {N} {c['what']} per GPU" + (f" (ONE batch of {info['N_total']}, QP k on rank k mod {self.world})" if info["N_total"] else "")
                         + f", n={n} m={m} ms={ms}, {c['na']} active at the optimum, kappa=100 (reference generate_test_QP restated in torch on the GPU, "
                         + "daqp_amd/synthetic.py: same family as SURVEY 8d's numpy default_rng([seed, k]) stream, not the same draws), "
-                        + ("setup_daqp + cold solve untimed, then per step T=10 x {daqp_update_ldp(UPDATE_v) + daqp_solve}" if warm else
+                        + ("setup_daqp + cold solve untimed, then per step T=10 x {daqp_update_ldp(UPDATE_v) + daqp_solve} along the first 10 steps of the walk of f, forth and back (the CPU leg's walk)" if warm else
                            "daqp_quadprog semantics: setup + solve per step") + ", inputs and outputs resident in HBM",
             "batch_per_gpu": N, "mean_iterations": float(iters.mean()),
             "roofline": roof,

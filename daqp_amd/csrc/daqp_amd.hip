@@ -136,6 +136,10 @@ struct DAQPBatch {
     // rows held at all, so that at the same eight workgroups per CU more of them sit in LDS (the launch argument carries rows | cache, see k_ldp_reg)
     int img_rows_warm = 0, img_cache_warm = 0;
     size_t lds_img_warm = 0;
+    // hand-overs of the last solve launch, counted on the device and copied to pinned memory without waiting: when most of a batch goes to the
+    // full-register kernel anyway (working sets beyond what the image kernel holds), the next launches go there directly; every 16th tries again
+    int *img_ho_pin = nullptr;
+    unsigned img_skipped = 0;
     size_t lds_wg = 0;
     double *wide_u = nullptr, *wide_l = nullptr;   // daqp_batch_setup_shared: +-1e30 bounds of the one factorisation
     int *structural = nullptr, *shared_flag = nullptr;
@@ -356,17 +360,21 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         (void)descriptor_changed;
         if (push_descriptor(b)) return DAQP_EXIT_UNSUPPORTED;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
-        if (b->img32 && !exact_kernels) {
+        bool use_img = b->img32 && !exact_kernels;
+        if (use_img && b->img_ho_pin && (long long)*b->img_ho_pin * 2 > b->d.N && (++b->img_skipped & 15) != 0) use_img = false;
+        if (use_img) {
             // the image kernel first (two waves per SIMD); the problems whose working set outgrows its LDS are flagged and solved, from the
             // state they were stored in, by the full-register kernel right behind (mode | 4: flagged problems only)
             ldp_reg_kernel_t ki = pick_ldp_reg_img(b);
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(b->lds_img > b->lds_img_warm ? b->lds_img : b->lds_img_warm)));
             const bool warm = (mode & 3) == 2 && b->img_rows_warm > 0;
             const size_t lds = warm ? b->lds_img_warm : b->lds_img;
+            if (b->d.img_ho) HIPCHK(hipMemsetAsync(b->d.img_ho, 0, sizeof(int), b->stream));
             hipLaunchKernelGGL(ki, dim3(b->d.N), dim3(64), lds, b->stream, (const BatchDev *)b->d_dev, warm ? (mode | b->img_rows_warm << 16 | b->img_cache_warm << 22) : mode);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode | 4);
             HIPCHK(hipGetLastError());
+            if (b->d.img_ho && (mode & 3) != 1) HIPCHK(hipMemcpyAsync(b->img_ho_pin, b->d.img_ho, sizeof(int), hipMemcpyDeviceToHost, b->stream));
             return 0;
         }
         hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode);
@@ -788,6 +796,7 @@ void destroy_batch(DAQPBatch *b)
     (void)hipStreamSynchronize(b->stream);
     if (b->redo) { b->redo->stream = nullptr; destroy_batch(b->redo); b->redo = nullptr; }
     if (b->pin_redo) (void)hipHostFree(b->pin_redo);
+    if (b->img_ho_pin) (void)hipHostFree(b->img_ho_pin);
     for (void *p : b->owned) (void)hipFree(p);
     if (b->pin_in) (void)hipHostFree(b->pin_in);
     if (b->pin_out) (void)hipHostFree(b->pin_out);
@@ -920,7 +929,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.img_cache = cache;
         b->lds_img = (size_t)reg_img_lds_bytes(b->NB, 2, n, m, d.reg_rows, cache, d.ldrc);
         if (!getenv("DAQP_AMD_IMG_ROWS") && !getenv("DAQP_AMD_IMG_CACHE")) {      // (the tests' overrides apply to every launch)
-            int wrows = 36;
+            int wrows = 40;
             if (const char *e = getenv("DAQP_AMD_IMG_WARM_ROWS")) wrows = atoi(e);
             if (wrows >= 2 && wrows < d.reg_rows) {
                 int wc = wrows;
@@ -1060,6 +1069,11 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         rc |= dev_alloc(b, &d.wg_rowcT, (size_t)b->wg_grid * n * d.wg_capT);
         rc |= dev_alloc(b, &d.fallback, Nn);
         if (!rc && hipMemset(d.fallback, 0, Nn * sizeof(int)) != hipSuccess) rc = 1;
+    }
+    if (b->img32 && !rc) {
+        rc |= dev_alloc(b, &d.img_ho, 1);
+        if (!rc && hipHostMalloc(reinterpret_cast<void **>(&b->img_ho_pin), sizeof(int), hipHostMallocDefault) != hipSuccess) rc = 1;
+        if (!rc) *b->img_ho_pin = 0;
     }
     if ((b->reg_handover || b->img32) && !rc) {
         rc |= dev_alloc(b, &d.fallback, Nn);

@@ -207,6 +207,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         w.cache_slots = img_cache;
         w.rowg = as_global(b.rowc_g + (size_t)q * (size_t)((lds_rows > img_cache ? lds_rows - img_cache : 0) * b.ldrc));
         if (upd) {
+            // A warm launch looks at the stored working set FIRST: one that is within two rows of what this launch holds will outgrow it with the
+            // next constraints (an MPC step moves a few rows), so it goes to the full-register kernel now -- before 60 KB of M have been streamed
+            // for nothing.  (What a long drift of f does to C5's working sets -- 43 of 50 rows active after a hundred steps -- is in tools/c5_walk.py:
+            // such batches run at the full-register kernel's rate, not below it.)
+            copy_wait();
+            if (b.fallback != nullptr && __builtin_amdgcn_readfirstlane(rec_na) + 2 > lds_rows) {
+                if (lane == 0) { as_global(b.fallback)[q] = 1; if (b.img_ho) atomicAdd(b.img_ho, 1); }
+                return;
+            }
             double *vv = smem + o::u, *fl = smem + o::pend_lam;
             for (int e = lane; e < round_up(n > 64 ? n : 64, 2) + 2; e += 64) vv[e] = 0;
             if (upd & DAQP_UPDATE_v) {
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         // (no `fallback` array: nobody stands behind this launch -- the kernel keeps every problem, up to its 64 lanes)
         w.max_rows = IMG ? lds_rows : ((b.fallback != nullptr) ? b.reg_rows : 64);
         if (w.na > w.max_rows) {   // stored by the kernel behind this one with more rows than this one holds: its problem again
-            if (lane == 0 && b.fallback != nullptr) as_global(b.fallback)[q] = 1;
+            if (lane == 0 && b.fallback != nullptr) { as_global(b.fallback)[q] = 1; if (IMG != 0 && b.img_ho) atomicAdd(b.img_ho, 1); }
             copy_wait();
             return;
         }
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         // nothing of this problem has been stored yet (results, iterate, sense, record: all below): the generic kernel starts from the same state
         if (flag == kRegHandOverFlag) {
             if (b.fallback != nullptr) {
-                if (lane == 0) as_global(b.fallback)[q] = 1;
+                if (lane == 0) { as_global(b.fallback)[q] = 1; if (IMG != 0 && b.img_ho) atomicAdd(b.img_ho, 1); }
                 copy_wait();
                 return;
             }

@@ -484,7 +484,7 @@ class Runner:
                 if BOUND[cfg] == "issue":
                     roof["achieved"] = att * 1e-3 * VALU_PEAK_GCYC / max(t_ldp, 1e-12)
                     roof["frac"] = roof["achieved"] / VALU_PEAK_GCYC
-            if prof.get("setup") and not warm and "hbm_read_bytes" in prof["setup"]:
+            if prof.get("setup") and not warm and "hbm_read_bytes" in prof["setup"] and not prof.get("setup_launches"):
                 # the setup launch (QP -> LDP) on the HBM roof: the bytes it moved through the memory side (counter pass of this build:
                 # FETCH_SIZE x 2 + WRITE_SIZE) over its duration (HIP events, this run); next to it what it MUST move -- the inputs once in,
                 # the LDP once out -- and the issue-side counters that say what it waits for
@@ -496,6 +496,31 @@ class Runner:
                                  "frac": moved / max(t_setup, 1e-12) / 1e9 / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_launch": must, "algorithmic_frac": must / max(t_setup, 1e-12) / 1e9 / HBM_PEAK_GBS,
                                  "read_bytes": st["hbm_read_bytes"], "written_bytes": st["hbm_written_bytes"], "issue": st.get("issue")}
+            if prof.get("setup_launches") and not warm:
+                # a setup of several launches (C4: factorisation, general rows, the rest): ONE record per kernel -- that kernel's counter bytes over
+                # that kernel's own average duration (both from the committed round profile: rocprofv3 --pmc passes and --kernel-trace --stats of the
+                # same build; this run's HIP events only see the whole setup: `setup_ms_this_run`), and for the two matrix-core kernels the
+                # algorithmic flops against the fp64 matrix peak (MI355X_MICROARCH.md: 78.6 TFLOP/s, the vector pipe's rate)
+                F64_PEAK_TF = 78.6
+                flops = {"k_fact_wg": 2.0 * n ** 3 / 3.0 * N, "k_setup_m": 1.0 * (m - ms) * n * n * N}      # Cholesky + inverse; M = A R^-1 against a triangular R^-1
+                recs = []
+                for st in prof["setup_launches"]:
+                    ms_k = st.get("avg_ms_kernel_trace")
+                    moved = st.get("hbm_read_bytes", 0.0) + st.get("hbm_written_bytes", 0.0)
+                    rec = {"kernel": st["kernel"], "bound": "hbm", "avg_launch_ms": ms_k, "avg_launch_ms_source": "kernel trace of the committed round profile",
+                           "traffic": moved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "read_bytes": st.get("hbm_read_bytes"), "written_bytes": st.get("hbm_written_bytes"),
+                           "issue": st.get("issue")}
+                    if ms_k:
+                        rec["achieved"] = moved / (ms_k * 1e-3) / 1e9
+                        rec["frac"] = rec["achieved"] / HBM_PEAK_GBS
+                        fl = next((v for k_, v in flops.items() if k_ in st["kernel"]), None)
+                        if fl:
+                            rec["flops"] = fl
+                            rec["tflops"] = fl / (ms_k * 1e-3) / 1e12
+                            rec["mfma_frac"] = rec["tflops"] / F64_PEAK_TF
+                    recs.append(rec)
+                roof["setup"] = recs
+                roof["setup_ms_this_run"] = t_setup * 1e3
             if BOUND[cfg] == "hbm" and prof.get("traffic"):     # the memory system is the roof: measured HBM-side bytes over the launch time
                 roof["achieved"] = prof["traffic"] / max(t_ldp, 1e-12) / 1e9
                 roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
@@ -579,6 +604,8 @@ def committed_counters(cfg, N):
             out["issue"] = dict(d["issue"])
         if d.get("setup"):
             out["setup"] = dict(d["setup"], kernel=d.get("setup_kernel"))
+        if d.get("setup_launches"):
+            out["setup_launches"] = d["setup_launches"]
         return out
     return {"stale": True, "why": why}
 

@@ -60,7 +60,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 EXPORTS = [
     "daqp_quadprog", "daqp_solve", "setup_daqp", "setup_daqp_main", "daqp_update_ldp", "daqp_default_settings",
     "allocate_daqp_settings", "free_daqp_workspace", "free_daqp_ldp", "daqp_primal_init_active",
-    "daqp_dual_init_active", "daqp_set_primal_start", "daqp_minrep", "allocate_daqp_workspace", "allocate_daqp_ldp", "daqp_first_violating", "daqp_batch_create", "daqp_batch_free", "daqp_amd_release_pool", "daqp_batch_set_stream",
+    "daqp_dual_init_active", "daqp_set_primal_start", "daqp_minrep", "allocate_daqp_workspace", "allocate_daqp_ldp", "daqp_first_violating", "daqp_batch_create", "daqp_batch_free", "daqp_amd_release_pool", "daqp_amd_shutdown", "daqp_batch_set_stream",
     "daqp_batch_set_settings", "daqp_batch_set_exact", "daqp_batch_setup", "daqp_batch_setup_shared", "daqp_batch_update", "daqp_batch_solve",
     "daqp_batch_setup_flags", "daqp_batch_working_sets", "daqp_batch_set_primal_start", "daqp_batch_prox_info", "daqp_quadprog_batch", "daqp_quadprog_batch_multi", "daqp_batch_kernel_ms",
     "daqp_batch_create_multi", "daqp_batch_free_multi", "daqp_batch_multi_shards", "daqp_batch_multi_shard", "daqp_batch_setup_multi", "daqp_batch_update_multi",

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <atomic>
 #include <vector>
 #include <string>
 #include <thread>
@@ -778,6 +779,7 @@ namespace {
 // ~40 hipMalloc / hipFree and four events per call, an order of magnitude more than the solve itself.  A freed batch of ONE
 // problem is parked here instead and handed to the next create with the same shape, device and environment switches.
 std::mutex g_pool_mu;
+std::atomic<unsigned long long> g_devices_used{0};
 std::vector<DAQPBatch *> g_pool;
 constexpr size_t kPoolMax = 8;
 bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && atoi(e) != 0); }
@@ -840,7 +842,14 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     const int cap = n + ns_max + 1;
     if (cap > 512 || n > 511) { set_err("n + ns + 1 = %d exceeds the 512-row working-set limit of this build", cap); return DAQP_EXIT_UNSUPPORTED; }
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    const hipError_t dev_rc = hipGetDeviceCount(&ndev);
+    if (dev_rc == hipSuccess && ndev > 0 && device >= 0 && device < 64) {
+        // (registered AFTER the HIP runtime initialised itself -- the call above --, so it runs BEFORE that runtime's own exit handlers)
+        static std::once_flag once;
+        std::call_once(once, [] { if (!getenv("DAQP_AMD_NO_EXIT_SYNC")) atexit(daqp_amd_shutdown); });
+        g_devices_used.fetch_or(1ull << device);
+    }
+    if (dev_rc != hipSuccess || ndev == 0) {
         set_err("no HIP device: libdaqp_amd has no CPU path");
         return DAQP_EXIT_UNSUPPORTED;
     }
@@ -1123,6 +1132,21 @@ void daqp_batch_free(DAQPBatch *b)
         return;
     }
     destroy_batch(b);
+}
+// What a process owes the HIP runtime before it exits: nothing of this library's still in flight.  The one-problem path polls a mapped word
+// instead of synchronising its stream, so the runtime retires a call sequence's commands late -- a process that returned from main() within
+// microseconds of its last call met the runtime's own static teardown half way (about 2 deaths in 1 000 runs of tests/c/mask_caller.c inside
+// libamdhip64's completion thread; none with a synchronising call path: INTEGRATION.md "Process exit").  daqp_amd_shutdown() waits for every
+// device this library touched; it is registered with atexit() at the first batch creation (DAQP_AMD_NO_EXIT_SYNC=1: not), frees nothing
+// (parked workspaces are left to the operating system) and may be called by the host at any time, any number of times.
+void daqp_amd_shutdown(void)
+{
+    const unsigned long long used = g_devices_used.load();
+    int cur = -1;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (int dv = 0; dv < 64; ++dv)
+        if ((used >> dv) & 1ull) { if (hipSetDevice(dv) == hipSuccess) (void)hipDeviceSynchronize(); }
+    if (have) (void)hipSetDevice(cur);
 }
 // really release every parked single-problem workspace (tests; a host that wants its device memory back)
 void daqp_amd_release_pool(void)

@@ -200,6 +200,10 @@ void daqp_batch_free(DAQPBatch *b);
  * repeated single solves do not pay ~40 hipMalloc / hipFree each.  At most 8 are kept; this releases them all now.
  * Environment DAQP_AMD_NO_POOL=1 switches the parking off. */
 void daqp_amd_release_pool(void);
+/* waits for everything this library has in flight on every device it touched (frees nothing; any number of calls).  Registered with atexit() at
+   the first batch / workspace creation, so that a process that exits right after its last solve does not meet the HIP runtime's own teardown with
+   commands still retiring (INTEGRATION.md "Process exit"); DAQP_AMD_NO_EXIT_SYNC=1 leaves that to the host. */
+void daqp_amd_shutdown(void);
 /* hipStream_t the batch launches on (NULL: the legacy default stream). */
 void daqp_batch_set_stream(DAQPBatch *b, void *hip_stream);
 void daqp_batch_set_settings(DAQPBatch *b, const DAQPSettings *settings);

@@ -106,6 +106,5 @@ int main(int argc, char **argv)
         free_daqp_ldp(&work);
     }
     free(x); free(lam); free(sense);
-    fflush(stdout);
-    _exit(0);   /* (not through the exit handlers: see tests/c/mask_caller.c) */
+    return 0;   /* (an ordinary exit: see tests/c/mask_caller.c) */
 }

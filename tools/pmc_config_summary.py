@@ -1,5 +1,7 @@
 """profiles/r*_pmc_summary.json from the per-config PMC aggregates of tools/pmc_json.py:
-   python tools/pmc_config_summary.py <out.json> pmc_raw_C2.json pmc_raw_C3.json pmc_raw_C4.json pmc_raw_C5.json
+   python tools/pmc_config_summary.py <out.json> pmc_raw_C2.json pmc_raw_C3.json pmc_raw_C4.json pmc_raw_C5.json [kernel_stats.csv]
+(kernel_stats.csv: the rocprofv3 --kernel-trace --stats table of the same round profile -- the average duration of each setup kernel, so that a
+per-launch record divides a kernel's bytes by THAT kernel's time)
 Per config: the solve launch's HBM bytes (FETCH_SIZE in KiB units, doubled for 16-byte coalesced reads on gfx950 as
 MI355X_MICROARCH.md prescribes, + WRITE_SIZE) and the issue-side counters that say what binds the kernel; the same for
 the setup launch.  bench.py quotes `traffic_bytes_per_launch` and `binding` of the newest summary."""
@@ -8,17 +10,40 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import CONFIGS, library_stamp
 
 out = sys.argv[1]
-SOLVE = {"C2": r"k_ldp_reg<3, 25", "C3": r"k_ldp_reg<1, [68]", "C4": r"k_ldp_wg<4[,>]", "C5": r"k_ldp_reg<3, 25"}
+# the solve LAUNCH of C2 / C5 is two kernels: the image kernel (fp32 image of M, two waves per SIMD) and, right behind it, the full-register
+# kernel for the problems it handed over -- their counters are summed ("+")
+SOLVE = {"C2": r"k_ldp_reg<3, 25, true, 2>+k_ldp_reg<3, 25, true, 0>", "C3": r"k_ldp_reg<1, [68]", "C4": r"k_ldp_wg<4[,>]", "C5": r"k_ldp_reg<3, 25, true, 2>+k_ldp_reg<3, 25, true, 0>"}
+# C4's setup is three launches, each with its own record
+SETUP_LAUNCHES = {"C4": [r"k_fact_wg", r"k_setup_m", r"k_setup<true, 4, true, false>"]}
 SETUP = {"C2": r"k_setup_blk<4, 56||k_setup_fast<56", "C3": r"k_setup_tiny|k_setup_fast<16", "C4": r"k_setup<true", "C5": r"k_setup_blk<4, 56||k_setup_fast<56"}
 N_SIMD, F_CLK = 1024, 2.4e9        # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak (MI355X_MICROARCH.md); SQ_* cycle counters tick every 4 cycles
 
 
 def pick(raw, pats):
     for pat in pats.split("||"):       # alternatives in order of preference (the ordered setup kernel also runs, empty, behind k_setup_blk)
-        for k, v in raw.items():
-            if re.search(pat, k):
-                return k, {c: x["mean"] for c, x in v.items()}
+        names, tot = [], {}
+        for part in pat.split("+"):    # kernels of ONE launch sequence: counters summed
+            for k, v in raw.items():
+                if re.search(part, k):
+                    names.append(k)
+                    for c, x in v.items():
+                        tot[c] = tot.get(c, 0.0) + x["mean"]
+                    break
+        if names:
+            return " + ".join(names), tot
     return None, {}
+
+
+def kernel_ms(stats_csv):
+    """{kernel name (as pmc_json.py prints it): average duration in ms} from a rocprofv3 kernel_stats.csv"""
+    import csv
+    out_ = {}
+    if not stats_csv:
+        return out_
+    for r in csv.DictReader(open(stats_csv)):
+        name = re.sub(r"^void daqp_amd::|\(.*$", "", r["Name"])
+        out_[name] = float(r["AverageNs"]) * 1e-6
+    return out_
 
 
 def describe(c):
@@ -41,13 +66,20 @@ def describe(c):
 
 # the build of the library these counters were taken with: bench.py quotes a summary only when the loaded library carries the same stamp
 res = {"_stamp": library_stamp()}
-for path in sys.argv[2:]:
+stats = kernel_ms(next((a for a in sys.argv[2:] if a.endswith(".csv")), None))
+for path in [a for a in sys.argv[2:] if not a.endswith(".csv")]:
     cfg = re.search(r"(C\d)", os.path.basename(path)).group(1)
     raw = json.load(open(path))
     ks, cs = pick(raw, SOLVE[cfg])
     kt, ct = pick(raw, SETUP[cfg])
     s, t = describe(cs), describe(ct)
     entry = {"batch": CONFIGS[cfg]["per_gpu"], "solve_kernel": ks, "setup_kernel": kt, "solve": s, "setup": t}
+    if cfg in SETUP_LAUNCHES:
+        entry["setup_launches"] = []
+        for pat in SETUP_LAUNCHES[cfg]:
+            kn, cn = pick(raw, pat)
+            if kn:
+                entry["setup_launches"].append(dict(describe(cn), kernel=kn, avg_ms_kernel_trace=stats.get(kn)))
     if "hbm_read_bytes" in s:
         entry["traffic_bytes_per_launch"] = s["hbm_read_bytes"] + s["hbm_written_bytes"]
     if "issue" in s:

@@ -23,7 +23,7 @@ for cfg in C2 C3 C4 C5; do
   done
   python tools/pmc_json.py $O/pmc_raw_$cfg.json $dirs > $O/pmc_print_$cfg.txt 2>&1
 done
-python tools/pmc_config_summary.py $O/pmc_summary.json $O/pmc_raw_C2.json $O/pmc_raw_C3.json $O/pmc_raw_C4.json $O/pmc_raw_C5.json > $O/pmc_summary_print.txt 2>&1
+python tools/pmc_config_summary.py $O/pmc_summary.json $O/pmc_raw_C2.json $O/pmc_raw_C3.json $O/pmc_raw_C4.json $O/pmc_raw_C5.json $O/kernel_stats.csv > $O/pmc_summary_print.txt 2>&1
 timeout 900 python bench.py --full-out $O/bench_full.json > $O/bench.json 2> $O/bench.err
 tools/ubench4.bin > $O/ubench4.txt 2>&1
 tools/ubench5.bin > $O/ubench5.txt 2>&1

@@ -914,7 +914,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     // over, as an fp32 IMAGE of M at two waves per SIMD (reg_kernel.hip.h, IMG = 1).  Its LDS holds img_rows working-set rows (C2: the peak is
     // 27 rows on average, above 40 on 1.3 % of the problems -- those are handed to the full-register kernel behind it)
     if (b->NB == 3 && b->NP == 25 && d.nblk == 3 && m <= 160 && cap <= 64 && !b->reg_handover && !getenv("DAQP_AMD_NO_IMG32")) {
-        int min_batch = 1536, rows = 42;
+        int min_batch = 12288, rows = 42;      // (tools/img_threshold.py: below ~12 000 problems the device is not full twice over and a problem's latency decides -- one wave per SIMD is faster per problem)
         if (const char *e = getenv("DAQP_AMD_IMG_MIN_BATCH")) min_batch = atoi(e);
         if (const char *e = getenv("DAQP_AMD_IMG_ROWS")) { const int v = atoi(e); if (v >= 2 && v <= 64) rows = v; }
         if (N >= min_batch && ms == 0) { b->img32 = true; d.reg_rows = rows < cap ? rows : cap; }     // (simple bounds: the Gram column's start columns read their rows from LDS)

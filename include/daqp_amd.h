@@ -304,8 +304,13 @@ int daqp_batch_kernel_ms(DAQPBatch *b, float *setup_ms, float *solve_ms);
    switches it off for every batch).  daqp_batch_rechecked: how many problems of the last daqp_batch_solve took the second pass
    (-1: there were some and no memory for the companion batch -- the first pass's verdicts stand); daqp_batch_recheck_ms: its
    device time, which is part of the solve time daqp_batch_kernel_ms reports.  A WARM solve (after an update of f / bounds) that ends
-   INFEASIBLE has no such pass: its starting point already carries the default arithmetic's rounding; the exit flag is the
-   reference's, the iteration count and the working set left behind may differ by the last removal. */
+   INFEASIBLE has no such pass: its starting point already carries the default arithmetic's rounding.  THE BOUND: the exit flag is the
+   reference's; the iteration at which the verdict falls is within TWO of the reference's (tests/test_gpu_golden.py asserts it per problem).
+   Which comparison it is (tools/warm_infeasible_trace.py, profiles/r06_warm_infeasible_traces.txt): the event traces of the two arithmetics are
+   identical up to a singular-direction step (daqp.c:86-93); there the blocking test of auxiliary.c:284-287 compares components of the
+   singular direction that are zero in exact arithmetic -- rounding noise of the size of dual_tol = 1e-12 -- with dual_tol, and one side
+   removes one more row (and looks again) where the other already reports -1.  Not the fval bound of daqp.c:20-23.  DAQP_AMD_EXACT=1
+   reproduces the reference's trace event for event. */
 int daqp_batch_rechecked(const DAQPBatch *b);
 void daqp_batch_set_recheck(DAQPBatch *b, int on);
 int daqp_batch_recheck_ms(DAQPBatch *b, float *ms);

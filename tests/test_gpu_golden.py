@@ -267,6 +267,11 @@ def test_warm_updates_that_turn_infeasible_default_mode(oracle, gpu_lib, monkeyp
                 if ef == -1:
                     infeasible += 1
                     dd = abs(info["iterations"] - r[4])
+                    # the bound of include/daqp_amd.h, per problem: a FIRST infeasible warm verdict falls within two iterations of the reference's
+                    # (tools/warm_infeasible_trace.py, profiles/r06_warm_infeasible_traces.txt: the traces are identical up to a singular-direction
+                    # step, where one arithmetic still sees a component of that direction beyond dual_tol -- auxiliary.c:284-287 -- and removes one
+                    # more row before it gives up, the other does not; the exact mode's traces are the reference's)
+                    assert tainted or dd <= (0 if exact else 2), (exact, trial, t, info["iterations"], r[4])
                     if not tainted:
                         same_iter += dd == 0
                         max_diff = max(max_diff, dd)

@@ -42,9 +42,9 @@ def run(trial, exact):
         w = np.where(np.abs(w) < 1e20, w, 0.0)
         bu, bl = q["bupper"] - w, q["blower"] + 0.45 * w
         bm.update(bupper=bu[None], blower=bl[None]); om.update(O.UPDATE_d, bupper=bu, blower=bl)
-        l0 = len(bm.read_trace(marks=True)[0]); o0 = len(om.get_trace(marks=True))
+        o0 = len(om.get_trace(marks=True))                 # (the oracle's trace runs on; the library's restarts with every solve)
         g = bm.solve(); r = om.solve()
-        gt = bm.read_trace(marks=True)[0][l0:]; ot = om.get_trace(marks=True)[o0:]
+        gt = bm.read_trace(marks=True)[0]; ot = om.get_trace(marks=True)[o0:]
         out.append(dict(step=t, flag=int(g["exitflag"][0]), ref_flag=int(r[3]), iter=int(g["iter"][0]), ref_iter=int(r[4]), trace=fmt(gt), ref_trace=fmt(ot)))
     bm.close()
     return out

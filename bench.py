@@ -352,7 +352,7 @@ class Runner:
             f0 = q["f"].clone()
             cursor = [0]
 
-            def step():
+            def step(record=None):
                 res = None
                 back = cursor[0] & 1
                 cursor[0] += 1
@@ -360,6 +360,8 @@ class Runner:
                     t = (T - 2 - j) if back else j
                     bm.update(f=fs[t] if t >= 0 else f0)
                     res = bm.solve(out="torch")
+                    if record is not None:      # (untimed probe passes: every warm step's own launch time and iteration count)
+                        record.append((bm.kernel_ms()[1], res["iter"].double().mean().item()))
                 return res
 
             bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, init_mask=0)   # setup_daqp + the cold solve: untimed
@@ -380,6 +382,13 @@ class Runner:
         self.sync()
         elapsed = time.perf_counter() - t0
         elapsed = max_over_ranks(elapsed, device=self.red_device)
+        probe = None
+        if warm and self.rank == 0:
+            # the steps of a pass differ (working sets grow along the walk, the way back ends on the cold optimum): the launch time quoted for the
+            # roofline is the mean over ONE forward and ONE backward pass, sampled step by step outside the timed region (a sample waits for the device)
+            probe = []
+            step(probe); step(probe)
+            self.sync()
         exact = None
         if exact_steps > 0 and not warm and self.world == 1:
             # the same steps in the library's EXACT arithmetic (DAQP_AMD_EXACT=1: the reference's operation order throughout,
@@ -407,7 +416,7 @@ class Runner:
             bx.close()
             del bx, rx
         rechecked = int(bm.rechecked())   # problems of the last step whose INFEASIBLE verdict took the second pass in the reference's arithmetic: none here
-        return q, res, bm, dict(N=N, N_total=N_total, rechecked=rechecked, elapsed=elapsed, setup_ms=setup_ms, solve_ms=solve_ms, T=T if warm else 1, fs=fs, exact=exact)
+        return q, res, bm, dict(N=N, N_total=N_total, rechecked=rechecked, elapsed=elapsed, setup_ms=setup_ms, solve_ms=solve_ms, T=T if warm else 1, fs=fs, exact=exact, probe=probe)
 
     def report(self, cfg, q, res, info, steps, cpu_sample, headline):
         """rank 0: the JSON fields of one configuration"""
@@ -417,11 +426,13 @@ class Runner:
         N, T = info["N"], info["T"]
         units = (info["N_total"] if info["N_total"] else self.world * N) * steps * T
         iters = res["iter"].cpu().numpy()
+        if warm and info.get("probe"):      # mean over the warm steps of a forward and a backward pass (run.probe), not the last step's
+            iters = np.full(iters.shape, float(np.mean([p_[1] for p_ in info["probe"]])))
         b_in, b_out, stream = algorithmic_bytes(n, m, ms, iters, warm)
         ldp_bytes = float(stream.sum() + b_out * N)           # what one solve launch must move (SURVEY 8d without the inputs)
         all_bytes = float(stream.sum() + (b_in + b_out) * N)  # SURVEY 8(d) B summed over the batch
         io_bytes = float((b_in + b_out) * N)                  # B_io only: the floor if M never leaves the chip
-        t_ldp = float(np.mean(info["solve_ms"])) * 1e-3
+        t_ldp = float(np.mean([p_[0] for p_ in info["probe"]]) if (warm and info.get("probe")) else np.mean(info["solve_ms"])) * 1e-3
         t_setup = float(np.mean(info["setup_ms"])) * 1e-3
         ach = ldp_bytes / t_ldp / 1e9
         flags_ok = bool((res["exitflag"] == 1).all().item())

@@ -787,7 +787,7 @@ std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
                                   "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M", "DAQP_AMD_NO_BLK_SETUP",
-                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WARM_ROWS"};
+                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WARM_ROWS", "DAQP_AMD_IMG_WARM_WAVES"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -941,8 +941,11 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
             int wrows = 40;
             if (const char *e = getenv("DAQP_AMD_IMG_WARM_ROWS")) wrows = atoi(e);
             if (wrows >= 2 && wrows < d.reg_rows) {
+                int wwaves = waves;
+                if (const char *e = getenv("DAQP_AMD_IMG_WARM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) wwaves = v; }
+                const int wbudget = (160 * 1024 / wwaves) / 512 * 512;
                 int wc = wrows;
-                while (wc > 2 && reg_img_lds_bytes(b->NB, 2, n, m, wrows, wc, d.ldrc) > budget) --wc;
+                while (wc > 2 && reg_img_lds_bytes(b->NB, 2, n, m, wrows, wc, d.ldrc) > wbudget) --wc;
                 b->img_rows_warm = wrows; b->img_cache_warm = wc;
                 b->lds_img_warm = (size_t)reg_img_lds_bytes(b->NB, 2, n, m, wrows, wc, d.ldrc);
             }

@@ -13,7 +13,7 @@ namespace daqp_amd {
 // scratch).  Only the active-row cache, behind the run-time sized L, has a run-time base.
 template <int NB, int IMG = 0>
 struct RegLds {
-    static constexpr int u = 0, pend_lam = 68, pend_id = 132, prof = 164, rowv = 196, L = rowv + 3 * kRowvStride<NB, IMG>;   // doubles
+    static constexpr int u = 0, pend_lam = 68, pend_id = 132, prof = 164, u32 = 196, rowv = 196 + (IMG ? 32 : 0), L = rowv + 3 * kRowvStride<NB, IMG>;   // doubles (u32: 64 floats, IMG != 0 only)
 };
 __host__ __device__ inline int reg_lds_rowc_size(int n, int m, int cap, int ldrc)
 {
@@ -21,9 +21,9 @@ __host__ __device__ inline int reg_lds_rowc_size(int n, int m, int cap, int ldrc
     return rows > fin ? rows : fin;
 }
 // (IMG = 1: `cap` is the number of working-set rows the kernel holds -- BatchDev::reg_rows --, not the problem's own cap)
-__host__ __device__ inline int reg_lds_rowc(int NB, int cap, int IMG = 0) { return 196 + 3 * (IMG == 2 ? 64 * NB - 32 : 64 * NB) + round_up(cap * (cap + 1) / 2, 2); }
+__host__ __device__ inline int reg_lds_rowc(int NB, int cap, int IMG = 0) { return 196 + (IMG ? 32 : 0) + 3 * (IMG == 2 ? 64 * NB - 32 : 64 * NB) + round_up(cap * (cap + 1) / 2, 2); }
 __host__ __device__ inline int reg_lds_bytes(int NB, int n, int m, int cap, int ldrc, int IMG = 0) { return 8 * (reg_lds_rowc(NB, cap, IMG) + reg_lds_rowc_size(n, m, cap, ldrc)); }
-// IMG != 0: [front: u, pivot stack, probes][row view][L: tri(rows)][row cache], the cache tiered (RWave::cache_slots): `cache` rows + one
+// IMG != 0: [front: u, pivot stack, probes, u32][row view][L: tri(rows)][row cache], the cache tiered (RWave::cache_slots): `cache` rows + one
 // staging row when cache < rows, else all `rows`; L and the cache together at least as large as the epilogue's staging area (R^-1 + lam), which
 // starts at L (the factor has been stored by then)
 __host__ __device__ inline int reg_img_cache_rows(int rows, int cache) { return cache < rows ? cache + 1 : rows; }
@@ -34,7 +34,7 @@ __host__ __device__ inline int reg_img_stage_size(int n, int m, int rows, int ca
 }
 __host__ __device__ inline int reg_img_lds_bytes(int NB, int IMG, int n, int m, int rows, int cache, int ldrc)
 {
-    return 8 * (196 + 3 * (IMG == 2 ? 64 * NB - 32 : 64 * NB) + reg_img_stage_size(n, m, rows, cache, ldrc));
+    return 8 * (196 + 32 + 3 * (IMG == 2 ? 64 * NB - 32 : 64 * NB) + reg_img_stage_size(n, m, rows, cache, ldrc));
 }
 
 // ------------------------------------------------------------------------------------
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     if constexpr (IMG != 0) {
         // The fp64 rows pass through the registers once: each pair is rounded into the image as it arrives, and a pending update's
         // d = b s + M v (utils.c:499-544) takes its row . v from the passing fp64 values -- so v must be in LDS BEFORE the stream.
-        w.msrc = msrc; w.npair = npair_u; w.uf = 0.0f;
+        w.msrc = msrc; w.npair = npair_u; w.u32 = reinterpret_cast<float *>(smem + o::u32);
         w.cache_slots = img_cache;
         w.rowg = as_global(b.rowc_g + (size_t)q * (size_t)((lds_rows > img_cache ? lds_rows - img_cache : 0) * b.ldrc));
         if (upd) {

@@ -49,7 +49,7 @@ struct RWave {
     typedef double gv2d_ __attribute__((ext_vector_type(2)));
     typedef typename std::conditional<IMG != 0, float, double>::type mreg;
     const DAQP_GLOBAL(gv2d_) *msrc;    // IMG = 1: this problem's blocked fp64 image [nblk][npair][64][2]
-    float uf;                          // IMG != 0: lane j holds u_j rounded to fp32 (0 from n on): the screening scan reads its operands out of it (v_readlane)
+    float *u32;                        // IMG = 1: u rounded to fp32 (LDS), the screening scan's operand
     int npair;
     // IMG != 0: the active-row cache is TIERED.  Slots < cache_slots are rows in LDS (rowc); the others live in this problem's global scratch
     // (rowg, slot s at (s - cache_slots) ldr: L2-resident, 400 contiguous bytes a row at C2's shape), and LDS row `cache_slots` is where a row
@@ -103,7 +103,6 @@ constexpr bool kProfile = false;
 #define RPROF_ACC(w, slot) do { if (kProfile && (w).prof) { const long long t1_ = (long long)__builtin_readcyclecounter(); if (lane_id() == 0) (w).prof[slot] += t1_ - prof_t0_; prof_t0_ = t1_; } } while (0)
 
 __device__ __forceinline__ int rli(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
-__device__ __forceinline__ float rlf32(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
 // x - a*b and x + a*b.  FM = false: two roundings, the reference's arithmetic (the file is compiled with -ffp-contract=off).
 // FM = true (default arithmetic mode of the library, where M = A R^-1 already comes from the matrix cores): one v_fma_f64,
@@ -853,7 +852,7 @@ __device__ __forceinline__ void rprimal_u(RWave<NB, NP, FM, IMG> &w)
     }
     WSYNC();
     if (lane < n) w.u[lane_now()] = uu;
-    if constexpr (IMG != 0) w.uf = (lane < n) ? (float)uu : 0.0f;   // the screening scan's operand
+    if constexpr (IMG != 0) w.u32[lane_now()] = (lane < n) ? (float)uu : 0.0f;   // the screening scan's operand (64 floats: zero from n on)
     double fv = 0;
     if (w.has_soft) {
         const double sq = (lane < na && (w.wflag & DAQP_SOFT)) ? w.lams * w.lams : 0.0;
@@ -979,35 +978,43 @@ __device__ __forceinline__ int rscan_rows_img(RWave<NB, NP, FM, IMG> &w, int &up
 {
     static_assert(IMG != 0 && FM, "the screening image belongs to the default arithmetic");
     const int lane = lane_id();
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 *u2 = reinterpret_cast<const f2 *>(w.u32);
     float ax[NB], ay[NB];
     static_for<NB>([&](auto bb) __attribute__((always_inline)) { ax[bb] = 0.0f; ay[bb] = 0.0f; });
-    constexpr int NBF = kImgFullBlocks<NB, IMG>, NPH = (NP + 1) / 2;
-    // u is wave-uniform: column j's operand is a SCALAR read out of the lane that holds u_j (v_readlane with a constant lane) -- no LDS copy of u,
-    // no LDS round trips inside the scan.  Pairs t and t + NPH go together: the last row block (IMG = 2: at most 32 rows, TWO lanes per row -- lane
-    // 2k + h holds pairs NPH h .. NPH h + NPH - 1 of row 64 (NB-1) + k, half the registers) takes pair t's scalars in its even lanes and pair
-    // (t + NPH)'s in its odd ones (pairs beyond the row meet u = 0); its halves meet by one DPP swap and move to the row's own lane by one permute
-    const float uf = w.uf;
-    const bool h1 = (lane & 1) != 0;
-    static_for<NPH>([&](auto t) __attribute__((always_inline)) {
-        const float a0 = rlf32(uf, 2 * t), a1 = rlf32(uf, 2 * t + 1);
-        static_for<NBF>([&](auto bb) __attribute__((always_inline)) {
-            ax[bb] = __builtin_fmaf(w.Mx[bb][t], a0, ax[bb]);
-            ay[bb] = __builtin_fmaf(w.My[bb][t], a1, ay[bb]);
+    constexpr int NBF = kImgFullBlocks<NB, IMG>, NPH = (NP + 1) / 2, GU = 5;
+    // u pairs five at a time (broadcast reads), then their multiply-adds: a whole-row preload would take as many registers again as a block of the image
+    static_for<(NP + GU - 1) / GU>([&](auto g) __attribute__((always_inline)) {
+        f2 uk[GU];
+        static_for<GU>([&](auto k) __attribute__((always_inline)) { if constexpr (GU * g + k < NP) uk[k] = u2[GU * g + k]; });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<GU>([&](auto k) __attribute__((always_inline)) {
+            constexpr int t = GU * g + k;
+            if constexpr (t < NP)
+                static_for<NBF>([&](auto bb) __attribute__((always_inline)) {
+                    ax[bb] = __builtin_fmaf(w.Mx[bb][t], uk[k].x, ax[bb]);
+                    ay[bb] = __builtin_fmaf(w.My[bb][t], uk[k].y, ay[bb]);
+                });
         });
-        float b0 = 0.0f, b1 = 0.0f;
-        if constexpr (t + NPH < NP) {
-            b0 = rlf32(uf, 2 * (t + NPH)); b1 = rlf32(uf, 2 * (t + NPH) + 1);
-            static_for<NBF>([&](auto bb) __attribute__((always_inline)) {
-                ax[bb] = __builtin_fmaf(w.Mx[bb][t + NPH], b0, ax[bb]);
-                ay[bb] = __builtin_fmaf(w.My[bb][t + NPH], b1, ay[bb]);
-            });
-        }
-        if constexpr (IMG == 2) {
-            ax[NB - 1] = __builtin_fmaf(w.Mx[NB - 1][t], h1 ? b0 : a0, ax[NB - 1]);
-            ay[NB - 1] = __builtin_fmaf(w.My[NB - 1][t], h1 ? b1 : a1, ay[NB - 1]);
-        }
+        __builtin_amdgcn_sched_barrier(0);
     });
     if constexpr (IMG == 2) {
+        // the last row block holds at most 32 rows: TWO lanes per row (lane 2k + h: row 64 (NB-1) + k, pairs NPH h .. NPH h + NPH - 1; pairs beyond
+        // the row meet u = 0), half the registers; the halves meet by one DPP swap and move to the row's own lane (lane k) by one permute
+        const f2 *uh = u2 + NPH * (lane & 1);
+        static_for<(NPH + GU - 1) / GU>([&](auto g) __attribute__((always_inline)) {
+            f2 uk[GU];
+            static_for<GU>([&](auto k) __attribute__((always_inline)) { if constexpr (GU * g + k < NPH) uk[k] = uh[GU * g + k]; });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<GU>([&](auto k) __attribute__((always_inline)) {
+                constexpr int t = GU * g + k;
+                if constexpr (t < NPH) {
+                    ax[NB - 1] = __builtin_fmaf(w.Mx[NB - 1][t], uk[k].x, ax[NB - 1]);
+                    ay[NB - 1] = __builtin_fmaf(w.My[NB - 1][t], uk[k].y, ay[NB - 1]);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
         const float part = ax[NB - 1] + ay[NB - 1];
         const float both = part + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(part), 0xB1, 0xF, 0xF, false));
         ax[NB - 1] = __shfl(both, (2 * lane) & 63);

@@ -103,6 +103,7 @@ constexpr bool kProfile = false;
 #define RPROF_ACC(w, slot) do { if (kProfile && (w).prof) { const long long t1_ = (long long)__builtin_readcyclecounter(); if (lane_id() == 0) (w).prof[slot] += t1_ - prof_t0_; prof_t0_ = t1_; } } while (0)
 
 __device__ __forceinline__ int rli(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float rlf32(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
 // x - a*b and x + a*b.  FM = false: two roundings, the reference's arithmetic (the file is compiled with -ffp-contract=off).
 // FM = true (default arithmetic mode of the library, where M = A R^-1 already comes from the matrix cores): one v_fma_f64,
@@ -1020,37 +1021,47 @@ __device__ __forceinline__ int rscan_rows_img(RWave<NB, NP, FM, IMG> &w, int &up
         ax[NB - 1] = __shfl(both, (2 * lane) & 63);
         ay[NB - 1] = 0.0f;
     }
-    const double E = 1.001 * (double)(NP + 8) * 5.9604644775390625e-08 * __builtin_sqrt(w.fval - w.soft) + 1e-300;
-    double s1 = DAQP_INF, s2 = DAQP_INF, minq = DAQP_INF, q1 = DAQP_INF, gap1 = 0.0;
-    int i1 = kBig, up1 = 0, bad = 0;
+    // E, rounded UP in single precision (one v_sqrt_f32 instead of a double-precision square root's dozen instructions)
+    const double E = (double)(1.0002f * (float)(NP + 8) * 5.9604644775390625e-08f * __builtin_sqrtf((float)(w.fval - w.soft) * 1.0000003f) + 1e-37f);
+    // Per lane only what the verdict's FIRST question needs: the smallest slack s = min(d_upper - mu, mu - d_lower) of its open rows, the runner-up
+    // and the row.  Everything else -- the winner's threshold, side and side gap -- is formed once, for the winner, on wave-uniform values.
+    double s1 = DAQP_INF, s2 = DAQP_INF;
+    int i1 = kBig, bad = 0;
+    float msum[NB];
     static_for<NB>([&](auto bb) __attribute__((always_inline)) {
         const int r = bb * 64 + lane;
         const int rr = bb * 64 + lane_now();
         const bool open = r < w.m && !(rsense_get(w, bb) & (DAQP_ACTIVE + DAQP_IMMUTABLE));
-        const double du = w.rowv[rr], dl = w.rowv[kRowvStride<NB, IMG> + rr], bn = w.rowv[2 * kRowvStride<NB, IMG> + rr];
-        const double mu = (double)(ax[bb] + ay[bb]);
-        if (open && !(mu - mu == 0.0)) bad = 1;
-        const double cu = du - mu, cl = mu - dl;
-        const bool isup = cu <= cl;
-        const double s = open ? (isup ? cu : cl) : (double)DAQP_INF;
-        const double q = s - bn, gap = isup ? cl - cu : cu - cl;
-        minq = (open && q < minq) ? q : minq;
+        const double du = w.rowv[rr], dl = w.rowv[kRowvStride<NB, IMG> + rr];
+        msum[bb] = ax[bb] + ay[bb];
+        const double mu = (double)msum[bb];
+        if (open && !(msum[bb] - msum[bb] == 0.0f)) bad = 1;
+        const double sm = __builtin_fmin(du - mu, mu - dl);
+        const double s = open ? sm : (double)DAQP_INF;
         const bool first = s < s1;
-        s2 = first ? s1 : (s < s2 ? s : s2);
-        i1 = first ? r : i1; up1 = first ? (isup ? 1 : 0) : up1; q1 = first ? q : q1; gap1 = first ? gap : gap1;
-        s1 = first ? s : s1;
+        s2 = first ? s1 : __builtin_fmin(s, s2);
+        i1 = first ? r : i1;
+        s1 = __builtin_fmin(s, s1);
     });
     double bv = s1;
     int bi = i1, aux = lane;
     wave_argmin(bv, bi, aux);                       // aux: the lane that holds the winner
     const double other = (lane == aux && bi != kBig) ? s2 : s1;
-    const double w2 = wave_min(other), wq = wave_min(minq);
+    const double w2 = wave_min(other);
     const bool anybad = __ballot(bad) != 0;
     if (!anybad) {
-        if (wq >= E) { upper = 0; return kBig; }                                                   // certainly nothing violated
-        if (bi != kBig) {
-            const double wq1 = rl(q1, aux), wgap = rl(gap1, aux);
-            if (bv + 2.0 * E < w2 && wq1 < -E && wgap > 2.0 * E) { upper = rli(up1, aux); return bi; }
+        // every open row's exact slack is >= bv - E: with bv >= E none is below zero, let alone below its (negative) threshold
+        if (bv >= E) { upper = 0; return kBig; }                                                   // certainly nothing violated
+        if (bi != kBig && bv + 2.0 * E < w2) {                                                      // THE smallest slack, for certain
+            const int wb = bi >> 6;
+            float mw = msum[0];
+            static_for<NB>([&](auto bb) __attribute__((always_inline)) { if (bb > 0 && wb == bb) mw = msum[bb]; });
+            const double mu1 = (double)rlf32(mw, aux);
+            const double du1 = w.rowv[bi], dl1 = w.rowv[kRowvStride<NB, IMG> + bi], bn1 = w.rowv[2 * kRowvStride<NB, IMG> + bi];   // (wave-uniform addresses)
+            const double cu1 = du1 - mu1, cl1 = mu1 - dl1;
+            const bool up = cu1 <= cl1;
+            const double gap = up ? cl1 - cu1 : cu1 - cl1;
+            if (bv - bn1 < -E && gap > 2.0 * E) { upper = up ? 1 : 0; return bi; }                  // violated for certain, its side certain
         }
     }
     if (kProfile && w.prof && lane == 0) w.prof[15] += 1;      // (probe: scans the image left undecided)

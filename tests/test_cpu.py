@@ -355,3 +355,31 @@ def test_committed_counters_belong_to_this_build():
         got = bench.committed_counters(cfg, c["per_gpu"])
         assert not got.get("stale"), (cfg, got.get("why"))
         assert got["traffic"] > 0 and got["issue"]["attainable_ms"] > 0, cfg
+
+
+def test_setup_records_pair_bytes_and_time_of_the_same_kernel():
+    """C4's setup is three launches; the committed counter summary carries ONE record per kernel -- that kernel's HBM-side bytes
+    (its own rows of the --pmc passes) next to that kernel's average duration (its own row of the kernel trace) -- and bench.py builds
+    `roofline.setup` record by record from them: `traffic` and `avg_launch_ms` of a record cannot come from different kernels."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    assert files
+    doc = json.load(open(files[-1]))
+    recs = doc["C4"].get("setup_launches")
+    assert recs and len(recs) == 3, "the newest counter summary carries C4's setup launch by launch"
+    names = [r["kernel"] for r in recs]
+    assert len(set(names)) == 3 and any("k_fact_wg" in k for k in names) and any("k_setup_m" in k for k in names) and any(k.startswith("k_setup<") for k in names)
+    stats_file = files[-1].replace("_pmc_summary.json", "_kernel_stats.csv")
+    import csv
+    import re
+    trace = {re.sub(r"^void daqp_amd::|\(.*$", "", r["Name"]): float(r["AverageNs"]) * 1e-6 for r in csv.DictReader(open(stats_file))}
+    raw = json.load(open(files[-1].replace("_pmc_summary.json", "_pmc_raw_C4.json")))
+    for r in recs:
+        assert r["avg_ms_kernel_trace"] and abs(r["avg_ms_kernel_trace"] - trace[r["kernel"]]) < 1e-9, r["kernel"]          # the time: this kernel's trace row
+        assert abs(r["hbm_read_bytes"] - raw[r["kernel"]]["FETCH_SIZE"]["mean"] * 2048) < 1.0, r["kernel"]                  # the bytes: this kernel's counter rows
+        assert abs(r["hbm_written_bytes"] - raw[r["kernel"]]["WRITE_SIZE"]["mean"] * 1024) < 1.0, r["kernel"]
+    # and bench.py turns each into one roofline record whose numbers are those
+    import bench
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'for st in prof["setup_launches"]' in src and '"kernel": st["kernel"], "bound": "hbm", "avg_launch_ms": ms_k' in src

@@ -371,6 +371,7 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
             const bool warm = (mode & 3) == 2 && b->img_rows_warm > 0;
             const size_t lds = warm ? b->lds_img_warm : b->lds_img;
             if (b->d.img_ho) HIPCHK(hipMemsetAsync(b->d.img_ho, 0, sizeof(int), b->stream));
+            HIPCHK(hipMemsetAsync(b->d.fallback, 0, (size_t)b->d.N * sizeof(int), b->stream));      // (the kernels only ever SET a flag)
             hipLaunchKernelGGL(ki, dim3(b->d.N), dim3(64), lds, b->stream, (const BatchDev *)b->d_dev, warm ? (mode | b->img_rows_warm << 16 | b->img_cache_warm << 22) : mode);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode | 4);
@@ -378,6 +379,7 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
             if (b->d.img_ho && (mode & 3) != 1) HIPCHK(hipMemcpyAsync(b->img_ho_pin, b->d.img_ho, sizeof(int), hipMemcpyDeviceToHost, b->stream));
             return 0;
         }
+        if (b->reg_handover) HIPCHK(hipMemsetAsync(b->d.fallback, 0, (size_t)b->d.N * sizeof(int), b->stream));
         hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode);
         HIPCHK(hipGetLastError());
         if (b->reg_handover) {   // the problems it flagged (mode | 4: nobody else is touched; an empty pass costs a few microseconds)

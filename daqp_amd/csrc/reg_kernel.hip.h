@@ -72,9 +72,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     const int q = blockIdx.x, lane = lane_id();
     const int n = b.n, m = b.m, cap = b.cap;
     if (mode_in & 4) { if (b.fallback == nullptr || !__builtin_amdgcn_readfirstlane(as_global(b.fallback)[q])) return; }
-    else if constexpr (kRegHandOver<NB, NP, IMG>) {     // a first pass owns the flag: clear what an earlier solve left (early returns below included)
-        if (b.fallback != nullptr && lane == 0) as_global(b.fallback)[q] = 0;
-    }
+    // (a first pass finds every flag cleared: launch_ldp zeroes the array in front of it.  NOT here: a store pending at this point makes every
+    //  wait for the row loads below a wait for everything -- loads and stores share the counter and may retire out of order --, and the
+    //  double-buffered stream of the image degenerates into one memory round trip per unit)
     // rows of the working set the LDS carve-up is sized for: the problem's own cap, or (IMG = 1) what the host chose to keep two waves per SIMD
     // (IMG != 0: a launch may bring its own carve-up -- rows << 16 | cache << 22 in the launch argument, see launch_ldp: warm launches hold fewer rows)
     const int lds_rows = IMG ? (((mode_in >> 16) & 63) ? ((mode_in >> 16) & 63) : __builtin_amdgcn_readfirstlane(b.reg_rows)) : cap;
@@ -230,11 +230,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
             WSYNC();
         }
         const double2 *v2 = reinterpret_cast<const double2 *>(smem + o::u);
+        // (GB = 10: the code generator waits for EVERYTHING outstanding at a unit's first use -- vmcnt(0), whatever is done about the stores and LDS copies
+        //  around it --, so two units make one memory round trip: 20 pairs per trip instead of 12 took 4 % off the C2 launch and off a warm solve;
+        //  13 pairs per unit start to spill)
         // Units of GB pairs, double-buffered: unit U + 1 is in flight while unit U is rounded into the image -- and no further: left to itself
         // the scheduler hoists ALL the loads (300 registers of fp64 temporaries), and image values defined under that pressure are spilled
         // for good (reloaded by every scan).  Full blocks first (lane <-> row), then (IMG = 2) the last block with two lanes per row: lane
         // 2k + h holds pairs NPH h .. NPH h + NPH - 1 of row 64 (NB-1) + k (wave_ldp_reg.hip.h rscan_rows_img).
-        constexpr int GB = 6, NBF = kImgFullBlocks<NB, IMG>, NBAT = (NP + GB - 1) / GB, NPH = (NP + 1) / 2, NHB = (IMG == 2) ? (NPH + GB - 1) / GB : 0;
+#ifndef DAQP_IMG_GB
+#define DAQP_IMG_GB 10
+#endif
+        constexpr int GB = DAQP_IMG_GB, NBF = kImgFullBlocks<NB, IMG>, NBAT = (NP + GB - 1) / GB, NPH = (NP + 1) / 2, NHB = (IMG == 2) ? (NPH + GB - 1) / GB : 0;
         constexpr int NUNITS = NBF * NBAT + NHB;
         const int h = lane & 1, k2 = lane >> 1;
         const bool rowok2 = (NB - 1) < nblk_u && 64 * (NB - 1) + k2 < m;

@@ -55,6 +55,7 @@ struct BatchDev {
     int *fallback;                // [N] 1: the working set outgrew the LDS-resident L -- the one-wave kernel solves this problem
     int wg_capL, wg_capT;
     int *img_ho;                  // image kernels: problems handed over by the current launch (one counter per batch; the host reads it one launch late), or null
+    int img_rows;                 // image kernels: the working-set rows they hold at all (their L in LDS); beyond: hand-over to the full-register kernel of the shape
     int img_cache;                // image kernels (k_ldp_reg<..., IMG != 0>): rows of the active-row cache kept in LDS; slots from here on live in rowc_g (reg_rows - img_cache rows
                                   // per problem), see RWave::cache_slots.  reg_rows: the working-set rows such a kernel holds at all (its L in LDS)
     int reg_rows;                 // k_ldp_reg<2,32,*>: working-set rows it may hold (64 = one lane per row; below cap: an add beyond them flags the problem in

@@ -34,6 +34,7 @@ namespace daqp_amd {
     extern template __global__ void k_ldp_reg<NB, NP, false>(const BatchDev *__restrict__, int); \
     extern template __global__ void k_ldp_reg<NB, NP, true>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_reg<3, 25, true, 2>(const BatchDev *__restrict__, int);
+extern template __global__ void k_ldp_reg<2, 32, true, 1>(const BatchDev *__restrict__, int);
 DAQP_REG_SHAPE(1, 6)
 DAQP_REG_SHAPE(1, 8)
 DAQP_REG_SHAPE(3, 25)
@@ -131,8 +132,9 @@ struct DAQPBatch {
     bool reg_handover = false;   // k_ldp_reg<2,32,*> may flag problems (more working-set rows than lanes: n = 64) for k_ldp right behind it
     size_t lds_fb = 0;           // ... and that launch's LDS
     bool img32 = false;          // default arithmetic: the solve launch is k_ldp_reg<NB, NP, true, 1> -- an fp32 image of M in the registers, two waves per
-                                 // SIMD, at most d.reg_rows working-set rows -- with k_ldp_reg<NB, NP, true, 0> right behind it for the problems it flags
+                                 // SIMD, at most d.img_rows working-set rows -- with k_ldp_reg<NB, NP, true, 0> right behind it for the problems it flags
     size_t lds_img = 0;          // ... and the image kernel's LDS
+    int img_kind = 0;            // its IMG template argument (2: the last row block split over two lanes per row; 1: full blocks)
     // the carve-up of a WARM launch (daqp_update_ldp(UPDATE_v|UPDATE_d) fused into the solve: an MPC step starts from ~20 rows and moves a few): fewer
     // rows held at all, so that at the same eight workgroups per CU more of them sit in LDS (the launch argument carries rows | cache, see k_ldp_reg)
     int img_rows_warm = 0, img_cache_warm = 0;
@@ -141,6 +143,7 @@ struct DAQPBatch {
     // full-register kernel anyway (working sets beyond what the image kernel holds), the next launches go there directly; every 16th tries again
     int *img_ho_pin = nullptr;
     unsigned img_skipped = 0;
+    int img_min_warm = 16384;
     size_t lds_wg = 0;
     double *wide_u = nullptr, *wide_l = nullptr;   // daqp_batch_setup_shared: +-1e30 bounds of the one factorisation
     int *structural = nullptr, *shared_flag = nullptr;
@@ -295,6 +298,7 @@ const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {1, 13}, {1, 16}, {2, 16}, {3, 8}
 ldp_reg_kernel_t pick_ldp_reg_img(const DAQPBatch *b)
 {
     if (b->NB == 3 && b->NP == 25) return k_ldp_reg<3, 25, true, 2>;    // (IMG = 2: the third row block holds at most 32 rows)
+    if (b->NB == 2 && b->NP == 32) return k_ldp_reg<2, 32, true, 1>;    // (51 <= n <= 63, m <= 128: two full row blocks, 128 image registers)
     return nullptr;
 }
 ldp_reg_kernel_t pick_ldp_reg(const DAQPBatch *b, bool exact)
@@ -363,6 +367,7 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
         bool use_img = b->img32 && !exact_kernels;
         if (use_img && b->img_ho_pin && (long long)*b->img_ho_pin * 2 > b->d.N && (++b->img_skipped & 15) != 0) use_img = false;
+        if (use_img && (mode & 3) == 2 && b->d.N < b->img_min_warm) use_img = false;      // (a warm step is short: the crossover sits higher)
         if (use_img) {
             // the image kernel first (two waves per SIMD); the problems whose working set outgrows its LDS are flagged and solved, from the
             // state they were stored in, by the full-register kernel right behind (mode | 4: flagged problems only)
@@ -915,11 +920,13 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     // The shapes whose M fills the register file (one wave per SIMD) run, in the default arithmetic and on batches that fill the device twice
     // over, as an fp32 IMAGE of M at two waves per SIMD (reg_kernel.hip.h, IMG = 1).  Its LDS holds img_rows working-set rows (C2: the peak is
     // 27 rows on average, above 40 on 1.3 % of the problems -- those are handed to the full-register kernel behind it)
-    if (b->NB == 3 && b->NP == 25 && d.nblk == 3 && m <= 160 && cap <= 64 && !b->reg_handover && !getenv("DAQP_AMD_NO_IMG32")) {
-        int min_batch = 12288, rows = 42;      // (tools/img_threshold.py: below ~12 000 problems the device is not full twice over and a problem's latency decides -- one wave per SIMD is faster per problem)
+    b->img_kind = (b->NB == 3 && b->NP == 25 && d.nblk == 3 && m <= 160) ? 2 : ((b->NB == 2 && b->NP == 32) ? 1 : 0);
+    if (b->img_kind && cap <= 64 && !b->reg_handover && !getenv("DAQP_AMD_NO_IMG32")) {
+        int min_batch = 10240, rows = 42;      // (tools/img_threshold.py: below ~10 000 problems -- warm launches: ~16 000, see launch_ldp -- the device is not full twice over and a problem's latency decides: one wave per SIMD is faster per problem)
         if (const char *e = getenv("DAQP_AMD_IMG_MIN_BATCH")) min_batch = atoi(e);
         if (const char *e = getenv("DAQP_AMD_IMG_ROWS")) { const int v = atoi(e); if (v >= 2 && v <= 64) rows = v; }
-        if (N >= min_batch && ms == 0) { b->img32 = true; d.reg_rows = rows < cap ? rows : cap; }     // (simple bounds: the Gram column's start columns read their rows from LDS)
+        if (getenv("DAQP_AMD_IMG_MIN_BATCH")) b->img_min_warm = min_batch;      // (the tests' override applies to every launch)
+        if (N >= min_batch && ms == 0) { b->img32 = true; d.img_rows = rows < cap ? rows : cap; }     // (simple bounds: the Gram column's start columns read their rows from LDS)
     }
     d.ldrc = 0;
     if (b->NB > 0) {   // stride == 2 (mod 4): rows 16-byte aligned and 16 consecutive rows hit 16 distinct 4-bank groups
@@ -934,22 +941,22 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         int waves = 8;
         if (const char *e = getenv("DAQP_AMD_IMG_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
         const int budget = (160 * 1024 / waves) / 512 * 512;
-        int cache = d.reg_rows;
-        while (cache > 2 && reg_img_lds_bytes(b->NB, 2, n, m, d.reg_rows, cache, d.ldrc) > budget) --cache;
-        if (const char *e = getenv("DAQP_AMD_IMG_CACHE")) { const int v = atoi(e); if (v >= 1) cache = v < d.reg_rows ? v : d.reg_rows; }
+        int cache = d.img_rows;
+        while (cache > 2 && reg_img_lds_bytes(b->NB, b->img_kind, n, m, d.img_rows, cache, d.ldrc) > budget) --cache;
+        if (const char *e = getenv("DAQP_AMD_IMG_CACHE")) { const int v = atoi(e); if (v >= 1) cache = v < d.img_rows ? v : d.img_rows; }
         d.img_cache = cache;
-        b->lds_img = (size_t)reg_img_lds_bytes(b->NB, 2, n, m, d.reg_rows, cache, d.ldrc);
+        b->lds_img = (size_t)reg_img_lds_bytes(b->NB, b->img_kind, n, m, d.img_rows, cache, d.ldrc);
         if (!getenv("DAQP_AMD_IMG_ROWS") && !getenv("DAQP_AMD_IMG_CACHE")) {      // (the tests' overrides apply to every launch)
             int wrows = 40;
             if (const char *e = getenv("DAQP_AMD_IMG_WARM_ROWS")) wrows = atoi(e);
-            if (wrows >= 2 && wrows < d.reg_rows) {
+            if (wrows >= 2 && wrows < d.img_rows) {
                 int wwaves = waves;
                 if (const char *e = getenv("DAQP_AMD_IMG_WARM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) wwaves = v; }
                 const int wbudget = (160 * 1024 / wwaves) / 512 * 512;
                 int wc = wrows;
-                while (wc > 2 && reg_img_lds_bytes(b->NB, 2, n, m, wrows, wc, d.ldrc) > wbudget) --wc;
+                while (wc > 2 && reg_img_lds_bytes(b->NB, b->img_kind, n, m, wrows, wc, d.ldrc) > wbudget) --wc;
                 b->img_rows_warm = wrows; b->img_cache_warm = wc;
-                b->lds_img_warm = (size_t)reg_img_lds_bytes(b->NB, 2, n, m, wrows, wc, d.ldrc);
+                b->lds_img_warm = (size_t)reg_img_lds_bytes(b->NB, b->img_kind, n, m, wrows, wc, d.ldrc);
             }
         }
     }
@@ -1000,7 +1007,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &d.qs, Nn);
     if (b->spill) rc |= dev_alloc(b, &d.rowc_g, Nn * cap * d.ldr);
     if (b->img32) {
-        int t2 = d.reg_rows - d.img_cache;
+        int t2 = d.img_rows - d.img_cache;
         if (b->img_rows_warm - b->img_cache_warm > t2) t2 = b->img_rows_warm - b->img_cache_warm;
         if (t2 > 0) rc |= dev_alloc(b, &d.rowc_g, Nn * (size_t)(t2 * d.ldrc));
     }

@@ -20,7 +20,7 @@ __host__ __device__ inline int reg_lds_rowc_size(int n, int m, int cap, int ldrc
     const int rows = round_up(cap * ldrc, 2), fin = round_up(n * (n + 1) / 2, 2) + 2 + round_up(m, 2);   // epilogue: staged R^-1 + lam
     return rows > fin ? rows : fin;
 }
-// (IMG = 1: `cap` is the number of working-set rows the kernel holds -- BatchDev::reg_rows --, not the problem's own cap)
+// (IMG = 1: `cap` is the number of working-set rows the kernel holds -- BatchDev::img_rows --, not the problem's own cap)
 __host__ __device__ inline int reg_lds_rowc(int NB, int cap, int IMG = 0) { return 196 + (IMG ? 32 : 0) + 3 * (IMG == 2 ? 64 * NB - 32 : 64 * NB) + round_up(cap * (cap + 1) / 2, 2); }
 __host__ __device__ inline int reg_lds_bytes(int NB, int n, int m, int cap, int ldrc, int IMG = 0) { return 8 * (reg_lds_rowc(NB, cap, IMG) + reg_lds_rowc_size(n, m, cap, ldrc)); }
 // IMG != 0: [front: u, pivot stack, probes, u32][row view][L: tri(rows)][row cache], the cache tiered (RWave::cache_slots): `cache` rows + one
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
     //  double-buffered stream of the image degenerates into one memory round trip per unit)
     // rows of the working set the LDS carve-up is sized for: the problem's own cap, or (IMG = 1) what the host chose to keep two waves per SIMD
     // (IMG != 0: a launch may bring its own carve-up -- rows << 16 | cache << 22 in the launch argument, see launch_ldp: warm launches hold fewer rows)
-    const int lds_rows = IMG ? (((mode_in >> 16) & 63) ? ((mode_in >> 16) & 63) : __builtin_amdgcn_readfirstlane(b.reg_rows)) : cap;
+    const int lds_rows = IMG ? (((mode_in >> 16) & 63) ? ((mode_in >> 16) & 63) : __builtin_amdgcn_readfirstlane(b.img_rows)) : cap;
     DAQP_GLOBAL(QState) *qs = as_global(b.qs + q);   // (global pointers throughout: see DAQP_GLOBAL in wave_ldp.hip.h)
     if (mode == 1) {   // an activation launch looks at the record first: almost every problem leaves here, without touching M
         if (__builtin_amdgcn_readfirstlane(qs->setup_flag) < 0 || !__builtin_amdgcn_readfirstlane(qs->need_activate)) return;

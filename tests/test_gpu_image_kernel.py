@@ -55,11 +55,13 @@ def test_image_kernel_c2(oracle, gpu_lib, monkeypatch, rows, cache, waves):
     assert np.array_equal(g0["iter"], g["iter"]) and np.abs(g0["x"] - g["x"]).max() < 1e-12    # (the full-register kernel on the same problems)
 
 
-@pytest.mark.parametrize("shape", [(17, 129, 0, 6), (33, 140, 0, 12), (41, 160, 0, 15), (50, 129, 0, 20), (49, 151, 0, 24), (50, 160, 0, 35), (26, 133, 0, 25)])
+@pytest.mark.parametrize("shape", [(17, 129, 0, 6), (33, 140, 0, 12), (41, 160, 0, 15), (50, 129, 0, 20), (49, 151, 0, 24), (50, 160, 0, 35), (26, 133, 0, 25),
+                                   (51, 100, 0, 18), (56, 120, 0, 20), (63, 128, 0, 30), (60, 64, 0, 25), (63, 65, 0, 40), (55, 128, 0, 50)])   # (the last six: k_ldp_reg<2, 32, true, 1>)
 @pytest.mark.parametrize("cache", [0, 4])
 def test_image_kernel_shapes(oracle, gpu_lib, monkeypatch, shape, cache):
     """every shape the (3, 25) image serves has three row blocks with at most 32 rows in the last one (129 <= m <= 160) and 17 <= n <= 50:
-    odd n (the last pair's partner is padding), the fewest and the most rows of the split block, working sets up to n - 1 rows"""
+    odd n (the last pair's partner is padding), the fewest and the most rows of the split block, working sets up to n - 1 rows; the (2, 32)
+    image (full row blocks) serves 51 <= n <= 63 with m <= 128: one and two row blocks, working sets beyond what it holds (hand-over)"""
     import daqp_amd
     tier(monkeypatch, 0, cache)
     n, m, ms, na = shape
@@ -110,8 +112,9 @@ def test_image_kernel_warm_sequences(oracle, gpu_lib, monkeypatch, rows, cache):
     bm.close()
 
 
+@pytest.mark.parametrize("family", ["3x25", "2x32"])
 @pytest.mark.parametrize("cache", [0, 5])
-def test_image_kernel_degenerate_cases(oracle, gpu_lib, monkeypatch, cache):
+def test_image_kernel_degenerate_cases(oracle, gpu_lib, monkeypatch, cache, family):
     """near-duplicate rows (relative distance 1e-13 ... 1e-2), equalities (some dependent), soft rows on the image kernel's shapes: the pivot
     cascade, singular directions, the refinement step (which hands a problem over when rows sit in the scratch tier) and the refactor repair;
     exit flag and iterations identical, x to 1e-9, the multipliers' combined effect to 1e-7 (an ill-determined pair may share its multiplier
@@ -122,7 +125,10 @@ def test_image_kernel_degenerate_cases(oracle, gpu_lib, monkeypatch, cache):
     for trial in range(60):
         rng = np.random.default_rng([299, trial])
         eps = 10.0 ** rng.uniform(-13, -2)
-        n = int(rng.integers(17, 51)); m = int(rng.integers(129, 161)); ms = 0
+        if family == "3x25":
+            n = int(rng.integers(17, 51)); m = int(rng.integers(129, 161)); ms = 0
+        else:       # k_ldp_reg<2, 32, true, 1>: 51 <= n <= 63, at most two row blocks
+            n = int(rng.integers(51, 61)); m = int(rng.integers(n + 4, 129)); ms = 0
         na = int(rng.integers(n // 4, n - 4))
         q = O.generate_nasty(n, m, ms, na, eps, rng, n_dup=int(rng.integers(0, 6)), n_eq=int(rng.integers(0, 4)),
                              n_soft=int(rng.integers(0, 4)), dep_eq=bool(rng.integers(0, 2)))

@@ -9,7 +9,7 @@ import daqp_amd
 from daqp_amd.synthetic import generate_batch_torch
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 na = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-n, m, ms = 50, 150, 0
+n, m, ms = (int(x) for x in os.environ.get("SHAPE", "50,150,0").split(","))
 os.environ["DAQP_AMD_NO_RECHECK"] = "1"
 qt = generate_batch_torch(N, n, m, ms, na, seed=42, device="cuda:0")
 mask = daqp_amd.UPDATE_unconstrained | daqp_amd.UPDATE_eliminate

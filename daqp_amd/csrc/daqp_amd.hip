@@ -35,6 +35,7 @@ namespace daqp_amd {
     extern template __global__ void k_ldp_reg<NB, NP, true>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_reg<3, 25, true, 2>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_reg<2, 32, true, 1>(const BatchDev *__restrict__, int);
+extern template __global__ void k_ldp_reg<3, 25, true, 1>(const BatchDev *__restrict__, int);
 DAQP_REG_SHAPE(1, 6)
 DAQP_REG_SHAPE(1, 8)
 DAQP_REG_SHAPE(3, 25)
@@ -297,7 +298,8 @@ const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {1, 13}, {1, 16}, {2, 16}, {3, 8}
 // exact: the reference's arithmetic (two roundings per multiply-add); otherwise fused multiply-adds (default mode)
 ldp_reg_kernel_t pick_ldp_reg_img(const DAQPBatch *b)
 {
-    if (b->NB == 3 && b->NP == 25) return k_ldp_reg<3, 25, true, 2>;    // (IMG = 2: the third row block holds at most 32 rows)
+    if (b->NB == 3 && b->NP == 25) return b->img_kind == 2 ? k_ldp_reg<3, 25, true, 2>      // (IMG = 2: the third row block holds at most 32 rows)
+                                                            : k_ldp_reg<3, 25, true, 1>;     // (161 <= m <= 192: three full blocks, 150 image registers, 23 of the rest in scratch)
     if (b->NB == 2 && b->NP == 32) return k_ldp_reg<2, 32, true, 1>;    // (51 <= n <= 63, m <= 128: two full row blocks, 128 image registers)
     return nullptr;
 }
@@ -920,7 +922,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     // The shapes whose M fills the register file (one wave per SIMD) run, in the default arithmetic and on batches that fill the device twice
     // over, as an fp32 IMAGE of M at two waves per SIMD (reg_kernel.hip.h, IMG = 1).  Its LDS holds img_rows working-set rows (C2: the peak is
     // 27 rows on average, above 40 on 1.3 % of the problems -- those are handed to the full-register kernel behind it)
-    b->img_kind = (b->NB == 3 && b->NP == 25 && d.nblk == 3 && m <= 160) ? 2 : ((b->NB == 2 && b->NP == 32) ? 1 : 0);
+    b->img_kind = (b->NB == 3 && b->NP == 25) ? (m <= 160 ? 2 : 1) : ((b->NB == 2 && b->NP == 32) ? 1 : 0);
     if (b->img_kind && cap <= 64 && !b->reg_handover && !getenv("DAQP_AMD_NO_IMG32")) {
         int min_batch = 10240, rows = 42;      // (tools/img_threshold.py: below ~10 000 problems -- warm launches: ~16 000, see launch_ldp -- the device is not full twice over and a problem's latency decides: one wave per SIMD is faster per problem)
         if (const char *e = getenv("DAQP_AMD_IMG_MIN_BATCH")) min_batch = atoi(e);

@@ -4,6 +4,7 @@
 #include "reg_kernel.hip.h"
 
 namespace daqp_amd {
-template __global__ void k_ldp_reg<3, 25, true, 2>(const BatchDev *__restrict__, int);    // C2 / C5: 17 <= n <= 50, 129 <= m <= 160
+template __global__ void k_ldp_reg<3, 25, true, 2>(const BatchDev *__restrict__, int);    // C2 / C5: n <= 50 with 129 <= m <= 160 (and 33 <= n <= 50 with 65 <= m <= 128)
+template __global__ void k_ldp_reg<3, 25, true, 1>(const BatchDev *__restrict__, int);    // n <= 50, 161 <= m <= 192
 template __global__ void k_ldp_reg<2, 32, true, 1>(const BatchDev *__restrict__, int);    // 51 <= n <= 63, m <= 128
 }

@@ -56,7 +56,9 @@ def test_image_kernel_c2(oracle, gpu_lib, monkeypatch, rows, cache, waves):
 
 
 @pytest.mark.parametrize("shape", [(17, 129, 0, 6), (33, 140, 0, 12), (41, 160, 0, 15), (50, 129, 0, 20), (49, 151, 0, 24), (50, 160, 0, 35), (26, 133, 0, 25),
-                                   (51, 100, 0, 18), (56, 120, 0, 20), (63, 128, 0, 30), (60, 64, 0, 25), (63, 65, 0, 40), (55, 128, 0, 50)])   # (the last six: k_ldp_reg<2, 32, true, 1>)
+                                   (51, 100, 0, 18), (56, 120, 0, 20), (63, 128, 0, 30), (60, 64, 0, 25), (63, 65, 0, 40), (55, 128, 0, 50),   # (these six: k_ldp_reg<2, 32, true, 1>)
+                                   (40, 100, 0, 14), (50, 128, 0, 22), (33, 65, 0, 30),        # (two row blocks on the (3,25) image: the split block is empty)
+                                   (50, 161, 0, 20), (45, 192, 0, 18), (20, 180, 0, 8)])       # (k_ldp_reg<3, 25, true, 1>: three full row blocks)
 @pytest.mark.parametrize("cache", [0, 4])
 def test_image_kernel_shapes(oracle, gpu_lib, monkeypatch, shape, cache):
     """every shape the (3, 25) image serves has three row blocks with at most 32 rows in the last one (129 <= m <= 160) and 17 <= n <= 50:

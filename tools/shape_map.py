@@ -1,6 +1,6 @@
 """Where the steps in the shape space are: solve launch per QP and SIMD-cycles per iteration over a grid of (n, m), with the kernel family that
 serves each shape (the dispatch rule of daqp_batch_create restated: register shapes (NB, NP) for working sets of <= 64 rows -- 65 on (2,32) --,
-the workgroup kernel for 65 .. 256 rows, otherwise the one-wave generic kernel with M streamed).  nActive = n / 3.
+the fp32-image kernels of the (3,25) and (2,32) shapes for batches of >= 10 240 problems, the workgroup kernel for 65 .. 256 rows, otherwise the one-wave generic kernel with M streamed).  nActive = n / 3.
 usage: python tools/shape_map.py [N]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,6 +18,8 @@ def family(n, m):
         for nb, np_ in REG:
             if nblk <= nb and npair <= np_:
                 if cap <= 64 or (nb, np_) == (2, 32):
+                    if cap <= 64 and (nb, np_) in ((3, 25), (2, 32)) and N >= 10240:      # (round 6: the fp32-image kernels, two waves per SIMD, batches of >= 10 240)
+                        return f"image({nb},{np_}) x2"
                     return f"reg({nb},{np_}) x{WAVES[(nb, np_)]}" + (" +hand-over" if cap > 64 else "")
                 break
     if 64 < cap <= 256:

@@ -174,3 +174,47 @@ def test_image_kernel_limits_and_failures(oracle, gpu_lib, monkeypatch):
     assert g["exitflag"][3] == -1 and (g["exitflag"] == -4).any() and (g["exitflag"] == 1).any()
     okp = g["exitflag"] == 1
     assert np.abs(g["x"][okp] - ref[0][okp]).max() < XTOL
+    # settings.time_limit (daqp.c:95-103): the device clock is read every 32nd iteration; a budget of 100 ns stops every problem that needs more
+    # than 32 iterations there with -7, the others are untouched
+    q = O.generate_batch(64, n, m, ms, na, seed, start=721000)
+    free = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    lim = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms, time_limit=1e-7)
+    long_ = free["iter"] > 32
+    assert long_.any() and (lim["exitflag"][long_] == -7).all() and (lim["iter"][long_] == 32).all()
+    assert np.array_equal(lim["exitflag"][~long_], free["exitflag"][~long_]) and np.array_equal(lim["iter"][~long_], free["iter"][~long_])
+
+
+@pytest.mark.parametrize("cache", [0, 6])
+def test_image_kernel_shared_structure(oracle, gpu_lib, monkeypatch, cache):
+    """a shared-structure batch (ONE H and A, per-problem f and bounds: daqp_batch_setup_shared) at C2's shape: every problem's image is rounded
+    from the same blocked M, the exact rows of every append come from it; cold solve, then fused warm updates, each step against the oracle"""
+    import daqp_amd
+    tier(monkeypatch, 0, cache)
+    n, m, ms, na = 50, 150, 0, 20
+    N = 48
+    q0 = O.generate_qp(n, m, ms, na, rng=[921, n])
+    rng = np.random.default_rng([922, n])
+    f = q0["f"][None, :] + 0.02 * rng.standard_normal((N, n))
+    shift = 0.005 * rng.standard_normal((N, m))
+    bu, bl = q0["bupper"][None, :] + shift, q0["blower"][None, :] + shift
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup_shared(q0["H"], f, q0["A"], bu, bl, None)
+    models = []
+    for k in range(N):
+        om = oracle.model(n, m, ms)
+        om.setup(q0["H"], f[k], q0["A"], np.full(m, 1e30), np.full(m, -1e30), None)
+        assert om.update(O.UPDATE_v | O.UPDATE_d, f=f[k], bupper=bu[k], blower=bl[k]) == 0
+        models.append(om)
+    for t in range(3):
+        if t > 0:
+            f = f + 0.01 * rng.standard_normal((N, n))
+            bm.update(f=f)
+            for k in range(N):
+                assert models[k].update(O.UPDATE_v, f=f[k]) == 0
+        g = bm.solve()
+        for k in range(N):
+            r = models[k].solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (t, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            assert np.array_equal(np.sign(g["lam"][k]), np.sign(r[1])), (t, k)
+            assert np.abs(g["x"][k] - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max(), np.abs(r[1]).max()), (t, k)
+    bm.close()

@@ -928,7 +928,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         if (const char *e = getenv("DAQP_AMD_IMG_MIN_BATCH")) min_batch = atoi(e);
         if (const char *e = getenv("DAQP_AMD_IMG_ROWS")) { const int v = atoi(e); if (v >= 2 && v <= 64) rows = v; }
         if (getenv("DAQP_AMD_IMG_MIN_BATCH")) b->img_min_warm = min_batch;      // (the tests' override applies to every launch)
-        if (N >= min_batch && ms == 0) { b->img32 = true; d.img_rows = rows < cap ? rows : cap; }     // (simple bounds: the Gram column's start columns read their rows from LDS)
+        if (N >= min_batch) { b->img32 = true; d.img_rows = rows < cap ? rows : cap; }
     }
     d.ldrc = 0;
     if (b->NB > 0) {   // stride == 2 (mod 4): rows 16-byte aligned and 16 consecutive rows hit 16 distinct 4-bank groups

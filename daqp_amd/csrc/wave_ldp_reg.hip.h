@@ -481,9 +481,34 @@ __device__ __forceinline__ double rldl_append(RWave<NB, NP, FM, IMG> &w, int id,
     double g = 0;
     if (lane <= na) {
         const int idk = (lane < na) ? w.wsid : id;
-        const int sk = (lane < na) ? w.slot : newslot;
+        const int sk = (lane < na && (IMG == 0 || w.slot < w.cache_slots)) ? w.slot : newslot;     // (rows of the scratch tier: below)
         const int j = (lane < na && idk < w.ms) ? (c0 > idk ? c0 : idk) : c0;
         if (w.ms != 0) g = dot4_pipelined<FM>(w.rowc + (size_t)sk * w.ldr + j, Mi + j, n - j);
+    }
+    if constexpr (IMG != 0) {
+        if (w.ms != 0) {
+            // simple bounds with rows in the scratch tier: their dots lane <-> component from the start column on (factorization.c:64-72), by tree
+            unsigned long long m2 = __ballot(lane < na && w.slot >= w.cache_slots);
+            const double mine = (lane < n) ? Mi[lane_now()] : 0.0;
+            while (m2) {
+                int ii[kTier2];
+                double rr[kTier2];
+                static_for<kTier2>([&](auto c) __attribute__((always_inline)) {
+                    ii[c] = m2 ? __ffsll((long long)m2) - 1 : -1;
+                    if (m2) m2 &= m2 - 1;
+                    const int so = (ii[c] >= 0) ? (rli(w.slot, ii[c] & 63) - w.cache_slots) * w.ldr : 0;
+                    rr[c] = (lane < n && ii[c] >= 0) ? w.rowg[so + lane] : 0.0;
+                });
+                static_for<kTier2>([&](auto c) __attribute__((always_inline)) {
+                    if (ii[c] >= 0) {               // (wave-uniform)
+                        const int idk = rli(w.wsid, ii[c] & 63);
+                        const int j0 = (idk < w.ms) ? (c0 > idk ? c0 : idk) : c0;
+                        const double sum = wave_sum(lane >= j0 ? rr[c] * mine : 0.0);
+                        if (lane == ii[c]) g = sum;
+                    }
+                });
+            }
+        }
     }
     if (w.ms == 0) g = rdots_two_lanes(w, newslot, Mi);
     int ns_act = 0;

@@ -58,7 +58,8 @@ def test_image_kernel_c2(oracle, gpu_lib, monkeypatch, rows, cache, waves):
 @pytest.mark.parametrize("shape", [(17, 129, 0, 6), (33, 140, 0, 12), (41, 160, 0, 15), (50, 129, 0, 20), (49, 151, 0, 24), (50, 160, 0, 35), (26, 133, 0, 25),
                                    (51, 100, 0, 18), (56, 120, 0, 20), (63, 128, 0, 30), (60, 64, 0, 25), (63, 65, 0, 40), (55, 128, 0, 50),   # (these six: k_ldp_reg<2, 32, true, 1>)
                                    (40, 100, 0, 14), (50, 128, 0, 22), (33, 65, 0, 30),        # (two row blocks on the (3,25) image: the split block is empty)
-                                   (50, 161, 0, 20), (45, 192, 0, 18), (20, 180, 0, 8)])       # (k_ldp_reg<3, 25, true, 1>: three full row blocks)
+                                   (50, 161, 0, 20), (45, 192, 0, 18), (20, 180, 0, 8),        # (k_ldp_reg<3, 25, true, 1>: three full row blocks)
+                                   (50, 150, 10, 20), (40, 140, 40, 15), (33, 130, 5, 12), (60, 120, 8, 20), (63, 128, 63, 25), (50, 192, 12, 18)])   # (simple bounds: rows < ms are rows of R^-1, dots start at their column)
 @pytest.mark.parametrize("cache", [0, 4])
 def test_image_kernel_shapes(oracle, gpu_lib, monkeypatch, shape, cache):
     """every shape the (3, 25) image serves has three row blocks with at most 32 rows in the last one (129 <= m <= 160) and 17 <= n <= 50:
@@ -114,7 +115,7 @@ def test_image_kernel_warm_sequences(oracle, gpu_lib, monkeypatch, rows, cache):
     bm.close()
 
 
-@pytest.mark.parametrize("family", ["3x25", "2x32"])
+@pytest.mark.parametrize("family", ["3x25", "2x32", "bounds"])
 @pytest.mark.parametrize("cache", [0, 5])
 def test_image_kernel_degenerate_cases(oracle, gpu_lib, monkeypatch, cache, family):
     """near-duplicate rows (relative distance 1e-13 ... 1e-2), equalities (some dependent), soft rows on the image kernel's shapes: the pivot
@@ -127,7 +128,9 @@ def test_image_kernel_degenerate_cases(oracle, gpu_lib, monkeypatch, cache, fami
     for trial in range(60):
         rng = np.random.default_rng([299, trial])
         eps = 10.0 ** rng.uniform(-13, -2)
-        if family == "3x25":
+        if family == "bounds":      # simple bounds among the rows (the Gram column's start columns, rows of R^-1 in the image)
+            n = int(rng.integers(17, 51)); m = int(rng.integers(129, 161)); ms = int(rng.integers(1, n + 1))
+        elif family == "3x25":
             n = int(rng.integers(17, 51)); m = int(rng.integers(129, 161)); ms = 0
         else:       # k_ldp_reg<2, 32, true, 1>: 51 <= n <= 63, at most two row blocks
             n = int(rng.integers(51, 61)); m = int(rng.integers(n + 4, 129)); ms = 0
@@ -150,7 +153,8 @@ def test_image_kernel_degenerate_cases(oracle, gpu_lib, monkeypatch, cache, fami
         flag, it = int(g["exitflag"][0]), int(g["iter"][0])
         ok = flag == r[3] and it == r[4]
         if ok and flag > 0:
-            ok = np.abs(g["x"][0] - r[0]).max() < XTOL and np.abs(q["A"].T @ (g["lam"][0] - r[1])).max() < 1e-7
+            G = np.vstack([np.eye(n)[:ms], q["A"]])
+            ok = np.abs(g["x"][0] - r[0]).max() < XTOL and np.abs(G.T @ (g["lam"][0] - r[1])).max() < 1e-7
         if not ok:
             mism.append((trial, n, m, ns, flag, r[3], it, r[4]))
     assert not mism, mism[:10]

@@ -964,11 +964,15 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     }
     if (b->NB == 0 && cap > 64 && cap <= 256 && !getenv("DAQP_AMD_NO_WG")) {     // (beyond 256 rows: the one-wave kernel with eight chunks, everything large in HBM scratch)
         int W = d.nblk < 4 ? 4 : (d.nblk > kWgMaxWaves ? kWgMaxWaves : d.nblk);
-        if (const char *we = getenv("DAQP_AMD_WG_WAVES")) { const int v = atoi(we); if (v >= 4 && v <= kWgMaxWaves) W = v; }
         const int lds_max = 160 * 1024 - 512;          // (the kernel's static LDS -- 320 bytes by the code generator's report -- comes on top of the
                                                        //  dynamic allocation: with 256 bytes of reserve a shape whose packed factor ended within 64 bytes
                                                        //  of the limit, (n, m) = (187, 371), could not be launched at all)
         const int Cw = cap <= 128 ? 2 : 4;
+        // Two workgroups per CU beat one with more waves wherever the whole factor fits half the LDS: one problem's serial master phases then run
+        // under the other's bandwidth phases (n = 100, m = 300: solve launch 29.8 -> 17.9 ms per 4 096; n = 110, m = 330: 17.1 -> 10.8 ms,
+        // profiles/r06t_wg_two_per_cu.txt).  The register file holds eight waves per CU, so two workgroups means four waves each.
+        if (W > 4 && wg_lds_bytes(Cw, m, cap) <= lds_max / 2 - 256) W = 4;
+        if (const char *we = getenv("DAQP_AMD_WG_WAVES")) { const int v = atoi(we); if (v >= 4 && v <= kWgMaxWaves) W = v; }
         int capL = cap;
         while (capL > 16 && wg_lds_bytes(Cw, m, capL) > lds_max) --capL;
         if (const char *ce = getenv("DAQP_AMD_WG_CAPL")) { const int v = atoi(ce); if (v >= 2 && v < capL) capL = v; }   // (tests: force the hand-over)

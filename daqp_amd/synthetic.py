@@ -9,10 +9,11 @@ import torch
 
 
 def _right_solve_upper(Rc, Q):
-    """Q Rc^-1 for upper-triangular Rc, batched.  hipBLAS' batched trsm / getrf fail to allocate their workspace for n in the
-    hundreds (ROCm 7.2), so large n takes a column-by-column forward substitution made of batched mat-vecs."""
+    """Q Rc^-1 for upper-triangular Rc, batched.  hipBLAS' batched trsm / getrf fail to allocate their workspace beyond n = 64
+    (ROCm 7.2: HIPBLAS_STATUS_ALLOC_FAILED at n = 80 as at n = 200), so those take a column-by-column forward substitution made
+    of batched mat-vecs."""
     n = Q.shape[-1]
-    if n <= 128:
+    if n <= 64:
         return torch.linalg.solve_triangular(Rc, Q, upper=True, left=False)
     X = torch.empty_like(Q)
     for j in range(n):

@@ -124,7 +124,7 @@ def test_blocked_setup_hands_doubtful_hessians_to_the_ordered_kernel(oracle, gpu
         assert np.array_equal(g["x"][k].view(np.uint64), ref[0][k].view(np.uint64)) or np.abs(g["x"][k] - ref[0][k]).max() < XTOL
 
 
-@pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (129, 200, 10, 30), (229, 400, 20, 60), (229, 420, 0, 205), (187, 371, 0, 92)])
+@pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (129, 200, 10, 30), (229, 400, 20, 60), (229, 420, 0, 205), (187, 371, 0, 92), (110, 330, 0, 35), (114, 400, 3, 45)])
 def test_fast_mode_workgroup_kernel_shapes(oracle, gpu_lib, shape):
     """the workgroup solve kernel in the default arithmetic: the inverse factor W = L^-1 (CSP / append / delete as matrix-vector
     products over all waves), primal step and Gram column summed in per-wave segments, fp32-screened scan.  The last shape's

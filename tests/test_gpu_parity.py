@@ -104,9 +104,10 @@ def test_workgroup_kernel_hands_over_large_working_sets(oracle, gpu_lib, monkeyp
     check_batch(oracle, "C4", 12)
 
 
-@pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (128, 300, 0, 50), (129, 200, 10, 30), (229, 400, 20, 60)])
+@pytest.mark.parametrize("shape", [(65, 150, 0, 30), (100, 260, 7, 40), (128, 300, 0, 50), (129, 200, 10, 30), (229, 400, 20, 60), (110, 330, 0, 35), (114, 400, 3, 45)])
 def test_workgroup_kernel_shapes(oracle, gpu_lib, shape):
-    """working sets of 66 ... 230 rows (two- and four-chunk masters), simple bounds, odd n, fewer row blocks than waves"""
+    """working sets of 66 ... 230 rows (two- and four-chunk masters), simple bounds, odd n, fewer row blocks than waves; the last two: more row
+    blocks than the four waves of a workgroup that shares its CU with a second one (factor within half the LDS)"""
     n, m, ms, na = shape
     check_batch(oracle, (n, m, ms, na, 1900 + n, 0), 10)
 

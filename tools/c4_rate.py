@@ -7,6 +7,7 @@ from oracle import oracle as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 n, m, ms, na, seed, _ = O.CONFIGS["C4"]
 na = int(os.environ.get("C4_NA", na))      # (experiments: fewer rows active at the optimum -> smaller working sets)
+if os.environ.get("C4_SHAPE"): n, m, na = (int(v) for v in os.environ["C4_SHAPE"].split(","))   # (experiments: other workgroup-kernel shapes, "n,m,n_active")
 from daqp_amd.synthetic import generate_batch_torch
 q = generate_batch_torch(N, n, m, ms, na, seed=seed)
 qn = {k: q[k][:16].cpu().numpy() for k in ("H", "f", "A", "bupper", "blower")}
@@ -35,4 +36,4 @@ if len(sys.argv) > 2:
 if len(sys.argv) > 2 and not os.environ.get("DAQP_AMD_NO_WG"):
     adds = pr[:, 25].sum()
     print("  per append (cycles): row fetch until it is in LDS %.0f, Gram column after that %.0f, W g / l / new row of W %.0f" % (pr[:, 31].sum() / adds, (pr[:, 29].sum() - pr[:, 31].sum()) / adds, pr[:, 30].sum() / adds))
-print(f"C4 N={N}: {N / dt:.0f} QPs/s, kernels setup/solve ms {bm.kernel_ms()}, mean iter {r['iter'].double().mean().item():.1f}, optimal {(r['exitflag'] == 1).all().item()}, parity(16) {ok}, max|dx| {np.abs(r['x'][:16].cpu().numpy() - ref[0]).max():.1e}")
+print(f"n={n} m={m} active {na}, N={N}: {N / dt:.0f} QPs/s, kernels setup/solve ms {bm.kernel_ms()}, mean iter {r['iter'].double().mean().item():.1f}, optimal {(r['exitflag'] == 1).all().item()}, parity(16) {ok}, max|dx| {np.abs(r['x'][:16].cpu().numpy() - ref[0]).max():.1e}")

@@ -54,6 +54,7 @@ struct BatchDev {
     double *wg_rowc, *wg_rowcT;   // [grid][cap][ldr] active rows, [grid][n][wg_capT] the same transposed
     int *fallback;                // [N] 1: the working set outgrew the LDS-resident L -- the one-wave kernel solves this problem
     int wg_capL, wg_capT;
+    int wg_r0;                    // tiered launch of the workgroup kernel: rows of the inverse factor in LDS (0: no such launch)
     int *img_ho;                  // image kernels: problems handed over by the current launch (one counter per batch; the host reads it one launch late), or null
     int img_rows;                 // image kernels: the working-set rows they hold at all (their L in LDS); beyond: hand-over to the full-register kernel of the shape
     int img_cache;                // image kernels (k_ldp_reg<..., IMG != 0>): rows of the active-row cache kept in LDS; slots from here on live in rowc_g (reg_rows - img_cache rows

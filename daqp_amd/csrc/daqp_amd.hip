@@ -61,7 +61,8 @@ extern template __global__ void k_setup_tiny<4>(BatchDev, int);
 #define DAQP_BLK_SHAPE(NT, NW, TAIL) extern template __global__ void k_setup_blk<NT, NW, TAIL>(const BatchDev *__restrict__, int);
 DAQP_BLK_SHAPES
 #undef DAQP_BLK_SHAPE   // (the 16-per-wave SETUP kernel is the default for these shapes: setup_kernel.hip)
-template <int C, bool EX> __global__ void k_ldp_wg(BatchDev b, int mode);
+template <int C, bool EX, bool TIER = false> __global__ void k_ldp_wg(BatchDev b, int mode);
+extern template __global__ void k_ldp_wg<4, false, true>(BatchDev, int);
 extern template __global__ void k_ldp_wg<2, false>(BatchDev, int);
 extern template __global__ void k_ldp_wg<2, true>(BatchDev, int);
 extern template __global__ void k_ldp_wg<4, false>(BatchDev, int);
@@ -130,6 +131,7 @@ struct DAQPBatch {
     bool in_prox_loop = false;      // launches of the proximal outer loop (solve_with_prox)
     bool use_wg = false;
     int wg_W = 0, wg_C = 0, wg_grid = 0;
+    int wg_tier_grid = 0; size_t lds_wg_tier = 0;   // tiered launch of the workgroup kernel in front of a cold solve (0: none)
     bool reg_handover = false;   // k_ldp_reg<2,32,*> may flag problems (more working-set rows than lanes: n = 64) for k_ldp right behind it
     size_t lds_fb = 0;           // ... and that launch's LDS
     bool img32 = false;          // default arithmetic: the solve launch is k_ldp_reg<NB, NP, true, 1> -- an fp32 image of M in the registers, two waves per
@@ -349,9 +351,20 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
         BatchDev dd = b->d;
         if (b->in_prox_loop || b->exact_sticky) dd.exact_setup = 1;   // problems of the proximal outer loop keep the reference's arithmetic in both modes
         wg_kernel_t kw = dd.exact_setup ? (b->wg_C == 2 ? k_ldp_wg<2, true> : k_ldp_wg<4, true>) : (b->wg_C == 2 ? k_ldp_wg<2, false> : k_ldp_wg<4, false>);
+        int wg_mode = mode;
+        if (b->wg_tier_grid > 0 && b->fresh && mode == 0 && !dd.exact_setup) {
+            // a first solve in the default arithmetic: two four-wave workgroups per CU, the inverse factor tiered (LDS + the problem's slot of the
+            // stored factor); what it flags -- warm working sets, soft rows, a factor that left the inverse representation -- is solved by the
+            // launch behind it, which holds the whole factor in LDS
+            HIPCHK(hipMemsetAsync(b->d.wg_counter, 0, sizeof(int), b->stream));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldp_wg<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg_tier));
+            hipLaunchKernelGGL((k_ldp_wg<4, false, true>), dim3(b->wg_tier_grid), dim3(256), b->lds_wg_tier, b->stream, dd, mode);
+            HIPCHK(hipGetLastError());
+            wg_mode = mode | 4;
+        }
         HIPCHK(hipMemsetAsync(b->d.wg_counter, 0, sizeof(int), b->stream));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg));
-        hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, dd, mode);
+        hipLaunchKernelGGL(kw, dim3(b->wg_grid), dim3(64 * b->wg_W), b->lds_wg, b->stream, dd, wg_mode);
         HIPCHK(hipGetLastError());
         ldp_kernel_t kf = pick_ldp(b);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
@@ -795,7 +808,7 @@ bool pool_enabled() { const char *e = getenv("DAQP_AMD_NO_POOL"); return !(e && 
 std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
-                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M", "DAQP_AMD_NO_BLK_SETUP",
+                                  "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_NO_WG_TIER", "DAQP_AMD_WG_R0", "DAQP_AMD_WG_TIER_GRID", "DAQP_AMD_WG_TIER_MIN_BATCH", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M", "DAQP_AMD_NO_BLK_SETUP",
                                   "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WARM_ROWS", "DAQP_AMD_IMG_WARM_WAVES"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
@@ -1087,13 +1100,34 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         long long g = (long long)cus * per_cu;
         if (const char *ge = getenv("DAQP_AMD_WG_GRID")) { const long long v = atoll(ge); if (v >= 1) g = v; }   // tuning: problems in flight
         b->wg_grid = (int)(g < N ? g : N);
+        // Tiered launch (wg_kernel.hip.h, TIER): where the whole factor allows only one workgroup per CU, cold solves run two four-wave workgroups
+        // per CU with the rows of the inverse factor beyond what half the LDS holds in HBM.  Worth it only while enough problems are in flight.
+        d.wg_r0 = 0;
+        long long tier_min = 2LL * cus;
+        if (const char *te = getenv("DAQP_AMD_WG_TIER_MIN_BATCH")) { const long long v = atoll(te); if (v >= 1) tier_min = v; }    // (tests: small batches through the tiered launch)
+        if (b->use_wg && b->wg_C == 4 && per_cu == 1 && d.wg_inverse && !getenv("DAQP_AMD_NO_WG_TIER") && N >= tier_min) {
+            const int half = (160 * 1024 - 512) / 2 - 256;
+            int r0 = cap;
+            while (r0 > 16 && wg_lds_bytes(4, m, r0) > half) --r0;
+            if (const char *re = getenv("DAQP_AMD_WG_R0")) { const int v = atoi(re); if (v >= 8 && v < r0) r0 = v; }    // (tests: more rows in the HBM tier)
+            int per2 = 0;
+            const size_t lds2 = (size_t)wg_lds_bytes(4, m, r0);
+            if (r0 >= 32 && r0 < cap && hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldp_wg<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) == hipSuccess
+                && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per2, reinterpret_cast<const void *>(k_ldp_wg<4, false, true>), 256, lds2) == hipSuccess && per2 >= 2) {
+                d.wg_r0 = r0; b->lds_wg_tier = lds2;
+                long long g2 = (long long)cus * per2;
+                if (const char *ge = getenv("DAQP_AMD_WG_TIER_GRID")) { const long long v = atoll(ge); if (v >= 1) g2 = v; }
+                b->wg_tier_grid = (int)(g2 < N ? g2 : N);
+            } else (void)hipGetLastError();
+        }
+        const int wg_slots = b->wg_grid > b->wg_tier_grid ? b->wg_grid : b->wg_tier_grid;   // scratch per workgroup in flight, whichever launch has more
         rc |= dev_alloc(b, &d.wg_counter, 1);
         {   // row-major active rows per workgroup in flight, whole 32-column chunks per row; the pad columns are zero and stay zero
-            const size_t cnt = (size_t)b->wg_grid * cap * wg_row_stride(n);
+            const size_t cnt = (size_t)wg_slots * cap * wg_row_stride(n);
             rc |= dev_alloc(b, &d.wg_rowc, cnt);
             if (!rc && hipMemset(d.wg_rowc, 0, cnt * sizeof(double)) != hipSuccess) rc = 1;
         }
-        rc |= dev_alloc(b, &d.wg_rowcT, (size_t)b->wg_grid * n * d.wg_capT);
+        rc |= dev_alloc(b, &d.wg_rowcT, (size_t)wg_slots * n * d.wg_capT);
         rc |= dev_alloc(b, &d.fallback, Nn);
         if (!rc && hipMemset(d.fallback, 0, Nn * sizeof(int)) != hipSuccess) rc = 1;
     }

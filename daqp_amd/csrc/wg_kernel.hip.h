@@ -13,9 +13,17 @@ namespace daqp_amd {
 // is inlined into the kernel and branches on c.exact: as a run-time field both modes' code -- the reference's ordered chains AND the
 // inverse factor with its tree sums -- shared one register allocation, and the default mode's launch carried the chains' live ranges
 // (488 bytes of scratch per lane, 169 spilled registers in k_ldp_wg<4> at round 4).
-template <int C, bool EX>
-__global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mode)
+// TIER: the cold solves of the default arithmetic at TWO four-wave workgroups per CU (one problem's serial master phases under the other's bandwidth
+// phases): rows < wg_r0 of the inverse factor in LDS, the rest in the problem's slot of the stored factor (wg_ldp.hip.h: WROW).  Takes only problems
+// that start from an empty working set without soft rows; everything else -- and whatever leaves the inverse-factor representation beyond wg_r0 rows
+// -- is flagged in b.fallback for the launch behind it (the same kernel without tiers, mode | 4).
+// mode | 4 (no TIER): only the problems flagged in b.fallback.
+template <int C, bool EX, bool TIER = false>
+__global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mode_in)
 {
+    static_assert(!(TIER && EX), "the tiers hold the inverse factor: default arithmetic only");
+    const int mode = mode_in & 3;
+    const bool flagged_only = !TIER && (mode_in & 4) != 0;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int q_sh;
     __shared__ int m_int[8];       // master -> everybody after the iteration: flag, iterations, na, reuse, sing, lam swapped, overflow
@@ -23,9 +31,11 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
     const int wv = wg_wave();   // (wave-uniform by construction: say so, or the master's whole body sits in a "divergent" branch)
     const int n = b.n, m = b.m, cap = b.cap, W = (int)(blockDim.x >> 6);
     WgCtx c;
-    c.n = n; c.m = m; c.ms = b.ms; c.cap = cap; c.capL = b.wg_capL; c.npair = b.npair; c.nblk = b.nblk; c.ldr = wg_row_stride(n); c.capT = b.wg_capT;
+    const int capL = TIER ? b.wg_r0 : b.wg_capL;
+    c.n = n; c.m = m; c.ms = b.ms; c.cap = cap; c.capL = capL; c.npair = b.npair; c.nblk = b.nblk; c.ldr = wg_row_stride(n); c.capT = b.wg_capT;
     c.W = W; c.exact = EX ? 1 : 0;
-    c.oL = wg_lds_L(C, m); c.lmax = wg_round_up(b.wg_capL * (b.wg_capL + 1) / 2, 2) - 1;
+    c.oL = wg_lds_L(C, m); c.lmax = wg_round_up(capL * (capL + 1) / 2, 2) - 1;
+    c.tier = TIER ? 1 : 0; c.r0 = capL; c.capW = TIER ? cap : capL; c.gL = nullptr;
     c.rowc = b.wg_rowc + (size_t)blockIdx.x * cap * wg_row_stride(n);
     c.rowcT = b.wg_rowcT + (size_t)blockIdx.x * n * b.wg_capT;
     const int T = (int)blockDim.x;
@@ -40,6 +50,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
         __syncthreads();
         const int q = uni(q_sh);
         if (q >= b.N) break;
+        if (flagged_only && !uni(b.fallback[q])) continue;
         QState *qs = b.qs + q;
         const int sflag = uni(qs->setup_flag), need_act = uni(qs->need_activate), uflag = uni(qs->upd_flag);
         if (mode == 1) { if (sflag < 0 || !need_act) continue; }
@@ -69,6 +80,10 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
             continue;
         }
         const int na0 = uni(qs->n_active);
+        if (TIER && (na0 != 0 || need_act || mode != 0)) {      // not a cold start: the launch behind this one
+            if (tid == 0) b.fallback[q] = 1;
+            continue;
+        }
         if (na0 > c.capL) {        // a warm start that does not fit: the one-wave kernel takes the problem as it is
             if (tid == 0) b.fallback[q] = 1;
             continue;
@@ -82,6 +97,11 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
         int softbits = 0;
         for (int i = tid; i < m; i += T) { const int s = gsense[i]; SI(c, sense)[i] = s; softbits |= s & DAQP_SOFT; }
         const int has_soft = uni(__syncthreads_or(softbits) ? 1 : 0);
+        if (TIER && has_soft) {
+            if (tid == 0) b.fallback[q] = 1;
+            continue;
+        }
+        c.gL = b.L + (size_t)q * b.ltri;
         double *gv = b.vecs + (size_t)q * 5 * cap;
         int *gws = b.WS + (size_t)q * cap;
         for (int i = tid; i < cap; i += T) {
@@ -128,7 +148,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
             w.fast_na = -1;
             int iters = 0;
             const int flag = wrun(w, mode, need_act != 0, iters);
-            if (!w.overflow) wleave_w(w, w.na);                          // the stored iterate is always L   // (need_activate at mode 0: defensive, setup/update runs mode 1 itself)
+            if (!w.overflow) wleave_w(w, w.na, true);                    // the stored iterate is always L   // (need_activate at mode 0: defensive, setup/update runs mode 1 itself)
             if (lane == 0) {
                 m_int[0] = flag; m_int[1] = iters; m_int[2] = w.na; m_int[3] = w.reuse; m_int[4] = w.sing;
                 m_int[5] = w.lam_b; m_int[6] = w.overflow; m_int[7] = w.trace_len;
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(64 * kWgMaxWaves) void k_ldp_wg(BatchDev b, int mod
         }
         for (int i = tide; i < m; i += T) gsense[i] = SI(c, sense)[i];
         {
-            const int used = tri(na);
+            const int used = tri((TIER && na > c.r0) ? c.r0 : na);       // (TIER: the rows from r0 on are in place already)
             double *gL = b.L + (size_t)q * b.ltri;
             for (int e = tide; e < used; e += T) gL[e] = SDL(c)[e];
         }

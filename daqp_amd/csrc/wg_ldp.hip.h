@@ -47,6 +47,11 @@ struct WgL {
 // what every thread of the workgroup knows (sizes, HBM pointers; no iterate state)
 struct WgCtx {
     int n, m, ms, cap, capL, npair, nblk, ldr, capT, W, exact, oL, lmax;   // lmax: last valid index of packed L
+    // Tiered inverse factor (k_ldp_wg<C, false, true>: two four-wave workgroups per CU): rows < r0 of W in LDS, rows >= r0 in the problem's own
+    // slot of the stored factor in HBM (gL: element (i, j) at tri(i) + j -- the place where the row ends up anyway when the solve is over, and
+    // L2-resident while the problem is in flight).  tier = 0 (a compile-time constant in every other instantiation): everything in LDS.
+    int tier, r0, capW;                   // capW: rows the inverse factor may grow to (capL without tiers)
+    double *gL;
     double *rowc, *rowcT;                 // this workgroup's scratch in HBM: [cap][ldr] and [n][capT]
     const double *Mblk, *dupper, *dlower, *scaling;
     const float *M32;                     // fp32 image of M for the screening scan (null: every scan in fp64)
@@ -55,6 +60,8 @@ struct WgCtx {
 __device__ __forceinline__ double *wg_sm() { extern __shared__ __attribute__((aligned(16))) double wg_dyn_lds[]; return wg_dyn_lds; }
 #define SD(c, name) (wg_sm() + WgL<C>::name)
 #define SDL(c) (wg_sm() + (c).oL)
+// row i of the (inverse) factor, tier-aware: a pointer to its element (i, 0).  In a tiered launch the pointer is generic (LDS or HBM by the row)
+#define WROW(c, i) ((((c).tier && (i) >= (c).r0) ? (c).gL : SDL(c)) + tri(i))
 // index into packed L clamped to its LDS allocation: lanes whose row does not exist load anyway (the value is discarded),
 // so the address must stay inside the allocation
 #define WLIDX(c, e) ((e) < (c).lmax ? (e) : (c).lmax)
@@ -643,12 +650,13 @@ __device__ __forceinline__ void wg_w_rows(const WgCtx &c, const double *vec, int
     for (int i0 = from + 16 * wv; i0 < na; i0 += 16 * c.W) {
         const int i = i0 + r;
         const bool valid = i < na;
-        const int base = tri(valid ? i : na - 1);
+        const int irow = valid ? i : na - 1;
         const int ilast = (i0 + 15 < na) ? i0 + 15 : na - 1;
         const int kmax = (ilast + 3) >> 2;                  // steps of four columns that the longest row of the block needs
         const int kfull = i0 >> 2;                          // steps whose columns lie left of EVERY row's diagonal: no test inside
         double a0 = 0, a1 = 0;
-        const double *wr_ = SDL(c) + base + p, *vp_ = vec + p;
+        const double *wrow_ = WROW(c, irow);
+        const double *wr_ = wrow_ + p, *vp_ = vec + p;
         int k = 0;
         for (; k + 8 <= kfull; k += 8) {
             double wq[8], vq[8];
@@ -663,7 +671,7 @@ __device__ __forceinline__ void wg_w_rows(const WgCtx &c, const double *vec, int
             for (int q = 0; q < 4; ++q) {
                 const int j = 4 * (k + q) + p;
                 const bool in = valid && j < i;
-                wq[q] = SDL(c)[WLIDX(c, base + (in ? j : 0))];
+                wq[q] = wrow_[in ? j : 0];
                 vq[q] = vec[in ? j : 0];
                 if (!in) wq[q] = 0.0;
             }
@@ -713,17 +721,57 @@ __device__ __forceinline__ void wg_w_cols(const WgCtx &c, const double *vec, int
         double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (j < na) {
             int i = lo;
-            const double *wp = SDL(c) + tri(i) + j;          // W[i][j]; the next row is i + 1 doubles further
-            for (; i + 7 < hi; i += 8) {                     // eight rows in flight per trip
-                double wv8[8], vv8[8];
-                const double *q = wp;
+            if (!c.tier) {
+                const double *wp = SDL(c) + tri(i) + j;          // W[i][j]; the next row is i + 1 doubles further
+                for (; i + 7 < hi; i += 8) {                     // eight rows in flight per trip
+                    double wv8[8], vv8[8];
+                    const double *q = wp;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { wv8[k] = *q; vv8[k] = vec[i + k]; q += i + k + 1; }
-                wp = q;
+                    for (int k = 0; k < 8; ++k) { wv8[k] = *q; vv8[k] = vec[i + k]; q += i + k + 1; }
+                    wp = q;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) a[k] = __builtin_fma(wv8[k], vv8[k], a[k]);
+                    for (int k = 0; k < 8; ++k) a[k] = __builtin_fma(wv8[k], vv8[k], a[k]);
+                }
+                for (; i < hi; ++i) { a[0] = __builtin_fma(*wp, vec[i], a[0]); wp += i + 1; }
+            } else {
+                // tiered: the rows below r0 from LDS as above; the rows from r0 on from HBM, sixteen in flight per trip (an L2 round trip each)
+                const int hl = hi < c.r0 ? hi : c.r0;
+                if (i < hl) {
+                    const double *wp = SDL(c) + tri(i) + j;
+                    for (; i + 7 < hl; i += 8) {
+                        double wv8[8], vv8[8];
+                        const double *q = wp;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { wv8[k] = *q; vv8[k] = vec[i + k]; q += i + k + 1; }
+                        wp = q;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) a[k] = __builtin_fma(wv8[k], vv8[k], a[k]);
+                    }
+                    for (; i < hl; ++i) { a[0] = __builtin_fma(*wp, vec[i], a[0]); wp += i + 1; }
+                }
+                if (i < hi) {
+                    const DAQP_GLOBAL(double) *gp = as_global(const_cast<const double *>(c.gL)) + tri(i) + j;
+                    for (; i + 15 < hi; i += 16) {
+                        double wv16[16];
+                        const DAQP_GLOBAL(double) *q = gp;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) { wv16[k] = *q; q += i + k + 1; }
+                        gp = q;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) a[k & 7] = __builtin_fma(wv16[k], vec[i + k], a[k & 7]);
+                    }
+                    for (; i + 3 < hi; i += 4) {
+                        double wv4[4];
+                        const DAQP_GLOBAL(double) *q = gp;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { wv4[k] = *q; q += i + k + 1; }
+                        gp = q;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[k] = __builtin_fma(wv4[k], vec[i + k], a[k]);
+                    }
+                    for (; i < hi; ++i) { a[0] = __builtin_fma(*gp, vec[i], a[0]); gp += i + 1; }
+                }
             }
-            for (; i < hi; ++i) { a[0] = __builtin_fma(*wp, vec[i], a[0]); wp += i + 1; }
         }
         part[wv * 64 + lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
@@ -778,7 +826,7 @@ __device__ __forceinline__ void wg_wappend(const WgCtx &c, int na)
 #ifdef DAQP_WG_PROBE2
     WGPROBE(c, 20);
 #endif
-    wg_w_cols<C>(c, lv, na, [&](int j, double v) __attribute__((always_inline)) { SDL(c)[tri(na) + j] = -v; });
+    wg_w_cols<C>(c, lv, na, [&](int j, double v) __attribute__((always_inline)) { WROW(c, na)[j] = -v; });
 #ifdef DAQP_WG_PROBE2
     WGPROBE(c, 21);
 #endif
@@ -798,7 +846,8 @@ __device__ __forceinline__ void wg_wdelete(const WgCtx &c, int r, int na, bool x
             if (64 * cc < nupd) {
                 const int t = lane + 64 * cc;
                 const bool in = t < nupd;
-                const double p = in ? -SDL(c)[WLIDX(c, tri(r + 1 + t) + r)] : 0.0;
+                double p = 0.0;
+                if (in) p = -WROW(c, r + 1 + t)[r];
                 const double Dt = in ? SD(c, D)[r + 1 + t] : 1.0;
                 double sc = p * p / Dt;                                   // s_t
                 // inclusive prefix sum over the wave (Hillis-Steele through ds_bpermute: six steps)
@@ -817,12 +866,13 @@ __device__ __forceinline__ void wg_wdelete(const WgCtx &c, int r, int na, bool x
             }
         }
     } else {
-        for (int cidx = tid - 64; cidx < r; cidx += 64 * (c.W - 1)) wr[cidx] = SDL(c)[tri(r) + cidx];
+        for (int cidx = tid - 64; cidx < r; cidx += 64 * (c.W - 1)) wr[cidx] = WROW(c, r)[cidx];
         for (int t = tid - 64; t < nupd; t += 64 * (c.W - 1)) {
             const int ro = r + 1 + t;                                      // old row
             static_for<(C - 1 < 2 ? C - 1 : 2)>([&](auto k) __attribute__((always_inline)) {
                 constexpr int cb = 64 * (k + 1);                           // old column read by the last lane of chunk k
-                const double v = (cb < ro) ? SDL(c)[tri(ro) + cb] : 0.0;
+                double v = 0.0;
+                if (cb < ro) v = WROW(c, ro)[cb];
                 if (k == 0) bnd0[t] = v; else bnd1[t] = v;
             });
         }
@@ -852,14 +902,31 @@ __device__ __forceinline__ void wg_wdelete(const WgCtx &c, int r, int na, bool x
         // (a column of W22 enters the sweep at its own unit diagonal: x = 1 there, so the running sum starts at beta of that row)
         double s = shift ? bvec[cn - r] : 0.0;
         int t = shift ? cn - r + 1 : 0;                                    // first new row below this column's diagonal: r + t > cn
+        if (c.tier) {
+            // tiered: eight rows' old entries in flight before their chain (a row beyond r0 is an L2 round trip; left inside the chain, the
+            // store of a step and the load of the next one cannot be told apart by the code generator and every step waits for its load).
+            // Reading ahead is safe: what this thread reads in rows t .. t+7 is written -- by itself or by its right neighbour -- in later steps.
+            for (; t + 7 < nupd; t += 8) {
+                double w8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) w8[k] = seam ? bnd[t + k] : WROW(c, r + 1 + t + k)[co];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const double pt = pvec[t + k], bt = bvec[t + k];
+                    const double x = __builtin_fma(-pt, s, __builtin_fma(pt, wrc, w8[k]));
+                    s = __builtin_fma(bt, x, s);
+                    WROW(c, r + t + k)[cn] = x;
+                }
+            }
+        }
         for (; t < nupd; ++t) {
             const int ro = r + 1 + t, rn = r + t;
-            const double w0 = seam ? bnd[t] : SDL(c)[tri(ro) + co];
+            const double w0 = seam ? bnd[t] : WROW(c, ro)[co];
             const double pt = pvec[t], bt = bvec[t];
             const double x0 = __builtin_fma(pt, wrc, w0);
             const double x = __builtin_fma(-pt, s, x0);
             s = __builtin_fma(bt, x, s);
-            SDL(c)[tri(rn) + cn] = x;
+            WROW(c, rn)[cn] = x;
         }
     }
 }
@@ -870,12 +937,28 @@ __device__ __forceinline__ void wg_w2l(const WgCtx &c, int nrows)
     const int tid = wg_tid();
     double *wrow = SD(c, mnew);
     for (int i = 1; i < nrows; ++i) {
-        if (tid < i) wrow[tid] = SDL(c)[tri(i) + tid];
+        if (tid < i) wrow[tid] = WROW(c, i)[tid];
         __syncthreads();
         if (tid < i) {
             double acc = -wrow[tid];
-            for (int k = tid + 1; k < i; ++k) acc = __builtin_fma(-wrow[k], SDL(c)[tri(k) + tid], acc);
-            SDL(c)[tri(i) + tid] = acc;
+            if (!c.tier) {
+                for (int k = tid + 1; k < i; ++k) acc = __builtin_fma(-wrow[k], SDL(c)[tri(k) + tid], acc);
+            } else {
+                int k = tid + 1;
+                const int kl = i < c.r0 ? i : c.r0;
+                for (; k < kl; ++k) acc = __builtin_fma(-wrow[k], SDL(c)[tri(k) + tid], acc);
+                if (k < c.r0) k = c.r0;                       // (tid + 1 may lie beyond r0 already)
+                const DAQP_GLOBAL(double) *gp = as_global(const_cast<const double *>(c.gL));
+                for (; k + 7 < i; k += 8) {                   // the rows in HBM: eight loads in flight
+                    double l8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) l8[e] = gp[tri(k + e) + tid];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc = __builtin_fma(-wrow[k + e], l8[e], acc);
+                }
+                for (; k < i; ++k) acc = __builtin_fma(-wrow[k], gp[tri(k) + tid], acc);
+            }
+            WROW(c, i)[tid] = acc;
         }
         __syncthreads();
     }
@@ -1004,9 +1087,12 @@ __device__ __forceinline__ double wsum(const double (&a)[C])
 
 // leave the inverse-factor representation: W -> L over the first `rows` rows, then the chains take over for the rest of the solve
 template <int C>
-__device__ __forceinline__ void wleave_w(WgWave<C> &w, int rows)
+__device__ __forceinline__ void wleave_w(WgWave<C> &w, int rows, bool final = false)
 {
     if (!w.use_w) return;
+    // a tiered factor cannot continue on the chains (they walk L in LDS): the problem is handed to the launch behind this one, which holds
+    // the whole factor in LDS; only the END of a solve converts across the tiers (final: the stored iterate is always L)
+    if (w.c.tier && rows > w.c.r0 && !final) { w.overflow = 1; return; }
     wg_run(w, WG_W2L, rows);
     w.use_w = 0;
 }
@@ -1016,10 +1102,11 @@ template <int C>
 __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
 {
     if (w.use_w && w.na >= 191) wleave_w(w, w.na);   // (the inverse-factor commands serve up to three 64-row chunks: 192 rows)
+    if (w.overflow) return;
     if (w.use_w) {   // inverse factor: Gram column, l = D^-1 W g, new row of W = -l' W, all in one command
         const WgCtx &c = w.c;
         const int lane = wg_lane(), na = w.na;
-        if (na >= c.capL) { w.overflow = 1; return; }
+        if (na >= c.capW) { w.overflow = 1; return; }
         const int newslot = uni(SI(c, freestk)[w.nfree - 1]);
         w.nfree--;
         if (newslot > w.hi_slot) w.hi_slot = newslot;
@@ -1037,6 +1124,7 @@ __device__ __forceinline__ void wldl_append(WgWave<C> &w, int id)
         if (ub(dnew < w.stp->sing_tol) || na >= c.n) {
             // a singular pivot: back to L (the new row included: its L entries are l), then as the chains would leave it
             wleave_w(w, na + 1);
+            if (w.overflow) return;
             if (lane == 0) SD(c, D)[na] = 0;
             w.sing = na;
         } else { if (lane == 0) SD(c, D)[na] = dnew; w.fast_na = na + 1; }
@@ -1162,6 +1250,7 @@ __device__ __forceinline__ void wldl_delete(WgWave<C> &w, int r)
             return;
         }
         wleave_w(w, na);
+        if (w.overflow) return;
     }
     double wv[C];
 #pragma unroll
@@ -1260,7 +1349,7 @@ __device__ __forceinline__ int wdrop_core(WgWave<C> &w, int r)
     if (w.na > 0 && ub(SD(c, D)[w.na - 1] < w.stp->sing_tol)) {
         wleave_w(w, w.na);
         w.sing = w.na - 1;
-        took = 1;
+        took = w.overflow ? 0 : 1;
     }
     WSYNC();
     if (took && lane == 0) SD(c, D)[w.na - 1] = 0;
@@ -1413,7 +1502,8 @@ __device__ __forceinline__ void wdirection(WgWave<C> &w)
                 const bool in = i < nw;
                 part[cc] = in ? lv[i] * SD(c, xl)[i] : 0.0;
                 lold[cc] = in ? lam[i] : 0.0;
-                wn[cc] = in ? SDL(c)[WLIDX(c, tri(nw) + i)] : 0.0;
+                wn[cc] = 0.0;
+                if (in) wn[cc] = WROW(c, nw)[i];
             }
             const double xn = und(SD(c, rhs)[nw] - wsum<C>(part));
             const double zn = und(xn / SD(c, D)[nw]);
@@ -1792,6 +1882,7 @@ __device__ __forceinline__ int wrun(WgWave<C> &w, int mode, bool need_activate, 
                     if (w.na > 0 && ub(dmin < w.stp->pivot_tol)) {
                         wtrace(w, kTraceRefine);
                         wleave_w(w, w.na);
+                        if (w.overflow) break;
                         wrefine_active(w);
                         scan_first = 0; after_edit = WAFTER_NEXT_ITER; tl_skip = 1;
                         pc = WPC_SCAN;
@@ -1830,6 +1921,7 @@ __device__ __forceinline__ int wrun(WgWave<C> &w, int mode, bool need_activate, 
                     }
                     if (piv) {
                         wleave_w(w, w.na);
+                        if (w.overflow) break;
                         wtrace(w, kTracePivot);
                         if (lane == 0) { SI(c, pend_id)[depth] = SI(c, ws)[r]; SD(c, pend_lam)[depth] = WLAM(w)[r]; }
                         depth++;

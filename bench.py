@@ -555,14 +555,18 @@ class Runner:
 
 
 def pattern_ceiling():
-    """the chip-wide rate of tools/ubench5.hip (the C4 solve kernel's memory phases as a pure streaming pattern: 256 workgroups of 8 waves,
+    """the chip-wide rate of tools/ubench5.hip (the C4 solve kernel's memory phases as a pure streaming pattern: 512 workgroups of 4 waves -- 256 of 8 in runs before round 6's tiered launch --,
     each re-reading its own 0.8 MB working set with 16-byte loads, 16 in flight per lane) from the newest committed run"""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ubench5.txt")))
     if not files:
         return None
-    rates = [float(m.group(1)) for m in re.finditer(r"^256 workgroups x 8 waves, 1 working set.*?-> ([0-9.]+) TB/s", open(files[-1]).read(), re.M)]
+    text = open(files[-1]).read()
+    # (round 6: C4's cold solves run two four-wave workgroups per CU -- the ceiling is taken at THAT residency when the run has it)
+    rates = [float(m.group(1)) for m in re.finditer(r"^512 workgroups x 4 waves, 1 working set.*?-> ([0-9.]+) TB/s", text, re.M)]
+    if not rates:
+        rates = [float(m.group(1)) for m in re.finditer(r"^256 workgroups x 8 waves, 1 working set.*?-> ([0-9.]+) TB/s", text, re.M)]
     if not rates:
         return None
     return {"peak": 1e3 * float(np.median(rates)), "unit": "GB/s", "source": "profiles/" + os.path.basename(files[-1]),

@@ -12,7 +12,7 @@ from bench import CONFIGS, library_stamp
 out = sys.argv[1]
 # the solve LAUNCH of C2 / C5 is two kernels: the image kernel (fp32 image of M, two waves per SIMD) and, right behind it, the full-register
 # kernel for the problems it handed over -- their counters are summed ("+")
-SOLVE = {"C2": r"k_ldp_reg<3, 25, true, 2>+k_ldp_reg<3, 25, true, 0>", "C3": r"k_ldp_reg<1, [68]", "C4": r"k_ldp_wg<4[,>]", "C5": r"k_ldp_reg<3, 25, true, 2>+k_ldp_reg<3, 25, true, 0>"}
+SOLVE = {"C2": r"k_ldp_reg<3, 25, true, 2>+k_ldp_reg<3, 25, true, 0>", "C3": r"k_ldp_reg<1, [68]", "C4": r"k_ldp_wg<4, false, true>+k_ldp_wg<4, false, false>", "C5": r"k_ldp_reg<3, 25, true, 2>+k_ldp_reg<3, 25, true, 0>"}
 # C4's setup is three launches, each with its own record
 SETUP_LAUNCHES = {"C4": [r"k_fact_wg", r"k_setup_m", r"k_setup<true, 4, true, false>"]}
 SETUP = {"C2": r"k_setup_blk<4, 56||k_setup_fast<56", "C3": r"k_setup_tiny|k_setup_fast<16", "C4": r"k_setup<true", "C5": r"k_setup_blk<4, 56||k_setup_fast<56"}

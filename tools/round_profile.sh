@@ -27,6 +27,7 @@ python tools/pmc_config_summary.py $O/pmc_summary.json $O/pmc_raw_C2.json $O/pmc
 timeout 900 python bench.py --full-out $O/bench_full.json > $O/bench.json 2> $O/bench.err
 tools/ubench4.bin > $O/ubench4.txt 2>&1
 tools/ubench5.bin > $O/ubench5.txt 2>&1
+tools/ubench5.bin 512 200 4 >> $O/ubench5.txt 2>&1      # the residency of the tiered launch: two four-wave workgroups per CU
 python tools/gpu_profile.py 20000 > $O/c2_phases.txt 2>&1
 python tools/c4_rate.py 4096 prof > $O/c4_phases.txt 2>&1
 python tools/c5_phases.py > $O/c5_phases.txt 2>&1

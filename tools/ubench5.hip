@@ -3,7 +3,7 @@
 // lane (the kernel's scan depth): a 480 KB fp32 image of M (the screening scan) and `rows` active rows of 1.6 KB twice (primal step, Gram
 // column).  Two footprints: every workgroup keeps ONE working set (256 x ~0.64 MB = 164 MB: within the 256 MB Infinity Cache, as the
 // kernel's image + row cache mostly are while a problem iterates) or rotates over SETS working sets (beyond it: HBM).
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench5.hip -o tools/ubench5.bin ; tools/ubench5.bin [workgroups] [iterations]
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench5.hip -o tools/ubench5.bin ; tools/ubench5.bin [workgroups] [iterations] [waves per workgroup]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(512) void k_iter(const float4 *mem, size_t set_f4, 
 int main(int argc, char **argv)
 {
     const int wgs = argc > 1 ? atoi(argv[1]) : 256, iters = argc > 2 ? atoi(argv[2]) : 200;
+    const int waves = argc > 3 ? atoi(argv[3]) : 8;      // (round 6: 512 workgroups x 4 waves = the residency of the tiered launch, two workgroups per CU)
     const size_t set_bytes = (size_t)kImage + (size_t)kRows * kRow, set_f4 = set_bytes / 16;
     const double per_iter = (double)kImage + 2.0 * kRows * kRow;
     float *out;
@@ -58,17 +59,17 @@ int main(int argc, char **argv)
         hipMemset(mem, 0, bytes);
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
-        hipLaunchKernelGGL(k_iter, dim3(wgs), dim3(512), 0, 0, mem, set_f4, sets, 20, out);
+        hipLaunchKernelGGL(k_iter, dim3(wgs), dim3(64 * waves), 0, 0, mem, set_f4, sets, 20, out);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_iter, dim3(wgs), dim3(512), 0, 0, mem, set_f4, sets, iters, out);
+        hipLaunchKernelGGL(k_iter, dim3(wgs), dim3(64 * waves), 0, 0, mem, set_f4, sets, iters, out);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
         const double total = per_iter * iters * wgs;
-        printf("%d workgroups x 8 waves, %d working set(s) each (%.0f MB in all), %d iterations of %.0f KB: %.2f ms -> %.2f TB/s, %.1f B/clk/CU at 2.4 GHz, %.0f cycles per iteration\n",
-               wgs, sets, bytes / 1e6, iters, per_iter / 1024, ms, total / ms / 1e9, total / wgs / (ms * 1e-3 * 2.4e9), ms * 1e-3 * 2.4e9 / iters);
+        printf("%d workgroups x %d waves, %d working set(s) each (%.0f MB in all), %d iterations of %.0f KB: %.2f ms -> %.2f TB/s, %.1f B/clk/CU at 2.4 GHz, %.0f cycles per iteration\n",
+               wgs, waves, sets, bytes / 1e6, iters, per_iter / 1024, ms, total / ms / 1e9, total / wgs / (ms * 1e-3 * 2.4e9), ms * 1e-3 * 2.4e9 / iters);
         hipFree(mem);
     }
     return 0;

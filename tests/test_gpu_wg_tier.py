@@ -124,9 +124,9 @@ def test_degenerate_families_through_the_tiers(oracle, gpu_lib, tier):
     assert not mism, mism[:10]
 
 
-def test_tiered_launch_is_the_one_that_runs(gpu_lib, tier):
-    """the kernel-name check of the suite: with the launch forced, a cold default-mode solve of a four-chunk shape is timed under its own
-    name (BatchModel.kernel_ms counts the launches of a solve) and leaves the same results as the launch without tiers"""
+def test_tiered_and_untiered_launch_agree(gpu_lib, tier):
+    """the same C4 draws with the tiered launch forced and with it switched off (DAQP_AMD_NO_WG_TIER=1: eight waves, the whole factor in LDS):
+    iteration counts, exit flags and active sets identical, x to 1e-11 (the two sum W's products over different wave slices)"""
     import daqp_amd
     n, m, ms, na = 200, 600, 0, 80
     q = O.generate_batch(4, n, m, ms, na, 44)
@@ -135,3 +135,34 @@ def test_tiered_launch_is_the_one_that_runs(gpu_lib, tier):
     g0 = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
     assert np.array_equal(g1["iter"], g0["iter"]) and np.array_equal(g1["exitflag"], g0["exitflag"])
     assert np.abs(g1["x"] - g0["x"]).max() < 1e-11 and np.array_equal(np.sign(g1["lam"]), np.sign(g0["lam"]))
+
+
+@pytest.mark.parametrize("r0", [None, 33])
+def test_iteration_limit_inside_the_tiered_launch_then_on(oracle, gpu_lib, tier, r0):
+    """iter_limit = 150 stops a C4 solve in the middle (exit -4, the working set at ~100-130 rows: across the tier boundary): the W -> L conversion at
+    the end of the launch crosses the tiers, and the SECOND daqp_solve continues from that stored factor -- in the launch that holds everything in
+    LDS -- exactly where the reference's workspace continues (daqp.c:6-108: iterations restart at 1, the working set and L stay)"""
+    import daqp_amd
+    if r0:
+        tier.setenv("DAQP_AMD_WG_R0", str(r0))
+    n, m, ms, na, seed, _ = O.CONFIGS["C4"]
+    N = 6
+    q = O.generate_batch(N, n, m, ms, na, seed, start=80)
+    bm = daqp_amd.BatchModel(N, n, m, ms, iter_limit=150)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+    mods = []
+    for k in range(N):
+        md = oracle.model(n, m, ms, settings=O.default_settings(iter_limit=150))
+        md.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+        mods.append(md)
+    seen = set()
+    for rnd in range(3):
+        g = bm.solve()
+        for k, md in enumerate(mods):
+            r = md.solve()
+            assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (rnd, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+            seen.add(int(r[3]))
+            if r[3] > 0:
+                assert np.array_equal(np.sign(g["lam"][k]), np.sign(r[1])) and np.abs(g["x"][k] - r[0]).max() < XTOL
+    assert -4 in seen and 1 in seen
+    bm.close()

@@ -8,7 +8,7 @@
 namespace daqp_amd {
 
 // mode 0: daqp_solve; mode 1: only (re)build the working set from the ACTIVE bits (tail of daqp_update_ldp);
-// mode | 4: only the problems flagged in b.fallback are touched by the ONE-WAVE kernel (see k_ldp) -- not used here
+// mode | 4: only the problems flagged in b.fallback -- this kernel behind its own tiered launch (TIER below), and the ONE-WAVE kernel (k_ldp) behind both
 // EX: the arithmetic mode as a compile-time constant (b.exact_setup decides which instantiation is launched).  Every function below
 // is inlined into the kernel and branches on c.exact: as a run-time field both modes' code -- the reference's ordered chains AND the
 // inverse factor with its tree sums -- shared one register allocation, and the default mode's launch carried the chains' live ranges

@@ -15,6 +15,11 @@
 //     stay cache-resident because only as many problems are in flight as there are resident workgroups.
 // The master runs the reference's control flow unchanged and hands the parallel phases to the other waves through a
 // command word in LDS (post, s_barrier, everybody works, s_barrier).
+// Round 6: where two four-wave workgroups fit a CU, one problem's serial master phases run under the other's bandwidth phases (1.5-1.6x on
+// shapes whose factor fits half the LDS).  For the shapes whose factor does not (C4), the inverse factor of a cold solve is TIERED: rows below
+// r0 in LDS, the rest in the problem's slot of the stored factor in HBM -- WROW() below; the kernel instantiation <C, false, true> of
+// wg_kernel.hip.h.  Every matrix-vector product over W takes the HBM rows as one more batch of independent loads; nothing that walks a
+// dependent chain over the factor (the L representation, the exact mode) runs on a tiered factor.
 #pragma once
 #include "wave_ldp.hip.h"
 #include "wave_ldp_reg.hip.h"   // static_for

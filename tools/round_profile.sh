@@ -32,3 +32,4 @@ python tools/gpu_profile.py 20000 > $O/c2_phases.txt 2>&1
 python tools/c4_rate.py 4096 prof > $O/c4_phases.txt 2>&1
 python tools/c5_phases.py > $O/c5_phases.txt 2>&1
 python tools/latency_one.py > $O/latency_one.txt 2>&1
+timeout 900 python tools/shape_map.py > $O/shape_map.txt 2>&1

@@ -49,3 +49,33 @@ for n in (8, 12, 16, 17, 26, 27, 32, 33, 40, 50, 51, 56, 63, 64, 65):
             del q, r
         except Exception as e:   # (the torch generator of this tool, not the library: hipBLAS workspace at large n x N)
             print(f"{n:3d} {m:3d} | {family(n, m):28s} | skipped: {str(e)[:80]}", flush=True)
+
+
+# ---- the workgroup kernel's shapes (round 6): four-wave workgroups two per CU where the whole factor fits half the LDS, the tiered launch
+# (two per CU, the factor's tail in HBM) for cold solves of the four-chunk shapes beyond that
+NL = int(os.environ.get("SHAPE_MAP_LARGE_N", "4096"))
+print(f"\nworkgroup-kernel shapes, N = {NL} QPs per shape, nActive = n/3; columns: n m | residency | setup ms | solve launch ms | us per QP | mean iterations")
+for n in (72, 80, 100, 110, 120, 128, 150, 200, 229):
+    for m in (200, 300, 400, 600):
+        if m <= n + 8:
+            continue
+        try:
+            cap = n + 1
+            from_lds = 8 * ((8 * (128 if cap <= 128 else 256) + 516 + 136 * 8 + 24) + ((5 * (128 if cap <= 128 else 256) + 16 + (m + 3) // 4 * 4 + 3) // 4 * 4) // 2 + (cap * (cap + 1) // 2 + 1) // 2 * 2)
+            res = "4 waves x 2 per CU" if from_lds <= (160 * 1024 - 512) // 2 - 256 else ("tiered: 4 waves x 2 per CU" if cap > 128 else "up to 8 waves x 1 per CU")
+            q = generate_batch_torch(NL, n, m, 0, max(2, n // 3), 8100 + n)
+            bm = daqp_amd.BatchModel(NL, n, m, 0)
+            best = None
+            for rep in range(3):
+                bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None)
+                r = bm.solve(out="torch")
+                torch.cuda.synchronize()
+                ks, kl = bm.kernel_ms()
+                best = (ks, kl) if best is None or kl < best[1] else best
+            it = r["iter"].double().mean().item()
+            ok = bool((r["exitflag"] == 1).all().item())
+            print(f"{n:3d} {m:3d} | {res:28s} | {best[0]:7.2f} | {best[1]:8.2f} | {best[1] * 1e3 / NL:7.2f} | {it:6.1f}{'' if ok else '  (not all optimal)'}", flush=True)
+            bm.close()
+            del q, r
+        except Exception as e:
+            print(f"{n:3d} {m:3d} | skipped: {str(e)[:80]}", flush=True)

@@ -63,6 +63,7 @@ DAQP_BLK_SHAPES
 #undef DAQP_BLK_SHAPE   // (the 16-per-wave SETUP kernel is the default for these shapes: setup_kernel.hip)
 template <int C, bool EX, bool TIER = false> __global__ void k_ldp_wg(BatchDev b, int mode);
 extern template __global__ void k_ldp_wg<4, false, true>(BatchDev, int);
+extern template __global__ void k_ldp_wg<2, false, true>(BatchDev, int);
 extern template __global__ void k_ldp_wg<2, false>(BatchDev, int);
 extern template __global__ void k_ldp_wg<2, true>(BatchDev, int);
 extern template __global__ void k_ldp_wg<4, false>(BatchDev, int);
@@ -126,6 +127,7 @@ struct DAQPBatch {
     int NB = 0, NP = 0;   // register-resident M variant (0: stream M from HBM)
     bool tiny_setup = false;   // n <= 12, m <= 48: the 16-problems-per-wave setup kernel (tiny_setup.hip.h)
     bool fast_setup = false, setup_spill = false;
+    bool fact_gs = false;           // 64 < n, factors that WOULD fit the LDS of k_setup: the default arithmetic's full setup still takes k_fact_wg + the scratch variant
     double *fact_buf = nullptr;     // [N][4] records of k_fact_wg (setup_fact.hip.h), allocated for the shapes it serves
     // workgroup-per-problem solve kernel (wg_kernel.hip.h): shapes without a register variant and more than 64 working-set rows
     bool in_prox_loop = false;      // launches of the proximal outer loop (solve_with_prox)
@@ -357,8 +359,9 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
             // stored factor); what it flags -- warm working sets, soft rows, a factor that left the inverse representation -- is solved by the
             // launch behind it, which holds the whole factor in LDS
             HIPCHK(hipMemsetAsync(b->d.wg_counter, 0, sizeof(int), b->stream));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldp_wg<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg_tier));
-            hipLaunchKernelGGL((k_ldp_wg<4, false, true>), dim3(b->wg_tier_grid), dim3(256), b->lds_wg_tier, b->stream, dd, mode);
+            wg_kernel_t kt = b->wg_C == 2 ? k_ldp_wg<2, false, true> : k_ldp_wg<4, false, true>;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_wg_tier));
+            hipLaunchKernelGGL(kt, dim3(b->wg_tier_grid), dim3(256), b->lds_wg_tier, b->stream, dd, mode);
             HIPCHK(hipGetLastError());
             wg_mode = mode | 4;
         }
@@ -809,7 +812,7 @@ std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
                                   "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_NO_WG_TIER", "DAQP_AMD_WG_R0", "DAQP_AMD_WG_TIER_GRID", "DAQP_AMD_WG_TIER_MIN_BATCH", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M", "DAQP_AMD_NO_BLK_SETUP",
-                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WARM_ROWS", "DAQP_AMD_IMG_WARM_WAVES"};
+                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_FACT_SMALL", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WARM_ROWS", "DAQP_AMD_IMG_WARM_WAVES"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -1004,6 +1007,11 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     }
     b->setup_spill = !b->fast_setup && (setup_lds(n, m).total_bytes > 150 * 1024 || getenv("DAQP_AMD_FORCE_SPILL") || n > 256);
     b->lds_setup = b->fast_setup ? (size_t)fast_lds(n, m, 1, m - ms).total_bytes : (size_t)setup_lds(n, m, b->setup_spill).total_bytes;
+    // 64 < n <= ~134: both factors fit the LDS of k_setup, where ONE wave factors and inverts in the reference's order -- 13.5 ms per 4 096 problems at
+    // n = 100 against 5.2 ms at n = 150, where k_fact_wg (a workgroup per problem, matrix cores) does it.  The default arithmetic's full setup takes
+    // k_fact_wg + the scratch variant of k_setup for these shapes too (profiles/r06v_shape_map.txt -> r06w); exact mode, partial updates and the
+    // regularising passes keep the LDS variant.
+    b->fact_gs = !b->fast_setup && !b->setup_spill && n > 64 && n <= kFactMaxN && !getenv("DAQP_AMD_NO_FACT_WG") && !getenv("DAQP_AMD_NO_FACT_SMALL");
     b->lds_update = (size_t)round_up(n, 2) * 16;
     if (b->lds_ldp > 160 * 1024 || b->lds_setup > 160 * 1024) {
         set_err("problem too large for the LDS-staged setup (needs %zu / %zu bytes)", b->lds_setup, b->lds_ldp);
@@ -1030,7 +1038,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         if (b->img_rows_warm - b->img_cache_warm > t2) t2 = b->img_rows_warm - b->img_cache_warm;
         if (t2 > 0) rc |= dev_alloc(b, &d.rowc_g, Nn * (size_t)(t2 * d.ldrc));
     }
-    if (b->setup_spill) rc |= dev_alloc(b, &d.setup_g, Nn * 2 * (size_t)round_up(d.rtri, 2));
+    if (b->setup_spill || b->fact_gs) rc |= dev_alloc(b, &d.setup_g, Nn * 2 * (size_t)round_up(d.rtri, 2));
     // fp32 image of M for the workgroup kernel's screening scan (generic setup kernel only: it is the one that writes it)
     if (b->use_wg && !b->fast_setup && !getenv("DAQP_AMD_NO_SCAN32")) {
         const size_t cnt = Nn * (size_t)d.nblk * d.nquad * 256;
@@ -1042,7 +1050,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         rc |= dev_alloc(b, &d.setup_sq, sq);
         if (!rc) HIPCHK(hipMemset(d.setup_sq, 0, sq * sizeof(double)));
         rc |= dev_alloc(b, &d.m_tick, Nn);
-        if (b->setup_spill && n <= kFactMaxN && !getenv("DAQP_AMD_NO_FACT_WG")) rc |= dev_alloc(b, &b->fact_buf, Nn * 4);
+        if ((b->setup_spill || b->fact_gs) && n <= kFactMaxN && !getenv("DAQP_AMD_NO_FACT_WG")) rc |= dev_alloc(b, &b->fact_buf, Nn * 4);
         if (!rc) HIPCHK(hipMemset(d.m_tick, 0, Nn * sizeof(int)));
     }
     if (N == 1) {   // one slab: x[n] lam[m] fval soft | flag iter -- in mapped host memory, written by the solve kernel itself (see mapped_out)
@@ -1105,15 +1113,16 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.wg_r0 = 0;
         long long tier_min = 2LL * cus;
         if (const char *te = getenv("DAQP_AMD_WG_TIER_MIN_BATCH")) { const long long v = atoll(te); if (v >= 1) tier_min = v; }    // (tests: small batches through the tiered launch)
-        if (b->use_wg && b->wg_C == 4 && per_cu == 1 && d.wg_inverse && !getenv("DAQP_AMD_NO_WG_TIER") && N >= tier_min) {
+        if (b->use_wg && per_cu == 1 && d.wg_inverse && !getenv("DAQP_AMD_NO_WG_TIER") && N >= tier_min) {
             const int half = (160 * 1024 - 512) / 2 - 256;
+            wg_kernel_t kt = b->wg_C == 2 ? k_ldp_wg<2, false, true> : k_ldp_wg<4, false, true>;
             int r0 = cap;
-            while (r0 > 16 && wg_lds_bytes(4, m, r0) > half) --r0;
+            while (r0 > 16 && wg_lds_bytes(b->wg_C, m, r0) > half) --r0;
             if (const char *re = getenv("DAQP_AMD_WG_R0")) { const int v = atoi(re); if (v >= 8 && v < r0) r0 = v; }    // (tests: more rows in the HBM tier)
             int per2 = 0;
-            const size_t lds2 = (size_t)wg_lds_bytes(4, m, r0);
-            if (r0 >= 32 && r0 < cap && hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldp_wg<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) == hipSuccess
-                && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per2, reinterpret_cast<const void *>(k_ldp_wg<4, false, true>), 256, lds2) == hipSuccess && per2 >= 2) {
+            const size_t lds2 = (size_t)wg_lds_bytes(b->wg_C, m, r0);
+            if (r0 >= 32 && r0 < cap && hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) == hipSuccess
+                && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per2, reinterpret_cast<const void *>(kt), 256, lds2) == hipSuccess && per2 >= 2) {
                 d.wg_r0 = r0; b->lds_wg_tier = lds2;
                 long long g2 = (long long)cus * per2;
                 if (const char *ge = getenv("DAQP_AMD_WG_TIER_GRID")) { const long long v = atoll(ge); if (v >= 1) g2 = v; }
@@ -1419,14 +1428,16 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
         // descriptor: the batch's own never carries it, whichever way this function is left (a later shared setup copies b->d)
         BatchDev l = d;
         l.defer_m = defers_m(b, d) ? 1 : 0;
+        const bool gs_now = b->setup_spill || (b->fact_gs && l.defer_m && b->fact_buf && d.setup_g && !(d.st.eps_prox > 0.0));
         if (l.defer_m) {    // the instantiation without the general rows (k_setup_m follows): more waves per SIMD
-            ks = b->setup_spill ? k_setup<true, 4, true> : k_setup<false, 4, true>;
+            ks = gs_now ? k_setup<true, 4, true> : k_setup<false, 4, true>;
+            if (gs_now && !b->setup_spill) lds_setup = (size_t)setup_lds(d.n, d.m, true).total_bytes;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup));
         }
         // default arithmetic, factors out of LDS (the n = 200 class): Cholesky and inverse by k_fact_wg, a workgroup per problem with
         // the triangle in LDS and the matrix cores behind each panel (setup_fact.hip.h); k_setup takes R^-1 from the scratch
         l.fact = nullptr;
-        if (l.defer_m && b->setup_spill && b->fact_buf && d.n <= kFactMaxN && !(d.st.eps_prox > 0.0)) {
+        if (l.defer_m && gs_now && b->fact_buf && d.n <= kFactMaxN && !(d.st.eps_prox > 0.0)) {
             const size_t lds = fact_lds_bytes(d.n);
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fact_wg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
                 l.fact = b->fact_buf;

@@ -8,4 +8,5 @@ template __global__ void k_ldp_wg<2, true>(BatchDev, int);
 template __global__ void k_ldp_wg<4, false>(BatchDev, int);
 template __global__ void k_ldp_wg<4, true>(BatchDev, int);
 template __global__ void k_ldp_wg<4, false, true>(BatchDev, int);
+template __global__ void k_ldp_wg<2, false, true>(BatchDev, int);
 }

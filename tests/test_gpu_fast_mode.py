@@ -303,7 +303,8 @@ def test_general_rows_as_their_own_launch(oracle, gpu_lib, monkeypatch, shape):
         assert np.abs(g["x"][4] - ref[0][4]).max() < XTOL and not g["lam"][4].any()
 
 
-@pytest.mark.parametrize("shape", [(200, 600, 0, 80), (200, 480, 12, 60), (193, 300, 0, 40), (176, 520, 0, 50), (161, 610, 5, 30)])
+@pytest.mark.parametrize("shape", [(200, 600, 0, 80), (200, 480, 12, 60), (193, 300, 0, 40), (176, 520, 0, 50), (161, 610, 5, 30),
+                                   (100, 300, 0, 40), (65, 150, 0, 25), (128, 300, 7, 40), (81, 200, 3, 30), (134, 330, 0, 40)])   # (the second row: factors that would fit k_setup's LDS -- round 6 gives them the same launch)
 def test_factorisation_as_its_own_launch(oracle, gpu_lib, monkeypatch, shape):
     """k_fact_wg (csrc/setup_fact.hip.h): Cholesky factor and inverse of the generic setup for the shapes whose factors do not fit
     LDS twice (the n = 200 class), default arithmetic -- a workgroup per problem, the packed triangle in LDS, sixteen-row panels, the

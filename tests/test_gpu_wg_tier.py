@@ -39,7 +39,8 @@ def test_c4_through_the_tiers(oracle, gpu_lib, tier, r0):
     compare(g, ref)
 
 
-@pytest.mark.parametrize("shape", [(129, 200, 10, 30), (229, 400, 20, 60), (187, 371, 0, 92), (229, 420, 0, 205), (150, 512, 0, 70), (255, 300, 40, 90)])
+@pytest.mark.parametrize("shape", [(129, 200, 10, 30), (229, 400, 20, 60), (187, 371, 0, 92), (229, 420, 0, 205), (150, 512, 0, 70), (255, 300, 40, 90),
+                                   (120, 300, 0, 40), (127, 400, 5, 45), (116, 640, 0, 50)])     # (the last three: two-chunk shapes whose factor does not fit half the LDS: k_ldp_wg<2, false, true>)
 @pytest.mark.parametrize("r0", [None, 40])
 def test_shapes_through_the_tiers(oracle, gpu_lib, tier, shape, r0):
     """four-chunk shapes: simple bounds, odd n, fewer / more row blocks than the four waves, working sets that pass 191 rows (where the inverse

@@ -62,7 +62,7 @@ for n in (72, 80, 100, 110, 120, 128, 150, 200, 229):
         try:
             cap = n + 1
             from_lds = 8 * ((8 * (128 if cap <= 128 else 256) + 516 + 136 * 8 + 24) + ((5 * (128 if cap <= 128 else 256) + 16 + (m + 3) // 4 * 4 + 3) // 4 * 4) // 2 + (cap * (cap + 1) // 2 + 1) // 2 * 2)
-            res = "4 waves x 2 per CU" if from_lds <= (160 * 1024 - 512) // 2 - 256 else ("tiered: 4 waves x 2 per CU" if cap > 128 else "up to 8 waves x 1 per CU")
+            res = "4 waves x 2 per CU" if from_lds <= (160 * 1024 - 512) // 2 - 256 else ("tiered: 4 waves x 2 per CU" if NL >= 512 else "up to 8 waves x 1 per CU")
             q = generate_batch_torch(NL, n, m, 0, max(2, n // 3), 8100 + n)
             bm = daqp_amd.BatchModel(NL, n, m, 0)
             best = None

@@ -36,6 +36,7 @@ namespace daqp_amd {
 extern template __global__ void k_ldp_reg<3, 25, true, 2>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_reg<2, 32, true, 1>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_reg<3, 25, true, 1>(const BatchDev *__restrict__, int);
+extern template __global__ void k_ldp_reg<4, 32, true, 1>(const BatchDev *__restrict__, int);
 DAQP_REG_SHAPE(1, 6)
 DAQP_REG_SHAPE(1, 8)
 DAQP_REG_SHAPE(3, 25)
@@ -148,6 +149,7 @@ struct DAQPBatch {
     // full-register kernel anyway (working sets beyond what the image kernel holds), the next launches go there directly; every 16th tries again
     int *img_ho_pin = nullptr;
     unsigned img_skipped = 0;
+    bool img_only = false;       // no register shape holds M, but its fp32 image fits (k_ldp_reg<4,32,true,1>, one wave per SIMD): default-mode solves run it in front of k_ldp
     int img_min_warm = 16384;
     size_t lds_wg = 0;
     double *wide_u = nullptr, *wide_l = nullptr;   // daqp_batch_setup_shared: +-1e30 bounds of the one factorisation
@@ -418,6 +420,21 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
     }
     ldp_kernel_t k = pick_ldp(b);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
+    if (b->img_only && mode == 0 && !b->d.exact_setup && !b->in_prox_loop && !b->exact_sticky) {
+        // The shapes whose M fits no register file but whose fp32 IMAGE does (n <= 63, m <= 256): the image kernel alone at one wave per SIMD --
+        // the scan runs out of registers instead of streaming 8 (m - ms) n bytes per iteration from L2 / HBM --, and this kernel behind it for
+        // whatever it flags (mode | 4; the image kernel holds every working-set row the shape can have, so that is an empty pass)
+        if (push_descriptor(b)) return DAQP_EXIT_UNSUPPORTED;
+        ldp_reg_kernel_t ki = k_ldp_reg<4, 32, true, 1>;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_img));
+        if (b->d.img_ho) HIPCHK(hipMemsetAsync(b->d.img_ho, 0, sizeof(int), b->stream));
+        HIPCHK(hipMemsetAsync(b->d.fallback, 0, (size_t)b->d.N * sizeof(int), b->stream));
+        hipLaunchKernelGGL(ki, dim3(b->d.N), dim3(64), b->lds_img, b->stream, (const BatchDev *)b->d_dev, mode);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, b->d, mode | 4);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, b->d, mode);
     HIPCHK(hipGetLastError());
     return 0;
@@ -812,7 +829,7 @@ std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
                                   "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_NO_WG_TIER", "DAQP_AMD_WG_R0", "DAQP_AMD_WG_TIER_GRID", "DAQP_AMD_WG_TIER_MIN_BATCH", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M", "DAQP_AMD_NO_BLK_SETUP",
-                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_FACT_SMALL", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WARM_ROWS", "DAQP_AMD_IMG_WARM_WAVES"};
+                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_FACT_SMALL", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WARM_ROWS", "DAQP_AMD_IMG_WARM_WAVES", "DAQP_AMD_NO_IMG_ONLY", "DAQP_AMD_IMG_ONLY_MIN_BATCH"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -953,6 +970,26 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.ldrc = l;
     }
     b->lds_ldp = b->NB > 0 ? (size_t)reg_lds_bytes(b->NB, n, m, cap, d.ldrc) : (size_t)ldp_lds(n, m, cap, b->spill, d.ldrc).total_bytes;
+    // No register shape for (n, m), but the fp32 image of M fits one (k_ldp_reg<4,32,true,1>: n <= 63, m <= 256, one wave per SIMD): the default
+    // arithmetic's solves run on it (launch_ldp); everything else about the batch stays the generic one-wave path's.  Every working-set row the
+    // shape can have is held (img_rows = cap), as many of them in LDS as leave four workgroups per CU, the rest in the scratch tier.
+    // (n <= 16: M streamed is as fast -- n = 8, m = 256: 0.86 against 1.02 ms per 20 000 -- a scan is 16 column pairs of L2 hits)
+    if (b->NB == 0 && !b->spill && n > 16 && cap <= 64 && d.nblk <= 4 && d.npair <= 32 && !getenv("DAQP_AMD_STREAM_M") && !getenv("DAQP_AMD_NO_IMG32") && !getenv("DAQP_AMD_NO_IMG_ONLY")) {
+        int min_batch = 1;
+        if (const char *e = getenv("DAQP_AMD_IMG_ONLY_MIN_BATCH")) min_batch = atoi(e);
+        if (N >= min_batch) {
+            b->img_only = true;
+            int l = n > 64 ? n : 64;
+            while ((l & 3) != 2) ++l;
+            d.ldrc = l;                      // (the row-cache stride of the register kernels; k_ldp has its own)
+            d.img_rows = cap;
+            const int budget = (160 * 1024 / 4) / 512 * 512;
+            int cache = d.img_rows;
+            while (cache > 2 && reg_img_lds_bytes(4, 1, n, m, d.img_rows, cache, d.ldrc) > budget) --cache;
+            d.img_cache = cache;
+            b->lds_img = (size_t)reg_img_lds_bytes(4, 1, n, m, d.img_rows, cache, d.ldrc);
+        }
+    }
     if (b->img32) {
         // rows of the active-row cache in LDS: as many as leave `waves` workgroups per CU (the rest of a working set lives in rowc_g, L2-resident);
         // a workgroup's share of the CU's 160 KB is granted in 512-byte steps
@@ -1033,6 +1070,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     rc |= dev_alloc(b, &d.WS, Nn * cap);
     rc |= dev_alloc(b, &d.qs, Nn);
     if (b->spill) rc |= dev_alloc(b, &d.rowc_g, Nn * cap * d.ldr);
+    if (b->img_only && d.img_rows > d.img_cache) rc |= dev_alloc(b, &d.rowc_g, Nn * (size_t)((d.img_rows - d.img_cache) * d.ldrc));
     if (b->img32) {
         int t2 = d.img_rows - d.img_cache;
         if (b->img_rows_warm - b->img_cache_warm > t2) t2 = b->img_rows_warm - b->img_cache_warm;
@@ -1145,7 +1183,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         if (!rc && hipHostMalloc(reinterpret_cast<void **>(&b->img_ho_pin), sizeof(int), hipHostMallocDefault) != hipSuccess) rc = 1;
         if (!rc) *b->img_ho_pin = 0;
     }
-    if ((b->reg_handover || b->img32) && !rc) {
+    if ((b->reg_handover || b->img32 || b->img_only) && !rc) {
         rc |= dev_alloc(b, &d.fallback, Nn);
         if (!rc && hipMemset(d.fallback, 0, Nn * sizeof(int)) != hipSuccess) rc = 1;
     }

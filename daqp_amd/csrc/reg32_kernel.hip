@@ -7,4 +7,5 @@ namespace daqp_amd {
 template __global__ void k_ldp_reg<3, 25, true, 2>(const BatchDev *__restrict__, int);    // C2 / C5: n <= 50 with 129 <= m <= 160 (and 33 <= n <= 50 with 65 <= m <= 128)
 template __global__ void k_ldp_reg<3, 25, true, 1>(const BatchDev *__restrict__, int);    // n <= 50, 161 <= m <= 192
 template __global__ void k_ldp_reg<2, 32, true, 1>(const BatchDev *__restrict__, int);    // 51 <= n <= 63, m <= 128
+template __global__ void k_ldp_reg<4, 32, true, 1>(const BatchDev *__restrict__, int);    // n <= 63, m <= 256 where no register shape fits: the image alone (one wave per SIMD), k_ldp behind it
 }

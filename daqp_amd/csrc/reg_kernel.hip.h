@@ -52,7 +52,9 @@ __host__ __device__ inline int reg_img_lds_bytes(int NB, int IMG, int n, int m, 
 // (NB*NP <= 13, i.e. n <= 26 and m <= 64: three waves per SIMD -- twelve waves' LDS still fit a CU up to there, and the same code on
 // the (1,16) shape measured 16 % faster at three waves than at two for n = 20 / 24, 2 % slower for n = 30 / 32 where the LDS does not fit)
 // (IMG = 1: the large shapes with an fp32 image of M instead of M -- 2 NB NP registers -- at two waves per SIMD)
-constexpr int ldp_reg_waves(int NB, int NP, int IMG = 0) { return IMG ? 2 : (NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 13 ? 3 : (NB * NP <= 32 ? 2 : 1))); }
+// (IMG = 1 with more than 96 image pairs -- (4,32): n <= 63, m <= 256 --: one wave per SIMD again, but shapes that have NO full-register kernel at all:
+//  their M itself would be 512 registers.  Before round 6's last session they ran the one-wave kernel that streams M from HBM / L2 in every scan)
+constexpr int ldp_reg_waves(int NB, int NP, int IMG = 0) { return IMG ? (NB * NP > 96 ? 1 : 2) : (NB * NP <= 8 ? DAQP_AMD_SMALL_WAVES : (NB * NP <= 13 ? 3 : (NB * NP <= 32 ? 2 : 1))); }
 template <int NB, int NP, bool FM, int IMG = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_waves(NB, NP, IMG), ldp_reg_waves(NB, NP, IMG)))) void k_ldp_reg(const BatchDev *__restrict__ bp, int mode_in)
 {

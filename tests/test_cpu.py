@@ -299,7 +299,8 @@ def test_kernel_resource_budgets():
         "k_ldp_reg<3, 25, true, 2>": (64, 2), "k_ldp_reg<2, 32, true, 1>": (64, 2), "k_ldp_reg<3, 25, true, 1>": (96, 2),     # (the C2 / C5 iteration with an fp32 image of M, two waves per SIMD, <= 256 registers)
         "k_ldp<1, false, 0, 0>": (0, 2), "k_ldp<2, false, 0, 0>": (0, 2), "k_ldp<4, true, 0, 0>": (128, 2),
         "k_ldp_wg<2, false, false>": (64, 2), "k_ldp_wg<4, false, false>": (512, 2), "k_ldp_wg<2, true, false>": (64, 2), "k_ldp_wg<4, true, false>": (512, 2),
-        "k_ldp_wg<4, false, true>": (512, 2), "k_ldp_wg<2, false, true>": (64, 2),     # the tiered launch: two four-wave workgroups per CU = the same two waves per SIMD
+        "k_ldp_wg<4, false, true>": (512, 2), "k_ldp_wg<2, false, true>": (64, 2),
+        "k_ldp_reg<4, 32, true, 1>": (0, 1),        # the image alone, one wave per SIMD: 256 image registers     # the tiered launch: two four-wave workgroups per CU = the same two waves per SIMD
         "k_update": (0, 8),
     }
     for name, (scratch, occ) in budgets.items():

@@ -222,3 +222,99 @@ def test_image_kernel_shared_structure(oracle, gpu_lib, monkeypatch, cache):
             assert np.array_equal(np.sign(g["lam"][k]), np.sign(r[1])), (t, k)
             assert np.abs(g["x"][k] - r[0]).max() < XTOL * max(1.0, np.abs(r[0]).max(), np.abs(r[1]).max()), (t, k)
     bm.close()
+
+
+# ---- the image ALONE (k_ldp_reg<4,32,true,1>): shapes with no full-register kernel (n <= 63, m <= 256 beyond the (3,25) / (2,32) registers) -------------
+IMAGE_ONLY_SHAPES = [(50, 193, 0, 18), (50, 256, 0, 20), (40, 250, 12, 14), (63, 129, 0, 22), (63, 192, 0, 25), (56, 150, 8, 20), (51, 256, 51, 18),
+                     (17, 200, 0, 6), (33, 230, 5, 12), (63, 256, 0, 30), (20, 256, 3, 7)]
+
+
+@pytest.mark.parametrize("shape", IMAGE_ONLY_SHAPES)
+def test_image_only_shapes(oracle, gpu_lib, monkeypatch, shape):
+    """the shapes that ran the one-wave kernel with M streamed in every scan up to round 6: their fp32 image in 256 registers, one wave per SIMD,
+    every working-set row held (LDS + scratch tier), k_ldp behind it with mode | 4.  Exit flags, iteration counts and active sets as the oracle's,
+    x to 1e-9; the same draws with the image kernel switched off (DAQP_AMD_NO_IMG_ONLY=1) agree as well"""
+    import daqp_amd
+    monkeypatch.delenv("DAQP_AMD_EXACT", raising=False)
+    n, m, ms, na = shape
+    q = O.generate_batch(24, n, m, ms, na, 5200 + n + m)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("DAQP_AMD_NO_IMG_ONLY", "1")
+        g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+        assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4]), (off, g["iter"], ref[4])
+        assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1])) and np.abs(g["x"] - ref[0]).max() < XTOL
+
+
+def test_image_only_warm_sequence_and_limits(oracle, gpu_lib, monkeypatch):
+    """n = 50, m = 200: cold solve, then UPDATE_v / UPDATE_d steps (the stand-alone update kernel, then the image kernel from the stored working set),
+    and an iteration limit hit inside the image kernel followed by a second solve that continues"""
+    import daqp_amd
+    monkeypatch.delenv("DAQP_AMD_EXACT", raising=False)
+    n, m, ms, na = 50, 200, 4, 18
+    N = 16
+    q = O.generate_batch(N, n, m, ms, na, 5300)
+    for limit in (None, 12):
+        st = dict(iter_limit=limit) if limit else {}
+        bm = daqp_amd.BatchModel(N, n, m, ms, **st)
+        bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"])
+        mods = []
+        for k in range(N):
+            md = oracle.model(n, m, ms, settings=O.default_settings(**st) if st else None)
+            md.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None)
+            mods.append(md)
+        f, bu, bl = q["f"].copy(), q["bupper"].copy(), q["blower"].copy()
+        rng = np.random.default_rng(13)
+        for t in range(5):
+            if t in (2, 4):
+                f = f + 0.05 * rng.standard_normal(f.shape)
+                bm.update(f=f)
+            elif t == 3:
+                sh = 0.02 * rng.standard_normal(bu.shape)
+                bu = bu + sh; bl = bl + sh
+                bm.update(bupper=bu, blower=bl)
+            g = bm.solve()
+            for k, md in enumerate(mods):
+                if t in (2, 4):
+                    md.update(daqp_amd.UPDATE_v, f=f[k])
+                elif t == 3:
+                    md.update(daqp_amd.UPDATE_d, bupper=bu[k], blower=bl[k])
+                r = md.solve()
+                assert g["exitflag"][k] == r[3] and g["iter"][k] == r[4], (limit, t, k, g["exitflag"][k], r[3], g["iter"][k], r[4])
+                if r[3] > 0:
+                    assert np.array_equal(np.sign(g["lam"][k]), np.sign(r[1])) and np.abs(g["x"][k] - r[0]).max() < XTOL
+        bm.close()
+
+
+def test_image_only_degenerate_family(oracle, gpu_lib, monkeypatch):
+    """near-duplicate rows, equalities (some dependent), soft rows on the image-only shapes: singular pivots, pivoting, refinement, repair"""
+    import daqp_amd
+    monkeypatch.delenv("DAQP_AMD_EXACT", raising=False)
+    mism = []
+    for trial in range(60):
+        rng = np.random.default_rng([399, trial])
+        eps = 10.0 ** rng.uniform(-13, -2)
+        if trial % 2:
+            n = int(rng.integers(51, 63)); m = int(rng.integers(129, 257))
+        else:
+            n = int(rng.integers(10, 51)); m = int(rng.integers(193, 257))
+        ms = int(rng.integers(0, n // 3)); na = int(rng.integers(max(2, n // 4), n - 4))
+        q = O.generate_nasty(n, m, ms, na, eps, rng, n_dup=int(rng.integers(0, 6)), n_eq=int(rng.integers(0, 4)),
+                             n_soft=int(rng.integers(0, 3)) if n < 55 else 0, dep_eq=bool(rng.integers(0, 2)))
+        ns = int((q["sense"] & 8).astype(bool).sum())
+        bm = daqp_amd.BatchModel(1, n, m, ms, ns_max=ns)
+        bm.setup(q["H"][None], q["f"][None], q["A"][None], q["bupper"][None], q["blower"][None], q["sense"][None], init_mask=daqp_amd.UPDATE_unconstrained)
+        g = bm.solve()
+        bm.close()
+        md = oracle.model(n, m, ms, ns)         # (the same entry: setup with the unconstrained shortcut, no equality elimination)
+        sflag = md.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], q["sense"], init_mask=daqp_amd.UPDATE_unconstrained)
+        r = md.solve() if sflag >= 0 else (None, None, 0.0, sflag, 0)
+        flag, it = int(g["exitflag"][0]), int(g["iter"][0])
+        ok = flag == r[3] and it == r[4]
+        if ok and flag > 0:
+            G = np.vstack([np.eye(n)[:ms], q["A"]])
+            ok = np.abs(g["x"][0] - r[0]).max() < XTOL and np.abs(G.T @ (g["lam"][0] - r[1])).max() < 1e-7
+        if not ok:
+            mism.append((trial, n, m, ms, ns, flag, r[3], it, r[4]))
+    assert not mism, mism[:10]

@@ -22,6 +22,8 @@ def family(n, m):
                         return f"image({nb},{np_}) x2"
                     return f"reg({nb},{np_}) x{WAVES[(nb, np_)]}" + (" +hand-over" if cap > 64 else "")
                 break
+    if n > 16 and cap <= 64 and nblk <= 4 and npair <= 32:
+        return "image(4,32) x1, no full-register kernel"
     if 64 < cap <= 256:
         return "workgroup"
     return "generic (M streamed)"

@@ -37,6 +37,9 @@ extern template __global__ void k_ldp_reg<3, 25, true, 2>(const BatchDev *__rest
 extern template __global__ void k_ldp_reg<2, 32, true, 1>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_reg<3, 25, true, 1>(const BatchDev *__restrict__, int);
 extern template __global__ void k_ldp_reg<4, 32, true, 1>(const BatchDev *__restrict__, int);
+extern template __global__ void k_ldp_reg<8, 16, true, 1>(const BatchDev *__restrict__, int);
+extern template __global__ void k_ldp_reg<6, 25, true, 1>(const BatchDev *__restrict__, int);
+extern template __global__ void k_ldp_reg<5, 32, true, 1>(const BatchDev *__restrict__, int);
 DAQP_REG_SHAPE(1, 6)
 DAQP_REG_SHAPE(1, 8)
 DAQP_REG_SHAPE(3, 25)
@@ -149,7 +152,8 @@ struct DAQPBatch {
     // full-register kernel anyway (working sets beyond what the image kernel holds), the next launches go there directly; every 16th tries again
     int *img_ho_pin = nullptr;
     unsigned img_skipped = 0;
-    bool img_only = false;       // no register shape holds M, but its fp32 image fits (k_ldp_reg<4,32,true,1>, one wave per SIMD): default-mode solves run it in front of k_ldp
+    bool img_only = false;       // no register shape holds M, but its fp32 image fits (k_ldp_reg<NB,NP,true,1> of kImgOnlyShapes, one wave per SIMD): default-mode solves run it in front of k_ldp
+    int io_nb = 0, io_np = 0;
     int img_min_warm = 16384;
     size_t lds_wg = 0;
     double *wide_u = nullptr, *wide_l = nullptr;   // daqp_batch_setup_shared: +-1e30 bounds of the one factorisation
@@ -301,6 +305,17 @@ const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {3, 25}};
 #else
 const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {1, 13}, {1, 16}, {2, 16}, {3, 8}, {1, 25}, {3, 25}, {2, 32}};   // ((3,8): few variables, many rows -- n <= 16, m <= 192; (1,25): n <= 50 with m <= 64 -- both at two waves per SIMD)
 #endif
+// the shapes served by an fp32 image ALONE (no full-register kernel exists: M itself would not fit 512 registers), first fit:
+// (4,32) n <= 63, m <= 256 | (8,16) n <= 32, m <= 512 | (6,25) n <= 50, m <= 384 | (5,32) n <= 63, m <= 320 -- 256 ... 320 image registers, one wave per SIMD
+const RegShape kImgOnlyShapes[] = {{4, 32}, {8, 16}, {6, 25}, {5, 32}};
+ldp_reg_kernel_t pick_img_only(const DAQPBatch *b)
+{
+    if (b->io_nb == 4 && b->io_np == 32) return k_ldp_reg<4, 32, true, 1>;
+    if (b->io_nb == 8 && b->io_np == 16) return k_ldp_reg<8, 16, true, 1>;
+    if (b->io_nb == 6 && b->io_np == 25) return k_ldp_reg<6, 25, true, 1>;
+    if (b->io_nb == 5 && b->io_np == 32) return k_ldp_reg<5, 32, true, 1>;
+    return nullptr;
+}
 // exact: the reference's arithmetic (two roundings per multiply-add); otherwise fused multiply-adds (default mode)
 ldp_reg_kernel_t pick_ldp_reg_img(const DAQPBatch *b)
 {
@@ -421,11 +436,11 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
     ldp_kernel_t k = pick_ldp(b);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_ldp));
     if (b->img_only && mode == 0 && !b->d.exact_setup && !b->in_prox_loop && !b->exact_sticky) {
-        // The shapes whose M fits no register file but whose fp32 IMAGE does (n <= 63, m <= 256): the image kernel alone at one wave per SIMD --
+        // The shapes whose M fits no register file but whose fp32 IMAGE does (kImgOnlyShapes): the image kernel alone at one wave per SIMD --
         // the scan runs out of registers instead of streaming 8 (m - ms) n bytes per iteration from L2 / HBM --, and this kernel behind it for
         // whatever it flags (mode | 4; the image kernel holds every working-set row the shape can have, so that is an empty pass)
         if (push_descriptor(b)) return DAQP_EXIT_UNSUPPORTED;
-        ldp_reg_kernel_t ki = k_ldp_reg<4, 32, true, 1>;
+        ldp_reg_kernel_t ki = pick_img_only(b);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_img));
         if (b->d.img_ho) HIPCHK(hipMemsetAsync(b->d.img_ho, 0, sizeof(int), b->stream));
         HIPCHK(hipMemsetAsync(b->d.fallback, 0, (size_t)b->d.N * sizeof(int), b->stream));
@@ -970,24 +985,27 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         d.ldrc = l;
     }
     b->lds_ldp = b->NB > 0 ? (size_t)reg_lds_bytes(b->NB, n, m, cap, d.ldrc) : (size_t)ldp_lds(n, m, cap, b->spill, d.ldrc).total_bytes;
-    // No register shape for (n, m), but the fp32 image of M fits one (k_ldp_reg<4,32,true,1>: n <= 63, m <= 256, one wave per SIMD): the default
+    // No register shape for (n, m), but the fp32 image of M fits one (kImgOnlyShapes: n <= 63 with m <= 256 ... 512, one wave per SIMD): the default
     // arithmetic's solves run on it (launch_ldp); everything else about the batch stays the generic one-wave path's.  Every working-set row the
     // shape can have is held (img_rows = cap), as many of them in LDS as leave four workgroups per CU, the rest in the scratch tier.
     // (n <= 16: M streamed is as fast -- n = 8, m = 256: 0.86 against 1.02 ms per 20 000 -- a scan is 16 column pairs of L2 hits)
-    if (b->NB == 0 && !b->spill && n > 16 && cap <= 64 && d.nblk <= 4 && d.npair <= 32 && !getenv("DAQP_AMD_STREAM_M") && !getenv("DAQP_AMD_NO_IMG32") && !getenv("DAQP_AMD_NO_IMG_ONLY")) {
+    int io_nb = 0, io_np = 0;
+    for (const RegShape &rs : kImgOnlyShapes)
+        if (d.nblk <= rs.nb && d.npair <= rs.np) { io_nb = rs.nb; io_np = rs.np; break; }
+    if (b->NB == 0 && !b->spill && n > 16 && cap <= 64 && io_nb > 0 && !getenv("DAQP_AMD_STREAM_M") && !getenv("DAQP_AMD_NO_IMG32") && !getenv("DAQP_AMD_NO_IMG_ONLY")) {
         int min_batch = 1;
         if (const char *e = getenv("DAQP_AMD_IMG_ONLY_MIN_BATCH")) min_batch = atoi(e);
         if (N >= min_batch) {
-            b->img_only = true;
-            int l = n > 64 ? n : 64;
+            b->img_only = true; b->io_nb = io_nb; b->io_np = io_np;
+            int l = n > 2 * io_np ? n : 2 * io_np;
             while ((l & 3) != 2) ++l;
             d.ldrc = l;                      // (the row-cache stride of the register kernels; k_ldp has its own)
             d.img_rows = cap;
             const int budget = (160 * 1024 / 4) / 512 * 512;
             int cache = d.img_rows;
-            while (cache > 2 && reg_img_lds_bytes(4, 1, n, m, d.img_rows, cache, d.ldrc) > budget) --cache;
+            while (cache > 2 && reg_img_lds_bytes(io_nb, 1, n, m, d.img_rows, cache, d.ldrc) > budget) --cache;
             d.img_cache = cache;
-            b->lds_img = (size_t)reg_img_lds_bytes(4, 1, n, m, d.img_rows, cache, d.ldrc);
+            b->lds_img = (size_t)reg_img_lds_bytes(io_nb, 1, n, m, d.img_rows, cache, d.ldrc);
         }
     }
     if (b->img32) {

@@ -8,4 +8,7 @@ template __global__ void k_ldp_reg<3, 25, true, 2>(const BatchDev *__restrict__,
 template __global__ void k_ldp_reg<3, 25, true, 1>(const BatchDev *__restrict__, int);    // n <= 50, 161 <= m <= 192
 template __global__ void k_ldp_reg<2, 32, true, 1>(const BatchDev *__restrict__, int);    // 51 <= n <= 63, m <= 128
 template __global__ void k_ldp_reg<4, 32, true, 1>(const BatchDev *__restrict__, int);    // n <= 63, m <= 256 where no register shape fits: the image alone (one wave per SIMD), k_ldp behind it
+template __global__ void k_ldp_reg<8, 16, true, 1>(const BatchDev *__restrict__, int);    // the same for n <= 32, m <= 512
+template __global__ void k_ldp_reg<6, 25, true, 1>(const BatchDev *__restrict__, int);    // n <= 50, m <= 384
+template __global__ void k_ldp_reg<5, 32, true, 1>(const BatchDev *__restrict__, int);    // n <= 63, m <= 320
 }

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
             w.rowv[kRowvStride<NB, IMG> + r] = dlr[bb];
             w.rowv[2 * kRowvStride<NB, IMG> + r] = ep * scr[bb];
         }
-        w.rs |= (unsigned)snr[bb] << (8 * bb);
+        w.rs |= (typename RWave<NB, NP, FM, IMG>::rs_t)snr[bb] << (8 * bb);
         softbits |= snr[bb] & DAQP_SOFT;
     });
     w.has_soft = __any(softbits) ? 1 : 0;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
             const int r = bb * 64 + lane;
             const int sn = rsense_get(w, bb);
             if (r < m && r < first_bad && !(sn & DAQP_IMMUTABLE) && !(sn & DAQP_SOFT) && bur[bb] - blr[bb] < w.stp->zero_tol) {
-                w.rs |= (unsigned)(DAQP_ACTIVE | DAQP_IMMUTABLE) << (8 * bb); bad |= 4;
+                w.rs |= (typename RWave<NB, NP, FM, IMG>::rs_t)(DAQP_ACTIVE | DAQP_IMMUTABLE) << (8 * bb); bad |= 4;
             }
         });
         if (first_bad != kBig) {
@@ -547,7 +547,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ldp_reg_wave
         int fl = 0;
         double bu = 0, bl = 0;
         static_for<NB>([&](auto bb) __attribute__((always_inline)) {
-            const int s8 = (int)((__shfl((int)w.rs, src) >> (8 * bb)) & 0xff);
+            int s8;
+            if constexpr (NB > 4) s8 = (int)((__shfl((long long)w.rs, src) >> (8 * bb)) & 0xff);
+            else s8 = (int)((__shfl((int)w.rs, src) >> (8 * bb)) & 0xff);
             const double u_ = __shfl(dur[bb], src), l_ = __shfl(dlr[bb], src);
             if (blk == bb) { fl = s8; bu = u_; bl = l_; }
         });

@@ -70,7 +70,8 @@ struct RWave {
     // d_upper, d_lower and -primal_tol*scaling of every row live in LDS (rowv[r], rowv[R + r], rowv[2R + r], R = 64*NB): they are read once per iteration at the end of the scan, and 18 more registers held across the whole
     // loop push the allocator into scratch spills (the register file is full: 300 registers of M + the working set)
     double *rowv;
-    unsigned rs;   // sense bits of this lane's rows, 8 bits per row block (a register, never an array)
+    typedef typename std::conditional<(NB > 4), unsigned long long, unsigned>::type rs_t;     // (more than four row blocks: the image-only shapes)
+    rs_t rs;       // sense bits of this lane's rows, 8 bits per row block (a register, never an array)
     // uniform
     int na, reuse, sing, has_soft;
     int max_rows;   // (2,32) only -- see kRegHandOver: an add that finds this many rows in place hands the problem over
@@ -135,7 +136,8 @@ __device__ __forceinline__ void sense_set(RWave<NB, NP, FM, IMG> &w, int id, int
 {
     if (lane_id() == (id & 63)) {
         const int sh = 8 * (id >> 6);
-        w.rs = (w.rs | ((unsigned)set_bits << sh)) & ~((unsigned)clear_bits << sh);
+        typedef typename RWave<NB, NP, FM, IMG>::rs_t rs_t;
+        w.rs = (w.rs | ((rs_t)set_bits << sh)) & ~((rs_t)clear_bits << sh);
     }
 }
 // bound of constraint id: broadcast every block's candidate first, THEN pick (selecting between
@@ -1348,7 +1350,7 @@ __device__ __forceinline__ int rrun(RWave<NB, NP, FM, IMG> &w, int mode, bool ne
                     const int sn = rsense_get(w, b2);
                     const bool later = r >= act_i && r < w.m && (sn & DAQP_ACTIVE);
                     if (__any(later && (sn & DAQP_IMMUTABLE))) fl = DAQP_EXIT_OVERDETERMINED_INITIAL;
-                    if (later && !(sn & DAQP_IMMUTABLE)) w.rs &= ~((unsigned)DAQP_ACTIVE << (8 * b2));
+                    if (later && !(sn & DAQP_IMMUTABLE)) w.rs &= ~((typename RWave<NB, NP, FM, IMG>::rs_t)DAQP_ACTIVE << (8 * b2));
                 });
                 w.slotmask &= ~(1ull << rli(w.slot, w.na - 1));
                 w.na--;

@@ -226,7 +226,10 @@ def test_image_kernel_shared_structure(oracle, gpu_lib, monkeypatch, cache):
 
 # ---- the image ALONE (k_ldp_reg<4,32,true,1>): shapes with no full-register kernel (n <= 63, m <= 256 beyond the (3,25) / (2,32) registers) -------------
 IMAGE_ONLY_SHAPES = [(50, 193, 0, 18), (50, 256, 0, 20), (40, 250, 12, 14), (63, 129, 0, 22), (63, 192, 0, 25), (56, 150, 8, 20), (51, 256, 51, 18),
-                     (17, 200, 0, 6), (33, 230, 5, 12), (63, 256, 0, 30), (20, 256, 3, 7)]
+                     (17, 200, 0, 6), (33, 230, 5, 12), (63, 256, 0, 30), (20, 256, 3, 7),
+                     (30, 300, 0, 10), (32, 512, 4, 12), (24, 450, 0, 9),         # (8,16)
+                     (50, 300, 0, 18), (45, 384, 10, 16), (33, 330, 0, 12),       # (6,25)
+                     (63, 300, 0, 25), (56, 320, 7, 20), (51, 257, 0, 18)]        # (5,32)
 
 
 @pytest.mark.parametrize("shape", IMAGE_ONLY_SHAPES)
@@ -295,10 +298,12 @@ def test_image_only_degenerate_family(oracle, gpu_lib, monkeypatch):
     for trial in range(60):
         rng = np.random.default_rng([399, trial])
         eps = 10.0 ** rng.uniform(-13, -2)
-        if trial % 2:
-            n = int(rng.integers(51, 63)); m = int(rng.integers(129, 257))
+        if trial % 4 == 1:
+            n = int(rng.integers(51, 63)); m = int(rng.integers(129, 321))       # (4,32) / (5,32)
+        elif trial % 4 == 3:
+            n = int(rng.integers(18, 33)); m = int(rng.integers(257, 513))       # (8,16)
         else:
-            n = int(rng.integers(10, 51)); m = int(rng.integers(193, 257))
+            n = int(rng.integers(18, 51)); m = int(rng.integers(193, 385))       # (4,32) / (6,25)
         ms = int(rng.integers(0, n // 3)); na = int(rng.integers(max(2, n // 4), n - 4))
         q = O.generate_nasty(n, m, ms, na, eps, rng, n_dup=int(rng.integers(0, 6)), n_eq=int(rng.integers(0, 4)),
                              n_soft=int(rng.integers(0, 3)) if n < 55 else 0, dep_eq=bool(rng.integers(0, 2)))

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import torch, daqp_amd
 from daqp_amd.synthetic import generate_batch_torch
 N = 20000
-for (n, m) in ((50, 193), (50, 256), (40, 256), (26, 256), (63, 150), (63, 192), (56, 129), (8, 256)):
+for (n, m) in ((50, 193), (50, 256), (40, 256), (26, 256), (63, 150), (63, 192), (56, 129), (30, 300), (32, 512), (50, 300), (50, 384), (63, 300), (60, 320)):
     q = generate_batch_torch(N, n, m, 0, max(2, n // 3), 8000 + n)
     out = []
     for off in ("", "1"):

@@ -22,8 +22,10 @@ def family(n, m):
                         return f"image({nb},{np_}) x2"
                     return f"reg({nb},{np_}) x{WAVES[(nb, np_)]}" + (" +hand-over" if cap > 64 else "")
                 break
-    if n > 16 and cap <= 64 and nblk <= 4 and npair <= 32:
-        return "image(4,32) x1, no full-register kernel"
+    if n > 16 and cap <= 64:
+        for nb, np_ in ((4, 32), (8, 16), (6, 25), (5, 32)):
+            if nblk <= nb and npair <= np_:
+                return f"image({nb},{np_}) x1, image alone"
     if 64 < cap <= 256:
         return "workgroup"
     return "generic (M streamed)"

@@ -48,6 +48,7 @@ DAQP_REG_SHAPE(1, 13)
 DAQP_REG_SHAPE(1, 16)
 DAQP_REG_SHAPE(2, 16)
 DAQP_REG_SHAPE(3, 8)
+DAQP_REG_SHAPE(4, 8)
 DAQP_REG_SHAPE(1, 25)
 DAQP_REG_SHAPE(2, 32)
 #endif
@@ -303,7 +304,7 @@ struct RegShape { int nb, np; };
 #ifdef DAQP_AMD_FEW_VARIANTS   // development builds: fewer instantiations, faster compile
 const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {3, 25}};
 #else
-const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {1, 13}, {1, 16}, {2, 16}, {3, 8}, {1, 25}, {3, 25}, {2, 32}};   // ((3,8): few variables, many rows -- n <= 16, m <= 192; (1,25): n <= 50 with m <= 64 -- both at two waves per SIMD)
+const RegShape kRegShapes[] = {{1, 6}, {1, 8}, {1, 13}, {1, 16}, {2, 16}, {3, 8}, {4, 8}, {1, 25}, {3, 25}, {2, 32}};   // ((3,8), (4,8): few variables, many rows -- n <= 16, m <= 192; (1,25): n <= 50 with m <= 64 -- both at two waves per SIMD)
 #endif
 // the shapes served by an fp32 image ALONE (no full-register kernel exists: M itself would not fit 512 registers), first fit:
 // (4,32) n <= 63, m <= 256 | (8,16) n <= 32, m <= 512 | (6,25) n <= 50, m <= 384 | (5,32) n <= 63, m <= 320 -- 256 ... 320 image registers, one wave per SIMD
@@ -335,6 +336,7 @@ ldp_reg_kernel_t pick_ldp_reg(const DAQPBatch *b, bool exact)
     DAQP_REG_PICK(1, 16)
     DAQP_REG_PICK(2, 16)
     DAQP_REG_PICK(3, 8)
+    DAQP_REG_PICK(4, 8)
     DAQP_REG_PICK(1, 25)
     DAQP_REG_PICK(2, 32)
 #endif
@@ -992,7 +994,9 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
     int io_nb = 0, io_np = 0;
     for (const RegShape &rs : kImgOnlyShapes)
         if (d.nblk <= rs.nb && d.npair <= rs.np) { io_nb = rs.nb; io_np = rs.np; break; }
-    if (b->NB == 0 && !b->spill && n > 16 && cap <= 64 && io_nb > 0 && !getenv("DAQP_AMD_STREAM_M") && !getenv("DAQP_AMD_NO_IMG32") && !getenv("DAQP_AMD_NO_IMG_ONLY")) {
+    // (cap = 65 is n = 64 without soft rows: a 65th row exists only while a constraint is exchanged at a full vertex -- the image kernel holds 64
+    //  and flags such a problem for k_ldp behind it, as the (2,32) registers do for m <= 128)
+    if (b->NB == 0 && !b->spill && n > 16 && cap <= 65 && n <= 64 && io_nb > 0 && !getenv("DAQP_AMD_STREAM_M") && !getenv("DAQP_AMD_NO_IMG32") && !getenv("DAQP_AMD_NO_IMG_ONLY")) {
         int min_batch = 1;
         if (const char *e = getenv("DAQP_AMD_IMG_ONLY_MIN_BATCH")) min_batch = atoi(e);
         if (N >= min_batch) {
@@ -1000,7 +1004,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
             int l = n > 2 * io_np ? n : 2 * io_np;
             while ((l & 3) != 2) ++l;
             d.ldrc = l;                      // (the row-cache stride of the register kernels; k_ldp has its own)
-            d.img_rows = cap;
+            d.img_rows = cap < 64 ? cap : 64;
             const int budget = (160 * 1024 / 4) / 512 * 512;
             int cache = d.img_rows;
             while (cache > 2 && reg_img_lds_bytes(io_nb, 1, n, m, d.img_rows, cache, d.ldrc) > budget) --cache;
@@ -1033,7 +1037,7 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
             }
         }
     }
-    if (b->NB == 0 && cap > 64 && cap <= 256 && !getenv("DAQP_AMD_NO_WG")) {     // (beyond 256 rows: the one-wave kernel with eight chunks, everything large in HBM scratch)
+    if (b->NB == 0 && !b->img_only && cap > 64 && cap <= 256 && !getenv("DAQP_AMD_NO_WG")) {     // (beyond 256 rows: the one-wave kernel with eight chunks, everything large in HBM scratch)
         int W = d.nblk < 4 ? 4 : (d.nblk > kWgMaxWaves ? kWgMaxWaves : d.nblk);
         const int lds_max = 160 * 1024 - 512;          // (the kernel's static LDS -- 320 bytes by the code generator's report -- comes on top of the
                                                        //  dynamic allocation: with 256 bytes of reserve a shape whose packed factor ended within 64 bytes

@@ -15,6 +15,7 @@ DAQP_REG_SHAPE(1, 13)
 DAQP_REG_SHAPE(1, 16)
 DAQP_REG_SHAPE(2, 16)
 DAQP_REG_SHAPE(3, 8)
+DAQP_REG_SHAPE(4, 8)
 DAQP_REG_SHAPE(1, 25)
 DAQP_REG_SHAPE(2, 32)
 #endif

@@ -295,7 +295,7 @@ def test_kernel_resource_budgets():
         "k_ldp_reg<1, 6, true, 0>": (48, 4), "k_ldp_reg<1, 6, false, 0>": (64, 4), "k_ldp_reg<1, 8, true, 0>": (80, 4), "k_ldp_reg<1, 8, false, 0>": (96, 4),   # (four waves per SIMD: measured faster with these few spilled registers than three without)
         "k_ldp_reg<1, 13, true, 0>": (32, 3), "k_ldp_reg<1, 13, false, 0>": (48, 3),   # (n <= 26: three waves per SIMD, twelve waves' LDS fit a CU)
         "k_ldp_reg<1, 16, true, 0>": (0, 2), "k_ldp_reg<2, 16, true, 0>": (16, 2),
-        "k_ldp_reg<3, 8, true, 0>": (0, 2), "k_ldp_reg<3, 8, false, 0>": (0, 2), "k_ldp_reg<1, 25, true, 0>": (0, 2), "k_ldp_reg<1, 25, false, 0>": (0, 2),   # (few variables / many rows; n <= 50 with one row block)
+        "k_ldp_reg<3, 8, true, 0>": (0, 2), "k_ldp_reg<3, 8, false, 0>": (0, 2), "k_ldp_reg<4, 8, true, 0>": (0, 2), "k_ldp_reg<4, 8, false, 0>": (32, 2), "k_ldp_reg<1, 25, true, 0>": (0, 2), "k_ldp_reg<1, 25, false, 0>": (0, 2),   # (few variables / many rows; n <= 50 with one row block)
         "k_ldp_reg<3, 25, true, 2>": (64, 2), "k_ldp_reg<2, 32, true, 1>": (64, 2), "k_ldp_reg<3, 25, true, 1>": (96, 2),     # (the C2 / C5 iteration with an fp32 image of M, two waves per SIMD, <= 256 registers)
         "k_ldp<1, false, 0, 0>": (0, 2), "k_ldp<2, false, 0, 0>": (0, 2), "k_ldp<4, true, 0, 0>": (128, 2),
         "k_ldp_wg<2, false, false>": (64, 2), "k_ldp_wg<4, false, false>": (512, 2), "k_ldp_wg<2, true, false>": (64, 2), "k_ldp_wg<4, true, false>": (512, 2),

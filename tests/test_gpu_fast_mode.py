@@ -38,6 +38,7 @@ def test_fast_mode_parity(oracle, gpu_lib, cfg, N):
                                    (48, 100, 0, 16), (56, 120, 0, 20), (57, 120, 0, 20), (64, 128, 0, 24),
                                    (17, 64, 0, 8), (21, 33, 4, 7), (25, 64, 3, 9), (26, 60, 0, 10), (26, 64, 26, 10),   # (these five: k_ldp_reg<1, 13, true>)
                                    (8, 150, 0, 3), (16, 192, 4, 6), (12, 130, 12, 5), (15, 160, 0, 14),   # (k_ldp_reg<3, 8, true>)
+                                   (8, 256, 0, 3), (16, 193, 4, 6), (12, 250, 12, 5),                      # (k_ldp_reg<4, 8, true>)
                                    (40, 64, 0, 13), (50, 64, 6, 16), (33, 34, 0, 30), (45, 60, 45, 12)])   # (k_ldp_reg<1, 25, true>)
 def test_fast_mode_shapes(oracle, gpu_lib, shape):
     """the MFMA fragment guards of every setup variant (partial k / column tiles) at the north_star bar"""

@@ -229,7 +229,8 @@ IMAGE_ONLY_SHAPES = [(50, 193, 0, 18), (50, 256, 0, 20), (40, 250, 12, 14), (63,
                      (17, 200, 0, 6), (33, 230, 5, 12), (63, 256, 0, 30), (20, 256, 3, 7),
                      (30, 300, 0, 10), (32, 512, 4, 12), (24, 450, 0, 9),         # (8,16)
                      (50, 300, 0, 18), (45, 384, 10, 16), (33, 330, 0, 12),       # (6,25)
-                     (63, 300, 0, 25), (56, 320, 7, 20), (51, 257, 0, 18)]        # (5,32)
+                     (63, 300, 0, 25), (56, 320, 7, 20), (51, 257, 0, 18),        # (5,32)
+                     (64, 150, 0, 22), (64, 256, 5, 25), (64, 320, 0, 30)]        # n = 64: 65 rows only while a constraint is exchanged at a full vertex -- held rows 64, k_ldp behind
 
 
 @pytest.mark.parametrize("shape", IMAGE_ONLY_SHAPES)

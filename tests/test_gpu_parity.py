@@ -481,7 +481,8 @@ def test_register_kernel_hand_over_event_trace_and_warm_sequence(oracle, gpu_lib
     bm.close()
 
 
-@pytest.mark.parametrize("shape", [(8, 150, 0, 3), (16, 192, 4, 6), (12, 130, 12, 5), (15, 160, 0, 14), (2, 129, 0, 1), (16, 129, 16, 8)])
+@pytest.mark.parametrize("shape", [(8, 150, 0, 3), (16, 192, 4, 6), (12, 130, 12, 5), (15, 160, 0, 14), (2, 129, 0, 1), (16, 129, 16, 8),
+                                   (8, 256, 0, 3), (16, 193, 4, 6), (12, 250, 12, 5), (15, 200, 0, 14), (3, 256, 0, 1)])      # (the second row: k_ldp_reg<4, 8, *>, 193 .. 256 rows)
 def test_register_shape_few_variables_many_rows(oracle, gpu_lib, shape):
     """k_ldp_reg<3, 8, *>: n <= 16 with 129 .. 192 rows (three row blocks, eight column pairs) at two waves per SIMD"""
     n, m, ms, na = shape

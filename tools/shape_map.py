@@ -8,8 +8,8 @@ import torch, daqp_amd
 from daqp_amd.synthetic import generate_batch_torch
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-REG = [(1, 6), (1, 8), (1, 13), (1, 16), (2, 16), (3, 8), (1, 25), (3, 25), (2, 32)]      # kRegShapes of daqp_amd.hip, first fit
-WAVES = {(1, 6): 4, (1, 8): 4, (1, 13): 3, (1, 16): 2, (2, 16): 2, (3, 8): 2, (1, 25): 2, (3, 25): 1, (2, 32): 1}
+REG = [(1, 6), (1, 8), (1, 13), (1, 16), (2, 16), (3, 8), (4, 8), (1, 25), (3, 25), (2, 32)]      # kRegShapes of daqp_amd.hip, first fit
+WAVES = {(1, 6): 4, (1, 8): 4, (1, 13): 3, (1, 16): 2, (2, 16): 2, (3, 8): 2, (4, 8): 2, (1, 25): 2, (3, 25): 1, (2, 32): 1}
 
 
 def family(n, m):
@@ -22,7 +22,7 @@ def family(n, m):
                         return f"image({nb},{np_}) x2"
                     return f"reg({nb},{np_}) x{WAVES[(nb, np_)]}" + (" +hand-over" if cap > 64 else "")
                 break
-    if n > 16 and cap <= 64:
+    if n > 16 and n <= 64:
         for nb, np_ in ((4, 32), (8, 16), (6, 25), (5, 32)):
             if nblk <= nb and npair <= np_:
                 return f"image({nb},{np_}) x1, image alone"

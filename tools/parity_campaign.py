@@ -49,6 +49,14 @@ for s in range(nsh):
     for exact in (True, False):
         ok = run(f"shape n={n} m={m} ms={ms} na={na}", q, ms, exact)
         allok &= ok
+# shapes beyond the full-register kernels with at most 64 working-set rows (round 6: the image-only kernels (4,32) (8,16) (6,25) (5,32), the (4,8) registers,
+# n = 64 with 65 rows at a full vertex): n <= 64 with 129 ... 520 rows; some with nearly every row active
+for s in range(int(os.environ.get("DAQP_CAMPAIGN_WIDE", "120"))):
+    n = int(rng.integers(4, 65)); m = int(rng.integers(max(n + 1, 129), 521)); ms = int(rng.integers(0, min(n, m // 2) + 1))
+    na = int(rng.integers(1, max(2, min(n, m - ms)))) if s % 5 else min(n - 1, m - ms)
+    q = O.generate_batch(24, n, m, ms, na, 13000 + s + 100000 * SALT)
+    for exact in (True, False):
+        allok &= run(f"wide n={n} m={m} ms={ms} na={na}", q, ms, exact)
 # shapes of the workgroup kernel / the generic setup with its own M launch (n > 64; working sets beyond 64 rows)
 for s in range(nbig):
     n = int(rng.integers(65, 209)); m = int(rng.integers(n + 1, min(640, 3 * n + 8))); ms = int(rng.integers(0, min(n, m // 3) + 1))

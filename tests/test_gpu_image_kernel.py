@@ -188,13 +188,14 @@ def test_image_kernel_limits_and_failures(oracle, gpu_lib, monkeypatch):
     assert np.array_equal(lim["exitflag"][~long_], free["exitflag"][~long_]) and np.array_equal(lim["iter"][~long_], free["iter"][~long_])
 
 
-@pytest.mark.parametrize("cache", [0, 6])
-def test_image_kernel_shared_structure(oracle, gpu_lib, monkeypatch, cache):
+@pytest.mark.parametrize("cache,shape", [(0, (50, 150, 0, 20)), (6, (50, 150, 0, 20)), (0, (50, 220, 0, 18)), (0, (60, 300, 6, 20))])
+def test_image_kernel_shared_structure(oracle, gpu_lib, monkeypatch, cache, shape):
     """a shared-structure batch (ONE H and A, per-problem f and bounds: daqp_batch_setup_shared) at C2's shape: every problem's image is rounded
-    from the same blocked M, the exact rows of every append come from it; cold solve, then fused warm updates, each step against the oracle"""
+    from the same blocked M, the exact rows of every append come from it; cold solve, then fused warm updates, each step against the oracle.
+    The last two shapes: the image-only kernels (4,32) and (5,32) on a shared image (their updates run as a launch of their own)"""
     import daqp_amd
     tier(monkeypatch, 0, cache)
-    n, m, ms, na = 50, 150, 0, 20
+    n, m, ms, na = shape
     N = 48
     q0 = O.generate_qp(n, m, ms, na, rng=[921, n])
     rng = np.random.default_rng([922, n])

@@ -421,6 +421,19 @@ int launch_ldp(DAQPBatch *b, int mode, bool descriptor_changed = true)
             if (b->d.img_ho && (mode & 3) != 1) HIPCHK(hipMemcpyAsync(b->img_ho_pin, b->d.img_ho, sizeof(int), hipMemcpyDeviceToHost, b->stream));
             return 0;
         }
+        if (b->reg_handover && b->img_only && mode == 0 && !exact_kernels) {
+            // n = 64 in the default arithmetic: the image-only kernel (64 rows held), k_ldp behind it for the problems that need a 65th row
+            ldp_reg_kernel_t ki = pick_img_only(b);
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_img));
+            HIPCHK(hipMemsetAsync(b->d.fallback, 0, (size_t)b->d.N * sizeof(int), b->stream));
+            hipLaunchKernelGGL(ki, dim3(b->d.N), dim3(64), b->lds_img, b->stream, (const BatchDev *)b->d_dev, mode);
+            HIPCHK(hipGetLastError());
+            ldp_kernel_t kf = pick_ldp(b);
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_fb));
+            hipLaunchKernelGGL(kf, dim3(b->d.N), dim3(64), b->lds_fb, b->stream, b->d, mode | 4);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
         if (b->reg_handover) HIPCHK(hipMemsetAsync(b->d.fallback, 0, (size_t)b->d.N * sizeof(int), b->stream));
         hipLaunchKernelGGL(kr, dim3(b->d.N), dim3(64), b->lds_ldp, b->stream, (const BatchDev *)b->d_dev, mode);
         HIPCHK(hipGetLastError());
@@ -996,7 +1009,10 @@ int daqp_batch_create(DAQPBatch **out, int N, int n, int m, int ms, int ns_max, 
         if (d.nblk <= rs.nb && d.npair <= rs.np) { io_nb = rs.nb; io_np = rs.np; break; }
     // (cap = 65 is n = 64 without soft rows: a 65th row exists only while a constraint is exchanged at a full vertex -- the image kernel holds 64
     //  and flags such a problem for k_ldp behind it, as the (2,32) registers do for m <= 128)
-    if (b->NB == 0 && !b->spill && n > 16 && cap <= 65 && n <= 64 && io_nb > 0 && !getenv("DAQP_AMD_STREAM_M") && !getenv("DAQP_AMD_NO_IMG32") && !getenv("DAQP_AMD_NO_IMG_ONLY")) {
+    // (n = 64 with m <= 128 keeps its (2,32) registers for the exact mode, fused updates and one-problem calls; the default arithmetic's plain
+    //  solves of a batch take the image-only kernel there as well: 6.5 -> 4.0 ms per 20 000 at m = 128 -- the fp32 scan is half the issue slots)
+    const bool n64 = b->NB == 2 && b->NP == 32 && b->reg_handover && N > 1;
+    if ((b->NB == 0 || n64) && !b->spill && n > 16 && cap <= 65 && n <= 64 && io_nb > 0 && !getenv("DAQP_AMD_STREAM_M") && !getenv("DAQP_AMD_NO_IMG32") && !getenv("DAQP_AMD_NO_IMG_ONLY")) {
         int min_batch = 1;
         if (const char *e = getenv("DAQP_AMD_IMG_ONLY_MIN_BATCH")) min_batch = atoi(e);
         if (N >= min_batch) {

@@ -20,7 +20,9 @@ def family(n, m):
                 if cap <= 64 or (nb, np_) == (2, 32):
                     if cap <= 64 and (nb, np_) in ((3, 25), (2, 32)) and N >= 10240:      # (round 6: the fp32-image kernels, two waves per SIMD, batches of >= 10 240)
                         return f"image({nb},{np_}) x2"
-                    return f"reg({nb},{np_}) x{WAVES[(nb, np_)]}" + (" +hand-over" if cap > 64 else "")
+                    if cap > 64:
+                        return "image(4,32) x1, image alone"      # (n = 64: the default arithmetic's batch solves; (2,32) registers for the rest)
+                    return f"reg({nb},{np_}) x{WAVES[(nb, np_)]}"
                 break
     if n > 16 and n <= 64:
         for nb, np_ in ((4, 32), (8, 16), (6, 25), (5, 32)):

@@ -859,7 +859,7 @@ std::string env_signature()
 {
     static const char *names[] = {"DAQP_AMD_LDS_LIMIT", "DAQP_AMD_FORCE_SPILL", "DAQP_AMD_STREAM_M", "DAQP_AMD_NO_WG", "DAQP_AMD_WG_WAVES",
                                   "DAQP_AMD_WG_CAPL", "DAQP_AMD_WG_GRID", "DAQP_AMD_NO_WG_TIER", "DAQP_AMD_WG_R0", "DAQP_AMD_WG_TIER_GRID", "DAQP_AMD_WG_TIER_MIN_BATCH", "DAQP_AMD_SLOW_SETUP", "DAQP_AMD_NO_SCAN32", "DAQP_AMD_WG_INVERSE", "DAQP_AMD_NO_TINY_SETUP", "DAQP_AMD_NO_RECHECK", "DAQP_AMD_NO_SETUP_M", "DAQP_AMD_NO_BLK_SETUP",
-                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_FACT_SMALL", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WARM_ROWS", "DAQP_AMD_IMG_WARM_WAVES", "DAQP_AMD_NO_IMG_ONLY", "DAQP_AMD_IMG_ONLY_MIN_BATCH"};
+                                  "DAQP_AMD_REG_ROWS", "DAQP_AMD_NO_REG_HANDOVER", "DAQP_AMD_NO_FACT_WG", "DAQP_AMD_NO_FACT_SMALL", "DAQP_AMD_NO_IMG32", "DAQP_AMD_IMG_ROWS", "DAQP_AMD_IMG_MIN_BATCH", "DAQP_AMD_IMG_WAVES", "DAQP_AMD_IMG_CACHE", "DAQP_AMD_IMG_WARM_ROWS", "DAQP_AMD_IMG_WARM_WAVES", "DAQP_AMD_NO_IMG_ONLY", "DAQP_AMD_IMG_ONLY_MIN_BATCH", "DAQP_AMD_NO_BLK_BOUNDS"};
     std::string k;
     for (const char *nme : names) { const char *v = getenv(nme); k += v ? v : "-"; k += '|'; }
     return k;
@@ -1483,7 +1483,7 @@ int batch_setup(DAQPBatch *b, const DAQPBatchProblem *p, int init_mask, bool fre
     if (!lp && b->tiny_setup) {     // sixteen problems per wavefront; singular Hessians leave flagged for the regularising re-run below
         hipLaunchKernelGGL(k_setup_tiny<4>, dim3((d.N + 15) / 16), dim3(64), 0, b->stream, d, mask);
         HIPCHK(hipGetLastError());
-    } else if (!lp && b->fast_setup && d.ms == 0 && d.n > 16 && d.exact_setup == 0 && blk_setup_enabled()) {
+    } else if (!lp && b->fast_setup && (d.ms == 0 || !getenv("DAQP_AMD_NO_BLK_BOUNDS")) && d.n > 16 && d.exact_setup == 0 && blk_setup_enabled()) {
         // the factorisation on the matrix cores (setup_blk.hip.h); what it does not call clearly regular it marks, and the ordered
         // kernel right behind it takes exactly those problems (every other wave of that launch leaves at its first scalar load)
         const int NT = (d.n + 15) / 16;

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int NTT = NT * (NT + 1) / 2, KT = TAIL ? 4 * (NT - 1) + 1 : NW / 4, CT = TAIL ? NT - 1 : NT;   // (k steps of the A operand; column tiles on the matrix cores)
     const BatchDev &b = *bp;
     const int q = blockIdx.x, lane = lane_id(), lr = lane & 15, lk = lane >> 4;
-    const int n = b.n, m = b.m, mA = b.mA;
+    const int n = b.n, m = b.m, mA = b.mA, ms = b.ms;
     const BlkLds o = blk_lds<NT>(n, m);
     const int TR = blk_tile_rows(n, blk_scratch_doubles<NT>());
     double *Hs = smem + o.R, *fl = smem + o.fv, *vv = smem + o.vv, *xu = smem + o.xu, *tile = smem + o.R;
@@ -332,7 +332,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         int offd;
         blk_load<NT>(Hs, n, zero_tol, T, offd);
         SPROF(9);
-        if (!__any(offd)) {
+        if (!__any(offd) && ms > 0) flag = DAQP_NEEDS_ORDERED;     // (a diagonal H with simple bounds: the RinvD branch scales them its own way, utils.c:284-312 -- the ordered kernel's)
+        else if (!__any(offd)) {
             // RinvD_i = 1/sqrt(H_ii) (utils.c:245-312); a diagonal entry at or below zero_tol * max|H_ii| is shifted by the regularising
             // re-run and solved by the proximal outer loop
             const double hd = (lane < n) ? Hs[lane * n + lane] : 1.0;
@@ -419,8 +420,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     SPROF(2);
     int feasible = 1;
+    if (flag > 0 && ms > 0) {
+        // --- simple bounds (rows < ms of the LDP: the rows of R^-1, normalised: utils.c:569-585; their d: utils.c:499-544 / 664-676 + 151-159).
+        // R^-1 goes through LDS once as a dense upper image (the tile region: H's image has been used up), lane <-> bound row from there.
+        double *Rd = tile;
+        for (int e = lane; e < n * n; e += 64) Rd[e] = 0.0;
+        static_for<NT>([&](auto Jc) __attribute__((always_inline)) { if (lk == 0 && 16 * Jc + lr < n) vv[16 * Jc + lr] = vcol[Jc]; });
+        WSYNC();
+        static_for<NT>([&](auto Ic) __attribute__((always_inline)) {
+            static_for<NT>([&](auto Jc) __attribute__((always_inline)) {
+                constexpr int I = Ic, J = Jc;
+                if constexpr (I <= J) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * I + lk + 4 * r, j = 16 * J + lr;
+                        if (i < n && j < n && j >= i) Rd[i * n + j] = X[blk_tix<NT>(I, J)][r];
+                    }
+                }
+            });
+        });
+        WSYNC();
+        const BLK_GLOBAL(double) *bu = blk_g(b.bu + (size_t)q * m), *bl = blk_g(b.bl + (size_t)q * m);
+        BLK_GLOBAL(double) *sc = blk_g(b.scaling + (size_t)q * m), *du = blk_g(b.dupper + (size_t)q * m), *dl = blk_g(b.dlower + (size_t)q * m);
+        BLK_GLOBAL(blk_v2d) *Mq2 = blk_g(reinterpret_cast<blk_v2d *>(b.Mblk + (size_t)q * b.nblk * b.npair * 128));
+        const bool own = lane < ms;
+        const int i = own ? lane : 0;
+        const double *a = Rd + i * n;
+        double s0 = 0, s1 = 0, d0 = 0, d1 = 0;
+        for (int j = 0; j + 1 < n; j += 2) {
+            const double x0 = a[j], x1 = a[j + 1];
+            s0 = __builtin_fma(x0, x0, s0); s1 = __builtin_fma(x1, x1, s1);
+            d0 = __builtin_fma(x0, vv[j], d0); d1 = __builtin_fma(x1, vv[j + 1], d1);
+        }
+        if (n & 1) { const double x0 = a[n - 1]; s0 = __builtin_fma(x0, x0, s0); d0 = __builtin_fma(x0, vv[n - 1], d0); }
+        const double scal = rsqrt(s0 + s1), draw = d0 + d1;
+        WSYNC();
+        fl[lane] = own ? scal : 1.0;           // (f has been used up: the rows' scalings for the packed image below)
+        if (own) {
+            const double bu_i = bu[i], bl_i = bl[i];
+            sc[i] = scal;
+            if (unc) {
+                const double u0 = bu_i - xu[i], l0 = bl_i - xu[i];
+                if (u0 < -primal_tol || l0 > primal_tol) feasible = 0;
+                du[i] = u0 * scal; dl[i] = l0 * scal;
+            } else {
+                const double dsum = draw * scal;
+                du[i] = bu_i * scal + dsum;
+                dl[i] = bl_i * scal + dsum;
+            }
+            BLK_GLOBAL(blk_v2d) *dst = Mq2 + i;      // (row block 0: ms <= n <= 64)
+            const int npair = b.npair;
+            for (int t = 0; t < npair; ++t) {
+                const double x0 = a[2 * t], x1 = (2 * t + 1 < n) ? a[2 * t + 1] : 0.0;
+                dst[(size_t)t * 64] = (blk_v2d){x0 * scal, x1 * scal};
+            }
+        }
+        WSYNC();
+    }
     if (flag > 0) {
-        // packed upper image of R^-1 for the solve kernel / warm updates, straight from the tiles
+        // packed upper image of R^-1 for the solve kernel / warm updates, straight from the tiles (rows < ms normalised: the reference keeps them so)
         BLK_GLOBAL(double) *Rp = blk_g(b.Rinv + (size_t)q * b.rtri);
         static_for<NT>([&](auto Ic) __attribute__((always_inline)) {
             static_for<NT>([&](auto Jc) __attribute__((always_inline)) {
@@ -429,11 +487,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 16 * I + lk + 4 * r, j = 16 * J + lr;
-                        if (i < n && j < n && j >= i) Rp[roff(i, n) + j] = X[blk_tix<NT>(I, J)][r];
+                        double x = X[blk_tix<NT>(I, J)][r];
+                        if (ms > 0 && i < ms) x *= fl[i];
+                        if (i < n && j < n && j >= i) Rp[roff(i, n) + j] = x;
                     }
                 }
             });
         });
+        WSYNC();
     }
     SPROF(6);
     // --- general rows, TR at a time through the LDS tile (which takes the place of H's image)
@@ -452,7 +513,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             SPROF(7);
             const bool own = lane < rows;
             const double *a = tile + (own ? lane : 0) * ldr;
-            const int gi = own ? tb + lane : tb;
+            const int gi = ms + (own ? tb + lane : tb);
             const double bu_gi = bu[gi], bl_gi = bl[gi];   // issued now, used after the tile's arithmetic: no exposed trip to HBM
             double sunc = 0;
             if (unc) sunc = chain_add8(0.0, n, [&](int j) { return a[j]; }, [&](int j) { return xu[j]; });

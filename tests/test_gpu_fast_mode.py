@@ -69,9 +69,53 @@ def test_fast_mode_register_kernel_hand_over(oracle, gpu_lib, monkeypatch, shape
     assert np.abs(g["x"] - ref[0]).max() < XTOL
 
 
+@pytest.mark.parametrize("n,ms", [(17, 17), (20, 3), (25, 25), (33, 1), (36, 36), (41, 20), (49, 7), (50, 50), (52, 30), (57, 57), (61, 16), (63, 63), (64, 40)])
+def test_blocked_setup_with_simple_bounds(oracle, gpu_lib, monkeypatch, n, ms):
+    """k_setup_blk with simple bounds (round 6): rows < ms of the LDP are the rows of R^-1, normalised (utils.c:569-585), their scaling, their d by
+    both routes (utils.c:499-544 and the unconstrained shortcut's 664-676), the packed R^-1 with those rows normalised as the reference keeps it --
+    the LDP against the oracle's, the solve at the north_star bar, and the same problems through k_setup_fast (DAQP_AMD_NO_BLK_BOUNDS=1)."""
+    import daqp_amd
+    m, na = ms + n + 9 + (n % 5), max(2, n // 3)
+    N = 16
+    q = O.generate_batch(N, n, m, ms, na, 7400 + n + ms)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    bm = daqp_amd.BatchModel(N, n, m, ms)
+    bm.setup(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None)
+    assert (bm.setup_flags() == 1).all()
+    for k in (0, N - 1):
+        om = oracle.model(n, m, ms)
+        assert om.setup(q["H"][k], q["f"][k], q["A"][k], q["bupper"][k], q["blower"][k], None) == 1
+        for name, a, b in zip(("M", "Rinv", "v", "dupper", "dlower", "scaling"), bm.read_ldp(k), om.ldp()):
+            assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), (n, ms, k, name, np.abs(a - b).max())
+    g = bm.solve()
+    bm.close()
+    assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4])
+    assert np.array_equal(np.sign(g["lam"]), np.sign(ref[1])) and np.abs(g["x"] - ref[0]).max() < XTOL
+    g1 = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)      # the unconstrained shortcut's d
+    assert np.array_equal(g1["iter"], ref[4]) and np.abs(g1["x"] - ref[0]).max() < XTOL
+    monkeypatch.setenv("DAQP_AMD_NO_BLK_BOUNDS", "1")
+    g2 = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert np.array_equal(g2["iter"], ref[4]) and np.abs(g2["x"] - g1["x"]).max() < 1e-11
+
+
+def test_blocked_setup_diagonal_hessian_with_bounds_goes_to_the_ordered_kernel(oracle, gpu_lib):
+    """a diagonal H with simple bounds is the reference's RinvD branch, which scales the bounds its own way (utils.c:284-312): k_setup_blk hands
+    such a problem, untouched, to the ordered kernel behind it -- bit-identical LDP to the oracle's there"""
+    import daqp_amd
+    n, m, ms, na = 40, 90, 12, 10
+    q = O.generate_batch(6, n, m, ms, na, 7600)
+    for k in range(0, 6, 2):
+        q["H"][k] = np.diag(np.abs(np.diag(q["H"][k])) + 0.5)
+    ref = oracle.quadprog_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    g = daqp_amd.solve_batch(q["H"], q["f"], q["A"], q["bupper"], q["blower"], None, ms=ms)
+    assert np.array_equal(g["exitflag"], ref[3]) and np.array_equal(g["iter"], ref[4]), (g["exitflag"], ref[3], g["iter"], ref[4])
+    ok = ref[3] > 0
+    assert np.abs(g["x"][ok] - ref[0][ok]).max() < XTOL and np.array_equal(np.sign(g["lam"][ok]), np.sign(ref[1][ok]))
+
+
 @pytest.mark.parametrize("n", [17, 19, 20, 21, 25, 32, 33, 35, 36, 37, 41, 48, 49, 50, 51, 52, 53, 55, 56, 57, 61, 64])
 def test_blocked_setup_every_block_shape(oracle, gpu_lib, monkeypatch, n):
-    """k_setup_blk (csrc/setup_blk.hip.h: 16 < n <= 64 without simple bounds, default arithmetic -- Cholesky and inverse as 16 x 16 tiles
+    """k_setup_blk (csrc/setup_blk.hip.h: 16 < n <= 64, default arithmetic -- Cholesky and inverse as 16 x 16 tiles
     on the matrix cores): every block count, column width and tail width (n mod 16 in 1..4: the last columns on the vector pipe), odd n
     (rows staged through registers) and even n (direct HBM -> LDS copies), row counts that end in a partial row tile; the LDP against
     the oracle's (R^-1, M, v, d to ~1e-13 relative: another summation order), then the solve at the north_star bar; and the same
